@@ -1,0 +1,257 @@
+/*
+ * tdnnf_hip.h -- C-ABI of libtdnnf_hip.so: the MI355X (gfx950) implementation of the
+ * LF-MMI TDNN-F / DARTS hot path of skhu101/TDNN-F_NAS.
+ *
+ * Every entry point replaces one nnet3 Component virtual (or one optimizer helper)
+ * of the reference; the reference symbol is cited next to it as
+ * /root/reference-relative file:line.  INTEGRATION.md shows the Kaldi-side adapter
+ * that forwards CuMatrixBase<float> views to these functions.
+ *
+ * Conventions
+ *  - tdnnf_mat is exactly Kaldi's CuMatrixBase<float> view: device pointer, rows,
+ *    cols, row stride in ELEMENTS, row-major (usage: src/nnet3/nnet-tdnn-component.cc:815-819).
+ *  - Pointers named *_dev are device memory; "host" pointers are small index
+ *    arrays read during the call.  The caller owns every buffer.
+ *  - stream is a hipStream_t (NULL = default stream).  No call synchronises the
+ *    stream or the device; scalars (objf, dot products, taps' s_i) are written
+ *    to device memory.  Random draws are INPUTS (device buffers) so results are
+ *    reproducible (SURVEY.md 7 "Randomness").
+ *  - Return value: 0 = ok, TDNNF_EINVAL = bad argument (nothing launched),
+ *    TDNNF_EHIP = a HIP runtime call failed.  tdnnf_last_error() gives the text.
+ *    Nothing throws across this boundary (the reference's KALDI_ERR/KALDI_ASSERT
+ *    become error codes; the C++ adapter turns them back into exceptions).
+ *  - kBackpropAdds / kPropagateAdds semantics of the reference are kept: where
+ *    the reference adds into its output, so do we.
+ */
+#ifndef TDNNF_HIP_H_
+#define TDNNF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TDNNF_OK 0
+#define TDNNF_EINVAL 1
+#define TDNNF_EHIP 2
+
+#define TDNNF_MAX_OFFSETS 16
+
+typedef struct {
+  float *data;
+  int rows, cols, stride;
+} tdnnf_mat;
+
+typedef void *tdnnf_stream;
+
+const char *tdnnf_last_error(void);
+int tdnnf_abi_version(void);
+
+/* ---- TdnnDARTSV3Component coefficient flags (nnet-tdnn-component.cc:150-163) */
+#define TDNNF_DARTS_USE_GUMBEL 1
+#define TDNNF_DARTS_FREE_SELECT 2
+#define TDNNF_DARTS_UNIFORM_SAMPLE 4
+#define TDNNF_DARTS_USE_ENTROPY 8
+#define TDNNF_DARTS_UPDATE_ALPHA 16
+
+/* precomputed indexes: TdnnDARTSV3Component::PrecomputedIndexes
+   (src/nnet3/nnet-convolutional-component.h:208-218) */
+typedef struct {
+  int row_stride;
+  int num_offsets;
+  int row_offsets[TDNNF_MAX_OFFSETS];
+} tdnnf_tdnn_indexes;
+
+/* ======================================================================= A1/A2
+ * TdnnComponent / TdnnDARTSV3Component (src/nnet3/nnet-tdnn-component.cc).
+ * linear_params_dev is Do x (K*Di) with row stride ldw (column block i = tap i).
+ */
+
+/* Coefficients of Propagate :250-289.  Reads log_alpha (bias_params_[0:K]),
+   the K uniform draws for the Gumbel noise and ONE uniform draw for the tap
+   sample; writes coef_memo_dev[K] (the memo of :330-332) and eff_coef_dev[K] (the
+   weight each tap's GEMM gets in :292-328).  share_index per :232-240. */
+int tdnnf_tdnn_darts_coef(const float *log_alpha_dev, int K, int flags, float temp_proportion,
+                          const float *gumbel_u_dev, const float *sample_u_dev, int share_index,
+                          float *coef_memo_dev, float *eff_coef_dev, tdnnf_stream stream);
+
+/* Propagate :214-333 (plain TdnnComponent: eff_coef_dev == NULL, all ones).
+   init_mode 0: out += ... (no bias, kPropagateAdds); 1: out = bias + ... (:233-235);
+   2: out = 0 + ... (:238, reference quirk q1 for layers whose offsets[1] < 0). */
+int tdnnf_tdnn_propagate(const tdnnf_tdnn_indexes *indexes, const tdnnf_mat *in,
+                         const float *linear_params_dev, int ldw, int Do, int Di,
+                         const float *bias_dev, const float *eff_coef_dev, int init_mode,
+                         tdnnf_mat *out, tdnnf_stream stream);
+
+/* Backprop, data part :366-416: in_deriv views += c_i * out_deriv * W_i (kBackpropAdds). */
+int tdnnf_tdnn_backprop_data(const tdnnf_tdnn_indexes *indexes, const tdnnf_mat *out_deriv,
+                             const float *linear_params_dev, int ldw, int Do, int Di,
+                             const float *eff_coef_dev, tdnnf_mat *in_deriv, tdnnf_stream stream);
+
+/* UpdateSimple :433-455 (raw gradient, is_gradient_ path): bias_acc += lr*colsum(dY),
+   W_acc_i += lr * c_i * dY^T X_i.  workspace: tdnnf_tdnn_update_workspace_bytes(). */
+size_t tdnnf_tdnn_update_workspace_bytes(int Do, int Di, int K, int num_rows);
+int tdnnf_tdnn_update_simple(const tdnnf_tdnn_indexes *indexes, const tdnnf_mat *in_value,
+                             const tdnnf_mat *out_deriv, int Do, int Di,
+                             const float *eff_coef_dev, float lr, float *W_acc_dev, int ldw,
+                             float *bias_acc_dev, void *workspace_dev, size_t workspace_bytes,
+                             tdnnf_stream stream);
+
+/* Architecture-logit update of UpdateNaturalGradient :490-590.  s_i = <X_i W_i^T, dY>
+   is obtained as <dW_i, W_i> from tap_grad_dev (K blocks of dY^T X_i, Do x K*Di,
+   UNSCALED by coefficients and lr), avoiding the reference's extra forward GEMM
+   per tap (:534-539).  alpha_acc_dev = to_update->bias_params_[0:K]. */
+int tdnnf_tdnn_darts_alpha_update(const float *tap_grad_dev, int ldg, const float *linear_params_dev,
+                                  int ldw, int Do, int Di, int K, const float *coef_memo_dev,
+                                  int flags, int share_index, float temp_proportion, float lr,
+                                  float *alpha_acc_dev, double *tap_dots_dev /* K, may be NULL */,
+                                  tdnnf_stream stream);
+
+/* ======================================================================= A3/A4
+ * BatchNormComponent / BatchNormTestComponent (src/nnet3/nnet-normalize-component.cc) */
+
+/* Column reductions (BatchNorm statistics, ReLU stats, bias/alpha column sums) are done in two
+   deterministic stages through a caller-supplied scratch buffer of this size. */
+size_t tdnnf_colreduce_workspace_bytes(int rows, int cols);
+
+/* train-mode Propagate :421-452; memo_dev is the 5 x D Memo::mean_uvar_scale. */
+int tdnnf_batchnorm_propagate(const tdnnf_mat *in, float epsilon, float target_rms, tdnnf_mat *out,
+                              float *memo_dev, void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream);
+/* train-mode Backprop :505-542 */
+int tdnnf_batchnorm_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_deriv, float target_rms,
+                             float *memo_dev, tdnnf_mat *in_deriv, void *workspace_dev, size_t workspace_bytes,
+                             tdnnf_stream stream);
+/* StoreStats :551-589; stats are double as in the reference (h:458-462); stats_dev = [count, sum[D], sumsq[D]] */
+int tdnnf_batchnorm_store_stats(const float *memo_dev, int D, int num_frames, double *stats_dev,
+                                tdnnf_stream stream);
+/* ComputeDerived :682-715 -> scale_dev[D], offset_dev[D] */
+int tdnnf_batchnorm_compute_derived(const double *stats_dev, int D, float epsilon, float target_rms,
+                                    float *scale_dev, float *offset_dev, tdnnf_stream stream);
+/* BatchNormTestComponent::Propagate :872-874 / Backprop :919-920 */
+int tdnnf_batchnorm_test_propagate(const tdnnf_mat *in, const float *scale_dev, const float *offset_dev,
+                                   tdnnf_mat *out, tdnnf_stream stream);
+int tdnnf_batchnorm_test_backprop(const tdnnf_mat *out_deriv, const float *scale_dev, tdnnf_mat *in_deriv,
+                                  tdnnf_stream stream);
+
+/* ========================================================================== A5
+ * DARTS mixing ops (src/nnet3/nnet-simple-component.cc) */
+
+/* SoftmaxFlopsComponent::Propagate :9968-9981 (gumbel_u_dev NULL, temp 1) and
+   GumbelSoftmax[Flops]Component::Propagate :10088-10113 / :9774-9799. */
+int tdnnf_softmax_flops_propagate(const tdnnf_mat *in, const float *gumbel_u_dev, float temp_proportion,
+                                  tdnnf_mat *out, tdnnf_stream stream);
+/* Backprop :9984-10020 / :10116-10158: out_deriv[:, :dim] += scale/(rows*cols)*flops (IN PLACE, as the
+   reference does), in_deriv = DiffSoftmax(out_value, out_deriv) / temp.  flops_dev NULL = no penalty. */
+int tdnnf_softmax_flops_backprop(const tdnnf_mat *out_value, tdnnf_mat *out_deriv, float scale,
+                                 const float *flops_dev, int dim, float temp_proportion,
+                                 tdnnf_mat *in_deriv, tdnnf_stream stream);
+/* OnehotFunctionComponent::Propagate :9504-9519 (one uniform draw, device) */
+int tdnnf_onehot_propagate(const float *sample_u_dev, tdnnf_mat *out, tdnnf_stream stream);
+/* CopyNComponent :4843-4867 (AddMatBlocks: both directions ADD) */
+int tdnnf_copyn_propagate(const tdnnf_mat *in, float scale, tdnnf_mat *out, tdnnf_stream stream);
+int tdnnf_copyn_backprop(const tdnnf_mat *out_deriv, float scale, tdnnf_mat *in_deriv, tdnnf_stream stream);
+/* ConstantFunctionComponent :2602-2642 (non-NG branch: output += 5*lr*colsum) */
+int tdnnf_constant_function_propagate(const float *output_dev, tdnnf_mat *out, tdnnf_stream stream);
+int tdnnf_constant_function_backprop(const tdnnf_mat *out_deriv, float lr, float *output_acc_dev,
+                                     void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream);
+/* FlopsConstraintComponent::Backprop :9465-9478 */
+int tdnnf_flops_constraint_backprop(const float *flops_dev, float scale, int rows_in, int cols_in,
+                                    tdnnf_mat *in_deriv, tdnnf_stream stream);
+
+/* ========================================================================== A6 */
+/* ElementwiseProductComponent :256-299 */
+int tdnnf_elementwise_product_propagate(const tdnnf_mat *in, int output_dim, tdnnf_mat *out, tdnnf_stream);
+int tdnnf_elementwise_product_backprop(const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int output_dim,
+                                       tdnnf_mat *in_deriv, tdnnf_stream);
+/* RectifiedLinearComponent :958-1091 */
+int tdnnf_relu_propagate(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_stream);
+int tdnnf_relu_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_deriv, tdnnf_mat *in_deriv, tdnnf_stream);
+/* RepairGradients :990-1074 after the coin flip; stats_dev = [count, value_sum[D], deriv_sum[D]] doubles */
+int tdnnf_relu_repair(const double *stats_dev, int dim, float self_repair_scale, float lower, float upper,
+                      tdnnf_mat *in_deriv, tdnnf_stream);
+int tdnnf_relu_store_stats(const tdnnf_mat *out_value, double *stats_dev, void *workspace_dev,
+                           size_t workspace_bytes, tdnnf_stream);
+/* AffineComponent :1235-1279 / LinearComponent :3211-3254 (bias_dev NULL).  Same MFMA kernels as Tdnn. */
+int tdnnf_affine_propagate(const tdnnf_mat *in, const float *W_dev, int ldw, const float *bias_dev, int Do,
+                           tdnnf_mat *out, tdnnf_stream);
+int tdnnf_affine_backprop(const tdnnf_mat *out_deriv, const float *W_dev, int ldw, int Di, tdnnf_mat *in_deriv,
+                          tdnnf_stream);
+int tdnnf_affine_update_simple(const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, float lr, float *W_acc_dev,
+                               int ldw, float *bias_acc_dev, void *workspace_dev, size_t workspace_bytes,
+                               tdnnf_stream);
+/* LogSoftmaxComponent :3607-3632 */
+int tdnnf_log_softmax_propagate(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_stream);
+int tdnnf_log_softmax_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_deriv, tdnnf_mat *in_deriv,
+                               tdnnf_stream);
+/* out = sa*a + sb*b  (descriptor Sum(Scale(..), ..) into NoOpComponent, composite_layers.py:205-213);
+   b may be NULL (plain scaled copy).  In-place (out aliasing a or b) is allowed. */
+int tdnnf_sum_scaled(const tdnnf_mat *a, float sa, const tdnnf_mat *b, float sb, tdnnf_mat *out, tdnnf_stream);
+/* out += s * a */
+int tdnnf_add_scaled(const tdnnf_mat *a, float s, tdnnf_mat *out, tdnnf_stream);
+/* GeneralDropoutComponent (UPSTREAM), continuous mask shared over time: row r uses mask row r % num_seq */
+int tdnnf_general_dropout(const tdnnf_mat *in, const float *mask_dev, int num_seq, tdnnf_mat *out, tdnnf_stream);
+
+/* ========================================================================== A7
+ * chain::ComputeChainObjfAndDeriv (UPSTREAM; options from
+ * local/chain_NAS/run_TDNN_DARTSV3_fbk_stride_pretrain.sh:185-195). */
+typedef struct tdnnf_den_graph tdnnf_den_graph;       /* device-resident denominator HMM */
+typedef struct tdnnf_supervision tdnnf_supervision;   /* device-resident numerator graphs of one minibatch */
+
+/* host arrays in, device copy out.  initial_probs may be NULL (computed as 100-step average occupancy
+   from start_state, DenominatorGraph::SetInitialProbs). */
+int tdnnf_den_graph_create(int num_states, int num_arcs, int num_pdfs, const int *arc_src, const int *arc_dst,
+                           const int *arc_pdf, const float *arc_prob, const float *initial_probs, int start_state,
+                           tdnnf_den_graph **out);
+void tdnnf_den_graph_destroy(tdnnf_den_graph *);
+int tdnnf_supervision_create(int num_sequences, int frames_per_sequence, const int *seq_state_begin,
+                             const int *seq_arc_begin, const int *state_time, const float *final_logprob,
+                             const int *arc_src, const int *arc_dst, const int *arc_pdf, const float *arc_logprob,
+                             float weight, tdnnf_supervision **out);
+void tdnnf_supervision_destroy(tdnnf_supervision *);
+
+size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *, int num_sequences, int frames_per_sequence);
+/* results_dev (device doubles): [0] objf, [1] l2_term, [2] weight, [3] num logprob (weighted),
+   [4] den logprob (weighted), [5] ok flag (1.0 / 0.0), [6] xent objf when xent_output given.
+   nnet_output_deriv is OVERWRITTEN; xent_deriv (may be NULL) receives the numerator posteriors
+   already multiplied by xent_regularize (NnetChainTrainer::ProcessOutputs). */
+int tdnnf_chain_objf_and_deriv(const tdnnf_den_graph *, const tdnnf_supervision *, const tdnnf_mat *nnet_output,
+                               const tdnnf_mat *xent_output /* may be NULL */, float leaky_hmm_coefficient,
+                               float l2_regularize, float xent_regularize, double *results_dev,
+                               tdnnf_mat *nnet_output_deriv, tdnnf_mat *xent_deriv, void *workspace_dev,
+                               size_t workspace_bytes, tdnnf_stream);
+
+/* ========================================================================== A8
+ * OnlineNaturalGradient::PreconditionDirections (UPSTREAM; call sites
+ * src/nnet3/nnet-tdnn-component.cc:598-599, nnet-simple-component.cc:3001-3002). */
+typedef struct tdnnf_ng tdnnf_ng;
+int tdnnf_ng_create(int rank, int update_period, float num_samples_history, float alpha, tdnnf_ng **out);
+void tdnnf_ng_destroy(tdnnf_ng *);
+/* X is modified in place; *scale_host receives the scalar (this call synchronises the stream on the
+   steps where the low-rank state is refreshed, as the reference does for its R x R eig on the host). */
+int tdnnf_ng_precondition(tdnnf_ng *, tdnnf_mat *X, float *scale_host, tdnnf_stream);
+
+/* ========================================================================== A9
+ * src/nnet3/nnet-utils.cc */
+/* ConstrainOrthonormalInternal :914-1032 on M (rows <= cols; pass the transpose otherwise, :1068-1075).
+   workspace: (rows*rows + rows*cols + 8) floats. */
+size_t tdnnf_constrain_orthonormal_workspace_bytes(int rows, int cols);
+int tdnnf_constrain_orthonormal(float scale, float *M_dev, int rows, int cols, int ld, void *workspace_dev,
+                                size_t workspace_bytes, tdnnf_stream);
+/* ApplyL2Regularization :2223-2245 : delta += scale * params */
+int tdnnf_axpy(const float *x_dev, float a, float *y_dev, size_t n, tdnnf_stream);
+/* UpdateNnetWithMaxChange :2085-2175 on a flat parameter vector partitioned into num_comp components
+   (comp_begin_host[num_comp+1] element offsets).  params += factor_i * delta_i with the per-component and
+   global max-change factors computed ON DEVICE (no D2H of the dot products).  delta is zeroed afterwards
+   when zero_delta != 0 (momentum 0).  info_dev (may be NULL): [num_comp] factors then [1] ok flag. */
+size_t tdnnf_max_change_workspace_bytes(int num_comp);
+int tdnnf_update_with_max_change(float *params_dev, float *delta_dev, int num_comp, const long long *comp_begin_host,
+                                 const float *max_change_host, float max_param_change, float max_change_scale,
+                                 float scale, int zero_delta, void *workspace_dev, size_t workspace_bytes,
+                                 float *info_dev, tdnnf_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDNNF_HIP_H_ */

@@ -1,0 +1,619 @@
+// chain.hip -- LF-MMI objective and derivative on gfx950: chain::ComputeChainObjfAndDeriv,
+// DenominatorComputation and NumeratorComputation (UPSTREAM Kaldi, not shipped in the reference;
+// reached via /root/reference/steps/nnet3/chain/train.py:515; options pinned by
+// local/chain_NAS/run_TDNN_DARTSV3_fbk_stride_pretrain.sh:185-195).  SURVEY.md 8(a) row A7.
+//
+// MI355X design (vs. upstream's 2*T kernel launches with atomics):
+//  * ONE persistent workgroup per sequence walks all T frames inside a single launch; the HMM state
+//    vectors (alpha/beta) and the exponentiated output row live in LDS, the per-frame renormaliser
+//    is a workgroup reduction.  Sequences are independent, so there is no inter-workgroup traffic.
+//  * the denominator graph is stored three times in sliced-ELL (SELL-64) form -- by destination
+//    (forward), by source (beta) and by pdf (occupancies) -- so every arc gather is a coalesced
+//    stream and every sum is a fixed-order per-thread loop: no float atomics, results are bitwise
+//    reproducible.  An arc is 8 bytes: (state | pdf << 16, prob).
+//  * the numerator (tiny time-synchronous graphs) runs one wave per sequence in the log domain.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include <vector>
+
+#include "common.h"
+
+struct tdnnf_den_graph {
+  int H, A, P;
+  // SELL-64: slice k covers rows 64k..64k+63, entries at base[k] + j*64 + lane, j < width[k]
+  struct Sell {
+    int nrows, nslices;
+    int *base;       // nslices + 1 (device)
+    unsigned *key;   // packed (other-state-or-src | pdf << 16), or (src | dst << 16) for the by-pdf table
+    float *prob;
+    long long entries;
+  } by_dst, by_src, by_pdf;
+  float *init;  // H
+  float init_sum;
+};
+
+struct tdnnf_supervision {
+  int B, T;
+  int num_states, num_arcs;
+  float weight;
+  int *seq_state_begin;  // B+1
+  int *state_time;
+  float *final_logprob;
+  // arcs grouped by destination state (forward) and by source state (backward), CSR over global state ids
+  int *in_begin, *in_src, *in_pdf;
+  float *in_lp;
+  int *out_begin, *out_dst, *out_pdf;
+  float *out_lp;
+  // states of a sequence are sorted by time; frame_state_begin[s*(T+2) + t] = first state with time t
+  int *frame_state_begin;
+  int max_states_per_seq;
+};
+
+namespace tdnnf {
+namespace {
+
+constexpr int kDenThreads = 1024;
+
+__device__ __forceinline__ float block_sum(float v, float *red, int nwaves) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();  // protect red from the previous use
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int w = 0; w < nwaves; w++) s += red[w];
+  return s;
+}
+
+// ApplyExpLimited(-30, 30): comparisons (not fmin/fmax) so that a NaN stays a NaN and trips the
+// objf-not-finite failure path, as in the reference stack.
+__device__ __forceinline__ float exp_limited(float v) {
+  v = v < -30.f ? -30.f : (v > 30.f ? 30.f : v);
+  return expf(v);
+}
+
+struct DenDev {
+  int H, P;
+  tdnnf_den_graph::Sell by_dst, by_src, by_pdf;
+  const float *init;
+  float init_sum;
+};
+
+// Forward: alpha_dash(t, .) for t = 0..T stored to `alpha` [(T+1) x Hs] per sequence, alpha sums to
+// `asum` [T+1], per-sequence log-prob to logprob[s].
+template <bool LDS_STATE>
+__global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatView y, int B, int T, float leaky,
+                                                                  float *alpha_all, float *asum_all, int Hs,
+                                                                  double *logprob, float *gstate) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[kDenThreads / 64];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int H = g.H, P = g.P;
+  float *x = smem;  // P
+  float *prev = LDS_STATE ? smem + ((P + 3) & ~3) : gstate + (size_t)s * 2 * Hs;
+  float *alpha = alpha_all + (size_t)s * (T + 1) * Hs;
+  float *asum = asum_all + (size_t)s * (T + 1);
+
+  // AlphaFirstFrame + AlphaDash(0)
+  for (int h = tid; h < H; h += kDenThreads) {
+    const float a = g.init[h] + leaky * g.init_sum * g.init[h];
+    prev[h] = a;
+    alpha[h] = a;
+  }
+  if (tid == 0) asum[0] = g.init_sum;
+  float prev_sum = g.init_sum;
+  double logcorr = 0.0;
+  __syncthreads();
+  for (int t = 1; t <= T; t++) {
+    const float *yr = y.data + (size_t)((t - 1) * B + s) * y.stride;
+    for (int p = tid; p < P; p += kDenThreads) x[p] = exp_limited(yr[p]);
+    __syncthreads();
+    const float inv = 1.0f / prev_sum;
+    logcorr += (double)logf(prev_sum);
+    float *cur = alpha + (size_t)t * Hs;
+    float local = 0.f;
+    for (int h = tid; h < ((H + 63) & ~63); h += kDenThreads) {
+      const int sl = h >> 6, ln = h & 63;
+      const int b0 = g.by_dst.base[sl], w = (g.by_dst.base[sl + 1] - b0) >> 6;
+      float acc = 0.f;
+      for (int j = 0; j < w; j++) {
+        const unsigned k = g.by_dst.key[b0 + j * 64 + ln];
+        const float pr = g.by_dst.prob[b0 + j * 64 + ln];
+        acc += prev[k & 0xffffu] * pr * x[k >> 16];
+      }
+      if (h < H) {
+        acc *= inv;
+        cur[h] = acc;  // alpha(t,h) before the leaky term
+        local += acc;
+      }
+    }
+    const float sum = block_sum(local, red, kDenThreads / 64);
+    if (tid == 0) asum[t] = sum;
+    for (int h = tid; h < H; h += kDenThreads) {  // AlphaDash(t)
+      const float a = cur[h] + leaky * sum * g.init[h];
+      cur[h] = a;
+      prev[h] = a;
+    }
+    prev_sum = sum;
+    __syncthreads();
+  }
+  float local = 0.f;
+  for (int h = tid; h < H; h += kDenThreads) local += prev[h];
+  const float tot = block_sum(local, red, kDenThreads / 64);
+  if (tid == 0) {
+    logprob[s] = (double)logf(tot) + logcorr;
+    asum[T] = tot;  // reuse: total of alpha_dash(T) (asum[T] itself is not needed by the backward pass)
+  }
+}
+
+// Backward: deriv[t*B+s][p] = deriv_weight * gamma_den(t, p)   (overwrites the whole row)
+template <bool LDS_STATE>
+__global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, MatView y, int B, int T, float leaky,
+                                                                   const float *alpha_all, const float *asum_all,
+                                                                   int Hs, float deriv_weight, MatView deriv,
+                                                                   float *gstate) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[kDenThreads / 64];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int H = g.H, P = g.P, P4 = (P + 3) & ~3, H4 = (H + 3) & ~3;
+  float *x = smem;
+  float *bnext = LDS_STATE ? smem + P4 : gstate + (size_t)s * 3 * Hs;
+  float *bcur = LDS_STATE ? bnext + H4 : bnext + Hs;
+  float *ad = LDS_STATE ? bcur + H4 : bcur + Hs;  // alpha_dash(t) * inv_asum(t)
+  const float *alpha = alpha_all + (size_t)s * (T + 1) * Hs;
+  const float *asum = asum_all + (size_t)s * (T + 1);
+
+  {  // BetaDashLastFrame + Beta(T)
+    const float bd = 1.0f / asum[T];
+    const float lsum = g.init_sum * bd;
+    for (int h = tid; h < H; h += kDenThreads) bnext[h] = bd + leaky * lsum;
+  }
+  __syncthreads();
+  for (int t = T - 1; t >= 0; t--) {
+    const float *yr = y.data + (size_t)(t * B + s) * y.stride;
+    const float inv = 1.0f / asum[t];
+    for (int p = tid; p < P; p += kDenThreads) x[p] = exp_limited(yr[p]);
+    for (int h = tid; h < H; h += kDenThreads) ad[h] = alpha[(size_t)t * Hs + h] * inv;
+    __syncthreads();
+    // beta_dash(t, i) = sum over out-arcs
+    float local = 0.f;
+    for (int h = tid; h < ((H + 63) & ~63); h += kDenThreads) {
+      const int sl = h >> 6, ln = h & 63;
+      const int b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
+      float acc = 0.f;
+      for (int j = 0; j < w; j++) {
+        const unsigned k = g.by_src.key[b0 + j * 64 + ln];
+        const float pr = g.by_src.prob[b0 + j * 64 + ln];
+        acc += pr * x[k >> 16] * bnext[k & 0xffffu];
+      }
+      if (h < H) {
+        acc *= inv;
+        bcur[h] = acc;
+        local += g.init[h] * acc;
+      }
+    }
+    // occupancies by pdf: gamma(t,p) = x[p] * sum_arcs prob * alpha_dash(t,src)/A(t) * beta(t+1,dst)
+    float *dr = deriv.data + (size_t)(t * B + s) * deriv.stride;
+    for (int p = tid; p < ((P + 63) & ~63); p += kDenThreads) {
+      const int sl = p >> 6, ln = p & 63;
+      const int b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
+      float acc = 0.f;
+      for (int j = 0; j < w; j++) {
+        const unsigned k = g.by_pdf.key[b0 + j * 64 + ln];
+        const float pr = g.by_pdf.prob[b0 + j * 64 + ln];
+        acc += pr * ad[k & 0xffffu] * bnext[k >> 16];
+      }
+      if (p < P) dr[p] = deriv_weight * acc * x[p];
+    }
+    const float ls = block_sum(local, red, kDenThreads / 64);  // also orders the reads of bnext above
+    for (int h = tid; h < H; h += kDenThreads) bcur[h] += leaky * ls;  // Beta(t)
+    float *tmp = bnext;
+    bnext = bcur;
+    bcur = tmp;
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ float log_add(float a, float b) {
+  if (a == -INFINITY) return b;
+  if (b == -INFINITY) return a;
+  const float m = fmaxf(a, b), d = fminf(a, b) - m;
+  return m + log1pf(expf(d));
+}
+
+struct SupDev {
+  int B, T;
+  float weight;
+  const int *seq_state_begin, *frame_state_begin;
+  const float *final_logprob;
+  const int *in_begin, *in_src, *in_pdf;
+  const float *in_lp;
+  const int *out_begin, *out_dst, *out_pdf;
+  const float *out_lp;
+};
+
+// one wave per sequence.  la/lb: global scratch indexed by global state id.
+__global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, MatView xent_out, float *la, float *lb,
+                                                       double *num_logprob, double *xent_objf, MatView deriv,
+                                                       MatView xent_deriv, float xent_scale) {
+  const int s = blockIdx.x, lane = threadIdx.x, B = sp.B, T = sp.T;
+  const int *fsb = sp.frame_state_begin + (size_t)s * (T + 2);
+  const int s0 = sp.seq_state_begin[s], s1 = sp.seq_state_begin[s + 1];
+  for (int i = s0 + lane; i < s1; i += 64) la[i] = (i == s0) ? 0.f : -INFINITY;
+  __syncthreads();
+  for (int t = 1; t <= T; t++) {  // states entered at time t
+    for (int st = fsb[t] + lane; st < fsb[t + 1]; st += 64) {
+      float v = -INFINITY;
+      for (int a = sp.in_begin[st]; a < sp.in_begin[st + 1]; a++)
+        v = log_add(v, la[sp.in_src[a]] + sp.in_lp[a] + y.data[(size_t)((t - 1) * B + s) * y.stride + sp.in_pdf[a]]);
+      la[st] = v;
+    }
+    __syncthreads();
+  }
+  float tot = -INFINITY;
+  for (int st = fsb[T] + lane; st < fsb[T + 1]; st += 64) {
+    const float f = sp.final_logprob[st];
+    lb[st] = f;
+    if (f != -INFINITY) tot = log_add(tot, la[st] + f);
+  }
+  for (int o = 32; o > 0; o >>= 1) tot = log_add(tot, __shfl_xor(tot, o, 64));
+  __syncthreads();
+  for (int t = T - 1; t >= 0; t--) {
+    for (int st = fsb[t] + lane; st < fsb[t + 1]; st += 64) {
+      float v = -INFINITY;
+      for (int a = sp.out_begin[st]; a < sp.out_begin[st + 1]; a++)
+        v = log_add(v, sp.out_lp[a] + y.data[(size_t)(t * B + s) * y.stride + sp.out_pdf[a]] + lb[sp.out_dst[a]]);
+      lb[st] = v;
+    }
+    __syncthreads();
+  }
+  // posteriors: lane = frame (distinct output rows per lane, fixed arc order -> deterministic)
+  double xo = 0.0;
+  for (int t = lane; t < T; t += 64) {
+    const size_t row = (size_t)(t * B + s);
+    for (int st = fsb[t]; st < fsb[t + 1]; st++)
+      for (int a = sp.out_begin[st]; a < sp.out_begin[st + 1]; a++) {
+        const int pdf = sp.out_pdf[a];
+        const float ll = sp.out_lp[a] + y.data[row * y.stride + pdf];
+        const float gam = sp.weight * expf(la[st] + ll + lb[sp.out_dst[a]] - tot);
+        if (deriv.data) deriv.data[row * deriv.stride + pdf] += gam;
+        if (xent_deriv.data) xent_deriv.data[row * xent_deriv.stride + pdf] += xent_scale * gam;
+        if (xent_out.data) xo += (double)gam * (double)xent_out.data[row * xent_out.stride + pdf];
+      }
+  }
+  for (int o = 32; o > 0; o >>= 1) xo += __shfl_xor(xo, o, 64);
+  if (lane == 0) {
+    num_logprob[s] = (double)tot;
+    xent_objf[s] = xo;
+  }
+}
+
+// results: [0] objf [1] l2_term [2] weight [3] num [4] den [5] ok [6] xent objf
+__global__ void chain_finalize_kernel(const double *num_lp, const double *den_lp, const double *xent, const double *l2sum,
+                                      int B, int T, float weight, float l2_regularize, double *results) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double num = 0, den = 0, xo = 0;
+  for (int s = 0; s < B; s++) {
+    num += num_lp[s];
+    den += den_lp[s];
+    xo += xent[s];
+  }
+  num *= weight;
+  den *= weight;
+  double objf = num - den;
+  const double w = (double)weight * B * T;
+  const bool ok = (objf - objf == 0.0);
+  if (!ok) objf = -10.0 * w;
+  results[0] = objf;
+  results[1] = (l2_regularize == 0.f || !l2sum) ? 0.0 : -0.5 * (double)weight * l2_regularize * l2sum[0];
+  results[2] = w;
+  results[3] = num;
+  results[4] = den;
+  results[5] = ok ? 1.0 : 0.0;
+  results[6] = ok ? xo : 0.0;
+}
+
+// failure path (objf not finite): zero the derivatives; otherwise add the l2 term's derivative.
+__global__ void chain_guard_kernel(const double *results, MatView y, float l2_scale, MatView d, MatView xd) {
+  const bool ok = results[5] != 0.0;
+  if (ok && l2_scale == 0.f) return;
+  const long long total = (long long)d.rows * d.cols;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int r = (int)(e / d.cols), c = (int)(e % d.cols);
+    if (!ok) {
+      d.data[(size_t)r * d.stride + c] = 0.f;
+      if (xd.data) xd.data[(size_t)r * xd.stride + c] = 0.f;
+    } else {
+      d.data[(size_t)r * d.stride + c] += -l2_scale * y.data[(size_t)r * y.stride + c];
+    }
+  }
+}
+__global__ __launch_bounds__(256) void sumsq_kernel(MatView y, double *out) {
+  __shared__ double red[4];
+  double s = 0;
+  const long long total = (long long)y.rows * y.cols;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const double v = y.data[(size_t)(e / y.cols) * y.stride + e % y.cols];
+    s += v * v;
+  }
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (red[0] + red[1]) + (red[2] + red[3]));
+}
+__global__ void zero_rows_kernel(MatView m) {
+  const long long total = (long long)m.rows * m.cols;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL)
+    m.data[(size_t)(e / m.cols) * m.stride + e % m.cols] = 0.f;
+}
+
+// -------------------------------------------------------------------------------- host helpers
+template <class T>
+int to_device(const std::vector<T> &v, T **out) {
+  *out = nullptr;
+  if (v.empty()) {
+    TDNNF_HIP(hipMalloc((void **)out, sizeof(T)));
+    return TDNNF_OK;
+  }
+  TDNNF_HIP(hipMalloc((void **)out, sizeof(T) * v.size()));
+  TDNNF_HIP(hipMemcpy(*out, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+  return TDNNF_OK;
+}
+
+// rows[r] = list of (key, prob); builds SELL-64
+int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, float>>> &rows, tdnnf_den_graph::Sell *out) {
+  const int ns = (nrows + 63) / 64;
+  std::vector<int> base(ns + 1, 0);
+  for (int k = 0; k < ns; k++) {
+    size_t w = 0;
+    for (int r = 64 * k; r < 64 * k + 64 && r < nrows; r++) w = std::max(w, rows[r].size());
+    base[k + 1] = base[k] + (int)w * 64;
+  }
+  std::vector<unsigned> key(base[ns], 0u);
+  std::vector<float> prob(base[ns], 0.f);
+  for (int r = 0; r < nrows; r++)
+    for (size_t j = 0; j < rows[r].size(); j++) {
+      key[base[r / 64] + j * 64 + r % 64] = rows[r][j].first;
+      prob[base[r / 64] + j * 64 + r % 64] = rows[r][j].second;
+    }
+  out->nrows = nrows;
+  out->nslices = ns;
+  out->entries = base[ns];
+  int rc;
+  if ((rc = to_device(base, &out->base))) return rc;
+  if ((rc = to_device(key, &out->key))) return rc;
+  return to_device(prob, &out->prob);
+}
+
+struct ChainPlan {
+  int Hs;
+  bool lds_state;
+  size_t alpha_floats, asum_floats, gstate_floats, la_floats;
+  size_t lds_fwd, lds_bwd;
+};
+ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup) {
+  ChainPlan p;
+  p.Hs = (g->H + 3) & ~3;
+  const int P4 = (g->P + 3) & ~3;
+  p.lds_fwd = sizeof(float) * (P4 + p.Hs);
+  p.lds_bwd = sizeof(float) * (P4 + 3 * p.Hs);
+  p.lds_state = p.lds_bwd <= 150 * 1024;
+  if (!p.lds_state) {
+    p.lds_fwd = sizeof(float) * P4;
+    p.lds_bwd = sizeof(float) * P4;
+  }
+  p.alpha_floats = (size_t)B * (T + 1) * p.Hs;
+  p.asum_floats = (size_t)B * (T + 1);
+  p.gstate_floats = p.lds_state ? 0 : (size_t)B * 3 * p.Hs;
+  p.la_floats = 2 * (size_t)num_states_sup;
+  return p;
+}
+
+}  // namespace
+}  // namespace tdnnf
+
+using namespace tdnnf;
+
+extern "C" {
+
+int tdnnf_den_graph_create(int H, int A, int P, const int *src, const int *dst, const int *pdf, const float *prob,
+                           const float *initial_probs, int start_state, tdnnf_den_graph **out) {
+  TDNNF_REQUIRE(out && H > 0 && A > 0 && P > 0 && src && dst && pdf && prob, "den_graph_create: bad arguments");
+  TDNNF_REQUIRE(H <= 65535 && P <= 65535, "den_graph_create: num_states and num_pdfs must be <= 65535 (16-bit packed arcs)");
+  for (int a = 0; a < A; a++)
+    TDNNF_REQUIRE(src[a] >= 0 && src[a] < H && dst[a] >= 0 && dst[a] < H && pdf[a] >= 0 && pdf[a] < P && prob[a] >= 0,
+                  "den_graph_create: arc %d out of range", a);
+  std::vector<float> init(H);
+  if (initial_probs) {
+    init.assign(initial_probs, initial_probs + H);
+  } else {  // DenominatorGraph::SetInitialProbs: 100-step average occupancy of the row-normalised graph
+    TDNNF_REQUIRE(start_state >= 0 && start_state < H, "den_graph_create: bad start state");
+    std::vector<double> norm(H, 0.0), cur(H, 0.0), nxt(H), avg(H, 0.0);
+    for (int a = 0; a < A; a++) norm[src[a]] += prob[a];
+    cur[start_state] = 1.0;
+    for (int it = 0; it < 100; it++) {
+      for (int h = 0; h < H; h++) avg[h] += cur[h] / 100;
+      std::fill(nxt.begin(), nxt.end(), 0.0);
+      for (int a = 0; a < A; a++)
+        if (norm[src[a]] > 0) nxt[dst[a]] += cur[src[a]] * prob[a] / norm[src[a]];
+      cur.swap(nxt);
+    }
+    for (int h = 0; h < H; h++) init[h] = (float)avg[h];
+  }
+  tdnnf_den_graph *g = new tdnnf_den_graph();
+  memset(g, 0, sizeof(*g));
+  g->H = H;
+  g->A = A;
+  g->P = P;
+  std::vector<std::vector<std::pair<unsigned, float>>> bd(H), bs(H), bp(P);
+  for (int a = 0; a < A; a++) {
+    bd[dst[a]].push_back({(unsigned)src[a] | ((unsigned)pdf[a] << 16), prob[a]});
+    bs[src[a]].push_back({(unsigned)dst[a] | ((unsigned)pdf[a] << 16), prob[a]});
+    bp[pdf[a]].push_back({(unsigned)src[a] | ((unsigned)dst[a] << 16), prob[a]});
+  }
+  int rc;
+  if ((rc = build_sell(H, bd, &g->by_dst)) || (rc = build_sell(H, bs, &g->by_src)) || (rc = build_sell(P, bp, &g->by_pdf)) ||
+      (rc = to_device(init, &g->init))) {
+    tdnnf_den_graph_destroy(g);
+    return rc;
+  }
+  float s = 0.f;  // float sum in index order, as the device kernels assume
+  double sd = 0;
+  for (int h = 0; h < H; h++) sd += init[h];
+  s = (float)sd;
+  g->init_sum = s;
+  *out = g;
+  return TDNNF_OK;
+}
+
+void tdnnf_den_graph_destroy(tdnnf_den_graph *g) {
+  if (!g) return;
+  tdnnf_den_graph::Sell *t[3] = {&g->by_dst, &g->by_src, &g->by_pdf};
+  for (auto *x : t) {
+    hipFree(x->base);
+    hipFree(x->key);
+    hipFree(x->prob);
+  }
+  hipFree(g->init);
+  delete g;
+}
+
+int tdnnf_supervision_create(int B, int T, const int *seq_state_begin, const int *seq_arc_begin, const int *state_time,
+                             const float *final_logprob, const int *arc_src, const int *arc_dst, const int *arc_pdf,
+                             const float *arc_logprob, float weight, tdnnf_supervision **out) {
+  TDNNF_REQUIRE(out && B > 0 && T > 0 && seq_state_begin && seq_arc_begin && state_time && final_logprob && arc_src &&
+                    arc_dst && arc_pdf && arc_logprob,
+                "supervision_create: bad arguments");
+  const int NS = seq_state_begin[B], NA = seq_arc_begin[B];
+  std::vector<int> fsb((size_t)B * (T + 2), 0);
+  int max_states = 0;
+  for (int s = 0; s < B; s++) {
+    const int s0 = seq_state_begin[s], s1 = seq_state_begin[s + 1];
+    max_states = std::max(max_states, s1 - s0);
+    TDNNF_REQUIRE(s1 > s0 && state_time[s0] == 0, "supervision_create: sequence %d must start with its time-0 start state", s);
+    int st = s0;
+    for (int t = 0; t <= T + 1; t++) {
+      while (st < s1 && state_time[st] < t) st++;
+      fsb[(size_t)s * (T + 2) + t] = st;
+    }
+    for (int i = s0 + 1; i < s1; i++)
+      TDNNF_REQUIRE(state_time[i] >= state_time[i - 1] && state_time[i] <= T, "supervision_create: states must be sorted by time");
+    TDNNF_REQUIRE(fsb[(size_t)s * (T + 2) + 1] == s0 + 1, "supervision_create: exactly one time-0 state per sequence");
+    for (int a = seq_arc_begin[s]; a < seq_arc_begin[s + 1]; a++)
+      TDNNF_REQUIRE(arc_src[a] >= s0 && arc_src[a] < s1 && arc_dst[a] >= s0 && arc_dst[a] < s1 && arc_pdf[a] >= 0 &&
+                        state_time[arc_dst[a]] == state_time[arc_src[a]] + 1,
+                    "supervision_create: arc %d must advance exactly one frame inside its sequence", a);
+  }
+  std::vector<int> in_begin(NS + 1, 0), out_begin(NS + 1, 0);
+  for (int a = 0; a < NA; a++) {
+    in_begin[arc_dst[a] + 1]++;
+    out_begin[arc_src[a] + 1]++;
+  }
+  for (int i = 0; i < NS; i++) {
+    in_begin[i + 1] += in_begin[i];
+    out_begin[i + 1] += out_begin[i];
+  }
+  std::vector<int> in_src(NA), in_pdf(NA), out_dst(NA), out_pdf(NA), ipos(in_begin.begin(), in_begin.end() - 1),
+      opos(out_begin.begin(), out_begin.end() - 1);
+  std::vector<float> in_lp(NA), out_lp(NA);
+  for (int a = 0; a < NA; a++) {  // stable: original arc order within each state
+    int i = ipos[arc_dst[a]]++, o = opos[arc_src[a]]++;
+    in_src[i] = arc_src[a];
+    in_pdf[i] = arc_pdf[a];
+    in_lp[i] = arc_logprob[a];
+    out_dst[o] = arc_dst[a];
+    out_pdf[o] = arc_pdf[a];
+    out_lp[o] = arc_logprob[a];
+  }
+  tdnnf_supervision *sp = new tdnnf_supervision();
+  memset(sp, 0, sizeof(*sp));
+  sp->B = B;
+  sp->T = T;
+  sp->num_states = NS;
+  sp->num_arcs = NA;
+  sp->weight = weight;
+  sp->max_states_per_seq = max_states;
+  std::vector<int> ssb(seq_state_begin, seq_state_begin + B + 1), stime(state_time, state_time + NS);
+  std::vector<float> fin(final_logprob, final_logprob + NS);
+  int rc;
+  if ((rc = to_device(ssb, &sp->seq_state_begin)) || (rc = to_device(stime, &sp->state_time)) ||
+      (rc = to_device(fin, &sp->final_logprob)) || (rc = to_device(in_begin, &sp->in_begin)) ||
+      (rc = to_device(in_src, &sp->in_src)) || (rc = to_device(in_pdf, &sp->in_pdf)) || (rc = to_device(in_lp, &sp->in_lp)) ||
+      (rc = to_device(out_begin, &sp->out_begin)) || (rc = to_device(out_dst, &sp->out_dst)) ||
+      (rc = to_device(out_pdf, &sp->out_pdf)) || (rc = to_device(out_lp, &sp->out_lp)) ||
+      (rc = to_device(fsb, &sp->frame_state_begin))) {
+    tdnnf_supervision_destroy(sp);
+    return rc;
+  }
+  *out = sp;
+  return TDNNF_OK;
+}
+
+void tdnnf_supervision_destroy(tdnnf_supervision *sp) {
+  if (!sp) return;
+  void *ptrs[] = {sp->seq_state_begin, sp->state_time, sp->final_logprob, sp->in_begin, sp->in_src, sp->in_pdf,
+                  sp->in_lp, sp->out_begin, sp->out_dst, sp->out_pdf, sp->out_lp, sp->frame_state_begin};
+  for (void *p : ptrs) hipFree(p);
+  delete sp;
+}
+
+// workspace layout: [doubles: den_lp[B], num_lp[B], xent[B], l2sum[1]] [alpha] [asum] [gstate] [la, lb]
+// (the numerator scratch is sized for up to 4*(T+1) states per sequence; larger graphs are rejected)
+size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *g, int B, int T) {
+  if (!g || B <= 0 || T <= 0) return 0;
+  ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
+  return sizeof(double) * (3 * (size_t)B + 2) + sizeof(float) * (p.alpha_floats + p.asum_floats + p.gstate_floats + p.la_floats) + 256;
+}
+
+int tdnnf_chain_objf_and_deriv(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y,
+                               const tdnnf_mat *xent_output, float leaky, float l2_regularize, float xent_regularize,
+                               double *results, tdnnf_mat *deriv, tdnnf_mat *xent_deriv, void *ws, size_t ws_bytes,
+                               tdnnf_stream stream) {
+  TDNNF_REQUIRE(g && sp && mat_ok(y) && mat_ok(deriv) && results, "chain_objf_and_deriv: bad arguments");
+  const int B = sp->B, T = sp->T;
+  TDNNF_REQUIRE(y->rows == B * T && y->cols == g->P && same_dim(y, deriv), "chain_objf_and_deriv: nnet_output must be (B*T) x num_pdfs, t-major");
+  TDNNF_REQUIRE(!xent_deriv || (mat_ok(xent_deriv) && same_dim(y, xent_deriv)), "chain_objf_and_deriv: bad xent_deriv");
+  TDNNF_REQUIRE(!xent_output || (mat_ok(xent_output) && same_dim(y, xent_output)), "chain_objf_and_deriv: bad xent_output");
+  TDNNF_REQUIRE(sp->num_states <= B * 4 * (T + 1), "chain_objf_and_deriv: supervision has more than 4*(T+1) states per sequence on average");
+  TDNNF_REQUIRE(ws && ws_bytes >= tdnnf_chain_workspace_bytes(g, B, T), "chain_objf_and_deriv: workspace too small");
+  hipStream_t s = (hipStream_t)stream;
+  ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
+  double *den_lp = (double *)ws, *num_lp = den_lp + B, *xent = num_lp + B, *l2sum = xent + B;
+  float *alpha = (float *)(l2sum + 2);
+  float *asum = alpha + p.alpha_floats;
+  float *gstate = asum + p.asum_floats;
+  float *la = gstate + p.gstate_floats, *lb = la + p.la_floats / 2;
+  DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
+  MatView yv = view(y), dv = view(deriv);
+  MatView xdv = xent_deriv ? view(xent_deriv) : MatView{nullptr, 0, 0, 0};
+  MatView xov = xent_output ? view(xent_output) : MatView{nullptr, 0, 0, 0};
+  if (p.lds_state) {
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fwd));
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bwd));
+    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), p.lds_fwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, den_lp, gstate);
+    hipLaunchKernelGGL(den_backward_kernel<true>, dim3(B), dim3(kDenThreads), p.lds_bwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, -sp->weight, dv, gstate);
+  } else {
+    hipLaunchKernelGGL(den_forward_kernel<false>, dim3(B), dim3(kDenThreads), p.lds_fwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, den_lp, gstate);
+    hipLaunchKernelGGL(den_backward_kernel<false>, dim3(B), dim3(kDenThreads), p.lds_bwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, -sp->weight, dv, gstate);
+  }
+  TDNNF_LAUNCH_CHECK();
+  if (xent_deriv)
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long long)xdv.rows * xdv.cols, 256)), dim3(256), 0, s, xdv);
+  SupDev sd{B, T, sp->weight, sp->seq_state_begin, sp->frame_state_begin, sp->final_logprob, sp->in_begin, sp->in_src,
+            sp->in_pdf, sp->in_lp, sp->out_begin, sp->out_dst, sp->out_pdf, sp->out_lp};
+  hipLaunchKernelGGL(numerator_kernel, dim3(B), dim3(64), 0, s, sd, yv, xov, la, lb, num_lp, xent, dv, xdv, xent_regularize);
+  if (l2_regularize != 0.f) {
+    TDNNF_HIP(hipMemsetAsync(l2sum, 0, sizeof(double), s));
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((long long)yv.rows * yv.cols, 256, 1024)), dim3(256), 0, s, yv, l2sum);
+  }
+  hipLaunchKernelGGL(chain_finalize_kernel, dim3(1), dim3(64), 0, s, num_lp, den_lp, xent, l2_regularize != 0.f ? l2sum : nullptr,
+                     B, T, sp->weight, l2_regularize, results);
+  hipLaunchKernelGGL(chain_guard_kernel, dim3(grid_for((long long)dv.rows * dv.cols, 256)), dim3(256), 0, s, results, yv,
+                     sp->weight * l2_regularize, dv, xdv);
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// common.h -- shared helpers of libtdnnf_hip (error reporting, matrix views).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "tdnnf_hip.h"
+
+namespace tdnnf {
+
+struct MatView {
+  float *data;
+  int rows, cols, stride;
+};
+inline MatView view(const tdnnf_mat *m) { return MatView{m->data, m->rows, m->cols, m->stride}; }
+
+void set_error(const char *fmt, ...);
+int hip_status(hipError_t e, const char *what);
+
+inline bool mat_ok(const tdnnf_mat *m) {
+  return m && m->rows >= 0 && m->cols >= 0 && m->stride >= m->cols && (m->data || m->rows * m->cols == 0);
+}
+inline bool same_dim(const tdnnf_mat *a, const tdnnf_mat *b) { return a->rows == b->rows && a->cols == b->cols; }
+
+inline bool vec4_ok(const MatView &m) {
+  return (reinterpret_cast<uintptr_t>(m.data) & 15) == 0 && m.stride % 4 == 0 && m.cols % 4 == 0;
+}
+
+#define TDNNF_REQUIRE(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::tdnnf::set_error(__VA_ARGS__);      \
+      return TDNNF_EINVAL;                  \
+    }                                       \
+  } while (0)
+
+#define TDNNF_HIP(expr)                                         \
+  do {                                                          \
+    hipError_t e__ = (expr);                                    \
+    if (e__ != hipSuccess) return ::tdnnf::hip_status(e__, #expr); \
+  } while (0)
+
+#define TDNNF_LAUNCH_CHECK(name) TDNNF_HIP(hipGetLastError())
+
+inline int grid_for(long long work, int block, int cap = 2048) {
+  long long g = (work + block - 1) / block;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// two-stage deterministic column reduction (colreduce.hip)
+struct ColReducePlan {
+  int chunks, rows_per_chunk;
+};
+ColReducePlan colreduce_plan(int rows, int cols);
+size_t colreduce_bytes(int rows, int cols);
+// partial[q][chunk][col] for q < nq; kind: 0 = (sum a), 1 = (sum a, sum a*a), 2 = (sum a*b, sum b), 3 = (sum a, sum a>0)
+hipError_t colreduce_partial(int kind, MatView a, MatView b, float *partial, hipStream_t s);
+
+}  // namespace tdnnf

@@ -1,0 +1,56 @@
+// gemm_f32.h -- host-side interface of the exact-f32 MFMA GEMM kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace tdnnf {
+
+constexpr int kMaxSeg = 16;
+
+// One K-segment of a "rows" GEMM: C[m][n] (+)= sum_s coef[s] * sum_k A_s[m][k] * B_s[k][n].
+struct GemmSeg {
+  long long a_off;  // element offset added to A for this segment
+  long long b_off;  // element offset added to B for this segment
+  int klen;         // reduction length of this segment
+  int m_lo, m_hi;   // output rows for which A_s is defined (others contribute 0)
+};
+
+struct RowsGemmArgs {
+  const float *A;
+  long long lda;  // elements between consecutive A rows (already multiplied by any row step)
+  const float *B;
+  long long ldb;  // B_KC: B[n*ldb + k]; else B[k*ldb + n]
+  float *C;
+  long long ldc;  // elements between consecutive C rows (already multiplied by any row step)
+  int M, N;
+  const float *bias;  // N floats (init_mode 1)
+  const float *coef;  // nseg floats or nullptr (= ones); a segment with coef == 0 is skipped
+  int init_mode;      // 0: C += acc, 1: C = bias + acc, 2: C = acc
+  int relu;           // 1: C = max(C, 0) after everything else
+  int nseg;
+  GemmSeg seg[kMaxSeg];
+};
+
+// b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).
+hipError_t rows_gemm(const RowsGemmArgs &args, bool b_kcontig, hipStream_t stream);
+
+// Weight gradient: G[o][i*Di + d] (+)= scale * coef[i] * sum_r dY[r][o] * X[(row_off[i] + r*row_stride)][d]
+struct WgradArgs {
+  const float *dY;
+  long long lddy;
+  const float *X;
+  long long ldx;
+  int Do, Di, K, N;
+  int row_stride;
+  int row_offsets[kMaxSeg];
+  const float *coef;  // K floats or nullptr
+  float scale;        // learning rate
+  float *G;           // Do x (K*Di), ld = ldg
+  long long ldg;
+  int accumulate;     // 1: G += ..., 0: G = ...
+  float *bias_acc;    // optional: bias_acc[o] += scale * sum_r dY[r][o]
+};
+size_t wgrad_workspace_bytes(int Do, int Di, int K, int N);
+hipError_t wgrad(const WgradArgs &args, void *workspace, size_t workspace_bytes, hipStream_t stream);
+
+}  // namespace tdnnf

@@ -1,0 +1,483 @@
+// gemm_f32.hip -- exact-f32 MFMA GEMM kernels for gfx950 (MI355X, CDNA4).
+//
+// These replace the per-tap cuBLAS SGEMMs the reference issues from
+// TdnnDARTSV3Component::Propagate / Backprop / UpdateSimple
+// (/root/reference/src/nnet3/nnet-tdnn-component.cc:302-324, :378-411, :452) and the
+// AffineComponent / LinearComponent GEMMs (nnet-simple-component.cc:1235-1279).
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate; bit-for-bit an fmaf
+// chain, so parity with the reference's fp32 BaseFloat path is limited only by
+// summation order).  One launch covers ALL taps of a layer:
+//   rows_gemm : C[m][n] (+)= sum_taps c_i * A_i[m][:] . B_i[:][n]   (fwd and bwd-data,
+//               bwd-data in gather form so overlapping taps need no atomics)
+//   wgrad     : G[o][i*Di+d] += lr * c_i * sum_rows dY[r][o] X_i[r][d] (split over rows,
+//               deterministic slab reduction)
+// Tiles: 4 waves / 256 threads, each wave owns TM x TN blocks of 32x32 accumulators;
+// A/B tiles are staged global -> registers -> LDS (double buffered, one barrier per
+// K-step); LDS rows are padded by 4 floats so the ds_read_b128 fragment reads are
+// bank-conflict free (stride 36 / 20 dwords).
+#include "gemm_f32.h"
+
+namespace tdnnf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float *p, bool v0, bool v1, bool v2, bool v3, bool vec) {
+  float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (vec && v3) {  // whole float4 in range (validity is monotone in the element index)
+    r = *reinterpret_cast<const float4 *>(p);
+  } else {
+    if (v0) r.x = p[0];
+    if (v1) r.y = p[1];
+    if (v2) r.z = p[2];
+    if (v3) r.w = p[3];
+  }
+  return r;
+}
+
+// ------------------------------------------------------------------------ rows_gemm
+template <int WM, int WN, int TM, int TN, int BK, bool B_KC, int VEC>
+__global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, int ntm, int ntn) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int LDAS = BK + 4;
+  constexpr int LDBS = B_KC ? BK + 4 : BN + 4;
+  constexpr int A_TILE = BM * LDAS;
+  constexpr int B_TILE = B_KC ? BN * LDBS : BK * LDBS;
+  constexpr int A_F4 = (BM * BK / 4 + 255) / 256;
+  constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
+  constexpr int KF4 = BK / 4;  // float4 per k-row of a k-contiguous tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem;               // [2][A_TILE]
+  float *Bs = smem + 2 * A_TILE;  // [2][B_TILE]
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+  // XCD a contiguous run of logical tile ids; within it tile_n varies fastest so the blocks
+  // that re-read the same A rows (and the taps' neighbouring rows) hit the same L2.
+  const int nblk = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m = bid / ntn, tile_n = bid % ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  // ---- K iterator over (segment, chunk), skipping zero-coefficient segments
+  int seg = -1, kc = 0, klen = 0;
+  float cf = 1.f;
+  auto next_seg = [&]() {
+    for (++seg; seg < p.nseg; ++seg) {
+      cf = p.coef ? p.coef[seg] : 1.f;
+      if (cf != 0.f && p.seg[seg].klen > 0) break;
+    }
+    kc = 0;
+    klen = seg < p.nseg ? p.seg[seg].klen : 0;
+  };
+  next_seg();
+
+  float4 ra[A_F4], rb[B_F4];
+  auto load_tile = [&]() {  // global -> registers for chunk (seg, kc)
+    const GemmSeg sg = p.seg[seg];
+    const float *Ab = p.A + sg.a_off;
+    const float *Bb = p.B + sg.b_off;
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j;
+      const int row = idx / KF4, k = kc + (idx % KF4) * 4;
+      const int m = m0 + row;
+      const bool rv = (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) && m < p.M && m >= sg.m_lo && m < sg.m_hi;
+      const float *ptr = Ab + (long long)m * p.lda + k;
+      ra[j] = ld4(ptr, rv && k < klen, rv && k + 1 < klen, rv && k + 2 < klen, rv && k + 3 < klen, VEC == 4);
+    }
+    if (B_KC) {
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) {
+        const int idx = t + 256 * j;
+        const int row = idx / KF4, k = kc + (idx % KF4) * 4;
+        const int n = n0 + row;
+        const bool rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n < p.N;
+        const float *ptr = Bb + (long long)n * p.ldb + k;
+        float4 v = ld4(ptr, rv && k < klen, rv && k + 1 < klen, rv && k + 2 < klen, rv && k + 3 < klen, VEC == 4);
+        v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
+        rb[j] = v;
+      }
+    } else {
+      constexpr int NF4 = BN / 4;
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) {
+        const int idx = t + 256 * j;
+        const int kr = idx / NF4, n = n0 + (idx % NF4) * 4;
+        const bool rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && kc + kr < klen;
+        const float *ptr = Bb + (long long)(kc + kr) * p.ldb + n;
+        float4 v = ld4(ptr, rv && n < p.N, rv && n + 1 < p.N, rv && n + 2 < p.N, rv && n + 3 < p.N, VEC == 4);
+        v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
+        rb[j] = v;
+      }
+    }
+  };
+  auto store_tile = [&](int buf) {  // registers -> LDS
+    float *as = As + buf * A_TILE, *bs = Bs + buf * B_TILE;
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j;
+      if (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4)
+        *reinterpret_cast<float4 *>(as + (idx / KF4) * LDAS + (idx % KF4) * 4) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; j++) {
+      const int idx = t + 256 * j;
+      if (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) {
+        if (B_KC)
+          *reinterpret_cast<float4 *>(bs + (idx / KF4) * LDBS + (idx % KF4) * 4) = rb[j];
+        else
+          *reinterpret_cast<float4 *>(bs + (idx / (BN / 4)) * LDBS + (idx % (BN / 4)) * 4) = rb[j];
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const float *as = As + buf * A_TILE + (wm * TM * 32 + li) * LDAS + lh * 4;
+    const float *bs = B_KC ? Bs + buf * B_TILE + (wn * TN * 32 + li) * LDBS + lh * 4
+                           : Bs + buf * B_TILE + (lh * 4) * LDBS + wn * TN * 32 + li;
+#pragma unroll
+    for (int kg = 0; kg < BK / 8; kg++) {
+      float4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a[i] = *reinterpret_cast<const float4 *>(as + i * 32 * LDAS + kg * 8);
+#pragma unroll
+      for (int i = 0; i < TN; i++) {
+        if (B_KC) {
+          b[i] = *reinterpret_cast<const float4 *>(bs + i * 32 * LDBS + kg * 8);
+        } else {
+          const float *q = bs + (kg * 8) * LDBS + i * 32;
+          b[i] = make_float4(q[0], q[LDBS], q[2 * LDBS], q[3 * LDBS]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  if (seg < p.nseg) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+      kc += BK;
+      if (kc >= klen) next_seg();
+      const bool more = seg < p.nseg;
+      if (more) load_tile();  // in flight while the MFMAs run
+      compute(buf);
+      if (!more) break;
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = n0 + (wn * TN + j) * 32 + li;
+      if (n >= p.N) continue;
+      const float bv = p.init_mode == 1 ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.M) {
+          float *c = p.C + (long long)m * p.ldc + n;
+          float v = acc[i][j][r] + bv;
+          if (p.init_mode == 0) v += *c;
+          if (p.relu) v = fmaxf(v, 0.f);
+          *c = v;
+        }
+      }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int BK>
+hipError_t launch_rows(const RowsGemmArgs &a, bool b_kc, bool vec, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  const size_t lds_kc = sizeof(float) * 2 * (BM * (BK + 4) + BN * (BK + 4));
+  const size_t lds_nc = sizeof(float) * 2 * (BM * (BK + 4) + BK * (BN + 4));
+  dim3 grid(ntm * ntn), block(256);
+  static bool attr_done = false;  // > 64 KiB of dynamic LDS must be opted into, once per instantiation
+  if (!attr_done) {
+    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kc);
+    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kc);
+    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
+    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
+    attr_done = true;
+  }
+  if (b_kc) {
+    if (vec) hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 4>), grid, block, lds_kc, s, a, ntm, ntn);
+    else hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 1>), grid, block, lds_kc, s, a, ntm, ntn);
+  } else {
+    if (vec) hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, false, 4>), grid, block, lds_nc, s, a, ntm, ntn);
+    else hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, false, 1>), grid, block, lds_nc, s, a, ntm, ntn);
+  }
+  return hipGetLastError();
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+hipError_t rows_gemm(const RowsGemmArgs &a, bool b_kc, hipStream_t s) {
+  if (a.M <= 0 || a.N <= 0 || a.nseg <= 0) return hipSuccess;
+  // float4 path needs 16-byte aligned rows and segment starts; ragged tails fall back per float4
+  bool vec = aligned16(a.A) && aligned16(a.B) && a.lda % 4 == 0 && a.ldb % 4 == 0;
+  for (int i = 0; i < a.nseg; i++) vec = vec && a.seg[i].a_off % 4 == 0 && a.seg[i].b_off % 4 == 0;
+  // N == 160 (the TDNN-F bottleneck) gets a 128x160 tile so no column is wasted
+  const int waste128 = ((a.N + 127) / 128) * 128 - a.N, waste160 = ((a.N + 159) / 160) * 160 - a.N;
+  if (waste160 < waste128) return launch_rows<4, 1, 1, 5, 16>(a, b_kc, vec, s);
+  return launch_rows<2, 2, 2, 2, 32>(a, b_kc, vec, s);
+}
+
+// ---------------------------------------------------------------------------- wgrad
+namespace {
+
+// A = dY (k = row, m = output dim contiguous), B = X_tap (k = row, n = input dim contiguous).
+template <int WM, int WN, int TM, int TN, int VEC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, int ntn_tap, int rows_per_split,
+                                                    float *partial) {
+  constexpr int BK = 32;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int LDAS = BM + 4, LDBS = BN + 4;
+  constexpr int A_TILE = BK * LDAS, B_TILE = BK * LDBS;
+  constexpr int A_F4 = (BM * BK / 4 + 255) / 256, B_F4 = (BN * BK / 4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem, *Bs = smem + 2 * A_TILE;
+
+  const int tiles = ntm * p.K * ntn_tap;
+  int bid = blockIdx.x;  // tile id; blockIdx.y = row split
+  (void)tiles;
+  const int tile_m = bid % ntm;
+  const int tap = (bid / ntm) / ntn_tap, tile_n = (bid / ntm) % ntn_tap;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const int r_begin = split * rows_per_split;
+  const int r_end = min(p.N, r_begin + rows_per_split);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const float cf = p.coef ? p.coef[tap] : 1.f;
+  const float *Xb = p.X + (long long)p.row_offsets[tap] * p.ldx;
+  const long long xrow = (long long)p.row_stride * p.ldx;
+
+  float4 ra[A_F4], rb[B_F4];
+  auto load_tile = [&](int r0) {
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j;
+      const int kr = idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
+      const bool rv = (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) && r0 + kr < r_end;
+      const float *ptr = p.dY + (long long)(r0 + kr) * p.lddy + m;
+      ra[j] = ld4(ptr, rv && m < p.Do, rv && m + 1 < p.Do, rv && m + 2 < p.Do, rv && m + 3 < p.Do, VEC == 4);
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; j++) {
+      const int idx = t + 256 * j;
+      const int kr = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+      const bool rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && r0 + kr < r_end;
+      const float *ptr = Xb + (long long)(r0 + kr) * xrow + n;
+      rb[j] = ld4(ptr, rv && n < p.Di, rv && n + 1 < p.Di, rv && n + 2 < p.Di, rv && n + 3 < p.Di, VEC == 4);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    float *as = As + buf * A_TILE, *bs = Bs + buf * B_TILE;
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j;
+      if (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4)
+        *reinterpret_cast<float4 *>(as + (idx / (BM / 4)) * LDAS + (idx % (BM / 4)) * 4) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; j++) {
+      const int idx = t + 256 * j;
+      if (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4)
+        *reinterpret_cast<float4 *>(bs + (idx / (BN / 4)) * LDBS + (idx % (BN / 4)) * 4) = rb[j];
+    }
+  };
+  auto compute = [&](int buf) {
+    const float *as = As + buf * A_TILE + lh * LDAS + wm * TM * 32 + li;
+    const float *bs = Bs + buf * B_TILE + lh * LDBS + wn * TN * 32 + li;
+#pragma unroll
+    for (int k2 = 0; k2 < BK / 2; k2++) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) a[i] = as[(2 * k2) * LDAS + i * 32];
+#pragma unroll
+      for (int i = 0; i < TN; i++) b[i] = bs[(2 * k2) * LDBS + i * 32];
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (cf != 0.f && r_begin < r_end) {
+    load_tile(r_begin);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+      const bool more = r0 + BK < r_end;
+      if (more) load_tile(r0 + BK);
+      compute(buf);
+      if (!more) break;
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+  // partial slab [split][Do][K*Di]
+  float *P = partial + (long long)split * p.Do * (p.K * p.Di);
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = n0 + (wn * TN + j) * 32 + li;
+      if (n >= p.Di) continue;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.Do) P[(long long)m * (p.K * p.Di) + tap * p.Di + n] = acc[i][j][r];
+      }
+    }
+}
+
+// G[o][c] (+)= scale * coef[tap(c)] * sum_split partial[split][o][c]
+__global__ void wgrad_reduce_kernel(const float *partial, int splits, int Do, int KDi, int Di, const float *coef,
+                                    float scale, float *G, long long ldg, int accumulate) {
+  const long long total = (long long)Do * KDi;
+  for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int o = (int)(e / KDi), c = (int)(e % KDi);
+    float s = 0.f;
+    for (int sp = 0; sp < splits; sp++) s += partial[(long long)sp * total + e];
+    const float cf = coef ? coef[c / Di] : 1.f;
+    float *g = G + (long long)o * ldg + c;
+    const float v = scale * cf * s;
+    *g = accumulate ? *g + v : v;
+  }
+}
+
+// column sums of dY in two deterministic stages: partial[chunk][col] then bias_acc[col] += scale*sum
+__global__ void colsum_partial_kernel(const float *Y, long long ld, int rows, int cols, int rows_per_chunk,
+                                      float *partial) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
+  if (col >= cols) return;
+  float s = 0.f;
+  for (int r = r0; r < r1; r++) s += Y[(long long)r * ld + col];
+  partial[(long long)blockIdx.y * cols + col] = s;
+}
+__global__ void colsum_final_kernel(const float *partial, int chunks, int cols, float scale, float *acc) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  if (col >= cols) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; c++) s += partial[(long long)c * cols + col];
+  acc[col] += scale * s;
+}
+
+struct WgradPlan {
+  int splits, rows_per_split, chunks, rows_per_chunk;
+  size_t slab_floats, colsum_floats;
+};
+WgradPlan wgrad_plan(int Do, int Di, int K, int N) {
+  WgradPlan pl;
+  const int tiles = ((Do + 127) / 128) * K * ((Di + 127) / 128);
+  int splits = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
+  const int max_splits = (N + 255) / 256;   // at least 256 rows per split
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int rps = (N + splits - 1) / splits;
+  rps = ((rps + 31) / 32) * 32;
+  pl.splits = (N + rps - 1) / rps;
+  pl.rows_per_split = rps;
+  pl.slab_floats = (size_t)pl.splits * Do * K * Di;
+  pl.rows_per_chunk = 512;
+  pl.chunks = (N + 511) / 512;
+  pl.colsum_floats = (size_t)pl.chunks * Do;
+  return pl;
+}
+
+}  // namespace
+
+size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
+  WgradPlan pl = wgrad_plan(Do, Di, K, N);
+  return sizeof(float) * (pl.slab_floats + pl.colsum_floats) + 64;
+}
+
+hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hipStream_t s) {
+  if (a.N <= 0 || a.Do <= 0 || a.Di <= 0) return hipSuccess;
+  if (workspace_bytes < wgrad_workspace_bytes(a.Do, a.Di, a.K, a.N)) return hipErrorInvalidValue;
+  WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N);
+  float *partial = reinterpret_cast<float *>(workspace);
+  float *cs_partial = partial + pl.slab_floats;
+  const bool vec = aligned16(a.dY) && aligned16(a.X) && a.lddy % 4 == 0 && a.ldx % 4 == 0;
+  constexpr int BM = 128, BN = 128;
+  const int ntm = (a.Do + BM - 1) / BM, ntn = (a.Di + BN - 1) / BN;
+  dim3 grid(ntm * a.K * ntn, pl.splits), block(256);
+  const size_t lds = sizeof(float) * 2 * (32 * (BM + 4) + 32 * (BN + 4));
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void *)wgrad_kernel<2, 2, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)wgrad_kernel<2, 2, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  if (vec) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 4>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
+  else hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 1>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const long long total = (long long)a.Do * a.K * a.Di;
+  int rb = (int)((total + 255) / 256);
+  if (rb > 2048) rb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, pl.splits, a.Do, a.K * a.Di, a.Di, a.coef,
+                     a.scale, a.G, a.ldg, a.accumulate);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if (a.bias_acc) {
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((a.Do + 255) / 256, pl.chunks), dim3(256), 0, s, a.dY, a.lddy, a.N,
+                       a.Do, pl.rows_per_chunk, cs_partial);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((a.Do + 255) / 256), dim3(256), 0, s, cs_partial, pl.chunks, a.Do,
+                       a.scale, a.bias_acc);
+    e = hipGetLastError();
+  }
+  return e;
+}
+
+}  // namespace tdnnf

@@ -1,0 +1,44 @@
+"""CPU-side checks of the boundary: the library loads without a GPU and exports every symbol
+include/tdnnf_hip.h declares; argument validation rejects bad calls before anything is launched."""
+import ctypes as C
+import os
+import subprocess
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.hipabi.load()
+    names = pkg.hipabi.declared_symbols()
+    assert len(names) >= 50
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.hipabi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    assert set(names) <= exported, sorted(set(names) - exported)
+    assert lib.tdnnf_abi_version() == 1
+
+
+def test_code_object_is_gfx950_only(pkg):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", pkg.hipabi.LIB_PATH], capture_output=True,
+                         text=True)
+    text = out.stdout + out.stderr
+    if "gfx" in text:
+        assert "gfx950" in text and "gfx90a" not in text and "gfx942" not in text
+
+
+def test_argument_validation_without_gpu(pkg):
+    lib = pkg.hipabi.load()
+    M = pkg.hipabi.Mat
+    a = M(None, 4, 8, 8)      # rows*cols != 0 with a null pointer
+    rc = lib.tdnnf_relu_propagate(C.byref(a), C.byref(a), None)
+    assert rc == 1 and b"relu_propagate" in lib.tdnnf_last_error()
+    rc = lib.tdnnf_constrain_orthonormal(0.0, None, 4, 8, 8, None, 0, None)
+    assert rc == 1
+    assert lib.tdnnf_tdnn_update_workspace_bytes(160, 1536, 2, 19200) > 0
+    assert lib.tdnnf_colreduce_workspace_bytes(19200, 1536) > 0
+
+
+def test_product_never_touches_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for dirpath, _, files in os.walk(os.path.join(root, "tdnn-f_nas_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in text.lower(), os.path.join(dirpath, f)
