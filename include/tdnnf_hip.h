@@ -106,7 +106,7 @@ int tdnnf_tdnn_update_simple(const tdnnf_tdnn_indexes *indexes, const tdnnf_mat 
 int tdnnf_tdnn_darts_alpha_update(const float *tap_grad_dev, int ldg, const float *linear_params_dev,
                                   int ldw, int Do, int Di, int K, const float *coef_memo_dev,
                                   int flags, int share_index, float temp_proportion, float lr,
-                                  float *alpha_acc_dev, double *tap_dots_dev /* K, may be NULL */,
+                                  float *alpha_acc_dev, double *tap_dots_dev /* K doubles, receives s_i */,
                                   tdnnf_stream stream);
 
 /* ======================================================================= A3/A4
@@ -250,6 +250,65 @@ int tdnnf_update_with_max_change(float *params_dev, float *delta_dev, int num_co
                                  const float *max_change_host, float max_param_change, float max_change_scale,
                                  float scale, int zero_delta, void *workspace_dev, size_t workspace_bytes,
                                  float *info_dev, tdnnf_stream);
+
+/* ====================================================================== descriptors
+ * Row plumbing the nnet3 compiler does with kCopyRows commands for the graphs of SURVEY.md 3.4. */
+/* lda input Append(-1,0,1,ReplaceIndex(ivector,t,0)) (run_tdnn_fbk_40_iv_sp_7q.sh:164): out row (k,b) =
+   [feats(k + j, b) for j in 0..num_splice-1, ivector(b)]; feats is t-major with num_seq sequences and
+   out->rows/num_seq + num_splice - 1 time steps. */
+int tdnnf_splice_input(const tdnnf_mat *feats, const tdnnf_mat *ivectors, int num_seq, int num_splice,
+                       tdnnf_mat *out, tdnnf_stream);
+/* Convert between plain t-major rows (row = tau*B + b) and the row order a Tdnn component with
+   row_stride rho > 1 expects on its input (row = (tau/rho)*rho*B + b*rho + tau%rho,
+   nnet-tdnn-component.cc:897-902).  to_rho != 0: t-major -> rho order; else the inverse. */
+int tdnnf_reorder_rows(const tdnnf_mat *in, int num_seq, int rho, int to_rho, tdnnf_mat *out, tdnnf_stream);
+
+/* ===================================================================== chain trainer
+ * One minibatch of nnet3-chain-train (UPSTREAM NnetChainTrainer::TrainInternal; the shipped pieces are
+ * ApplyL2Regularization, UpdateNnetWithMaxChange, ConstrainOrthonormal in src/nnet3/nnet-utils.cc) for the
+ * TDNN-F graphs of local/chain_NAS/run_tdnn_fbk_40_iv_sp_7q.sh:160-186 / run_tdnn_7q_fbk_40_manual.sh:138-151:
+ * lda -> tdnn1 -> num_layers x tdnnf-layer -> prefinal-l -> {prefinal-chain -> output, prefinal-xent -> output-xent}.
+ * Parameters and raw gradients live in two caller-owned flat device buffers (so a data-parallel caller can
+ * all-reduce the gradient buffer between tdnnf_net_forward_backward and tdnnf_net_update). */
+#define TDNNF_NET_MAX_LAYERS 32
+typedef struct {
+  int feat_dim, ivector_dim, num_pdfs;       /* 40, 100, 6034 */
+  int hidden_dim, prefinal_small_dim;        /* 1536, 256 */
+  int num_layers;                            /* tdnnf layers (14 for 7q) */
+  int bottleneck_dim[TDNNF_NET_MAX_LAYERS];  /* 160 */
+  int time_stride[TDNNF_NET_MAX_LAYERS];     /* 1,1,1,0,3 x 10 */
+  float bypass_scale;                        /* 0.66 */
+  int frames_per_chunk, num_sequences;       /* T (multiple of frame_subsampling), B */
+  int frame_subsampling;                     /* 3 */
+  float leaky_hmm, xent_regularize, chain_l2_regularize; /* 0.1, 0.1, 0.0 */
+  float l2_hidden, l2_output;                /* 0.01, 0.002 (per-component l2-regularize) */
+  float max_change_hidden, max_change_output, max_param_change; /* 0.75, 1.5, 2.0 */
+  float relu_self_repair_scale;              /* 1e-5 */
+  float batchnorm_stats_scale;               /* 0.8 (ScaleBatchnormStats, UPSTREAM trainer default) */
+} tdnnf_net_config;
+typedef struct tdnnf_net tdnnf_net;
+
+int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out);
+void tdnnf_net_destroy(tdnnf_net *);
+long long tdnnf_net_num_params(const tdnnf_net *);
+int tdnnf_net_num_components(const tdnnf_net *);
+/* name_out: >= 64 bytes.  Weights are rows x cols at [begin, begin + rows*cols), bias (if has_bias) follows. */
+int tdnnf_net_component_info(const tdnnf_net *, int index, char *name_out, long long *begin, int *rows, int *cols,
+                             int *has_bias, float *lr_factor, float *l2, float *max_change, float *orthonormal);
+/* rows of the t-major feature matrix the net consumes: (frames_per_chunk + left + right context) * B */
+int tdnnf_net_input_frames(const tdnnf_net *, int *num_t_in, int *first_t);
+int tdnnf_net_set_buffers(tdnnf_net *, float *params_dev, float *grads_dev);
+/* forward + chain objective + backward; ACCUMULATES raw gradients (is_gradient_ semantics) into grads.
+   results_dev: as tdnnf_chain_objf_and_deriv.  step selects the pseudo-random decisions of this minibatch
+   (ReLU stats / self-repair coin flips). */
+int tdnnf_net_forward_backward(tdnnf_net *, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *,
+                               const tdnnf_supervision *, double *results_dev, long long step, tdnnf_stream);
+/* delta = lr_c*(grad) - 2*l2_scale*lr_c*l2_c*params; max-change; params += delta; grads = 0; orthonormal
+   constraint on the scheduled quarter of the constrained matrices; batchnorm stats *= batchnorm_stats_scale. */
+int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale, long long step, tdnnf_stream);
+/* debugging / parity: copy an internal activation by name ("tdnnf2.linear", "output", ...) into out */
+int tdnnf_net_get_activation(const tdnnf_net *, const char *name, tdnnf_mat *out, tdnnf_stream);
+int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, int *cols);
 
 #ifdef __cplusplus
 }

@@ -7,3 +7,4 @@ synthetic data, torch.distributed glue); the product is csrc/ (HIP kernels, C++
 host mirror of the nnet3 components and the chain trainer step)."""
 from . import synth  # noqa: F401
 from . import hipabi  # noqa: F401
+from . import trainer  # noqa: F401

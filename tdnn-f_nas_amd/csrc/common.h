@@ -49,6 +49,16 @@ inline int grid_for(long long work, int block, int cap = 2048) {
   return (int)g;
 }
 
+// Reproducible stand-in for the reference's RandInt()/RandUniform() control decisions (orthonormal
+// schedule nnet-utils.cc:1062, ReLU stats / self-repair coin flips nnet-simple-component.cc:1017,1084):
+// splitmix64 of (step, k).  Tests restate it in Python.
+inline unsigned long long tdnnf_decision(unsigned long long step, unsigned long long k) {
+  unsigned long long z = step * 0x9E3779B97F4A7C15ULL + k * 0xBF58476D1CE4E5B9ULL + 0x94D049BB133111EBULL;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return (z ^ (z >> 31)) >> 8;
+}
+
 // two-stage deterministic column reduction (colreduce.hip)
 struct ColReducePlan {
   int chunks, rows_per_chunk;

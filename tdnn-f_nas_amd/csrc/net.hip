@@ -1,0 +1,714 @@
+// net.hip -- one minibatch of nnet3-chain-train for the TDNN-F graphs of the reference recipes, as a
+// host-side C++ executor over the component kernels of this library.
+//
+// Mirrors (UPSTREAM) NnetChainTrainer::TrainInternal:  forward through every component's Propagate,
+// chain::ComputeChainObjfAndDeriv, Backprop through every component (raw-gradient / is_gradient_
+// UpdateSimple path), then the shipped optimizer helpers ApplyL2Regularization,
+// UpdateNnetWithMaxChange, ConstrainOrthonormal (/root/reference/src/nnet3/nnet-utils.cc:2223-2245,
+// :2085-2175, :1040-1077).  Graph: /root/reference/local/chain_NAS/run_tdnn_fbk_40_iv_sp_7q.sh:160-186;
+// one tdnnf-layer = steps/libs/nnet3/xconfig/composite_layers.py:135-215, prefinal-layer :1283-1331.
+//
+// Time bookkeeping replaces the nnet3 compiler for these graphs: every layer's output lives on a regular
+// grid (t0, step, n) in t-major row order (row = k*B + b), derived backwards from the output grid
+// (0, 3, T/3) exactly as the compiler's dependency analysis would (tdnnf4.linear is computed on the
+// padded step-1 grid, as TdnnComponent::ReorderIndexes pads it).
+#include <math.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "gemm_f32.h"
+
+namespace tdnnf {
+namespace {
+
+struct Grid {
+  int t0, step, n;
+  int last() const { return t0 + step * (n - 1); }
+};
+
+struct CompDesc {
+  std::string name;
+  long long begin;
+  int rows, cols, has_bias;
+  float lr_factor, l2, max_change, orthonormal;
+  long long size() const { return (long long)rows * cols + (has_bias ? rows : 0); }
+};
+
+struct Tdnn {  // one TdnnComponent instance inside the net
+  int comp;    // index into comps
+  int Di, Do, K;
+  int offsets[2];
+  Grid in, out;
+  tdnnf_tdnn_indexes ix;
+  int rows_in, rows_out;
+};
+
+struct TdnnfLayer {
+  int stride, bn;
+  Tdnn lin, aff;
+  Grid gin, gout;
+  bool perm;  // affine input needs the rho row order
+  int bypass_row0, bypass_rowstep;  // rows of the layer input that line up with the output grid
+  // activations (arena)
+  float *lin_out, *lin_perm, *relu_out, *bn_out, *noop_out;
+  float *bn_memo;
+  double *bn_stats, *relu_stats;
+};
+
+// per-component table for the update kernels
+struct UpdTable {
+  long long begin[129];
+  float lr[128];
+  float l2coef[128];
+};
+
+__global__ __launch_bounds__(256) void make_delta_kernel(float *grads, const float *params, UpdTable tb) {
+  const int c = blockIdx.y;
+  const long long b = tb.begin[c], e = tb.begin[c + 1];
+  const float lr = tb.lr[c], l2 = tb.l2coef[c];
+  for (long long i = b + blockIdx.x * 256LL + threadIdx.x; i < e; i += gridDim.x * 256LL)
+    grads[i] = lr * grads[i] + l2 * params[i];
+}
+__global__ void scale_doubles_kernel(double *x, int n, double s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= s;
+}
+// lda input: [feats(k+j, b), j < S ; ivector(b)]
+__global__ void splice_input_kernel(MatView feats, MatView iv, int B, int S, MatView out) {
+  const int C = out.cols, fd = feats.cols;
+  const long long total = (long long)out.rows * C;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int r = (int)(e / C), c = (int)(e % C), k = r / B, b = r % B;
+    float v;
+    if (c < S * fd) v = feats.data[(size_t)((k + c / fd) * B + b) * feats.stride + c % fd];
+    else v = iv.data[(size_t)b * iv.stride + (c - S * fd)];
+    out.data[(size_t)r * out.stride + c] = v;
+  }
+}
+__global__ void reorder_rows_kernel(MatView in, int B, int rho, int to_rho, MatView out) {
+  const int C = in.cols;
+  const long long total = (long long)in.rows * C;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int r = (int)(e / C), c = (int)(e % C);
+    const int tau = r / B, b = r % B;  // plain t-major coordinates
+    const int pr = (tau / rho) * rho * B + b * rho + tau % rho;
+    if (to_rho) out.data[(size_t)pr * out.stride + c] = in.data[(size_t)r * in.stride + c];
+    else out.data[(size_t)r * out.stride + c] = in.data[(size_t)pr * in.stride + c];
+  }
+}
+
+}  // namespace
+}  // namespace tdnnf
+
+using namespace tdnnf;
+
+struct tdnnf_net {
+  tdnnf_net_config cfg;
+  std::vector<CompDesc> comps;
+  long long num_params;
+  float *params, *grads;
+  int B, T, Tout;
+  // graph
+  Grid g_lda, g_feat;
+  Tdnn tdnn1;  // affine 220 -> hidden on g_lda
+  std::vector<TdnnfLayer> layers;
+  int c_lda, c_prefinal_l;
+  struct Head {
+    int c_affine, c_linear, c_output;
+    float *aff_relu, *bn1_out, *lin_out, *bn2_out, *y;
+    float *bn1_memo, *bn2_memo;
+    double *bn1_stats, *bn2_stats, *relu_stats;
+  } head[2];  // 0 chain, 1 xent
+  float *xent_logsoftmax;
+  // arena
+  char *arena;
+  size_t arena_bytes;
+  float *lda_in, *lda_out, *t1_relu, *t1_bn;
+  float *t1_bn_memo;
+  double *t1_bn_stats, *t1_relu_stats;
+  float *prefinal_l_out;
+  float *dA, *dB, *dC, *d_small, *d_small2;  // derivative scratch
+  float *d_y, *d_xent;
+  void *ws;
+  size_t ws_bytes;
+  void *chain_ws;
+  size_t chain_ws_bytes;
+  std::vector<std::pair<std::string, tdnnf_mat>> named;
+};
+
+namespace {
+
+int N_of(const Grid &g, int B) { return g.n * B; }
+
+void make_tdnn(Tdnn *t, int comp, int Di, int Do, int K, int o0, int o1, const Grid &in, const Grid &out, int B) {
+  t->comp = comp;
+  t->Di = Di;
+  t->Do = Do;
+  t->K = K;
+  t->offsets[0] = o0;
+  t->offsets[1] = o1;
+  t->in = in;
+  t->out = out;
+  memset(&t->ix, 0, sizeof(t->ix));
+  const int rho = out.step / in.step;
+  t->ix.row_stride = rho;
+  t->ix.num_offsets = K;
+  for (int i = 0; i < K; i++) {  // PrecomputeIndexes, nnet-tdnn-component.cc:878-903
+    const int req = out.t0 + t->offsets[i];
+    const int input_t = (req - in.t0) / in.step;
+    t->ix.row_offsets[i] = rho * (input_t / rho) * B + input_t % rho;
+  }
+  t->rows_in = in.n * B;
+  t->rows_out = out.n * B;
+}
+
+tdnnf_mat M(float *p, int rows, int cols) { return tdnnf_mat{p, rows, cols, (cols + 3) & ~3}; }
+
+struct Arena {
+  size_t off = 0;
+  char *base = nullptr;
+  template <class T>
+  T *take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+    off += sizeof(T) * n;
+    return p;
+  }
+  float *mat(int rows, int cols) { return take<float>((size_t)rows * ((cols + 3) & ~3)); }
+};
+
+int add_comp(tdnnf_net *n, const std::string &name, int rows, int cols, int has_bias, float lr_factor, float l2, float mc,
+             float ortho) {
+  CompDesc c;
+  c.name = name;
+  c.begin = n->num_params;
+  c.rows = rows;
+  c.cols = cols;
+  c.has_bias = has_bias;
+  c.lr_factor = lr_factor;
+  c.l2 = l2;
+  c.max_change = mc;
+  c.orthonormal = ortho;
+  n->num_params += c.size();
+  n->num_params = (n->num_params + 3) & ~3LL;  // keep every matrix 16-byte aligned
+  n->comps.push_back(c);
+  return (int)n->comps.size() - 1;
+}
+
+float *Wp(const tdnnf_net *n, int comp) { return n->params + n->comps[comp].begin; }
+float *Bp(const tdnnf_net *n, int comp) {
+  const CompDesc &c = n->comps[comp];
+  return c.has_bias ? n->params + c.begin + (long long)c.rows * c.cols : nullptr;
+}
+float *Wg(const tdnnf_net *n, int comp) { return n->grads + n->comps[comp].begin; }
+float *Bg(const tdnnf_net *n, int comp) {
+  const CompDesc &c = n->comps[comp];
+  return c.has_bias ? n->grads + c.begin + (long long)c.rows * c.cols : nullptr;
+}
+
+// carve (or, with base == nullptr, just size) every activation buffer
+void layout_arena(tdnnf_net *n, Arena &A) {
+  const tdnnf_net_config &c = n->cfg;
+  const int B = n->B, Hd = c.hidden_dim, S = c.prefinal_small_dim, P = c.num_pdfs;
+  const int lda_dim = 3 * c.feat_dim + c.ivector_dim;
+  const int N0 = N_of(n->g_lda, B);
+  n->lda_in = A.mat(N0, lda_dim);
+  n->lda_out = A.mat(N0, lda_dim);
+  n->t1_relu = A.mat(N0, Hd);
+  n->t1_bn = A.mat(N0, Hd);
+  n->t1_bn_memo = A.take<float>(5 * Hd);
+  n->t1_bn_stats = A.take<double>(1 + 2 * Hd);
+  n->t1_relu_stats = A.take<double>(1 + 2 * Hd);
+  int max_rows = N0, max_lin_rows = 0;
+  for (auto &L : n->layers) {
+    const int nl = N_of(L.lin.out, B), no = N_of(L.gout, B);
+    L.lin_out = A.mat(nl, L.bn);
+    L.lin_perm = L.perm ? A.mat(nl, L.bn) : nullptr;
+    L.relu_out = A.mat(no, Hd);
+    L.bn_out = A.mat(no, Hd);
+    L.noop_out = A.mat(no, Hd);
+    L.bn_memo = A.take<float>(5 * Hd);
+    L.bn_stats = A.take<double>(1 + 2 * Hd);
+    L.relu_stats = A.take<double>(1 + 2 * Hd);
+    max_rows = std::max(max_rows, std::max(no, N_of(L.gin, B)));
+    max_lin_rows = std::max(max_lin_rows, nl);
+  }
+  const int No = n->Tout * B;
+  n->prefinal_l_out = A.mat(No, S);
+  for (int h = 0; h < 2; h++) {
+    auto &H = n->head[h];
+    H.aff_relu = A.mat(No, Hd);
+    H.bn1_out = A.mat(No, Hd);
+    H.lin_out = A.mat(No, S);
+    H.bn2_out = A.mat(No, S);
+    H.y = A.mat(No, P);
+    H.bn1_memo = A.take<float>(5 * Hd);
+    H.bn2_memo = A.take<float>(5 * S);
+    H.bn1_stats = A.take<double>(1 + 2 * Hd);
+    H.bn2_stats = A.take<double>(1 + 2 * S);
+    H.relu_stats = A.take<double>(1 + 2 * Hd);
+  }
+  n->xent_logsoftmax = A.mat(No, P);
+  n->d_y = A.mat(No, P);
+  n->d_xent = A.mat(No, P);
+  n->dA = A.mat(max_rows, Hd);
+  n->dB = A.mat(max_rows, Hd);
+  n->dC = A.mat(max_rows, Hd);
+  n->d_small = A.mat(std::max(max_lin_rows, No), std::max(S, 512));
+  n->d_small2 = A.mat(std::max(max_lin_rows, No), std::max(S, 512));
+  // shared workspace: wgrad slabs, column reductions, orthonormal
+  size_t ws = 0;
+  auto upd = [&](size_t b) { ws = std::max(ws, b); };
+  upd(wgrad_workspace_bytes(Hd, lda_dim, 1, N0));
+  upd(colreduce_bytes(max_rows, Hd));
+  for (auto &L : n->layers) {
+    upd(wgrad_workspace_bytes(L.lin.Do, L.lin.Di, L.lin.K, L.lin.rows_out));
+    upd(wgrad_workspace_bytes(L.aff.Do, L.aff.Di, L.aff.K, L.aff.rows_out));
+    upd(tdnnf_constrain_orthonormal_workspace_bytes(L.bn, L.lin.K * Hd));
+  }
+  upd(wgrad_workspace_bytes(S, Hd, 1, No));
+  upd(wgrad_workspace_bytes(Hd, S, 1, No));
+  upd(wgrad_workspace_bytes(P, S, 1, No));
+  upd(colreduce_bytes(No, P));
+  upd(tdnnf_constrain_orthonormal_workspace_bytes(S, Hd));
+  upd(tdnnf_max_change_workspace_bytes((int)n->comps.size()));
+  n->ws_bytes = ws + 256;
+  n->ws = A.take<char>(n->ws_bytes);
+}
+
+#define CK(expr)             \
+  do {                       \
+    int rc__ = (expr);       \
+    if (rc__) return rc__;   \
+  } while (0)
+
+// view of the rows of a t-major matrix (grid g, B sequences, `cols` wide) that lie on a coarser grid `sub`
+tdnnf_mat sub_grid_view(float *data, const Grid &g, const Grid &sub, int B, int cols) {
+  const int stride = (cols + 3) & ~3;
+  const int tau0 = (sub.t0 - g.t0) / g.step, ratio = sub.step / g.step;
+  if (ratio == 1) return tdnnf_mat{data + (size_t)tau0 * B * stride, sub.n * B, cols, stride};
+  // every ratio-th block of B rows: n "super rows" of B*stride elements
+  return tdnnf_mat{data + (size_t)tau0 * B * stride, sub.n, B * stride - (stride - cols), ratio * B * stride};
+}
+
+int bn_fwd(tdnnf_net *n, float *in, float *out, int rows, int cols, float *memo, double *stats, hipStream_t s) {
+  tdnnf_mat a = M(in, rows, cols), o = M(out, rows, cols);
+  CK(tdnnf_batchnorm_propagate(&a, 1.0e-3f, 1.0f, &o, memo, n->ws, n->ws_bytes, s));
+  return tdnnf_batchnorm_store_stats(memo, cols, rows, stats, s);  // StoreStats runs on every minibatch
+}
+
+}  // namespace
+
+extern "C" {
+
+int tdnnf_splice_input(const tdnnf_mat *feats, const tdnnf_mat *iv, int B, int S, tdnnf_mat *out, tdnnf_stream stream) {
+  TDNNF_REQUIRE(mat_ok(feats) && mat_ok(iv) && mat_ok(out) && B > 0 && S > 0, "splice_input: bad arguments");
+  TDNNF_REQUIRE(out->rows % B == 0 && feats->rows == (out->rows / B + S - 1) * B && iv->rows == B &&
+                    out->cols == S * feats->cols + iv->cols,
+                "splice_input: feats must have out_frames + num_splice - 1 time steps and out.cols = S*feat_dim + ivector_dim");
+  if (out->rows == 0) return TDNNF_OK;
+  hipLaunchKernelGGL(splice_input_kernel, dim3(grid_for((long long)out->rows * out->cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                     view(feats), view(iv), B, S, view(out));
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
+int tdnnf_reorder_rows(const tdnnf_mat *in, int B, int rho, int to_rho, tdnnf_mat *out, tdnnf_stream stream) {
+  TDNNF_REQUIRE(mat_ok(in) && mat_ok(out) && same_dim(in, out) && B > 0 && rho >= 1 && in->rows % (B * rho) == 0 && in->data != out->data,
+                "reorder_rows: rows must be a multiple of num_seq*rho and in != out");
+  if (in->rows == 0) return TDNNF_OK;
+  hipLaunchKernelGGL(reorder_rows_kernel, dim3(grid_for((long long)in->rows * in->cols, 256)), dim3(256), 0, (hipStream_t)stream,
+                     view(in), B, rho, to_rho, view(out));
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
+int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
+  TDNNF_REQUIRE(cfg && out, "net_create: null argument");
+  const tdnnf_net_config &c = *cfg;
+  TDNNF_REQUIRE(c.feat_dim > 0 && c.ivector_dim > 0 && c.num_pdfs > 0 && c.hidden_dim > 0 && c.prefinal_small_dim > 0,
+                "net_create: dims must be positive");
+  TDNNF_REQUIRE(c.num_layers >= 1 && c.num_layers <= TDNNF_NET_MAX_LAYERS, "net_create: 1..%d tdnnf layers", TDNNF_NET_MAX_LAYERS);
+  TDNNF_REQUIRE(c.frame_subsampling >= 1 && c.frames_per_chunk > 0 && c.frames_per_chunk % c.frame_subsampling == 0 && c.num_sequences > 0,
+                "net_create: frames_per_chunk must be a positive multiple of frame_subsampling");
+  tdnnf_net *n = new tdnnf_net();
+  n->cfg = c;
+  n->num_params = 0;
+  n->params = n->grads = nullptr;
+  n->arena = nullptr;
+  n->B = c.num_sequences;
+  n->T = c.frames_per_chunk;
+  n->Tout = c.frames_per_chunk / c.frame_subsampling;
+  const int B = n->B, Hd = c.hidden_dim, S = c.prefinal_small_dim, P = c.num_pdfs, lda_dim = 3 * c.feat_dim + c.ivector_dim;
+  // ---- grids, derived backwards from the output grid
+  n->layers.resize(c.num_layers);
+  Grid g{0, c.frame_subsampling, n->Tout};
+  for (int l = c.num_layers - 1; l >= 0; l--) {
+    TdnnfLayer &L = n->layers[l];
+    L.stride = c.time_stride[l];
+    L.bn = c.bottleneck_dim[l];
+    TDNNF_REQUIRE(L.bn > 0 && L.bn <= 512 && L.stride >= 0, "net_create: layer %d: bottleneck-dim must be in 1..512, time-stride >= 0", l);
+    L.gout = g;
+    L.perm = false;
+    Grid lin = g, in = g;
+    if (L.stride > 0) {
+      const int s = L.stride;
+      if (s % g.step == 0) {
+        lin = Grid{g.t0, g.step, g.n + s / g.step};
+      } else {
+        TDNNF_REQUIRE(g.step % s == 0 && s < g.step, "net_create: layer %d: time-stride %d does not fit output step %d", l, s, g.step);
+        lin = Grid{g.t0, s, (g.step / s) * g.n};  // padded to a multiple of rho (nnet-tdnn-component.cc:841-843)
+        L.perm = true;
+      }
+      TDNNF_REQUIRE(s % lin.step == 0, "net_create: layer %d: unsupported stride combination", l);
+      in = Grid{lin.t0 - s, lin.step, lin.n + s / lin.step};
+    }
+    L.gin = in;
+    g = in;
+  }
+  n->g_lda = g;
+  n->g_feat = Grid{g.t0 - 1, 1, g.n * g.step + 2};
+  TDNNF_REQUIRE(g.step == 1, "net_create: the first tdnnf layers must run at the input frame rate");
+  // ---- components, in nnet3 config order
+  n->c_lda = add_comp(n, "lda", lda_dim, lda_dim, 1, 0.f, 0.f, 0.f, 0.f);
+  const int c_t1 = add_comp(n, "tdnn1.affine", Hd, lda_dim, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f);
+  make_tdnn(&n->tdnn1, c_t1, lda_dim, Hd, 1, 0, 0, n->g_lda, n->g_lda, B);
+  for (int l = 0; l < c.num_layers; l++) {
+    TdnnfLayer &L = n->layers[l];
+    const int K = L.stride > 0 ? 2 : 1;
+    char nm[64];
+    snprintf(nm, sizeof(nm), "tdnnf%d.linear", l + 2);
+    const int cl = add_comp(n, nm, L.bn, K * Hd, 0, 1.f, c.l2_hidden, c.max_change_hidden, -1.0f);
+    snprintf(nm, sizeof(nm), "tdnnf%d.affine", l + 2);
+    const int ca = add_comp(n, nm, Hd, K * L.bn, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f);
+    Grid lin_grid = L.gout;
+    if (L.stride > 0) lin_grid = L.perm ? Grid{L.gout.t0, L.stride, (L.gout.step / L.stride) * L.gout.n}
+                                        : Grid{L.gout.t0, L.gout.step, L.gout.n + L.stride / L.gout.step};
+    make_tdnn(&L.lin, cl, Hd, L.bn, K, K == 2 ? -L.stride : 0, 0, L.gin, lin_grid, B);
+    make_tdnn(&L.aff, ca, L.bn, Hd, K, 0, K == 2 ? L.stride : 0, lin_grid, L.gout, B);
+  }
+  n->c_prefinal_l = add_comp(n, "prefinal-l", S, Hd, 0, 1.f, c.l2_hidden, c.max_change_hidden, -1.0f);
+  const char *hn[2] = {"chain", "xent"};
+  for (int h = 0; h < 2; h++) {
+    char nm[64];
+    snprintf(nm, sizeof(nm), "prefinal-%s.affine", hn[h]);
+    n->head[h].c_affine = add_comp(n, nm, Hd, S, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f);
+    snprintf(nm, sizeof(nm), "prefinal-%s.linear", hn[h]);
+    n->head[h].c_linear = add_comp(n, nm, S, Hd, 0, 1.f, c.l2_hidden, c.max_change_hidden, -1.0f);
+    // output-xent: learning-rate-factor = 0.5 / xent_regularize (run_tdnn_fbk_40_iv_sp_7q.sh:151,184)
+    const float lrf = h == 1 && c.xent_regularize > 0 ? 0.5f / c.xent_regularize : 1.f;
+    n->head[h].c_output = add_comp(n, h == 0 ? "output.affine" : "output-xent.affine", P, S, 1, lrf, c.l2_output,
+                                   c.max_change_output, 0.f);
+  }
+  TDNNF_REQUIRE(n->comps.size() <= 128, "net_create: too many components");
+  // ---- activations
+  Arena sizing;
+  layout_arena(n, sizing);
+  n->arena_bytes = sizing.off + 1024;
+  n->chain_ws = nullptr;
+  n->chain_ws_bytes = 0;
+  if (hipMalloc((void **)&n->arena, n->arena_bytes) != hipSuccess) {
+    set_error("net_create: cannot allocate %zu bytes of activations", n->arena_bytes);
+    delete n;
+    return TDNNF_EHIP;
+  }
+  hipMemset(n->arena, 0, n->arena_bytes);
+  Arena real;
+  real.base = n->arena;
+  layout_arena(n, real);
+  // named activations for parity tests
+  auto name = [&](const std::string &s, float *p, int rows, int cols) { n->named.push_back({s, M(p, rows, cols)}); };
+  name("lda", n->lda_out, N_of(n->g_lda, B), lda_dim);
+  name("tdnn1.batchnorm", n->t1_bn, N_of(n->g_lda, B), Hd);
+  for (int l = 0; l < c.num_layers; l++) {
+    TdnnfLayer &L = n->layers[l];
+    const std::string p = "tdnnf" + std::to_string(l + 2);
+    name(p + ".linear", L.lin_out, L.lin.rows_out, L.bn);
+    name(p + ".relu", L.relu_out, L.aff.rows_out, Hd);
+    name(p + ".batchnorm", L.bn_out, L.aff.rows_out, Hd);
+    name(p + ".noop", L.noop_out, L.aff.rows_out, Hd);
+  }
+  name("prefinal-l", n->prefinal_l_out, n->Tout * B, S);
+  name("output", n->head[0].y, n->Tout * B, P);
+  name("output-xent", n->xent_logsoftmax, n->Tout * B, P);
+  name("output.deriv", n->d_y, n->Tout * B, P);
+  *out = n;
+  return TDNNF_OK;
+}
+
+void tdnnf_net_destroy(tdnnf_net *n) {
+  if (!n) return;
+  hipFree(n->arena);
+  hipFree(n->chain_ws);
+  delete n;
+}
+
+long long tdnnf_net_num_params(const tdnnf_net *n) { return n ? n->num_params : 0; }
+int tdnnf_net_num_components(const tdnnf_net *n) { return n ? (int)n->comps.size() : 0; }
+
+int tdnnf_net_component_info(const tdnnf_net *n, int i, char *name_out, long long *begin, int *rows, int *cols, int *has_bias,
+                             float *lr_factor, float *l2, float *max_change, float *orthonormal) {
+  TDNNF_REQUIRE(n && i >= 0 && i < (int)n->comps.size(), "net_component_info: bad index");
+  const CompDesc &c = n->comps[i];
+  if (name_out) snprintf(name_out, 64, "%s", c.name.c_str());
+  if (begin) *begin = c.begin;
+  if (rows) *rows = c.rows;
+  if (cols) *cols = c.cols;
+  if (has_bias) *has_bias = c.has_bias;
+  if (lr_factor) *lr_factor = c.lr_factor;
+  if (l2) *l2 = c.l2;
+  if (max_change) *max_change = c.max_change;
+  if (orthonormal) *orthonormal = c.orthonormal;
+  return TDNNF_OK;
+}
+
+int tdnnf_net_input_frames(const tdnnf_net *n, int *num_t_in, int *first_t) {
+  TDNNF_REQUIRE(n, "net_input_frames: null net");
+  if (num_t_in) *num_t_in = n->g_feat.n;
+  if (first_t) *first_t = n->g_feat.t0;
+  return TDNNF_OK;
+}
+
+int tdnnf_net_set_buffers(tdnnf_net *n, float *params, float *grads) {
+  TDNNF_REQUIRE(n && params && grads && ((uintptr_t)params & 15) == 0 && ((uintptr_t)grads & 15) == 0,
+                "net_set_buffers: buffers must be non-null and 16-byte aligned");
+  n->params = params;
+  n->grads = grads;
+  return TDNNF_OK;
+}
+
+int tdnnf_net_activation_dims(const tdnnf_net *n, const char *name, int *rows, int *cols) {
+  TDNNF_REQUIRE(n && name, "net_activation_dims: null argument");
+  for (auto &kv : n->named)
+    if (kv.first == name) {
+      if (rows) *rows = kv.second.rows;
+      if (cols) *cols = kv.second.cols;
+      return TDNNF_OK;
+    }
+  set_error("net_activation_dims: unknown activation '%s'", name);
+  return TDNNF_EINVAL;
+}
+
+int tdnnf_net_get_activation(const tdnnf_net *n, const char *name, tdnnf_mat *out, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && name && mat_ok(out), "net_get_activation: bad argument");
+  for (auto &kv : n->named)
+    if (kv.first == name) {
+      TDNNF_REQUIRE(out->rows == kv.second.rows && out->cols == kv.second.cols, "net_get_activation: %s is %d x %d", name,
+                    kv.second.rows, kv.second.cols);
+      return tdnnf_sum_scaled(&kv.second, 1.0f, nullptr, 0.f, out, stream);
+    }
+  set_error("net_get_activation: unknown activation '%s'", name);
+  return TDNNF_EINVAL;
+}
+
+int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *den,
+                               const tdnnf_supervision *sup, double *results, long long step, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && n->params && n->grads, "net_forward_backward: call net_set_buffers first");
+  TDNNF_REQUIRE(mat_ok(feats) && mat_ok(ivectors) && den && sup && results, "net_forward_backward: bad arguments");
+  const tdnnf_net_config &c = n->cfg;
+  const int B = n->B, Hd = c.hidden_dim, S = c.prefinal_small_dim, P = c.num_pdfs, lda_dim = 3 * c.feat_dim + c.ivector_dim;
+  TDNNF_REQUIRE(feats->rows == n->g_feat.n * B && feats->cols == c.feat_dim, "net_forward_backward: feats must be %d x %d (t-major)",
+                n->g_feat.n * B, c.feat_dim);
+  TDNNF_REQUIRE(ivectors->rows == B && ivectors->cols == c.ivector_dim, "net_forward_backward: ivectors must be %d x %d", B, c.ivector_dim);
+  hipStream_t s = (hipStream_t)stream;
+  if (!n->chain_ws) {
+    n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout);
+    TDNNF_HIP(hipMalloc(&n->chain_ws, n->chain_ws_bytes));
+  }
+  TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout), "net_forward_backward: denominator graph changed size");
+  // the reference's RandInt()/RandUniform() coin flips, made reproducible: k-th decision of this minibatch
+  unsigned long long coin_k = 0;
+  auto coin = [&]() { return (int)(::tdnnf::tdnnf_decision((unsigned long long)step, 2 * coin_k++) & 1); };
+
+  // ================================================================= forward
+  const int N0 = N_of(n->g_lda, B);
+  tdnnf_mat lda_in = M(n->lda_in, N0, lda_dim), lda_out = M(n->lda_out, N0, lda_dim);
+  CK(tdnnf_splice_input(feats, ivectors, B, 3, &lda_in, s));
+  CK(tdnnf_affine_propagate(&lda_in, Wp(n, n->c_lda), lda_dim, Bp(n, n->c_lda), lda_dim, &lda_out, s));
+  tdnnf_mat t1r = M(n->t1_relu, N0, Hd);
+  CK(tdnnf_affine_propagate(&lda_out, Wp(n, n->tdnn1.comp), lda_dim, Bp(n, n->tdnn1.comp), Hd, &t1r, s));
+  CK(tdnnf_relu_propagate(&t1r, &t1r, s));
+  CK(bn_fwd(n, n->t1_relu, n->t1_bn, N0, Hd, n->t1_bn_memo, n->t1_bn_stats, s));
+  float *prev = n->t1_bn;
+  Grid prev_grid = n->g_lda;
+  for (auto &L : n->layers) {
+    tdnnf_mat in = M(prev, N_of(L.gin, B), Hd);
+    tdnnf_mat lin = M(L.lin_out, L.lin.rows_out, L.bn);
+    CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, nullptr, 2, &lin, s));
+    tdnnf_mat aff_in = lin;
+    if (L.perm) {
+      aff_in = M(L.lin_perm, L.lin.rows_out, L.bn);
+      CK(tdnnf_reorder_rows(&lin, B, L.aff.ix.row_stride, 1, &aff_in, s));
+    }
+    tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
+    CK(tdnnf_tdnn_propagate(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), nullptr, 1, &relu, s));
+    CK(tdnnf_relu_propagate(&relu, &relu, s));
+    CK(bn_fwd(n, L.relu_out, L.bn_out, L.aff.rows_out, Hd, L.bn_memo, L.bn_stats, s));
+    // noop = Sum(Scale(bypass, input), batchnorm)  (dropout-proportion 0 -> GeneralDropout is a copy)
+    tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
+    tdnnf_mat bno = M(L.bn_out, L.aff.rows_out, Hd), out = M(L.noop_out, L.aff.rows_out, Hd);
+    if (byp.rows != out.rows) {  // strided bypass rows: view both as (n, B*stride) super rows
+      bno = tdnnf_mat{L.bn_out, L.gout.n, byp.cols, B * ((Hd + 3) & ~3)};
+      out = tdnnf_mat{L.noop_out, L.gout.n, byp.cols, B * ((Hd + 3) & ~3)};
+    }
+    CK(tdnnf_sum_scaled(&byp, c.bypass_scale, &bno, 1.0f, &out, s));
+    prev = L.noop_out;
+    prev_grid = L.gout;
+  }
+  (void)prev_grid;
+  const int No = n->Tout * B;
+  tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
+  CK(tdnnf_affine_propagate(&top, Wp(n, n->c_prefinal_l), Hd, nullptr, S, &pl, s));
+  for (int h = 0; h < 2; h++) {
+    auto &H = n->head[h];
+    tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), y = M(H.y, No, P);
+    CK(tdnnf_affine_propagate(&pl, Wp(n, H.c_affine), S, Bp(n, H.c_affine), Hd, &ar, s));
+    CK(tdnnf_relu_propagate(&ar, &ar, s));
+    CK(bn_fwd(n, H.aff_relu, H.bn1_out, No, Hd, H.bn1_memo, H.bn1_stats, s));
+    CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
+    CK(bn_fwd(n, H.lin_out, H.bn2_out, No, S, H.bn2_memo, H.bn2_stats, s));
+    CK(tdnnf_affine_propagate(&b2, Wp(n, H.c_output), S, Bp(n, H.c_output), P, &y, s));
+  }
+  tdnnf_mat yx = M(n->head[1].y, No, P), lsm = M(n->xent_logsoftmax, No, P);
+  CK(tdnnf_log_softmax_propagate(&yx, &lsm, s));
+
+  // ============================================================ objective + derivative
+  tdnnf_mat y = M(n->head[0].y, No, P), dy = M(n->d_y, No, P), dx = M(n->d_xent, No, P);
+  CK(tdnnf_chain_objf_and_deriv(den, sup, &y, &lsm, c.leaky_hmm, c.chain_l2_regularize, c.xent_regularize, results, &dy, &dx,
+                                n->chain_ws, n->chain_ws_bytes, s));
+  // log-softmax backward, in place into d_xent
+  CK(tdnnf_log_softmax_backprop(&lsm, &dx, &dx, s));
+
+  // ================================================================= backward
+  // relu helper: deriv through relu (+ self-repair and stats with the reference's coin flips)
+  auto relu_bwd = [&](float *relu_out, float *d, int rows, double *stats) -> int {
+    tdnnf_mat ro = M(relu_out, rows, Hd), dm = M(d, rows, Hd);
+    CK(tdnnf_relu_backprop(&ro, &dm, &dm, s));
+    if (c.relu_self_repair_scale > 0.f && coin()) CK(tdnnf_relu_repair(stats, Hd, c.relu_self_repair_scale, 0.05f, 0.95f, &dm, s));
+    if (coin() || step == 0) CK(tdnnf_relu_store_stats(&ro, stats, n->ws, n->ws_bytes, s));
+    return TDNNF_OK;
+  };
+  tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
+  for (int h = 0; h < 2; h++) {
+    auto &H = n->head[h];
+    tdnnf_mat dout = h == 0 ? dy : dx;
+    tdnnf_mat b2 = M(H.bn2_out, No, S), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), ar = M(H.aff_relu, No, Hd);
+    tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
+    CK(tdnnf_affine_update_simple(&b2, &dout, 1.0f, Wg(n, H.c_output), S, Bg(n, H.c_output), n->ws, n->ws_bytes, s));
+    CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
+    CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
+    CK(tdnnf_affine_update_simple(&b1, &d_b2, 1.0f, Wg(n, H.c_linear), Hd, nullptr, n->ws, n->ws_bytes, s));
+    CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
+    CK(tdnnf_batchnorm_backprop(&b1, &d_b1, 1.0f, H.bn1_memo, &d_b1, n->ws, n->ws_bytes, s));  // -> d relu
+    CK(relu_bwd(H.aff_relu, n->dA, No, H.relu_stats));
+    CK(tdnnf_affine_update_simple(&pl, &d_b1, 1.0f, Wg(n, H.c_affine), S, Bg(n, H.c_affine), n->ws, n->ws_bytes, s));
+    (void)lo;
+    (void)ar;
+    if (h == 0) {
+      CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
+    } else {
+      tdnnf_mat tmp = M(n->d_small2, No, S);
+      CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &tmp, s));
+      CK(tdnnf_add_scaled(&tmp, 1.0f, &d_pl, s));
+    }
+  }
+  CK(tdnnf_affine_update_simple(&top, &d_pl, 1.0f, Wg(n, n->c_prefinal_l), Hd, nullptr, n->ws, n->ws_bytes, s));
+  float *d_cur = n->dA, *d_next = n->dB;  // d_cur: deriv w.r.t. the current layer's output (noop)
+  {
+    tdnnf_mat d_top = M(d_cur, No, Hd);
+    CK(tdnnf_affine_backprop(&d_pl, Wp(n, n->c_prefinal_l), Hd, Hd, &d_top, s));
+  }
+  for (int l = c.num_layers - 1; l >= 0; l--) {
+    TdnnfLayer &L = n->layers[l];
+    float *in_act = l > 0 ? n->layers[l - 1].noop_out : n->t1_bn;
+    const int no = L.aff.rows_out, nl = L.lin.rows_out, ni = N_of(L.gin, B);
+    tdnnf_mat d_out = M(d_cur, no, Hd), d_relu = M(n->dC, no, Hd);
+    tdnnf_mat bno = M(L.bn_out, no, Hd);
+    CK(tdnnf_batchnorm_backprop(&bno, &d_out, 1.0f, L.bn_memo, &d_relu, n->ws, n->ws_bytes, s));
+    CK(relu_bwd(L.relu_out, n->dC, no, L.relu_stats));  // dC = deriv w.r.t. affine output
+    tdnnf_mat lin = M(L.lin_out, nl, L.bn);
+    tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : lin;
+    CK(tdnnf_tdnn_update_simple(&L.aff.ix, &aff_in, &d_relu, Hd, L.bn, nullptr, 1.0f, Wg(n, L.aff.comp), L.aff.K * L.bn,
+                                Bg(n, L.aff.comp), n->ws, n->ws_bytes, s));
+    tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
+    TDNNF_HIP(hipMemsetAsync(d_lin.data, 0, sizeof(float) * (size_t)nl * d_lin.stride, s));
+    CK(tdnnf_tdnn_backprop_data(&L.aff.ix, &d_relu, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, nullptr, &d_lin, s));
+    if (L.perm) {
+      tdnnf_mat un = M(n->d_small2, nl, L.bn);
+      CK(tdnnf_reorder_rows(&d_lin, B, L.aff.ix.row_stride, 0, &un, s));
+      d_lin = un;
+    }
+    tdnnf_mat in = M(in_act, ni, Hd);
+    CK(tdnnf_tdnn_update_simple(&L.lin.ix, &in, &d_lin, L.bn, Hd, nullptr, 1.0f, Wg(n, L.lin.comp), L.lin.K * Hd, nullptr, n->ws,
+                                n->ws_bytes, s));
+    // deriv w.r.t. the layer input = linear backprop + bypass_scale * d_out on the output-grid rows
+    tdnnf_mat d_in = M(d_next, ni, Hd);
+    TDNNF_HIP(hipMemsetAsync(d_in.data, 0, sizeof(float) * (size_t)ni * d_in.stride, s));
+    CK(tdnnf_tdnn_backprop_data(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, &d_in, s));
+    tdnnf_mat d_byp = sub_grid_view(d_next, L.gin, L.gout, B, Hd);
+    tdnnf_mat d_o = d_out;
+    if (d_byp.rows != d_o.rows) d_o = tdnnf_mat{d_cur, L.gout.n, d_byp.cols, B * ((Hd + 3) & ~3)};
+    CK(tdnnf_add_scaled(&d_o, c.bypass_scale, &d_byp, s));
+    std::swap(d_cur, d_next);
+  }
+  {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
+    tdnnf_mat d_out = M(d_cur, N0, Hd), d_relu = M(n->dC, N0, Hd), bno = M(n->t1_bn, N0, Hd);
+    CK(tdnnf_batchnorm_backprop(&bno, &d_out, 1.0f, n->t1_bn_memo, &d_relu, n->ws, n->ws_bytes, s));
+    CK(relu_bwd(n->t1_relu, n->dC, N0, n->t1_relu_stats));
+    CK(tdnnf_affine_update_simple(&lda_out, &d_relu, 1.0f, Wg(n, n->tdnn1.comp), lda_dim, Bg(n, n->tdnn1.comp), n->ws, n->ws_bytes, s));
+  }
+  return TDNNF_OK;
+}
+
+int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && n->params && n->grads, "net_update: call net_set_buffers first");
+  TDNNF_REQUIRE(lr >= 0.f && l2_scale >= 0.f, "net_update: learning rate and l2 scale must be >= 0 (nnet-utils.cc:2240)");
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = (int)n->comps.size();
+  UpdTable tb;
+  memset(&tb, 0, sizeof(tb));
+  std::vector<long long> begin(nc + 1);
+  std::vector<float> mc(nc);
+  for (int i = 0; i < nc; i++) {
+    const CompDesc &c = n->comps[i];
+    begin[i] = tb.begin[i] = c.begin;
+    const float lrc = lr * c.lr_factor;
+    tb.lr[i] = lrc;
+    tb.l2coef[i] = -2.0f * l2_scale * lrc * c.l2;  // ApplyL2Regularization, nnet-utils.cc:2241
+    mc[i] = c.max_change;
+  }
+  begin[nc] = tb.begin[nc] = n->num_params;
+  // component i owns [begin[i], begin[i+1]) including alignment padding (padding stays zero)
+  hipLaunchKernelGGL(make_delta_kernel, dim3(32, nc), dim3(256), 0, s, n->grads, n->params, tb);
+  CK(tdnnf_update_with_max_change(n->params, n->grads, nc, begin.data(), mc.data(), n->cfg.max_param_change, 1.0f, 1.0f, 1,
+                                  n->ws, n->ws_bytes, nullptr, s));
+  // ScaleBatchnormStats
+  if (n->cfg.batchnorm_stats_scale != 1.0f) {
+    const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
+    auto sc = [&](double *st, int D) {
+      hipLaunchKernelGGL(scale_doubles_kernel, dim3((1 + 2 * D + 255) / 256), dim3(256), 0, s, st, 1 + 2 * D,
+                         (double)n->cfg.batchnorm_stats_scale);
+    };
+    sc(n->t1_bn_stats, Hd);
+    for (auto &L : n->layers) sc(L.bn_stats, Hd);
+    for (int h = 0; h < 2; h++) {
+      sc(n->head[h].bn1_stats, Hd);
+      sc(n->head[h].bn2_stats, S);
+    }
+  }
+  // ConstrainOrthonormal: each constrained component with probability 1/4 (nnet-utils.cc:1062)
+  for (int i = 0; i < nc; i++) {
+    const CompDesc &c = n->comps[i];
+    if (c.orthonormal == 0.f) continue;
+    if (::tdnnf::tdnnf_decision((unsigned long long)step, 2 * (unsigned long long)i + 1) % 4 != 0) continue;  // RandInt(0,3) != 0
+    TDNNF_REQUIRE(c.rows <= c.cols, "net_update: constrained matrix %s has rows > cols", c.name.c_str());
+    CK(tdnnf_constrain_orthonormal(c.orthonormal, n->params + c.begin, c.rows, c.cols, c.cols, n->ws, n->ws_bytes, s));
+  }
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
+}  // extern "C"

@@ -60,6 +60,8 @@ def _prototypes():
             res = None
         elif ret.startswith("size_t"):
             res = C.c_size_t
+        elif ret.startswith("long long"):
+            res = C.c_longlong
         else:
             res = C.c_int
         protos[name] = (res, args)

@@ -1,0 +1,169 @@
+"""Python plumbing around the C++ chain trainer in libtdnnf_hip.so (include/tdnnf_hip.h,
+"chain trainer" section): owns the flat parameter / gradient tensors (torch device memory),
+initialises parameters the way the reference's components do, and shards minibatches
+data-parallel with one RCCL all-reduce of the raw gradient buffer per step.
+
+Reference graph and hyper-parameters: local/chain_NAS/run_tdnn_fbk_40_iv_sp_7q.sh:149-186,
+local/chain_NAS/run_TDNN_DARTSV3_fbk_stride_pretrain.sh:185-203.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import hipabi
+
+MAX_LAYERS = 32
+
+
+class NetConfig(C.Structure):
+    _fields_ = [("feat_dim", C.c_int), ("ivector_dim", C.c_int), ("num_pdfs", C.c_int),
+                ("hidden_dim", C.c_int), ("prefinal_small_dim", C.c_int), ("num_layers", C.c_int),
+                ("bottleneck_dim", C.c_int * MAX_LAYERS), ("time_stride", C.c_int * MAX_LAYERS),
+                ("bypass_scale", C.c_float), ("frames_per_chunk", C.c_int), ("num_sequences", C.c_int),
+                ("frame_subsampling", C.c_int), ("leaky_hmm", C.c_float), ("xent_regularize", C.c_float),
+                ("chain_l2_regularize", C.c_float), ("l2_hidden", C.c_float), ("l2_output", C.c_float),
+                ("max_change_hidden", C.c_float), ("max_change_output", C.c_float), ("max_param_change", C.c_float),
+                ("relu_self_repair_scale", C.c_float), ("batchnorm_stats_scale", C.c_float)]
+
+
+# time strides of the fixed 7q net (run_tdnn_fbk_40_iv_sp_7q.sh:171-184) and of the "manual" variant
+STRIDES_7Q = [1, 1, 1, 0] + [3] * 10
+STRIDES_MANUAL_OFFSET6 = [1, 1, 1, 0] + [6] * 10   # run_tdnn_7q_fbk_40_manual.sh --offset 6
+
+
+def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck=160, feat_dim=40, ivector_dim=100,
+                num_pdfs=6034, hidden_dim=1536, small_dim=256, **kw):
+    strides = list(STRIDES_7Q if strides is None else strides)
+    bns = bottleneck if isinstance(bottleneck, (list, tuple)) else [bottleneck] * len(strides)
+    c = NetConfig()
+    c.feat_dim, c.ivector_dim, c.num_pdfs = feat_dim, ivector_dim, num_pdfs
+    c.hidden_dim, c.prefinal_small_dim, c.num_layers = hidden_dim, small_dim, len(strides)
+    for i, (s, b) in enumerate(zip(strides, bns)):
+        c.time_stride[i], c.bottleneck_dim[i] = s, b
+    c.bypass_scale = kw.get("bypass_scale", 0.66)
+    c.frames_per_chunk, c.num_sequences, c.frame_subsampling = frames_per_chunk, num_sequences, kw.get("frame_subsampling", 3)
+    c.leaky_hmm, c.xent_regularize, c.chain_l2_regularize = kw.get("leaky_hmm", 0.1), kw.get("xent_regularize", 0.1), kw.get("chain_l2", 0.0)
+    c.l2_hidden, c.l2_output = kw.get("l2_hidden", 0.01), kw.get("l2_output", 0.002)
+    c.max_change_hidden, c.max_change_output, c.max_param_change = 0.75, 1.5, 2.0
+    c.relu_self_repair_scale = kw.get("relu_self_repair_scale", 1.0e-5)
+    c.batchnorm_stats_scale = kw.get("batchnorm_stats_scale", 0.8)
+    return c
+
+
+class ChainNet:
+    """One replica of the TDNN-F chain model on the current CUDA device."""
+
+    def __init__(self, config):
+        import torch
+        self.lib = hipabi.load()
+        self.cfg = config
+        self.h = C.c_void_p()
+        hipabi.check(self.lib.tdnnf_net_create(C.byref(config), C.byref(self.h)))
+        self.num_params = int(self.lib.tdnnf_net_num_params(self.h))
+        self.params = torch.zeros(self.num_params, dtype=torch.float32, device="cuda")
+        self.grads = torch.zeros(self.num_params, dtype=torch.float32, device="cuda")
+        hipabi.check(self.lib.tdnnf_net_set_buffers(self.h, hipabi.ptr(self.params), hipabi.ptr(self.grads)))
+        self.components = []
+        for i in range(self.lib.tdnnf_net_num_components(self.h)):
+            name = C.create_string_buffer(64)
+            begin, rows, cols, hb = C.c_longlong(), C.c_int(), C.c_int(), C.c_int()
+            lrf, l2, mc, orth = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+            hipabi.check(self.lib.tdnnf_net_component_info(self.h, i, name, C.byref(begin), C.byref(rows), C.byref(cols),
+                                                           C.byref(hb), C.byref(lrf), C.byref(l2), C.byref(mc), C.byref(orth)))
+            self.components.append(dict(name=name.value.decode(), begin=begin.value, rows=rows.value, cols=cols.value,
+                                        has_bias=hb.value, lr_factor=lrf.value, l2=l2.value, max_change=mc.value,
+                                        orthonormal=orth.value))
+        nt, t0 = C.c_int(), C.c_int()
+        hipabi.check(self.lib.tdnnf_net_input_frames(self.h, C.byref(nt), C.byref(t0)))
+        self.num_t_in, self.first_t = nt.value, t0.value
+        self.results = torch.zeros(8, dtype=torch.float64, device="cuda")
+
+    def close(self):
+        if self.h:
+            self.lib.tdnnf_net_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ parameters
+    def init_params_numpy(self, seed=0, output_stddev=None):
+        """Flat float32 vector initialised like the reference's InitFromConfig: weights N(0, 1/input_dim),
+        biases N(0,1) (TdnnDARTSV3Component nnet-tdnn-component.cc:145-175; affine layers alike); the lda
+        transform is a random orthonormal matrix; output layers are zero in the recipes (param-stddev=0),
+        `output_stddev` overrides that for parity tests."""
+        rng = np.random.default_rng(seed)
+        p = np.zeros(self.num_params, np.float32)
+        for c in self.components:
+            n = c["rows"] * c["cols"]
+            if c["name"] == "lda":
+                q = np.linalg.qr(rng.standard_normal((c["rows"], c["cols"])))[0]
+                W, b = q.astype(np.float32), np.zeros(c["rows"], np.float32)
+            elif c["name"].startswith("output"):
+                sd = 0.0 if output_stddev is None else output_stddev
+                W = (rng.standard_normal((c["rows"], c["cols"])) * sd).astype(np.float32)
+                b = (rng.standard_normal(c["rows"]) * sd).astype(np.float32)
+            else:
+                W = (rng.standard_normal((c["rows"], c["cols"])) / np.sqrt(c["cols"])).astype(np.float32)
+                b = rng.standard_normal(c["rows"]).astype(np.float32)
+            p[c["begin"]:c["begin"] + n] = W.ravel()
+            if c["has_bias"]:
+                p[c["begin"] + n:c["begin"] + n + c["rows"]] = b
+        return p
+
+    def set_params(self, flat):
+        import torch
+        self.params.copy_(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)))
+
+    # ------------------------------------------------------------------------ steps
+    def forward_backward(self, feats, ivectors, den_graph, supervision, step=0):
+        hipabi.check(self.lib.tdnnf_net_forward_backward(self.h, hipabi.pmat(feats), hipabi.pmat(ivectors), den_graph.h,
+                                                         supervision.h, hipabi.ptr(self.results), int(step), hipabi.stream()))
+        return self.results
+
+    def update(self, learning_rate, l2_regularize_scale=None, step=0):
+        if l2_regularize_scale is None:  # GetNumNvalues(eg.inputs) * l2_regularize_factor (UPSTREAM trainer)
+            l2_regularize_scale = float(self.cfg.num_sequences)
+        hipabi.check(self.lib.tdnnf_net_update(self.h, float(learning_rate), float(l2_regularize_scale), int(step), hipabi.stream()))
+
+    def activation(self, name):
+        import torch
+        r, c = C.c_int(), C.c_int()
+        hipabi.check(self.lib.tdnnf_net_activation_dims(self.h, name.encode(), C.byref(r), C.byref(c)))
+        out = torch.zeros(r.value, c.value, dtype=torch.float32, device="cuda")
+        hipabi.check(self.lib.tdnnf_net_get_activation(self.h, name.encode(), hipabi.pmat(out), hipabi.stream()))
+        return out
+
+    # ------------------------------------------------------------ data-parallel step
+    def allreduce_grads(self, group=None):
+        """Sum the raw parameter gradients over ranks (RCCL all-reduce over xGMI: backend "nccl" on ROCm).
+        Sequences are sharded over ranks, so the summed gradient is the gradient of the global minibatch."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=group)
+
+
+def learning_rate(iteration, num_jobs, num_iters, num_archives_processed, num_archives_to_process,
+                  initial_effective_lrate=2.5e-4, final_effective_lrate=2.5e-5):
+    """get_learning_rate, steps/libs/nnet3/train/common.py:606-618: exponential decay in the fraction of
+    archives processed, the last iteration at the final rate, times num_jobs (rates from
+    run_TDNN_DARTSV3_fbk_stride_pretrain.sh:202-203)."""
+    if iteration + 1 >= num_iters:
+        eff = final_effective_lrate
+    else:
+        eff = initial_effective_lrate * np.exp(num_archives_processed *
+                                               np.log(float(final_effective_lrate) / initial_effective_lrate) /
+                                               num_archives_to_process)
+    return float(num_jobs * eff)
+
+
+def synthetic_egs(net, seed=0):
+    """fbank ~ N(0,1) [num_t_in*B, feat_dim] t-major and ivector ~ N(0,1) [B, ivector_dim]."""
+    rng = np.random.default_rng(seed)
+    B = net.cfg.num_sequences
+    feats = rng.standard_normal((net.num_t_in * B, net.cfg.feat_dim)).astype(np.float32)
+    iv = rng.standard_normal((B, net.cfg.ivector_dim)).astype(np.float32)
+    return feats, iv

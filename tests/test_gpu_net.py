@@ -1,0 +1,93 @@
+"""-m gpu: the C++ chain trainer (tdnnf_net_*) against the CPU reference of the whole step
+(tests/oracle_net.py) on identical seeded egs and parameters: activations, LF-MMI objective
+(BASELINE bar 1e-4 relative), raw parameter gradients (bar 1e-3 relative L2) and the optimizer step."""
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import dev, host, rel_l2
+from tests.oracle_net import OracleNet
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("tiny", dict(frames_per_chunk=12, num_sequences=2, strides=[1, 1, 0, 3, 3], bottleneck=8, feat_dim=8, ivector_dim=4,
+                  num_pdfs=24, hidden_dim=32, small_dim=16), 12),
+    ("7q-shape-small", dict(frames_per_chunk=30, num_sequences=4, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=40, feat_dim=40,
+                            ivector_dim=100, num_pdfs=300, hidden_dim=192, small_dim=64), 60),
+    ("manual-offset6", dict(frames_per_chunk=36, num_sequences=3, strides=[1, 1, 1, 0, 6, 6], bottleneck=20, feat_dim=40,
+                            ivector_dim=100, num_pdfs=150, hidden_dim=96, small_dim=32), 40),
+    ("ragged-dims", dict(frames_per_chunk=15, num_sequences=5, strides=[1, 0, 3], bottleneck=[10, 14, 6], feat_dim=13,
+                         ivector_dim=7, num_pdfs=50, hidden_dim=50, small_dim=18), 30),
+]
+
+
+@pytest.mark.parametrize("name,kw,H", CASES, ids=[c[0] for c in CASES])
+def test_net_step_matches_oracle(pkg, name, kw, H):
+    cfg = pkg.trainer.make_config(**kw)
+    net = pkg.trainer.ChainNet(cfg)
+    params = net.init_params_numpy(seed=3, output_stddev=0.3)
+    net.set_params(params)
+    ref = OracleNet(pkg, cfg, net.components)
+    assert ref.num_t_in == net.num_t_in
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=4)
+    den = pkg.synth.make_den_graph(H, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+    sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    fd, ivd = dev(feats), dev(iv)
+    for step in (0, 1):  # step 1 exercises ReLU self-repair with stats from step 0
+        res_ref, g_ref, acts = ref.forward_backward(params, feats, iv, den, sup, step=step)
+        net.grads.zero_()
+        r = host(net.forward_backward(fd, ivd, dg, ds, step=step))
+        for key in ["lda", "tdnn1.batchnorm", "tdnnf2.linear", "tdnnf2.noop", f"tdnnf{cfg.num_layers + 1}.noop", "prefinal-l",
+                    "output", "output-xent", "output.deriv"]:
+            e = rel_l2(host(net.activation(key)), acts[key])
+            assert e < 1e-4, (key, e)
+        assert r[5] == 1.0 and r[2] == res_ref["weight"]
+        assert abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"]), (r[0], res_ref["objf"])
+        assert abs(r[6] - res_ref["xent_objf"]) < 1e-4 * abs(res_ref["xent_objf"])
+        g = host(net.grads)
+        assert rel_l2(g, g_ref) < 1e-3, rel_l2(g, g_ref)
+        for c in net.components[1:]:
+            sl = slice(c["begin"], c["begin"] + c["rows"] * c["cols"] + (c["rows"] if c["has_bias"] else 0))
+            assert rel_l2(g[sl], g_ref[sl]) < 1e-3, (c["name"], rel_l2(g[sl], g_ref[sl]))
+        # optimizer step: L2 + max-change + scheduled orthonormal constraint
+        p_ref = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
+        net.update(1e-3, step=step)
+        p = host(net.params)
+        assert rel_l2(p - params, p_ref - params) < 2e-3, rel_l2(p - params, p_ref - params)
+        assert not host(net.grads).any()
+        params = p_ref
+        net.set_params(params)
+    net.close()
+
+
+def test_net_gradients_accumulate_and_are_reproducible(pkg):
+    cfg = pkg.trainer.make_config(**CASES[0][1])
+    net = pkg.trainer.ChainNet(cfg)
+    net.set_params(net.init_params_numpy(seed=1, output_stddev=0.3))
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=2)
+    den = pkg.synth.make_den_graph(12, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+    sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    fd, ivd = dev(feats), dev(iv)
+    net.forward_backward(fd, ivd, dg, ds, step=0)
+    g1 = net.grads.clone()
+    net.forward_backward(fd, ivd, dg, ds, step=0)
+    assert torch.allclose(net.grads, 2 * g1, rtol=1e-5, atol=1e-7)  # accumulates (delta-nnet semantics)
+    net.grads.zero_()
+    net.forward_backward(fd, ivd, dg, ds, step=0)
+    assert torch.equal(net.grads, g1)  # bitwise reproducible
+    net.close()
+
+
+def test_net_rejects_bad_shapes(pkg):
+    cfg = pkg.trainer.make_config(**CASES[0][1])
+    net = pkg.trainer.ChainNet(cfg)
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=2)
+    den = pkg.synth.make_den_graph(12, cfg.num_pdfs, seed=5)
+    sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    with pytest.raises(pkg.hipabi.HipAbiError, match="feats must be"):
+        net.forward_backward(dev(feats[:-2]), dev(iv), dg, ds)
+    net.close()
