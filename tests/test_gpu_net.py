@@ -63,7 +63,8 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
 
 
 def test_net_gradients_accumulate_and_are_reproducible(pkg):
-    cfg = pkg.trainer.make_config(**CASES[0][1])
+    # self-repair off: it depends on the ReLU statistics accumulated by earlier calls
+    cfg = pkg.trainer.make_config(relu_self_repair_scale=0.0, **CASES[0][1])
     net = pkg.trainer.ChainNet(cfg)
     net.set_params(net.init_params_numpy(seed=1, output_stddev=0.3))
     feats, iv = pkg.trainer.synthetic_egs(net, seed=2)
