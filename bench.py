@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- LF-MMI training throughput of the SWBD 7q TDNN-F chain model on MI355X.
+
+One "step" = one minibatch of nnet3-chain-train on synthetic egs already resident in HBM:
+forward through every component, chain objective (denominator + numerator forward-backward),
+backward with raw-gradient accumulation, [RCCL all-reduce of the gradient buffer when N > 1],
+L2 + max-change + parameter update + scheduled orthonormal constraint.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  metric = BASELINE.json's "LF-MMI training frames/sec per node".
+Workload (config.workload): BASELINE.json configs[1], the fixed 7q TDNN-F (14 tdnnf layers, bottleneck
+160, strides 1,1,1,0,3x10) on 40-dim fbank + 100-dim ivector egs, chunks of --chunk frames, --minibatch
+sequences per GPU (weak scaling: per-GPU work is fixed as N grows).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(pkg, args):
+    """The CPU restatement of the same training step (oracle, float-accumulating OpenMP build) timed on this
+    box's host cores on a bounded sample: same net, chunk 150, a few sequences."""
+    from tests.oracle_net import OracleNet
+    B, T = args.cpu_sequences, 150
+    cfg = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B)
+    comps, begin = [], 0
+    # component table without touching the GPU: same layout rule as the trainer (16-byte aligned blocks)
+    lda_dim = 3 * cfg.feat_dim + cfg.ivector_dim
+
+    def add(name, rows, cols, hb, lrf=1.0, l2=0.01, mc=0.75, orth=0.0):
+        nonlocal begin
+        comps.append(dict(name=name, begin=begin, rows=rows, cols=cols, has_bias=hb, lr_factor=lrf, l2=l2, max_change=mc, orthonormal=orth))
+        begin = (begin + rows * cols + (rows if hb else 0) + 3) // 4 * 4
+
+    add("lda", lda_dim, lda_dim, 1, lrf=0.0, l2=0.0, mc=0.0)
+    add("tdnn1.affine", cfg.hidden_dim, lda_dim, 1)
+    for i in range(cfg.num_layers):
+        K = 2 if cfg.time_stride[i] > 0 else 1
+        add(f"tdnnf{i + 2}.linear", cfg.bottleneck_dim[i], K * cfg.hidden_dim, 0, orth=-1.0)
+        add(f"tdnnf{i + 2}.affine", cfg.hidden_dim, K * cfg.bottleneck_dim[i], 1)
+    add("prefinal-l", cfg.prefinal_small_dim, cfg.hidden_dim, 0, orth=-1.0)
+    for hn in ("chain", "xent"):
+        add(f"prefinal-{hn}.affine", cfg.hidden_dim, cfg.prefinal_small_dim, 1)
+        add(f"prefinal-{hn}.linear", cfg.prefinal_small_dim, cfg.hidden_dim, 0, orth=-1.0)
+        add("output.affine" if hn == "chain" else "output-xent.affine", cfg.num_pdfs, cfg.prefinal_small_dim, 1,
+            lrf=1.0 if hn == "chain" else 5.0, l2=0.002, mc=1.5)
+    import numpy as np
+    rng = np.random.default_rng(0)
+    params = (rng.standard_normal(begin) * 0.02).astype(np.float32)
+    net = OracleNet(pkg, cfg, comps, fast=True)
+    feats = rng.standard_normal((net.num_t_in * B, cfg.feat_dim)).astype(np.float32)
+    iv = rng.standard_normal((B, cfg.ivector_dim)).astype(np.float32)
+    den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
+    sup = pkg.synth.make_supervision(B, T // 3, cfg.num_pdfs, seed=2)
+    t0 = time.time()
+    res, grads, _ = net.forward_backward(params, feats, iv, den, sup, step=0)
+    net.update(params, grads, 1e-3, float(B), 0)
+    dt = time.time() - t0
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(B * T / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"one full training step of the same 7q net on {B} sequences x {T} frames ({dt:.1f} s), "
+                      f"CPU restatement of the reference path (oracle/, OpenMP float build), not Kaldi"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunk", type=int, default=1500, help="frames per chunk (north_star: 1500-frame chunks)")
+    ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU")
+    ap.add_argument("--den-states", type=int, default=4000)
+    ap.add_argument("--den-degree", type=float, default=12.0)
+    ap.add_argument("--cpu-sequences", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+
+    lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
+    cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch)
+    net = pkg.trainer.ChainNet(cfg)
+    # identical initial model on every rank (seed), different egs per rank (data parallel over sequences)
+    net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=100 + rank)
+    den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
+    sup = pkg.synth.make_supervision(cfg.num_sequences, args.chunk // 3, cfg.num_pdfs, seed=200 + rank)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    fd, ivd = torch.from_numpy(feats).cuda(), torch.from_numpy(iv).cuda()
+    lr = pkg.trainer.learning_rate(0, world, 100, 0, 100)  # 2.5e-4 * num_jobs
+
+    def step(i):
+        net.forward_backward(fd, ivd, dg, ds, step=i)
+        net.allreduce_grads()
+        # l2 scale: GetNumNvalues * l2_regularize_factor(=1/num_jobs) -> per-GPU sequence count
+        net.update(lr, l2_regularize_scale=float(cfg.num_sequences), step=i)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    sync()
+    pkg.hipabi.check(lib.tdnnf_profile_enable(1))
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    sync()
+    dt = time.perf_counter() - t0
+    pkg.hipabi.check(lib.tdnnf_profile_enable(0))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res = net.results.cpu().numpy()
+
+    # live roofline of the dominant kernel class (HIP events recorded on the launch stream)
+    classes = []
+    for k in range(3):
+        n, ms, fl = C.c_double(), C.c_double(), C.c_double()
+        pkg.hipabi.check(lib.tdnnf_profile_read(k, C.byref(n), C.byref(ms), C.byref(fl)))
+        classes.append(dict(name=lib.tdnnf_profile_class_name(k).decode(), launches=n.value, ms=ms.value, flops=fl.value))
+    dom = max(classes, key=lambda c: c["ms"])
+    achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dom["name"], {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        frames = world * cfg.num_sequences * args.chunk * args.steps
+        out = {
+            "metric": "LF-MMI training frames/sec per node (SWBD 7q TDNN-F)",
+            "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: run_tdnn_7q fixed TDNN-F (14 tdnnf layers, bottleneck 160, strides 1,1,1,0,3x10, "
+                                   "6034 pdfs, 40-dim fbank + 100-dim ivector), LF-MMI chain objective + xent head, raw-gradient SGD step "
+                                   "with L2, max-change and orthonormal constraint (natural gradient off)",
+                       "frames_per_chunk": args.chunk, "sequences_per_gpu": cfg.num_sequences, "global_batch": world * cfg.num_sequences,
+                       "den_graph": {"states": args.den_states, "arcs": int(len(den["src"]))},
+                       "parallelism": f"dp{world}", "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4), "launches": int(dom["launches"]),
+                         "all_kernels": [{"kernel": c["name"], "launches": int(c["launches"]), "ms": round(c["ms"], 3),
+                                          "tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2) if c["ms"] > 0 else 0.0}
+                                         for c in classes]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pkg, args)
+        print(json.dumps(out), flush=True)
+    net.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -310,6 +310,14 @@ int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale
 int tdnnf_net_get_activation(const tdnnf_net *, const char *name, tdnnf_mat *out, tdnnf_stream);
 int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, int *cols);
 
+/* ======================================================================== profiling
+ * Optional per-launch timing of the MFMA GEMM kernels with HIP events recorded on the launch stream
+ * (bench.py's live roofline measurement).  Classes: 0 = rows_gemm 128x128 tile, 1 = rows_gemm 128x160 tile,
+ * 2 = wgrad.  tdnnf_profile_read synchronises the recorded events and returns totals since enable. */
+int tdnnf_profile_enable(int on);
+int tdnnf_profile_read(int kernel_class, double *launches, double *total_ms, double *total_flops);
+const char *tdnnf_profile_class_name(int kernel_class);
+
 #ifdef __cplusplus
 }
 #endif

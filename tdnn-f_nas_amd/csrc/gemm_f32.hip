@@ -18,7 +18,40 @@
 // bank-conflict free (stride 36 / 20 dwords).
 #include "gemm_f32.h"
 
+#include <vector>
+
+#include "tdnnf_hip.h"
+
 namespace tdnnf {
+
+// ---- optional event timing of every GEMM launch (tdnnf_profile_*)
+struct ProfClass {
+  const char *name;
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t used = 0;
+  double flops = 0;
+};
+static ProfClass g_prof[3] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32_128x128"}};
+static bool g_prof_on = false;
+constexpr size_t kProfMaxLaunches = 1 << 15;
+
+struct ProfScope {
+  ProfClass *c = nullptr;
+  hipStream_t s;
+  ProfScope(int cls, double flops, hipStream_t stream) : s(stream) {
+    if (!g_prof_on) return;
+    ProfClass &p = g_prof[cls];
+    if (p.used + 2 > p.ev.size()) return;
+    c = &p;
+    p.flops += flops;
+    hipEventRecord(p.ev[p.used], s);
+  }
+  ~ProfScope() {
+    if (!c) return;
+    hipEventRecord(c->ev[c->used + 1], s);
+    c->used += 2;
+  }
+};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -253,7 +286,16 @@ hipError_t rows_gemm(const RowsGemmArgs &a, bool b_kc, hipStream_t s) {
   for (int i = 0; i < a.nseg; i++) vec = vec && a.seg[i].a_off % 4 == 0 && a.seg[i].b_off % 4 == 0;
   // N == 160 (the TDNN-F bottleneck) gets a 128x160 tile so no column is wasted
   const int waste128 = ((a.N + 127) / 128) * 128 - a.N, waste160 = ((a.N + 159) / 160) * 160 - a.N;
-  if (waste160 < waste128) return launch_rows<4, 1, 1, 5, 16>(a, b_kc, vec, s);
+  double flops = 0;
+  for (int i = 0; i < a.nseg; i++) {
+    const int lo = a.seg[i].m_lo > 0 ? a.seg[i].m_lo : 0, hi = a.seg[i].m_hi < a.M ? a.seg[i].m_hi : a.M;
+    if (hi > lo) flops += 2.0 * (hi - lo) * a.N * a.seg[i].klen;
+  }
+  if (waste160 < waste128) {
+    ProfScope ps(1, flops, s);
+    return launch_rows<4, 1, 1, 5, 16>(a, b_kc, vec, s);
+  }
+  ProfScope ps(0, flops, s);
   return launch_rows<2, 2, 2, 2, 32>(a, b_kc, vec, s);
 }
 
@@ -459,8 +501,11 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
     hipFuncSetAttribute((const void *)wgrad_kernel<2, 2, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  if (vec) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 4>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
-  else hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 1>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
+  {
+    ProfScope ps(2, 2.0 * a.N * a.Do * a.K * a.Di, s);
+    if (vec) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 4>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
+    else hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 1>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const long long total = (long long)a.Do * a.K * a.Di;
@@ -481,3 +526,39 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
 }
 
 }  // namespace tdnnf
+
+extern "C" {
+int tdnnf_profile_enable(int on) {
+  using namespace tdnnf;
+  if (on) {
+    for (auto &p : g_prof) {
+      if (p.ev.empty()) {
+        p.ev.resize(2 * kProfMaxLaunches);
+        for (auto &e : p.ev)
+          if (hipEventCreate(&e) != hipSuccess) return TDNNF_EHIP;
+      }
+      p.used = 0;
+      p.flops = 0;
+    }
+  }
+  g_prof_on = on != 0;
+  return TDNNF_OK;
+}
+int tdnnf_profile_read(int cls, double *launches, double *total_ms, double *total_flops) {
+  using namespace tdnnf;
+  if (cls < 0 || cls > 2) return TDNNF_EINVAL;
+  ProfClass &p = g_prof[cls];
+  double ms = 0;
+  for (size_t i = 0; i + 1 < p.used; i += 2) {
+    if (hipEventSynchronize(p.ev[i + 1]) != hipSuccess) return TDNNF_EHIP;
+    float t = 0;
+    if (hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]) != hipSuccess) return TDNNF_EHIP;
+    ms += t;
+  }
+  if (launches) *launches = (double)(p.used / 2);
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = p.flops;
+  return TDNNF_OK;
+}
+const char *tdnnf_profile_class_name(int cls) { return cls >= 0 && cls <= 2 ? tdnnf::g_prof[cls].name : ""; }
+}

@@ -21,11 +21,11 @@ def decision(step, k):
 
 
 class OracleNet:
-    def __init__(self, pkg, cfg, components):
+    def __init__(self, pkg, cfg, components, fast=False):
         self.pkg, self.cfg = pkg, cfg
         self.comp = {c["name"]: c for c in components}
         self.order = [c["name"] for c in components]
-        self.L = ora.lib()
+        self.L = ora.lib(fast=fast)  # fast: float-accumulating OpenMP build (bench.py's cpu_baseline)
         self.B, self.T = cfg.num_sequences, cfg.frames_per_chunk
         self.sub = cfg.frame_subsampling
         self.Tout = self.T // self.sub
