@@ -23,12 +23,14 @@
 
 struct tdnnf_den_graph {
   int H, A, P;
-  // SELL-64: slice k covers rows 64k..64k+63, entries at base[k] + j*64 + lane, j < width[k]
+  // SELL-64 over rows sorted by descending degree (so a slice's rows have near-equal degree and padding is
+  // negligible): slot s = 64*k + lane holds original row row[s] (0xffffffff = padding slot); its j-th arc is
+  // arc[base[k] + j*64 + lane] = (packed key, prob bits), j < (base[k+1]-base[k])/64.
   struct Sell {
     int nrows, nslices;
     int *base;       // nslices + 1 (device)
-    unsigned *key;   // packed (other-state-or-src | pdf << 16), or (src | dst << 16) for the by-pdf table
-    float *prob;
+    unsigned *row;   // nslices * 64
+    uint2 *arc;      // key: (other-state-or-src | pdf << 16), or (src | dst << 16) for the by-pdf table
     long long entries;
   } by_dst, by_src, by_pdf;
   float *init;  // H
@@ -114,16 +116,18 @@ __global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatV
     logcorr += (double)logf(prev_sum);
     float *cur = alpha + (size_t)t * Hs;
     float local = 0.f;
-    for (int h = tid; h < ((H + 63) & ~63); h += kDenThreads) {
-      const int sl = h >> 6, ln = h & 63;
+    for (int slot = tid; slot < g.by_dst.nslices * 64; slot += kDenThreads) {
+      const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_dst.base[sl], w = (g.by_dst.base[sl + 1] - b0) >> 6;
+      const uint2 *ap = g.by_dst.arc + b0 + ln;
       float acc = 0.f;
+#pragma unroll 4
       for (int j = 0; j < w; j++) {
-        const unsigned k = g.by_dst.key[b0 + j * 64 + ln];
-        const float pr = g.by_dst.prob[b0 + j * 64 + ln];
-        acc += prev[k & 0xffffu] * pr * x[k >> 16];
+        const uint2 a = ap[j * 64];
+        acc += prev[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16];
       }
-      if (h < H) {
+      const unsigned h = g.by_dst.row[slot];
+      if (h != 0xffffffffu) {
         acc *= inv;
         cur[h] = acc;  // alpha(t,h) before the leaky term
         local += acc;
@@ -179,16 +183,18 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
     __syncthreads();
     // beta_dash(t, i) = sum over out-arcs
     float local = 0.f;
-    for (int h = tid; h < ((H + 63) & ~63); h += kDenThreads) {
-      const int sl = h >> 6, ln = h & 63;
+    for (int slot = tid; slot < g.by_src.nslices * 64; slot += kDenThreads) {
+      const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
+      const uint2 *ap = g.by_src.arc + b0 + ln;
       float acc = 0.f;
+#pragma unroll 4
       for (int j = 0; j < w; j++) {
-        const unsigned k = g.by_src.key[b0 + j * 64 + ln];
-        const float pr = g.by_src.prob[b0 + j * 64 + ln];
-        acc += pr * x[k >> 16] * bnext[k & 0xffffu];
+        const uint2 a = ap[j * 64];
+        acc += __uint_as_float(a.y) * x[a.x >> 16] * bnext[a.x & 0xffffu];
       }
-      if (h < H) {
+      const unsigned h = g.by_src.row[slot];
+      if (h != 0xffffffffu) {
         acc *= inv;
         bcur[h] = acc;
         local += g.init[h] * acc;
@@ -196,16 +202,18 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
     }
     // occupancies by pdf: gamma(t,p) = x[p] * sum_arcs prob * alpha_dash(t,src)/A(t) * beta(t+1,dst)
     float *dr = deriv.data + (size_t)(t * B + s) * deriv.stride;
-    for (int p = tid; p < ((P + 63) & ~63); p += kDenThreads) {
-      const int sl = p >> 6, ln = p & 63;
+    for (int slot = tid; slot < g.by_pdf.nslices * 64; slot += kDenThreads) {
+      const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
+      const uint2 *ap = g.by_pdf.arc + b0 + ln;
       float acc = 0.f;
+#pragma unroll 4
       for (int j = 0; j < w; j++) {
-        const unsigned k = g.by_pdf.key[b0 + j * 64 + ln];
-        const float pr = g.by_pdf.prob[b0 + j * 64 + ln];
-        acc += pr * ad[k & 0xffffu] * bnext[k >> 16];
+        const uint2 a = ap[j * 64];
+        acc += __uint_as_float(a.y) * ad[a.x & 0xffffu] * bnext[a.x >> 16];
       }
-      if (p < P) dr[p] = deriv_weight * acc * x[p];
+      const unsigned p = g.by_pdf.row[slot];
+      if (p != 0xffffffffu) dr[p] = deriv_weight * acc * x[p];
     }
     const float ls = block_sum(local, red, kDenThreads / 64);  // also orders the reads of bnext above
     for (int h = tid; h < H; h += kDenThreads) bcur[h] += leaky * ls;  // Beta(t)
@@ -362,29 +370,32 @@ int to_device(const std::vector<T> &v, T **out) {
   return TDNNF_OK;
 }
 
-// rows[r] = list of (key, prob); builds SELL-64
+// rows[r] = list of (key, prob); builds SELL-64 over rows sorted by descending degree (stable)
 int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, float>>> &rows, tdnnf_den_graph::Sell *out) {
   const int ns = (nrows + 63) / 64;
+  std::vector<int> order(nrows);
+  for (int r = 0; r < nrows; r++) order[r] = r;
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return rows[a].size() > rows[b].size(); });
   std::vector<int> base(ns + 1, 0);
-  for (int k = 0; k < ns; k++) {
-    size_t w = 0;
-    for (int r = 64 * k; r < 64 * k + 64 && r < nrows; r++) w = std::max(w, rows[r].size());
-    base[k + 1] = base[k] + (int)w * 64;
-  }
-  std::vector<unsigned> key(base[ns], 0u);
-  std::vector<float> prob(base[ns], 0.f);
-  for (int r = 0; r < nrows; r++)
+  for (int k = 0; k < ns; k++) base[k + 1] = base[k] + (int)rows[order[64 * k]].size() * 64;
+  std::vector<unsigned> rowid((size_t)ns * 64, 0xffffffffu);
+  std::vector<uint2> arc(base[ns], make_uint2(0u, 0u));  // padding: state 0 / pdf 0 with prob 0
+  for (int s = 0; s < nrows; s++) {
+    const int r = order[s];
+    rowid[s] = (unsigned)r;
     for (size_t j = 0; j < rows[r].size(); j++) {
-      key[base[r / 64] + j * 64 + r % 64] = rows[r][j].first;
-      prob[base[r / 64] + j * 64 + r % 64] = rows[r][j].second;
+      unsigned bits;
+      memcpy(&bits, &rows[r][j].second, 4);
+      arc[base[s / 64] + j * 64 + s % 64] = make_uint2(rows[r][j].first, bits);
     }
+  }
   out->nrows = nrows;
   out->nslices = ns;
   out->entries = base[ns];
   int rc;
   if ((rc = to_device(base, &out->base))) return rc;
-  if ((rc = to_device(key, &out->key))) return rc;
-  return to_device(prob, &out->prob);
+  if ((rc = to_device(rowid, &out->row))) return rc;
+  return to_device(arc, &out->arc);
 }
 
 struct ChainPlan {
@@ -473,8 +484,8 @@ void tdnnf_den_graph_destroy(tdnnf_den_graph *g) {
   tdnnf_den_graph::Sell *t[3] = {&g->by_dst, &g->by_src, &g->by_pdf};
   for (auto *x : t) {
     hipFree(x->base);
-    hipFree(x->key);
-    hipFree(x->prob);
+    hipFree(x->row);
+    hipFree(x->arc);
   }
   hipFree(g->init);
   delete g;

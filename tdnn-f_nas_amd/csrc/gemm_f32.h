@@ -27,6 +27,7 @@ struct RowsGemmArgs {
   const float *coef;  // nseg floats or nullptr (= ones); a segment with coef == 0 is skipped
   int init_mode;      // 0: C += acc, 1: C = bias + acc, 2: C = acc
   int relu;           // 1: C = max(C, 0) after everything else
+  int c_vec;          // set by rows_gemm(): C rows (and bias) allow 16-byte accesses
   int nseg;
   GemmSeg seg[kMaxSeg];
 };

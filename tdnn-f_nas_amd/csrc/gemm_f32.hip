@@ -18,6 +18,7 @@
 // bank-conflict free (stride 36 / 20 dwords).
 #include "gemm_f32.h"
 
+#include <algorithm>
 #include <vector>
 
 #include "tdnnf_hip.h"
@@ -31,7 +32,7 @@ struct ProfClass {
   size_t used = 0;
   double flops = 0;
 };
-static ProfClass g_prof[3] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32_128x128"}};
+static ProfClass g_prof[3] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32"}};
 static bool g_prof_on = false;
 constexpr size_t kProfMaxLaunches = 1 << 15;
 
@@ -228,26 +229,63 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
     }
   }
 
-  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // The accumulators go through LDS (reusing the staging buffers) so that C is read/written as whole
+  // 16-byte-per-lane row segments instead of 64 four-byte accesses per lane.
+  constexpr int LDCS = BN + 4;
+  constexpr int SMEM_FLOATS = 2 * (A_TILE + B_TILE);
+  constexpr int HALF = (BM * LDCS <= SMEM_FLOATS) ? BM : ((BM / 2) * LDCS <= SMEM_FLOATS ? BM / 2 : BM / 4);
+  static_assert(HALF * LDCS <= SMEM_FLOATS, "epilogue tile does not fit the staging LDS");
+  static_assert(HALF % (TM * 32) == 0, "a wave's rows must not straddle epilogue passes");
+  float *Cs = smem;
+  const bool cvec = p.c_vec != 0;
+  __syncthreads();
 #pragma unroll
-  for (int i = 0; i < TM; i++)
+  for (int pass = 0; pass < BM / HALF; pass++) {
+    if ((wm * TM * 32) / HALF == pass) {
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-      const int n = n0 + (wn * TN + j) * 32 + li;
-      if (n >= p.N) continue;
-      const float bv = p.init_mode == 1 ? p.bias[n] : 0.f;
+      for (int i = 0; i < TM; i++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m < p.M) {
-          float *c = p.C + (long long)m * p.ldc + n;
-          float v = acc[i][j][r] + bv;
-          if (p.init_mode == 0) v += *c;
-          if (p.relu) v = fmaxf(v, 0.f);
-          *c = v;
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh - pass * HALF;
+            Cs[row * LDCS + (wn * TN + j) * 32 + li] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    for (int idx = t; idx < HALF * (BN / 4); idx += 256) {
+      const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+      const int m = m0 + pass * HALF + row, n = n0 + c4;
+      if (m >= p.M || n >= p.N) continue;
+      float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDCS + c4);
+      float *c = p.C + (long long)m * p.ldc + n;
+      if (cvec && n + 3 < p.N) {
+        if (p.init_mode == 1) {
+          const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        } else if (p.init_mode == 0) {
+          const float4 o = *reinterpret_cast<const float4 *>(c);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *reinterpret_cast<float4 *>(c) = v;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (n + e < p.N) {
+            float x = vv[e];
+            if (p.init_mode == 1) x += p.bias[n + e];
+            else if (p.init_mode == 0) x += c[e];
+            if (p.relu) x = fmaxf(x, 0.f);
+            c[e] = x;
+          }
         }
       }
     }
+    if (pass + 1 < BM / HALF) __syncthreads();
+  }
 }
 
 template <int WM, int WN, int TM, int TN, int BK>
@@ -279,8 +317,10 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
-hipError_t rows_gemm(const RowsGemmArgs &a, bool b_kc, hipStream_t s) {
-  if (a.M <= 0 || a.N <= 0 || a.nseg <= 0) return hipSuccess;
+hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
+  if (a_in.M <= 0 || a_in.N <= 0 || a_in.nseg <= 0) return hipSuccess;
+  RowsGemmArgs a = a_in;
+  a.c_vec = aligned16(a.C) && a.ldc % 4 == 0 && (a.init_mode != 1 || aligned16(a.bias));
   // float4 path needs 16-byte aligned rows and segment starts; ragged tails fall back per float4
   bool vec = aligned16(a.A) && aligned16(a.B) && a.lda % 4 == 0 && a.ldb % 4 == 0;
   for (int i = 0; i < a.nseg; i++) vec = vec && a.seg[i].a_off % 4 == 0 && a.seg[i].b_off % 4 == 0;
@@ -459,13 +499,53 @@ struct WgradPlan {
   int splits, rows_per_split, chunks, rows_per_chunk;
   size_t slab_floats, colsum_floats;
 };
-WgradPlan wgrad_plan(int Do, int Di, int K, int N) {
+
+// tile shape of the weight-gradient kernel: 160-wide variants for the TDNN-F bottleneck dimension
+struct WgradTile {
+  int BM, BN, variant;  // variant 0: 128x128, 1: 160x128 (Do == 160-ish), 2: 128x160 (Di == 160-ish)
+};
+inline int waste_of(int n, int t) { return ((n + t - 1) / t) * t - n; }
+WgradTile wgrad_tile(int Do, int Di) {
+  if (waste_of(Do, 160) * 128 < waste_of(Do, 128) * 160 && waste_of(Do, 160) < waste_of(Do, 128)) return {160, 128, 1};
+  if (waste_of(Di, 160) < waste_of(Di, 128)) return {128, 160, 2};
+  return {128, 128, 0};
+}
+
+// resident wgrad blocks on the whole chip (blocks/CU from the occupancy API x CUs), queried once per variant
+template <int WM, int WN, int TM, int TN>
+int wgrad_slots_of() {
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 256, occ = 2;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    const size_t lds = sizeof(float) * 2 * (32 * (WM * TM * 32 + 4) + 32 * (WN * TN * 32 + 4));
+    hipFuncSetAttribute((const void *)wgrad_kernel<WM, WN, TM, TN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)wgrad_kernel<WM, WN, TM, TN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)wgrad_kernel<WM, WN, TM, TN, 4>, 256, lds) != hipSuccess || occ < 1) occ = 2;
+    slots = occ * cus;
+    (void)hipGetLastError();
+  }
+  return slots;
+}
+int wgrad_slots(int variant) {
+  return variant == 1 ? wgrad_slots_of<1, 4, 5, 1>() : variant == 2 ? wgrad_slots_of<4, 1, 1, 5>() : wgrad_slots_of<2, 2, 2, 2>();
+}
+
+// Split the row (reduction) range so that tiles * splits fills whole rounds of resident blocks: every block
+// runs equally long, so a grid of q*slots + r blocks costs q+1 rounds; we want r == 0 (just under a multiple).
+WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots) {
   WgradPlan pl;
-  const int tiles = ((Do + 127) / 128) * K * ((Di + 127) / 128);
-  int splits = (1024 + tiles - 1) / tiles;  // ~4 blocks per CU
-  const int max_splits = (N + 255) / 256;   // at least 256 rows per split
-  if (splits > max_splits) splits = max_splits;
+  const WgradTile wt = wgrad_tile(Do, Di);
+  const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
+  const int max_splits = std::max(1, (N + 255) / 256);  // at least 256 rows per split
+  int splits = 1;
+  for (int rounds = 1; rounds <= 4; rounds++) {
+    splits = (rounds * slots) / tiles;
+    if (splits >= 1 && (rounds * slots) / tiles * tiles >= rounds * slots * 3 / 4) break;  // >= 75 % of the round used
+  }
   if (splits < 1) splits = 1;
+  if (splits > max_splits) splits = max_splits;
   int rps = (N + splits - 1) / splits;
   rps = ((rps + 31) / 32) * 32;
   pl.splits = (N + rps - 1) / rps;
@@ -480,31 +560,34 @@ WgradPlan wgrad_plan(int Do, int Di, int K, int N) {
 }  // namespace
 
 size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
-  WgradPlan pl = wgrad_plan(Do, Di, K, N);
-  return sizeof(float) * (pl.slab_floats + pl.colsum_floats) + 64;
+  // sized for the largest split count any device can ask for (4 rounds of 8 blocks on 304 CUs), so the
+  // answer does not depend on the GPU being present
+  const WgradTile wt = wgrad_tile(Do, Di);
+  const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
+  size_t max_splits = std::max<size_t>(1, std::min<size_t>((N + 255) / 256, (4 * 8 * 304) / tiles + 1));
+  return sizeof(float) * (max_splits * Do * K * Di + (size_t)((N + 511) / 512) * Do) + 64;
 }
 
 hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hipStream_t s) {
   if (a.N <= 0 || a.Do <= 0 || a.Di <= 0) return hipSuccess;
   if (workspace_bytes < wgrad_workspace_bytes(a.Do, a.Di, a.K, a.N)) return hipErrorInvalidValue;
-  WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N);
+  const WgradTile wt = wgrad_tile(a.Do, a.Di);
+  WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant));
   float *partial = reinterpret_cast<float *>(workspace);
   float *cs_partial = partial + pl.slab_floats;
   const bool vec = aligned16(a.dY) && aligned16(a.X) && a.lddy % 4 == 0 && a.ldx % 4 == 0;
-  constexpr int BM = 128, BN = 128;
-  const int ntm = (a.Do + BM - 1) / BM, ntn = (a.Di + BN - 1) / BN;
+  const int ntm = (a.Do + wt.BM - 1) / wt.BM, ntn = (a.Di + wt.BN - 1) / wt.BN;
   dim3 grid(ntm * a.K * ntn, pl.splits), block(256);
-  const size_t lds = sizeof(float) * 2 * (32 * (BM + 4) + 32 * (BN + 4));
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipFuncSetAttribute((const void *)wgrad_kernel<2, 2, 2, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void *)wgrad_kernel<2, 2, 2, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_done = true;
-  }
+  const size_t lds = sizeof(float) * 2 * (32 * (wt.BM + 4) + 32 * (wt.BN + 4));
   {
     ProfScope ps(2, 2.0 * a.N * a.Do * a.K * a.Di, s);
-    if (vec) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 4>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
-    else hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, 1>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
+#define WG_LAUNCH(WM, WN, TM, TN)                                                                                              \
+  if (vec) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 4>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial); \
+  else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 1>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
+    if (wt.variant == 1) { WG_LAUNCH(1, 4, 5, 1) }
+    else if (wt.variant == 2) { WG_LAUNCH(4, 1, 1, 5) }
+    else { WG_LAUNCH(2, 2, 2, 2) }
+#undef WG_LAUNCH
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
