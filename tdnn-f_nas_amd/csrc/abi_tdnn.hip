@@ -47,8 +47,12 @@ extern "C" {
 const char *tdnnf_last_error(void) { return g_last_error.c_str(); }
 int tdnnf_abi_version(void) { return 1; }
 
-int tdnnf_tdnn_propagate(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
-                         const float *bias, const float *eff_coef, int init_mode, tdnnf_mat *out, tdnnf_stream stream) {
+}  // extern "C"
+
+namespace tdnnf {
+// Propagate with an optional fused ReLU in the GEMM epilogue (trainer-internal; the C-ABI entry has relu = 0)
+int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
+                        const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream) {
   TDNNF_REQUIRE(mat_ok(in) && mat_ok(out) && W, "tdnn_propagate: bad matrices");
   TDNNF_REQUIRE(Do > 0 && Di > 0 && in->cols == Di && out->cols == Do, "tdnn_propagate: dims: in.cols=%d Di=%d out.cols=%d Do=%d",
                 in ? in->cols : -1, Di, out ? out->cols : -1, Do);
@@ -68,6 +72,7 @@ int tdnnf_tdnn_propagate(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, cons
   a.bias = bias;
   a.coef = eff_coef;
   a.init_mode = init_mode;
+  a.relu = relu;
   a.nseg = ix->num_offsets;
   for (int i = 0; i < a.nseg; i++) {
     a.seg[i].a_off = (long long)ix->row_offsets[i] * in->stride;
@@ -79,12 +84,27 @@ int tdnnf_tdnn_propagate(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, cons
   TDNNF_HIP(rows_gemm(a, true, (hipStream_t)stream));
   return TDNNF_OK;
 }
+}  // namespace tdnnf
+
+extern "C" {
+
+int tdnnf_tdnn_propagate(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
+                         const float *bias, const float *eff_coef, int init_mode, tdnnf_mat *out, tdnnf_stream stream) {
+  return tdnn_propagate_impl(ix, in, W, ldw, Do, Di, bias, eff_coef, init_mode, 0, out, stream);
+}
 
 // Gather form of Backprop :366-416.  in_deriv row q receives sum over taps i with (q - off_i) % rho == 0 of
 // dY[(q - off_i)/rho] W_i, so every in_deriv element is written by exactly one thread (no atomics for
 // the overlapping taps).  One launch per residue class of q mod rho that has at least one tap.
-int tdnnf_tdnn_backprop_data(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_deriv, const float *W, int ldw, int Do,
-                             int Di, const float *eff_coef, tdnnf_mat *in_deriv, tdnnf_stream stream) {
+}  // extern "C"
+
+namespace tdnnf {
+// overwrite != 0: in_deriv = (instead of +=) the gathered sum, legal only when row_stride == 1 (every row of
+// in_deriv up to the last tap's range is produced by the single launch; rows beyond are zeroed by the caller's
+// contract that in_deriv->rows == max row reached).  add (may be null): in_deriv[m] += add_scale * add[m - add_lo].
+int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_deriv, const float *W, int ldw, int Do,
+                            int Di, const float *eff_coef, int overwrite, const tdnnf_mat *add, float add_scale, int add_lo,
+                            tdnnf_mat *in_deriv, tdnnf_stream stream) {
   TDNNF_REQUIRE(mat_ok(in_deriv) && mat_ok(out_deriv) && W, "tdnn_backprop_data: bad matrices");
   TDNNF_REQUIRE(Do > 0 && Di > 0 && in_deriv->cols == Di && out_deriv->cols == Do, "tdnn_backprop_data: bad dims");
   TDNNF_REQUIRE(tdnn_rows_ok(ix, in_deriv->rows, out_deriv->rows), "tdnn_backprop_data: in_deriv has too few rows for the time offsets");
@@ -124,6 +144,19 @@ int tdnnf_tdnn_backprop_data(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_
     a.M = u_max;
     a.N = Di;
     a.init_mode = 0;  // kBackpropAdds
+    if (overwrite) {
+      TDNNF_REQUIRE(rho == 1 && u_max == in_deriv->rows, "tdnn_backprop_data: overwrite needs row_stride 1 and full row coverage");
+      a.init_mode = 2;
+    }
+    if (add) {
+      TDNNF_REQUIRE(rho == 1 && add->cols == Di && add_lo >= 0 && add_lo + add->rows <= in_deriv->rows, "tdnn_backprop_data: bad addend");
+      a.add = add->data;
+      a.ldadd = add->stride;
+      a.add_scale = add_scale;
+      a.add_lo = add_lo;
+      a.add_hi = add_lo + add->rows;
+    }
+    TDNNF_REQUIRE(!(overwrite || add) || !eff_coef || contiguous, "tdnn_backprop_data: fused overwrite/addend needs a single launch");
     if (!eff_coef || contiguous) {
       a.coef = eff_coef ? eff_coef + seg_tap[0] : nullptr;
       a.nseg = nseg;
@@ -140,6 +173,14 @@ int tdnnf_tdnn_backprop_data(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_
     }
   }
   return TDNNF_OK;
+}
+}  // namespace tdnnf
+
+extern "C" {
+
+int tdnnf_tdnn_backprop_data(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_deriv, const float *W, int ldw, int Do,
+                             int Di, const float *eff_coef, tdnnf_mat *in_deriv, tdnnf_stream stream) {
+  return tdnn_backprop_data_impl(ix, out_deriv, W, ldw, Do, Di, eff_coef, 0, nullptr, 0.f, 0, in_deriv, stream);
 }
 
 size_t tdnnf_tdnn_update_workspace_bytes(int Do, int Di, int K, int num_rows) {

@@ -67,5 +67,14 @@ ColReducePlan colreduce_plan(int rows, int cols);
 size_t colreduce_bytes(int rows, int cols);
 // partial[q][chunk][col] for q < nq; kind: 0 = (sum a), 1 = (sum a, sum a*a), 2 = (sum a*b, sum b), 3 = (sum a, sum a>0)
 hipError_t colreduce_partial(int kind, MatView a, MatView b, float *partial, hipStream_t s);
+hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s);
+hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s);  // ws: colreduce_bytes(rows, cols)
+
+// trainer-internal variants of the TDNN entry points (abi_tdnn.hip)
+int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
+                        const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream);
+int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_deriv, const float *W, int ldw, int Do, int Di,
+                            const float *eff_coef, int overwrite, const tdnnf_mat *add, float add_scale, int add_lo,
+                            tdnnf_mat *in_deriv, tdnnf_stream stream);
 
 }  // namespace tdnnf

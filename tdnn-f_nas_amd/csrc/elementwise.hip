@@ -529,6 +529,26 @@ __global__ void axpy_kernel(const float *x, float a, float *y, size_t n) {
 }  // namespace
 }  // namespace tdnnf
 
+namespace tdnnf {
+// BatchNorm forward statistics only (memo rows 0-2); the trainer applies them in a fused pass (fused.hip)
+hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s) {
+  ColReducePlan pl = colreduce_plan(a.rows, a.cols);
+  hipError_t e = colreduce_partial(1, a, a, (float *)ws, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 255) / 256), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols,
+                     a.rows, epsilon, target_rms, memo);
+  return hipGetLastError();
+}
+// acc[c] += scale * colsum(a)[c]   (two-stage, float4 loads)
+hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s) {
+  ColReducePlan pl = colreduce_plan(a.rows, a.cols);
+  hipError_t e = colreduce_partial(0, a, a, (float *)ws, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a.cols + 255) / 256), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols, scale, acc);
+  return hipGetLastError();
+}
+}  // namespace tdnnf
+
 using namespace tdnnf;
 
 // =================================================================================== C-ABI

@@ -1,0 +1,16 @@
+// fused.h -- fused elementwise passes of the chain trainer (fused.hip)
+#pragma once
+#include "common.h"
+
+namespace tdnnf {
+
+// out = (x - memo.mean) * memo.scale + bypass * prev  (prev.data may be null); memo = 5 x D BatchNorm memo
+hipError_t bn_apply_bypass(MatView x, const float *memo, int D, MatView prev, float bypass, MatView out, hipStream_t s);
+
+size_t bn_relu_bwd_workspace_bytes(int rows, int cols);
+// BatchNorm backward + ReLU backward (+ self-repair, ReLU statistics, bias-gradient column sums) in two passes.
+hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, double *relu_stats, bool store_relu_stats,
+                       bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
+                       void *ws, size_t ws_bytes, hipStream_t s);
+
+}  // namespace tdnnf

@@ -1,0 +1,241 @@
+// fused.hip -- fused HBM-bound passes used by the chain trainer (net.hip) between the MFMA GEMMs.
+//
+// The reference runs ReLU, BatchNorm, (dropout) and the bypass Sum() of a tdnnf-layer
+// (/root/reference/steps/libs/nnet3/xconfig/composite_layers.py:177-213) as separate components, each a
+// chain of CuMatrix passes (~12 full passes over N x 1536 per layer and direction).  Here:
+//   forward : GEMM epilogue does bias + ReLU; one reduction pass for the BatchNorm statistics; ONE pass
+//             computes z = (x - mean) * scale and out = z + bypass * prev (z is not stored);
+//   backward: one reduction pass (sum z*dz, sum dz [, ReLU statistics]), ONE pass producing the derivative
+//             w.r.t. the affine output (BatchNorm backward, ReLU mask, self-repair) together with the
+//             per-column partial sums of the bias gradient.
+// Arithmetic is the components' (nnet-normalize-component.cc:421-452,505-542; nnet-simple-component.cc:
+// 958-1074), only the number of trips through HBM changes.  All column reductions are two-stage and
+// deterministic.
+#include "common.h"
+#include "fused.h"
+
+namespace tdnnf {
+namespace {
+
+__device__ __forceinline__ void ld(const float *p, float (&v)[4], bool vec) {
+  if (vec) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    v[0] = p[0];
+  }
+}
+__device__ __forceinline__ void st(float *p, const float (&v)[4], bool vec) {
+  if (vec) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else p[0] = v[0];
+}
+
+// out = (x - mean) * scale + bypass * prev   (prev.data may be null).  Views may be "super rows"
+// (cols = k * D): the column parameters repeat with period D.
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const float *mean, const float *scale, int D, int period,
+                                                              MatView prev, float bypass, MatView out) {
+  const int cv = x.cols / VEC;
+  const long long total = (long long)x.rows * cv;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int r = (int)(e / cv), c = (int)(e % cv) * VEC, cd = c % period;
+    if (cd >= D) continue;  // row padding inside a super row
+    float xv[4], pv[4] = {0, 0, 0, 0}, o[4];
+    ld(x.data + (long long)r * x.stride + c, xv, VEC == 4);
+    if (prev.data) ld(prev.data + (long long)r * prev.stride + c, pv, VEC == 4);
+#pragma unroll
+    for (int j = 0; j < VEC; j++) o[j] = (xv[j] - mean[cd + j]) * scale[cd + j] + bypass * pv[j];
+    st(out.data + (long long)r * out.stride + c, o, VEC == 4);
+  }
+}
+
+// Column-strip kernels: block = 64 (x VEC) columns x 4 row lanes, one chunk of rows per blockIdx.y.
+// partial layout: [quantity][chunk][col].
+template <int VEC, bool RELU_STATS>
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatView dz, const float *mean, const float *scale,
+                                                                 int rows_per_chunk, int chunks, float *partial) {
+  __shared__ float red[4][4][64 * 4 + 4];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + tc) * VEC;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(x.rows, r0 + rows_per_chunk);
+  float s[4][4] = {};
+  if (col < x.cols) {
+    float mu[4], sc[4];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      mu[j] = mean[col + j];
+      sc[j] = scale[col + j];
+    }
+    for (int r = r0 + tr; r < r1; r += 4) {
+      float xv[4], dv[4];
+      ld(x.data + (long long)r * x.stride + col, xv, VEC == 4);
+      ld(dz.data + (long long)r * dz.stride + col, dv, VEC == 4);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const float z = (xv[j] - mu[j]) * sc[j];
+        s[0][j] += z * dv[j];
+        s[1][j] += dv[j];
+        if (RELU_STATS) {
+          s[2][j] += xv[j];
+          s[3][j] += xv[j] > 0.f ? 1.f : 0.f;
+        }
+      }
+    }
+  }
+  constexpr int NQ = RELU_STATS ? 4 : 2;
+#pragma unroll
+  for (int q = 0; q < NQ; q++)
+#pragma unroll
+    for (int j = 0; j < VEC; j++) red[q][tr][tc * VEC + j] = s[q][j];
+  __syncthreads();
+  if (tr == 0 && col < x.cols) {
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const int k = tc * VEC + j;
+        partial[((long long)q * chunks + blockIdx.y) * x.cols + col + j] = (red[q][0][k] + red[q][1][k]) + (red[q][2][k] + red[q][3][k]);
+      }
+  }
+}
+
+// memo rows 3 (var_deriv_mod) and 4 (temp) from the partials (nnet-normalize-component.cc:520-526);
+// optionally the ReLU statistics [count, value_sum[D], deriv_sum[D]] (StoreStatsInternal).
+__global__ void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms, float *memo,
+                                            double *relu_stats) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (relu_stats && d == 0) relu_stats[0] += (double)N;
+  if (d >= D) return;
+  double zz = 0, sd = 0, vs = 0, ds = 0;
+  for (int c = 0; c < chunks; c++) {
+    zz += partial[(long long)c * D + d];
+    sd += partial[((long long)chunks + c) * D + d];
+    if (relu_stats) {
+      vs += partial[((long long)2 * chunks + c) * D + d];
+      ds += partial[((long long)3 * chunks + c) * D + d];
+    }
+  }
+  const float coeff = -1.0f / (target_rms * target_rms * N);
+  memo[3 * D + d] = (float)(coeff * zz) * memo[2 * D + d];
+  memo[4 * D + d] = (float)(-sd / N);
+  if (relu_stats) {
+    relu_stats[1 + d] += vs;
+    relu_stats[1 + D + d] += ds;
+  }
+}
+
+// d_aff = relu'(x) * [ (dz + temp) * scale + z * vdm ] + repair[col];  partial[chunk][col] = column sums of d_aff.
+// repair_stats (may be null): ReLU statistics deciding the self-repair term (nnet-simple-component.cc:1028-1073).
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatView dz, const float *memo, int D,
+                                                                const double *repair_stats, float self_repair_scale,
+                                                                int rows_per_chunk, int chunks, MatView d_aff, float *partial) {
+  __shared__ float red[4][64 * 4 + 4];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
+  const int col = (blockIdx.x * 64 + tc) * VEC;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(x.rows, r0 + rows_per_chunk);
+  float s[4] = {0, 0, 0, 0};
+  if (col < x.cols) {
+    float mu[4], sc[4], vdm[4], tmp[4], rep[4];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      mu[j] = memo[col + j];
+      sc[j] = memo[2 * D + col + j];
+      vdm[j] = memo[3 * D + col + j];
+      tmp[j] = memo[4 * D + col + j];
+      rep[j] = 0.f;
+      if (repair_stats) {
+        const float count = (float)repair_stats[0];
+        if (self_repair_scale != 0.f && count != 0.f) {
+          const float stv = (float)repair_stats[1 + D + col + j];
+          float v = (stv - 0.05f * count > 0.f ? 1.f : 0.f) + (stv - 0.95f * count > 0.f ? 1.f : 0.f) - 1.f;
+          rep[j] = v * (-self_repair_scale / 0.5f);
+        }
+      }
+    }
+    for (int r = r0 + tr; r < r1; r += 4) {
+      float xv[4], dv[4], o[4];
+      ld(x.data + (long long)r * x.stride + col, xv, VEC == 4);
+      ld(dz.data + (long long)r * dz.stride + col, dv, VEC == 4);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        const float z = (xv[j] - mu[j]) * sc[j];
+        const float dr = (dv[j] + tmp[j]) * sc[j] + z * vdm[j];
+        float v = (xv[j] > 0.f ? 1.f : 0.f) * dr;
+        if (rep[j] != 0.f) v += rep[j];
+        o[j] = v;
+        s[j] += v;
+      }
+      st(d_aff.data + (long long)r * d_aff.stride + col, o, VEC == 4);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; j++) red[tr][tc * VEC + j] = s[j];
+  __syncthreads();
+  if (tr == 0 && col < x.cols) {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const int k = tc * VEC + j;
+      partial[(long long)blockIdx.y * x.cols + col + j] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+    }
+  }
+}
+
+__global__ void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int c = 0; c < chunks; c++) s += partial[(long long)c * D + d];
+  acc[d] += scale * s;
+}
+
+}  // namespace
+
+hipError_t bn_apply_bypass(MatView x, const float *memo, int D, MatView prev, float bypass, MatView out, hipStream_t s) {
+  if (x.rows == 0) return hipSuccess;
+  const int period = (D + 3) & ~3;  // a super row (cols > D) is a run of rows of D values padded to a multiple of 4
+  const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0;
+  const long long work = (long long)x.rows * (vec ? x.cols / 4 : x.cols);
+  if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out);
+  else hipLaunchKernelGGL((bn_apply_bypass_kernel<1>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out);
+  return hipGetLastError();
+}
+
+size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
+  ColReducePlan p = colreduce_plan(rows, cols);
+  return sizeof(float) * 5 * (size_t)p.chunks * cols + 64;
+}
+
+// x: ReLU output (= BatchNorm input), dz: derivative w.r.t. the BatchNorm output, memo: forward memo (rows 0-2
+// valid).  Writes d_aff (may alias dz) and adds lr_scale * colsum(d_aff) into bias_acc (may be null).
+hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, double *relu_stats, bool store_relu_stats,
+                       bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
+                       void *ws, size_t ws_bytes, hipStream_t s) {
+  if (x.rows == 0) return hipSuccess;
+  if (ws_bytes < bn_relu_bwd_workspace_bytes(x.rows, x.cols)) return hipErrorInvalidValue;
+  const int D = x.cols;
+  ColReducePlan pl = colreduce_plan(x.rows, D);
+  const bool vec = vec4_ok(x) && vec4_ok(dz) && vec4_ok(d_aff);
+  const int per = vec ? 256 : 64;
+  dim3 grid((D + per - 1) / per, pl.chunks), block(256);
+  float *partial = (float *)ws;                                  // quantities 0..3 of the reduction
+  float *bias_partial = partial + 4 * (size_t)pl.chunks * D;     // column sums of d_aff
+  // Order as in the reference: StoreStats runs with the forward pass, RepairGradients in Backprop sees the
+  // statistics including this minibatch (when it was stored).
+  if (store_relu_stats) {
+    if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, true>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
+    else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, true>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
+  } else {
+    if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
+    else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
+  }
+  hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
+                     store_relu_stats ? relu_stats : (double *)nullptr);
+  const double *rep = self_repair ? relu_stats : nullptr;
+  if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);
+  else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);
+  if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 255) / 256), dim3(256), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
+  return hipGetLastError();
+}
+
+}  // namespace tdnnf

@@ -28,6 +28,11 @@ struct RowsGemmArgs {
   int init_mode;      // 0: C += acc, 1: C = bias + acc, 2: C = acc
   int relu;           // 1: C = max(C, 0) after everything else
   int c_vec;          // set by rows_gemm(): C rows (and bias) allow 16-byte accesses
+  // optional addend fused into the epilogue: C[m][n] += add_scale * add[(m - add_lo) * ldadd + n] for add_lo <= m < add_hi
+  const float *add;
+  long long ldadd;
+  float add_scale;
+  int add_lo, add_hi;
   int nseg;
   GemmSeg seg[kMaxSeg];
 };

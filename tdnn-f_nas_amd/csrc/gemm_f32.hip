@@ -18,6 +18,8 @@
 // bank-conflict free (stride 36 / 20 dwords).
 #include "gemm_f32.h"
 
+#include "common.h"
+
 #include <algorithm>
 #include <vector>
 
@@ -268,6 +270,10 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
           const float4 o = *reinterpret_cast<const float4 *>(c);
           v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
         }
+        if (p.add && m >= p.add_lo && m < p.add_hi) {
+          const float4 o = *reinterpret_cast<const float4 *>(p.add + (long long)(m - p.add_lo) * p.ldadd + n);
+          v.x += p.add_scale * o.x; v.y += p.add_scale * o.y; v.z += p.add_scale * o.z; v.w += p.add_scale * o.w;
+        }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *reinterpret_cast<float4 *>(c) = v;
       } else {
@@ -278,6 +284,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
             float x = vv[e];
             if (p.init_mode == 1) x += p.bias[n + e];
             else if (p.init_mode == 0) x += c[e];
+            if (p.add && m >= p.add_lo && m < p.add_hi) x += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n + e];
             if (p.relu) x = fmaxf(x, 0.f);
             c[e] = x;
           }
@@ -320,7 +327,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   if (a_in.M <= 0 || a_in.N <= 0 || a_in.nseg <= 0) return hipSuccess;
   RowsGemmArgs a = a_in;
-  a.c_vec = aligned16(a.C) && a.ldc % 4 == 0 && (a.init_mode != 1 || aligned16(a.bias));
+  a.c_vec = aligned16(a.C) && a.ldc % 4 == 0 && (a.init_mode != 1 || aligned16(a.bias)) && (!a.add || (aligned16(a.add) && a.ldadd % 4 == 0));
   // float4 path needs 16-byte aligned rows and segment starts; ragged tails fall back per float4
   bool vec = aligned16(a.A) && aligned16(a.B) && a.lda % 4 == 0 && a.ldb % 4 == 0;
   for (int i = 0; i < a.nseg; i++) vec = vec && a.seg[i].a_off % 4 == 0 && a.seg[i].b_off % 4 == 0;
@@ -565,7 +572,7 @@ size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
   const WgradTile wt = wgrad_tile(Do, Di);
   const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
   size_t max_splits = std::max<size_t>(1, std::min<size_t>((N + 255) / 256, (4 * 8 * 304) / tiles + 1));
-  return sizeof(float) * (max_splits * Do * K * Di + (size_t)((N + 511) / 512) * Do) + 64;
+  return sizeof(float) * (max_splits * Do * K * Di) + colreduce_bytes(N, Do) + 64;
 }
 
 hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hipStream_t s) {
@@ -599,11 +606,8 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.bias_acc) {
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((a.Do + 255) / 256, pl.chunks), dim3(256), 0, s, a.dY, a.lddy, a.N,
-                       a.Do, pl.rows_per_chunk, cs_partial);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((a.Do + 255) / 256), dim3(256), 0, s, cs_partial, pl.chunks, a.Do,
-                       a.scale, a.bias_acc);
-    e = hipGetLastError();
+    MatView dyv{const_cast<float *>(a.dY), a.N, a.Do, (int)a.lddy};
+    e = colsum_add(dyv, a.scale, a.bias_acc, cs_partial, s);
   }
   return e;
 }

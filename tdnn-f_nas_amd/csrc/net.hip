@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "fused.h"
 #include "gemm_f32.h"
 
 namespace tdnnf {
@@ -53,7 +54,7 @@ struct TdnnfLayer {
   bool perm;  // affine input needs the rho row order
   int bypass_row0, bypass_rowstep;  // rows of the layer input that line up with the output grid
   // activations (arena)
-  float *lin_out, *lin_perm, *relu_out, *bn_out, *noop_out;
+  float *lin_out, *lin_perm, *relu_out, *noop_out;
   float *bn_memo;
   double *bn_stats, *relu_stats;
 };
@@ -228,7 +229,6 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     L.lin_out = A.mat(nl, L.bn);
     L.lin_perm = L.perm ? A.mat(nl, L.bn) : nullptr;
     L.relu_out = A.mat(no, Hd);
-    L.bn_out = A.mat(no, Hd);
     L.noop_out = A.mat(no, Hd);
     L.bn_memo = A.take<float>(5 * Hd);
     L.bn_stats = A.take<double>(1 + 2 * Hd);
@@ -264,6 +264,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   auto upd = [&](size_t b) { ws = std::max(ws, b); };
   upd(wgrad_workspace_bytes(Hd, lda_dim, 1, N0));
   upd(colreduce_bytes(max_rows, Hd));
+  upd(bn_relu_bwd_workspace_bytes(max_rows, Hd));
   for (auto &L : n->layers) {
     upd(wgrad_workspace_bytes(L.lin.Do, L.lin.Di, L.lin.K, L.lin.rows_out));
     upd(wgrad_workspace_bytes(L.aff.Do, L.aff.Di, L.aff.K, L.aff.rows_out));
@@ -298,6 +299,12 @@ int bn_fwd(tdnnf_net *n, float *in, float *out, int rows, int cols, float *memo,
   tdnnf_mat a = M(in, rows, cols), o = M(out, rows, cols);
   CK(tdnnf_batchnorm_propagate(&a, 1.0e-3f, 1.0f, &o, memo, n->ws, n->ws_bytes, s));
   return tdnnf_batchnorm_store_stats(memo, cols, rows, stats, s);  // StoreStats runs on every minibatch
+}
+// statistics of BatchNorm(x) only; the normalisation itself is applied by a fused pass
+int bn_stats(tdnnf_net *n, float *x, int rows, int cols, float *memo, double *stats, hipStream_t s) {
+  tdnnf_mat a = M(x, rows, cols);
+  TDNNF_HIP(batchnorm_stats(view(&a), 1.0e-3f, 1.0f, memo, n->ws, s));
+  return tdnnf_batchnorm_store_stats(memo, cols, rows, stats, s);
 }
 
 }  // namespace
@@ -428,7 +435,6 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     const std::string p = "tdnnf" + std::to_string(l + 2);
     name(p + ".linear", L.lin_out, L.lin.rows_out, L.bn);
     name(p + ".relu", L.relu_out, L.aff.rows_out, Hd);
-    name(p + ".batchnorm", L.bn_out, L.aff.rows_out, Hd);
     name(p + ".noop", L.noop_out, L.aff.rows_out, Hd);
   }
   name("prefinal-l", n->prefinal_l_out, n->Tout * B, S);
@@ -528,12 +534,17 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   tdnnf_mat lda_in = M(n->lda_in, N0, lda_dim), lda_out = M(n->lda_out, N0, lda_dim);
   CK(tdnnf_splice_input(feats, ivectors, B, 3, &lda_in, s));
   CK(tdnnf_affine_propagate(&lda_in, Wp(n, n->c_lda), lda_dim, Bp(n, n->c_lda), lda_dim, &lda_out, s));
-  tdnnf_mat t1r = M(n->t1_relu, N0, Hd);
-  CK(tdnnf_affine_propagate(&lda_out, Wp(n, n->tdnn1.comp), lda_dim, Bp(n, n->tdnn1.comp), Hd, &t1r, s));
-  CK(tdnnf_relu_propagate(&t1r, &t1r, s));
-  CK(bn_fwd(n, n->t1_relu, n->t1_bn, N0, Hd, n->t1_bn_memo, n->t1_bn_stats, s));
+  tdnnf_tdnn_indexes ix1;
+  memset(&ix1, 0, sizeof(ix1));
+  ix1.row_stride = 1;
+  ix1.num_offsets = 1;
+  tdnnf_mat t1r = M(n->t1_relu, N0, Hd), t1b = M(n->t1_bn, N0, Hd);
+  const MatView none{nullptr, 0, 0, 0};
+  // tdnn1: affine (+bias, ReLU in the GEMM epilogue) -> BatchNorm
+  CK(tdnn_propagate_impl(&ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, 1, 1, &t1r, s));
+  CK(bn_stats(n, n->t1_relu, N0, Hd, n->t1_bn_memo, n->t1_bn_stats, s));
+  TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, none, 0.f, view(&t1b), s));
   float *prev = n->t1_bn;
-  Grid prev_grid = n->g_lda;
   for (auto &L : n->layers) {
     tdnnf_mat in = M(prev, N_of(L.gin, B), Hd);
     tdnnf_mat lin = M(L.lin_out, L.lin.rows_out, L.bn);
@@ -544,30 +555,27 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_reorder_rows(&lin, B, L.aff.ix.row_stride, 1, &aff_in, s));
     }
     tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
-    CK(tdnnf_tdnn_propagate(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), nullptr, 1, &relu, s));
-    CK(tdnnf_relu_propagate(&relu, &relu, s));
-    CK(bn_fwd(n, L.relu_out, L.bn_out, L.aff.rows_out, Hd, L.bn_memo, L.bn_stats, s));
-    // noop = Sum(Scale(bypass, input), batchnorm)  (dropout-proportion 0 -> GeneralDropout is a copy)
+    CK(tdnn_propagate_impl(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), nullptr, 1, 1, &relu, s));
+    CK(bn_stats(n, L.relu_out, L.aff.rows_out, Hd, L.bn_memo, L.bn_stats, s));
+    // noop = Sum(Scale(bypass, input), batchnorm(relu))  in one pass (dropout-proportion 0 -> GeneralDropout is a copy)
     tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
-    tdnnf_mat bno = M(L.bn_out, L.aff.rows_out, Hd), out = M(L.noop_out, L.aff.rows_out, Hd);
-    if (byp.rows != out.rows) {  // strided bypass rows: view both as (n, B*stride) super rows
-      bno = tdnnf_mat{L.bn_out, L.gout.n, byp.cols, B * ((Hd + 3) & ~3)};
+    tdnnf_mat x = relu, out = M(L.noop_out, L.aff.rows_out, Hd);
+    if (byp.rows != out.rows) {  // strided bypass rows: view everything as (n, B*stride) super rows
+      x = tdnnf_mat{L.relu_out, L.gout.n, byp.cols, B * ((Hd + 3) & ~3)};
       out = tdnnf_mat{L.noop_out, L.gout.n, byp.cols, B * ((Hd + 3) & ~3)};
     }
-    CK(tdnnf_sum_scaled(&byp, c.bypass_scale, &bno, 1.0f, &out, s));
+    TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, view(&byp), c.bypass_scale, view(&out), s));
     prev = L.noop_out;
-    prev_grid = L.gout;
   }
-  (void)prev_grid;
   const int No = n->Tout * B;
   tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
   CK(tdnnf_affine_propagate(&top, Wp(n, n->c_prefinal_l), Hd, nullptr, S, &pl, s));
   for (int h = 0; h < 2; h++) {
     auto &H = n->head[h];
     tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), y = M(H.y, No, P);
-    CK(tdnnf_affine_propagate(&pl, Wp(n, H.c_affine), S, Bp(n, H.c_affine), Hd, &ar, s));
-    CK(tdnnf_relu_propagate(&ar, &ar, s));
-    CK(bn_fwd(n, H.aff_relu, H.bn1_out, No, Hd, H.bn1_memo, H.bn1_stats, s));
+    CK(tdnn_propagate_impl(&ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, 1, 1, &ar, s));
+    CK(bn_stats(n, H.aff_relu, No, Hd, H.bn1_memo, H.bn1_stats, s));
+    TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, none, 0.f, view(&b1), s));
     CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
     CK(bn_fwd(n, H.lin_out, H.bn2_out, No, S, H.bn2_memo, H.bn2_stats, s));
     CK(tdnnf_affine_propagate(&b2, Wp(n, H.c_output), S, Bp(n, H.c_output), P, &y, s));
@@ -583,30 +591,30 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   CK(tdnnf_log_softmax_backprop(&lsm, &dx, &dx, s));
 
   // ================================================================= backward
-  // relu helper: deriv through relu (+ self-repair and stats with the reference's coin flips)
-  auto relu_bwd = [&](float *relu_out, float *d, int rows, double *stats) -> int {
-    tdnnf_mat ro = M(relu_out, rows, Hd), dm = M(d, rows, Hd);
-    CK(tdnnf_relu_backprop(&ro, &dm, &dm, s));
-    if (c.relu_self_repair_scale > 0.f && coin()) CK(tdnnf_relu_repair(stats, Hd, c.relu_self_repair_scale, 0.05f, 0.95f, &dm, s));
-    if (coin() || step == 0) CK(tdnnf_relu_store_stats(&ro, stats, n->ws, n->ws_bytes, s));
+  // BatchNorm backward + ReLU backward (+ StoreStats / self-repair coin flips as in the reference:
+  // RectifiedLinearComponent::StoreStats nnet-simple-component.cc:1084, RepairGradients :1017) in two fused
+  // passes; also yields the bias gradient of the affine layer in front of the ReLU.
+  auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc) -> int {
+    const bool store = coin() || step == 0;
+    const bool repair = c.relu_self_repair_scale > 0.f && coin();
+    tdnnf_mat x = M(relu_out, rows, Hd), d = M(d_io, rows, Hd);
+    TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
+                          n->ws, n->ws_bytes, s));
     return TDNNF_OK;
   };
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
   for (int h = 0; h < 2; h++) {
     auto &H = n->head[h];
     tdnnf_mat dout = h == 0 ? dy : dx;
-    tdnnf_mat b2 = M(H.bn2_out, No, S), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), ar = M(H.aff_relu, No, Hd);
+    tdnnf_mat b2 = M(H.bn2_out, No, S), b1 = M(H.bn1_out, No, Hd);
     tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
     CK(tdnnf_affine_update_simple(&b2, &dout, 1.0f, Wg(n, H.c_output), S, Bg(n, H.c_output), n->ws, n->ws_bytes, s));
     CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
     CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
     CK(tdnnf_affine_update_simple(&b1, &d_b2, 1.0f, Wg(n, H.c_linear), Hd, nullptr, n->ws, n->ws_bytes, s));
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
-    CK(tdnnf_batchnorm_backprop(&b1, &d_b1, 1.0f, H.bn1_memo, &d_b1, n->ws, n->ws_bytes, s));  // -> d relu
-    CK(relu_bwd(H.aff_relu, n->dA, No, H.relu_stats));
-    CK(tdnnf_affine_update_simple(&pl, &d_b1, 1.0f, Wg(n, H.c_affine), S, Bg(n, H.c_affine), n->ws, n->ws_bytes, s));
-    (void)lo;
-    (void)ar;
+    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, Bg(n, H.c_affine)));  // dA -> d affine out
+    CK(tdnnf_affine_update_simple(&pl, &d_b1, 1.0f, Wg(n, H.c_affine), S, nullptr, n->ws, n->ws_bytes, s));
     if (h == 0) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
     } else {
@@ -625,40 +633,50 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TdnnfLayer &L = n->layers[l];
     float *in_act = l > 0 ? n->layers[l - 1].noop_out : n->t1_bn;
     const int no = L.aff.rows_out, nl = L.lin.rows_out, ni = N_of(L.gin, B);
-    tdnnf_mat d_out = M(d_cur, no, Hd), d_relu = M(n->dC, no, Hd);
-    tdnnf_mat bno = M(L.bn_out, no, Hd);
-    CK(tdnnf_batchnorm_backprop(&bno, &d_out, 1.0f, L.bn_memo, &d_relu, n->ws, n->ws_bytes, s));
-    CK(relu_bwd(L.relu_out, n->dC, no, L.relu_stats));  // dC = deriv w.r.t. affine output
+    // d_cur is needed again for the bypass term, so the derivative w.r.t. the affine output goes to dC
+    tdnnf_mat d_out = M(d_cur, no, Hd), d_aff = M(n->dC, no, Hd);
+    {
+      const bool store = coin() || step == 0;
+      const bool repair = c.relu_self_repair_scale > 0.f && coin();
+      tdnnf_mat x = M(L.relu_out, no, Hd);
+      TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, L.relu_stats, store, repair, c.relu_self_repair_scale,
+                            view(&d_aff), Bg(n, L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
+    }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : lin;
-    CK(tdnnf_tdnn_update_simple(&L.aff.ix, &aff_in, &d_relu, Hd, L.bn, nullptr, 1.0f, Wg(n, L.aff.comp), L.aff.K * L.bn,
-                                Bg(n, L.aff.comp), n->ws, n->ws_bytes, s));
+    CK(tdnnf_tdnn_update_simple(&L.aff.ix, &aff_in, &d_aff, Hd, L.bn, nullptr, 1.0f, Wg(n, L.aff.comp), L.aff.K * L.bn, nullptr,
+                                n->ws, n->ws_bytes, s));
     tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
-    TDNNF_HIP(hipMemsetAsync(d_lin.data, 0, sizeof(float) * (size_t)nl * d_lin.stride, s));
-    CK(tdnnf_tdnn_backprop_data(&L.aff.ix, &d_relu, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, nullptr, &d_lin, s));
-    if (L.perm) {
+    if (L.perm) {  // rho > 1: some row classes receive no tap -> zero first, then add; un-permute afterwards
+      TDNNF_HIP(hipMemsetAsync(d_lin.data, 0, sizeof(float) * (size_t)nl * d_lin.stride, s));
+      CK(tdnnf_tdnn_backprop_data(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, nullptr, &d_lin, s));
       tdnnf_mat un = M(n->d_small2, nl, L.bn);
       CK(tdnnf_reorder_rows(&d_lin, B, L.aff.ix.row_stride, 0, &un, s));
       d_lin = un;
+    } else {
+      CK(tdnn_backprop_data_impl(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, nullptr, 1, nullptr, 0.f, 0, &d_lin, s));
     }
     tdnnf_mat in = M(in_act, ni, Hd);
     CK(tdnnf_tdnn_update_simple(&L.lin.ix, &in, &d_lin, L.bn, Hd, nullptr, 1.0f, Wg(n, L.lin.comp), L.lin.K * Hd, nullptr, n->ws,
                                 n->ws_bytes, s));
-    // deriv w.r.t. the layer input = linear backprop + bypass_scale * d_out on the output-grid rows
+    // deriv w.r.t. the layer input = linear backprop (overwrites) + bypass_scale * d_out on the output-grid rows
     tdnnf_mat d_in = M(d_next, ni, Hd);
-    TDNNF_HIP(hipMemsetAsync(d_in.data, 0, sizeof(float) * (size_t)ni * d_in.stride, s));
-    CK(tdnnf_tdnn_backprop_data(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, &d_in, s));
     tdnnf_mat d_byp = sub_grid_view(d_next, L.gin, L.gout, B, Hd);
-    tdnnf_mat d_o = d_out;
-    if (d_byp.rows != d_o.rows) d_o = tdnnf_mat{d_cur, L.gout.n, d_byp.cols, B * ((Hd + 3) & ~3)};
-    CK(tdnnf_add_scaled(&d_o, c.bypass_scale, &d_byp, s));
+    if (d_byp.rows == d_out.rows) {  // contiguous rows: fused into the GEMM epilogue
+      const int row0 = (int)((d_byp.data - d_in.data) / d_in.stride);
+      CK(tdnn_backprop_data_impl(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, 1, &d_out, c.bypass_scale, row0,
+                                 &d_in, s));
+    } else {
+      CK(tdnn_backprop_data_impl(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, 1, nullptr, 0.f, 0, &d_in, s));
+      tdnnf_mat d_o = tdnnf_mat{d_cur, L.gout.n, d_byp.cols, B * ((Hd + 3) & ~3)};
+      CK(tdnnf_add_scaled(&d_o, c.bypass_scale, &d_byp, s));
+    }
     std::swap(d_cur, d_next);
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
-    tdnnf_mat d_out = M(d_cur, N0, Hd), d_relu = M(n->dC, N0, Hd), bno = M(n->t1_bn, N0, Hd);
-    CK(tdnnf_batchnorm_backprop(&bno, &d_out, 1.0f, n->t1_bn_memo, &d_relu, n->ws, n->ws_bytes, s));
-    CK(relu_bwd(n->t1_relu, n->dC, N0, n->t1_relu_stats));
-    CK(tdnnf_affine_update_simple(&lda_out, &d_relu, 1.0f, Wg(n, n->tdnn1.comp), lda_dim, Bg(n, n->tdnn1.comp), n->ws, n->ws_bytes, s));
+    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, Bg(n, n->tdnn1.comp)));
+    tdnnf_mat d_aff = M(d_cur, N0, Hd);
+    CK(tdnnf_affine_update_simple(&lda_out, &d_aff, 1.0f, Wg(n, n->tdnn1.comp), lda_dim, nullptr, n->ws, n->ws_bytes, s));
   }
   return TDNNF_OK;
 }

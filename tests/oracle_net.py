@@ -233,12 +233,14 @@ class OracleNet:
         def relu_bwd(key, relu_out, d):
             dd = ((relu_out > 0) * d).astype(F)
             st = self.relu_stats.setdefault(key, dict(count=0.0, vs=np.zeros(relu_out.shape[1]), ds=np.zeros(relu_out.shape[1])))
-            if cfg.relu_self_repair_scale > 0 and coin():
-                Lb.oracle_relu_repair(ora.dptr(st["ds"]), st["count"], relu_out.shape[1], cfg.relu_self_repair_scale, 0.05, 0.95, ora.omat(dd))
+            # reference order: StoreStats runs with the forward pass (w.p. 1/2, always on the first minibatch,
+            # nnet-simple-component.cc:1084), RepairGradients in Backprop (w.p. 1/2, :1017) sees the updated stats
             if coin() or step == 0:
                 cnt = C.c_double(st["count"])
                 Lb.oracle_relu_store_stats(ora.omat(relu_out), ora.dptr(st["vs"]), ora.dptr(st["ds"]), C.byref(cnt))
                 st["count"] = cnt.value
+            if cfg.relu_self_repair_scale > 0 and coin():
+                Lb.oracle_relu_repair(ora.dptr(st["ds"]), st["count"], relu_out.shape[1], cfg.relu_self_repair_scale, 0.05, 0.95, ora.omat(dd))
             return dd
 
         d_pl = None
