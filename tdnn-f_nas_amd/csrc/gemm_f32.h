@@ -33,6 +33,12 @@ struct RowsGemmArgs {
   long long ldadd;
   float add_scale;
   int add_lo, add_hi;
+  // split-K over the concatenated reduction range (set by rows_gemm() for the tail tiles of a launch whose
+  // tile count does not fill whole rounds of resident blocks): block (tile, sp) reduces K-elements
+  // [sp*kchunk, (sp+1)*kchunk) and stores its raw partial tile to partial[sp][m][n] (ld = N rounded up to 4).
+  int ksplit;       // 0/1: no split
+  int kchunk;       // multiple of the kernel's K step
+  float *partial;
   int nseg;
   GemmSeg seg[kMaxSeg];
 };

@@ -97,6 +97,12 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
+  int sp = 0;
+  if (p.ksplit > 1) {  // split-K launch: consecutive block ids share a tile
+    sp = blockIdx.x % p.ksplit;
+    bid = blockIdx.x / p.ksplit;
+  }
+  const long long k_begin = (long long)sp * p.kchunk, k_end = p.ksplit > 1 ? k_begin + p.kchunk : (1LL << 60);
   const int tile_m = bid / ntn, tile_n = bid % ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -112,15 +118,25 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   // ---- K iterator over (segment, chunk), skipping zero-coefficient segments
+  // (a split-K block only visits the part of each segment inside its [k_begin, k_end) slice)
   int seg = -1, kc = 0, klen = 0;
+  long long seg_kstart = 0, seg_knext = 0;
   float cf = 1.f;
   auto next_seg = [&]() {
     for (++seg; seg < p.nseg; ++seg) {
+      seg_kstart = seg_knext;
+      seg_knext += p.seg[seg].klen;
       cf = p.coef ? p.coef[seg] : 1.f;
-      if (cf != 0.f && p.seg[seg].klen > 0) break;
+      const long long lo = k_begin > seg_kstart ? k_begin - seg_kstart : 0;
+      const long long hi = k_end < seg_knext ? k_end - seg_kstart : p.seg[seg].klen;
+      if (cf != 0.f && hi > lo) {
+        kc = (int)lo;
+        klen = (int)hi;
+        return;
+      }
     }
     kc = 0;
-    klen = seg < p.nseg ? p.seg[seg].klen : 0;
+    klen = 0;
   };
   next_seg();
 
@@ -261,6 +277,11 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       const int m = m0 + pass * HALF + row, n = n0 + c4;
       if (m >= p.M || n >= p.N) continue;
       float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDCS + c4);
+      if (p.ksplit > 1) {  // raw partial tile; the reduce kernel applies the epilogue
+        const int ldp = (p.N + 3) & ~3;
+        *reinterpret_cast<float4 *>(p.partial + ((long long)sp * p.M + m) * ldp + n) = v;
+        continue;
+      }
       float *c = p.C + (long long)m * p.ldc + n;
       if (cvec && n + 3 < p.N) {
         if (p.init_mode == 1) {
@@ -324,6 +345,126 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 }  // namespace
 
+namespace {
+
+// epilogue of a split-K tail: C[m][n] = f(sum_sp partial[sp][m][n]) with the same init/bias/addend/ReLU rules
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const RowsGemmArgs p) {
+  const int ldp = (p.N + 3) & ~3;
+  const long long total = (long long)p.M * p.N;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int m = (int)(e / p.N), n = (int)(e % p.N);
+    float v = 0.f;
+    for (int sp = 0; sp < p.ksplit; sp++) v += p.partial[((long long)sp * p.M + m) * ldp + n];
+    float *c = p.C + (long long)m * p.ldc + n;
+    if (p.init_mode == 1) v += p.bias[n];
+    else if (p.init_mode == 0) v += *c;
+    if (p.add && m >= p.add_lo && m < p.add_hi) v += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n];
+    if (p.relu) v = fmaxf(v, 0.f);
+    *c = v;
+  }
+}
+
+template <int WM, int WN, int TM, int TN, int BK>
+int rows_slots() {  // resident blocks on the chip for this tile variant
+  // 2 blocks per CU for both variants: the 128x128 tile is LDS-bound (73.7 KiB of 160), the 128x160 tile is
+  // register-bound (91 VGPR + 80 AGPR -> 176 allocated -> 2 waves per SIMD).  The occupancy API answers 3 for
+  // the latter (MI355X_MICROARCH.md: it can over-report), measured residency is 2 (511 vs 513 tiles).
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    slots = 2 * cus;
+    (void)hipGetLastError();
+  }
+  return slots;
+}
+
+// scratch for split-K partial tiles: allocated once, on first use (64 MiB covers slots x BM x BN floats)
+constexpr size_t kScratchBytes = 64u << 20;
+float *splitk_scratch() {
+  static float *buf = nullptr;
+  static bool tried = false;
+  if (!tried) {
+    tried = true;
+    if (hipMalloc((void **)&buf, kScratchBytes) != hipSuccess) buf = nullptr;
+    (void)hipGetLastError();
+  }
+  return buf;
+}
+
+template <int WM, int WN, int TM, int TN, int BK>
+hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int cls, double flops, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  const int tiles = ntm * ntn, slots = rows_slots<WM, WN, TM, TN, BK>();
+  const int q = tiles / slots, r = tiles % slots;
+  long long ktot = 0;
+  bool k4 = true;
+  for (int i = 0; i < a.nseg; i++) {
+    ktot += a.seg[i].klen;
+    k4 = k4 && a.seg[i].klen % 4 == 0;
+  }
+  // All blocks run equally long, so q*slots + r tiles cost q+1 rounds.  When the last round would be less than
+  // half full, finish the last rows with a split-K launch that spreads them over every CU instead.
+  const int main_mt = (q * slots) / ntn;  // full tile rows handled by the plain launch
+  float *scratch = nullptr;
+  if (q >= 1 && r > 0 && 2 * r <= slots && main_mt > 0 && main_mt < ntm && k4 && ktot >= 8 * BK && (scratch = splitk_scratch())) {
+    const int m_main = main_mt * BM;
+    RowsGemmArgs am = a;
+    am.M = m_main;
+    {
+      ProfScope ps(cls, flops * m_main / a.M, s);
+      hipError_t e = launch_rows<WM, WN, TM, TN, BK>(am, b_kc, vec, s);
+      if (e != hipSuccess) return e;
+    }
+    RowsGemmArgs at = a;
+    at.M = a.M - m_main;
+    at.A = a.A + (long long)m_main * a.lda;
+    at.C = a.C + (long long)m_main * a.ldc;
+    for (int i = 0; i < at.nseg; i++) {
+      at.seg[i].m_lo -= m_main;
+      at.seg[i].m_hi -= m_main;
+    }
+    at.add_lo -= m_main;
+    at.add_hi -= m_main;
+    const int tail_tiles = ((at.M + BM - 1) / BM) * ntn;
+    const long long kt = (ktot + BK - 1) / BK;
+    int S = slots / tail_tiles;
+    if (S > kt / 2) S = (int)(kt / 2);
+    const size_t need = sizeof(float) * (size_t)S * at.M * ((a.N + 3) & ~3);
+    if (S >= 2 && need <= kScratchBytes) {
+      at.kchunk = (int)(((kt + S - 1) / S) * BK);
+      at.ksplit = (int)((ktot + at.kchunk - 1) / at.kchunk);
+      at.partial = scratch;
+      {
+        ProfScope ps(cls, flops * at.M / a.M, s);
+        constexpr size_t lds_kc = sizeof(float) * 2 * (BM * (BK + 4) + BN * (BK + 4));
+        constexpr size_t lds_nc = sizeof(float) * 2 * (BM * (BK + 4) + BK * (BN + 4));
+        dim3 grid(tail_tiles * at.ksplit), block(256);
+        const int tntm = (at.M + BM - 1) / BM;
+        if (b_kc) {
+          if (vec) hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 4>), grid, block, lds_kc, s, at, tntm, ntn);
+          else hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 1>), grid, block, lds_kc, s, at, tntm, ntn);
+        } else {
+          if (vec) hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, false, 4>), grid, block, lds_nc, s, at, tntm, ntn);
+          else hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, false, 1>), grid, block, lds_nc, s, at, tntm, ntn);
+        }
+        const long long total = (long long)at.M * at.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, at);
+      }
+      return hipGetLastError();
+    }
+    // tail too small to split: plain launch of the remaining rows
+    ProfScope ps(cls, flops * at.M / a.M, s);
+    return launch_rows<WM, WN, TM, TN, BK>(at, b_kc, vec, s);
+  }
+  ProfScope ps(cls, flops, s);
+  return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
+}
+
+}  // namespace
+
 hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   if (a_in.M <= 0 || a_in.N <= 0 || a_in.nseg <= 0) return hipSuccess;
   RowsGemmArgs a = a_in;
@@ -338,12 +479,8 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     const int lo = a.seg[i].m_lo > 0 ? a.seg[i].m_lo : 0, hi = a.seg[i].m_hi < a.M ? a.seg[i].m_hi : a.M;
     if (hi > lo) flops += 2.0 * (hi - lo) * a.N * a.seg[i].klen;
   }
-  if (waste160 < waste128) {
-    ProfScope ps(1, flops, s);
-    return launch_rows<4, 1, 1, 5, 16>(a, b_kc, vec, s);
-  }
-  ProfScope ps(0, flops, s);
-  return launch_rows<2, 2, 2, 2, 32>(a, b_kc, vec, s);
+  if (waste160 < waste128) return launch_rows_balanced<4, 1, 1, 5, 16>(a, b_kc, vec, 1, flops, s);
+  return launch_rows_balanced<2, 2, 2, 2, 32>(a, b_kc, vec, 0, flops, s);
 }
 
 // ---------------------------------------------------------------------------- wgrad
