@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(MatView a, MatView b, in
 ColReducePlan colreduce_plan(int rows, int cols) {
   ColReducePlan p;
   const int colblocks = (cols + 255) / 256;
-  int chunks = (2048 + colblocks - 1) / colblocks;
+  int chunks = (1024 + colblocks - 1) / colblocks;  // ~4 blocks per CU
   const int maxc = (rows + 31) / 32;
   if (chunks > maxc) chunks = maxc;
   if (chunks < 1) chunks = 1;
@@ -101,15 +101,22 @@ namespace {
 
 // ---------------------------------------------------------------------------- batchnorm
 // finalize forward stats: memo rows 0 mean, 1 uvar, 2 scale  (nnet-normalize-component.cc:433-445)
-__global__ void bn_fwd_finalize_kernel(const float *partial, int chunks, int D, int N, float epsilon, float target_rms,
-                                       float *memo) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float *partial, int chunks, int D, int N, float epsilon,
+                                                              float target_rms, float *memo) {
+  __shared__ double red[2][4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
   double s = 0, s2 = 0;
-  for (int c = 0; c < chunks; c++) {
-    s += partial[(long long)c * D + d];
-    s2 += partial[((long long)chunks + c) * D + d];
-  }
+  if (d < D)
+    for (int c = tr; c < chunks; c += 4) {
+      s += partial[(long long)c * D + d];
+      s2 += partial[((long long)chunks + c) * D + d];
+    }
+  red[0][tr][tc] = s;
+  red[1][tr][tc] = s2;
+  __syncthreads();
+  if (tr != 0 || d >= D) return;
+  s = (red[0][0][tc] + red[0][1][tc]) + (red[0][2][tc] + red[0][3][tc]);
+  s2 = (red[1][0][tc] + red[1][1][tc]) + (red[1][2][tc] + red[1][3][tc]);
   const float mean = (float)(s / N), uvar = (float)(s2 / N);
   const float var_scale = 1.0f / (target_rms * target_rms);
   float v = var_scale * uvar - var_scale * mean * mean;
@@ -295,12 +302,15 @@ __global__ void relu_repair_kernel(const double *stats, int D, float self_repair
 }
 
 // colsum finalize: acc[c] += scale * sum_chunks partial
-__global__ void colsum_finalize_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
+  __shared__ float red[4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
   float s = 0.f;
-  for (int c = 0; c < chunks; c++) s += partial[(long long)c * D + d];
-  acc[d] += scale * s;
+  if (d < D)
+    for (int c = tr; c < chunks; c += 4) s += partial[(long long)c * D + d];
+  red[tr][tc] = s;
+  __syncthreads();
+  if (tr == 0 && d < D) acc[d] += scale * ((red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]));
 }
 
 // ----------------------------------------------------------------- softmax-style row ops (cols <= 64)
@@ -535,7 +545,7 @@ hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *me
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   hipError_t e = colreduce_partial(1, a, a, (float *)ws, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 255) / 256), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols,
                      a.rows, epsilon, target_rms, memo);
   return hipGetLastError();
 }
@@ -544,7 +554,7 @@ hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t 
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   hipError_t e = colreduce_partial(0, a, a, (float *)ws, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a.cols + 255) / 256), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols, scale, acc);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols, scale, acc);
   return hipGetLastError();
 }
 }  // namespace tdnnf
@@ -565,7 +575,7 @@ int tdnnf_batchnorm_propagate(const tdnnf_mat *in, float epsilon, float target_r
   MatView a = view(in), o = view(out);
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   TDNNF_HIP(colreduce_partial(1, a, a, (float *)ws, s));
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 255) / 256), dim3(256), 0, s, (const float *)ws, pl.chunks,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, s, (const float *)ws, pl.chunks,
                      a.cols, a.rows, epsilon, target_rms, memo);
   const bool vec = vec4_ok(a) && vec4_ok(o) && (reinterpret_cast<uintptr_t>(memo) & 15) == 0;
   const long long work = (long long)a.rows * (vec ? a.cols / 4 : a.cols);
@@ -703,7 +713,7 @@ int tdnnf_constant_function_backprop(const tdnnf_mat *out_deriv, float lr, float
   MatView a = view(out_deriv);
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   TDNNF_HIP(colreduce_partial(0, a, a, (float *)ws, (hipStream_t)stream));
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a.cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float *)ws, pl.chunks, a.cols, 5.0f * lr, output_acc);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float *)ws, pl.chunks, a.cols, 5.0f * lr, output_acc);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }

@@ -101,26 +101,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
 
 // memo rows 3 (var_deriv_mod) and 4 (temp) from the partials (nnet-normalize-component.cc:520-526);
 // optionally the ReLU statistics [count, value_sum[D], deriv_sum[D]] (StoreStatsInternal).
-__global__ void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms, float *memo,
-                                            double *relu_stats) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (relu_stats && d == 0) relu_stats[0] += (double)N;
-  if (d >= D) return;
-  double zz = 0, sd = 0, vs = 0, ds = 0;
-  for (int c = 0; c < chunks; c++) {
-    zz += partial[(long long)c * D + d];
-    sd += partial[((long long)chunks + c) * D + d];
-    if (relu_stats) {
-      vs += partial[((long long)2 * chunks + c) * D + d];
-      ds += partial[((long long)3 * chunks + c) * D + d];
-    }
-  }
+__global__ __launch_bounds__(256) void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms,
+                                                                   float *memo, double *relu_stats) {
+  __shared__ double red[4][4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
+  if (relu_stats && blockIdx.x == 0 && threadIdx.x == 0) relu_stats[0] += (double)N;
+  double q[4] = {0, 0, 0, 0};
+  const int nq = relu_stats ? 4 : 2;
+  if (d < D)
+    for (int c = tr; c < chunks; c += 4)
+      for (int k = 0; k < nq; k++) q[k] += partial[((long long)k * chunks + c) * D + d];
+  for (int k = 0; k < 4; k++) red[k][tr][tc] = q[k];
+  __syncthreads();
+  if (tr != 0 || d >= D) return;
+  for (int k = 0; k < 4; k++) q[k] = (red[k][0][tc] + red[k][1][tc]) + (red[k][2][tc] + red[k][3][tc]);
   const float coeff = -1.0f / (target_rms * target_rms * N);
-  memo[3 * D + d] = (float)(coeff * zz) * memo[2 * D + d];
-  memo[4 * D + d] = (float)(-sd / N);
+  memo[3 * D + d] = (float)(coeff * q[0]) * memo[2 * D + d];
+  memo[4 * D + d] = (float)(-q[1] / N);
   if (relu_stats) {
-    relu_stats[1 + d] += vs;
-    relu_stats[1 + D + d] += ds;
+    relu_stats[1 + d] += q[2];
+    relu_stats[1 + D + d] += q[3];
   }
 }
 
@@ -181,12 +181,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
   }
 }
 
-__global__ void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
+__global__ __launch_bounds__(256) void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
+  __shared__ float red[4][64];
+  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
   float s = 0.f;
-  for (int c = 0; c < chunks; c++) s += partial[(long long)c * D + d];
-  acc[d] += scale * s;
+  if (d < D)
+    for (int c = tr; c < chunks; c += 4) s += partial[(long long)c * D + d];
+  red[tr][tc] = s;
+  __syncthreads();
+  if (tr == 0 && d < D) acc[d] += scale * ((red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]));
 }
 
 }  // namespace
@@ -229,12 +232,12 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, dou
     if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
     else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
   }
-  hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
+  hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(256), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
                      store_relu_stats ? relu_stats : (double *)nullptr);
   const double *rep = self_repair ? relu_stats : nullptr;
   if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);
   else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);
-  if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 255) / 256), dim3(256), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
+  if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 63) / 64), dim3(256), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
   return hipGetLastError();
 }
 
