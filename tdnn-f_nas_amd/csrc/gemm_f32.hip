@@ -60,6 +60,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
+// 16 zero bytes: predicated-off float4 loads of the fast path read here instead of branching
+__device__ float4 g_zero4 = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ float4 ld4(const float *p, bool v0, bool v1, bool v2, bool v3, bool vec) {
   float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
   if (vec && v3) {  // whole float4 in range (validity is monotone in the element index)
@@ -141,7 +144,54 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
   next_seg();
 
   float4 ra[A_F4], rb[B_F4];
+  // Per-segment, per-thread source pointers for the fast path (full K-step inside the segment, float4 loads):
+  // rows/columns that are out of range read 16 zero bytes instead of branching.
+  const float *aptr[A_F4], *bptr[B_F4];
+  int astep[A_F4], bstep[B_F4];
+  int ptr_seg = -1;
+  auto setup_ptrs = [&]() {
+    const GemmSeg sg = p.seg[seg];
+    const float *zero = reinterpret_cast<const float *>(&g_zero4);
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j, row = idx / KF4, m = m0 + row;
+      const bool rv = (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) && m < p.M && m >= sg.m_lo && m < sg.m_hi;
+      aptr[j] = rv ? p.A + sg.a_off + (long long)m * p.lda + (idx % KF4) * 4 : zero;
+      astep[j] = rv ? 1 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; j++) {
+      const int idx = t + 256 * j;
+      bool rv;
+      if (B_KC) {
+        const int n = n0 + idx / KF4;
+        rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n < p.N;
+        bptr[j] = rv ? p.B + sg.b_off + (long long)n * p.ldb + (idx % KF4) * 4 : zero;
+        bstep[j] = rv ? 1 : 0;
+      } else {
+        const int kr = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+        rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n + 3 < p.N;
+        bptr[j] = rv ? p.B + sg.b_off + (long long)kr * p.ldb + n : zero;
+        bstep[j] = rv ? (int)p.ldb : 0;
+      }
+    }
+    ptr_seg = seg;
+  };
+  // !B_KC: a ragged last column group (n + 3 >= N) needs the general path for the whole launch
+  const bool fast_ok = VEC == 4 && (B_KC || p.N % 4 == 0);
   auto load_tile = [&]() {  // global -> registers for chunk (seg, kc)
+    if (fast_ok && kc + BK <= klen) {
+      if (ptr_seg != seg) setup_ptrs();
+#pragma unroll
+      for (int j = 0; j < A_F4; j++) ra[j] = *reinterpret_cast<const float4 *>(aptr[j] + (long long)kc * astep[j]);
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) {
+        float4 v = *reinterpret_cast<const float4 *>(bptr[j] + (long long)kc * bstep[j]);
+        v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
+        rb[j] = v;
+      }
+      return;
+    }
     const GemmSeg sg = p.seg[seg];
     const float *Ab = p.A + sg.a_off;
     const float *Bb = p.B + sg.b_off;
