@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--den-states", type=int, default=4000)
     ap.add_argument("--den-degree", type=float, default=12.0)
-    ap.add_argument("--cpu-sequences", type=int, default=4)
+    ap.add_argument("--cpu-sequences", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

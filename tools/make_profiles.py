@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs under gpurun_out/ into the tracked profiles/ summaries.
+  gpurun_out/<stats_dir>   : rocprofv3 --kernel-trace --stats  (python3 bench.py ...)
+  gpurun_out/pmc_fetch, pmc_write : rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (separate runs)
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half the bytes of a
+wide coalesced read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores."""
+import collections
+import csv
+import glob
+import json
+import re
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+stats_dir = sys.argv[2] if len(sys.argv) > 2 else "prof4"
+
+
+def short(nm):
+    nm = re.sub(r"\(anonymous namespace\)::", "", nm)
+    nm = re.sub(r"tdnnf::", "", nm)
+    return nm.split("(")[0].replace("void ", "")
+
+
+def klass(nm):
+    s = short(nm)
+    if s.startswith("rows_gemm_kernel<2, 2, 2, 2"):
+        return "rows_gemm_f32_128x128"
+    if s.startswith("rows_gemm_kernel<4, 1, 1, 5"):
+        return "rows_gemm_f32_128x160"
+    if s.startswith("wgrad_kernel"):
+        return "wgrad_f32"
+    return s
+
+
+stats = glob.glob(f"gpurun_out/{stats_dir}/*/*_kernel_stats.csv")[0]
+shutil.copy(stats, f"profiles/{tag}_bench_7q_T1500_B128_kernel_stats.csv")
+rows = list(csv.DictReader(open(stats)))
+by = collections.defaultdict(lambda: [0, 0])
+for r in rows:
+    k = klass(r["Name"])
+    by[k][0] += int(r["Calls"])
+    by[k][1] += int(r["TotalDurationNs"])
+tot = sum(v[1] for v in by.values())
+with open(f"profiles/{tag}_bench_7q_T1500_B128_kernel_classes.csv", "w") as f:
+    f.write("kernel_class,calls,total_ms,avg_us,percent\n")
+    for k, (n, ns) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+        f.write(f"{k},{n},{ns / 1e6:.3f},{ns / n / 1e3:.1f},{100.0 * ns / tot:.2f}\n")
+
+
+def load(d):
+    f = glob.glob(f"gpurun_out/{d}/*/*_counter_collection.csv")
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+traffic = collections.defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0))
+for r in load("pmc_fetch"):
+    t = traffic[klass(r["Kernel_Name"])]
+    t["launches"] += 1
+    t["fetch_kb"] += float(r["Counter_Value"])
+for r in load("pmc_write"):
+    traffic[klass(r["Kernel_Name"])]["write_kb"] += float(r["Counter_Value"])
+out = {}
+for k, t in traffic.items():
+    if t["launches"]:
+        out[k] = dict(launches=t["launches"], fetch_size_kb_per_launch=t["fetch_kb"] / t["launches"],
+                      write_size_kb_per_launch=t["write_kb"] / t["launches"],
+                      hbm_bytes_per_launch=(2 * t["fetch_kb"] + t["write_kb"]) * 1024 / t["launches"])
+json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+print("wrote profiles for", tag, "classes:", len(by), "pmc kernels:", len(out))
