@@ -63,7 +63,7 @@ def cpu_baseline(pkg, args):
     feats = rng.standard_normal((net.num_t_in * B, cfg.feat_dim)).astype(np.float32)
     iv = rng.standard_normal((B, cfg.ivector_dim)).astype(np.float32)
     den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
-    sup = pkg.synth.make_supervision(B, T // 3, cfg.num_pdfs, seed=2)
+    sup = pkg.synth.make_supervision_from_den(den, B, T // 3, num_paths=2, seed=2)
     t0 = time.time()
     res, grads, _ = net.forward_backward(params, feats, iv, den, sup, step=0)
     net.update(params, grads, 1e-3, float(B), 0)
@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--den-states", type=int, default=4000)
     ap.add_argument("--den-degree", type=float, default=12.0)
-    ap.add_argument("--cpu-sequences", type=int, default=16)
+    ap.add_argument("--cpu-sequences", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -111,7 +111,7 @@ def main():
     net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
     feats, iv = pkg.trainer.synthetic_egs(net, seed=100 + rank)
     den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
-    sup = pkg.synth.make_supervision(cfg.num_sequences, args.chunk // 3, cfg.num_pdfs, seed=200 + rank)
+    sup = pkg.synth.make_supervision_from_den(den, cfg.num_sequences, args.chunk // 3, num_paths=2, seed=200 + rank)
     dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
     fd, ivd = torch.from_numpy(feats).cuda(), torch.from_numpy(iv).cuda()
     lr = pkg.trainer.learning_rate(0, world, 100, 0, 100)  # 2.5e-4 * num_jobs

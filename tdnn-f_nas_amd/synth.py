@@ -74,6 +74,53 @@ def make_supervision(B, T, P, max_alt=2, seed=0, weight=1.0):
             "arc_logprob": np.asarray(a_lp, dtype=np.float32), "weight": float(weight)}
 
 
+def make_supervision_from_den(den, B, T, num_paths=2, seed=0, weight=1.0):
+    """Numerator graphs whose paths are paths of the denominator graph (as real chain supervisions are, after
+    composition with the normalization FST): per sequence `num_paths` independent random walks on the den graph
+    from one start state drawn from the initial distribution; arc log-weights are the den transition
+    log-probs.  With such supervision log p_num <= log p_den + const, so the LF-MMI objective per frame is
+    (essentially) negative, as in real training."""
+    rng = np.random.default_rng(seed)
+    H = den["H"]
+    order = np.argsort(den["src"], kind="stable")
+    src_sorted = den["src"][order]
+    begin = np.searchsorted(src_sorted, np.arange(H + 1))
+    init = den["init"].astype(np.float64)
+    init = init / init.sum()
+    state_time, final, a_src, a_dst, a_pdf, a_lp = [], [], [], [], [], []
+    seq_state_begin, seq_arc_begin = [0], [0]
+    ns = 0
+    for _ in range(B):
+        h0 = int(rng.choice(H, p=init))
+        # state ids: start, then per frame t = 1..T one state per path
+        state_time.append(0)
+        final.append(-np.inf)
+        for t in range(1, T + 1):
+            for _p in range(num_paths):
+                state_time.append(t)
+                final.append(0.0 if t == T else -np.inf)
+        cur = [h0] * num_paths
+        for t in range(T):
+            for pth in range(num_paths):
+                lo, hi = begin[cur[pth]], begin[cur[pth] + 1]
+                a = order[int(rng.integers(lo, hi))]
+                s_from = ns if t == 0 else ns + 1 + (t - 1) * num_paths + pth
+                s_to = ns + 1 + t * num_paths + pth
+                a_src.append(s_from)
+                a_dst.append(s_to)
+                a_pdf.append(int(den["pdf"][a]))
+                a_lp.append(float(np.log(max(float(den["prob"][a]), 1e-30))))
+                cur[pth] = int(den["dst"][a])
+        ns += 1 + T * num_paths
+        seq_state_begin.append(ns)
+        seq_arc_begin.append(len(a_src))
+    i32 = lambda x: np.asarray(x, dtype=np.int32)
+    return {"B": B, "T": T, "seq_state_begin": i32(seq_state_begin), "seq_arc_begin": i32(seq_arc_begin),
+            "state_time": i32(state_time), "final_logprob": np.asarray(final, dtype=np.float32), "arc_src": i32(a_src),
+            "arc_dst": i32(a_dst), "arc_pdf": i32(a_pdf), "arc_logprob": np.asarray(a_lp, dtype=np.float32),
+            "weight": float(weight)}
+
+
 def tdnn_indexes(time_offsets, num_t_out, B, start_t_in=None, t_step_in=1, t_step_out=1,
                  start_t_out=0):
     """Restates TdnnDARTSV3Component::PrecomputeIndexes for a regular grid
