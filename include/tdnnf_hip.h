@@ -285,6 +285,13 @@ typedef struct {
   float max_change_hidden, max_change_output, max_param_change; /* 0.75, 1.5, 2.0 */
   float relu_self_repair_scale;              /* 1e-5 */
   float batchnorm_stats_scale;               /* 0.8 (ScaleBatchnormStats, UPSTREAM trainer default) */
+  /* DARTS offset-search supernet (run_TDNN_DARTSV3_fbk_stride_pretrain.sh:143-156 + scripts/generate_config.py:8-43):
+     darts_num_offsets = K >= 2 turns every tdnnf layer's .linear / .affine into TdnnDARTSV3Components with offsets
+     -(K-1)..0 / 0..K-1 (time_stride is then ignored), bias forced on, K architecture logits in front of the bias.
+     darts_flags: TDNNF_DARTS_*; the pretrain recipe is TDNNF_DARTS_UNIFORM_SAMPLE (:124). 0 = plain TDNN-F. */
+  int darts_num_offsets;
+  int darts_flags;
+  float darts_temp_proportion;
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 
@@ -295,6 +302,13 @@ int tdnnf_net_num_components(const tdnnf_net *);
 /* name_out: >= 64 bytes.  Weights are rows x cols at [begin, begin + rows*cols), bias (if has_bias) follows. */
 int tdnnf_net_component_info(const tdnnf_net *, int index, char *name_out, long long *begin, int *rows, int *cols,
                              int *has_bias, float *lr_factor, float *l2, float *max_change, float *orthonormal);
+/* DARTS components: number K of architecture logits stored between the weights and the bias
+   (bias_params_[0:K] of the reference, nnet-tdnn-component.cc:172-176); 0 for every other component. */
+int tdnnf_net_component_num_alpha(const tdnnf_net *, int index);
+/* Uniform(0,1) draws consumed by one forward pass of a DARTS net: (K + 1) per DARTS component, in component
+   order (K Gumbel uniforms, then the tap-sample uniform).  The caller fills a device buffer before every step. */
+int tdnnf_net_num_random_draws(const tdnnf_net *);
+int tdnnf_net_set_random_draws(tdnnf_net *, const float *draws_dev);
 /* rows of the t-major feature matrix the net consumes: (frames_per_chunk + left + right context) * B */
 int tdnnf_net_input_frames(const tdnnf_net *, int *num_t_in, int *first_t);
 int tdnnf_net_set_buffers(tdnnf_net *, float *params_dev, float *grads_dev);

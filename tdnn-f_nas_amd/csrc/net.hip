@@ -35,14 +35,19 @@ struct CompDesc {
   long long begin;
   int rows, cols, has_bias;
   float lr_factor, l2, max_change, orthonormal;
-  long long size() const { return (long long)rows * cols + (has_bias ? rows : 0); }
+  int num_alpha;  // DARTS: K architecture logits between the weights and the bias
+  long long size() const { return (long long)rows * cols + num_alpha + (has_bias ? rows : 0); }
 };
 
 struct Tdnn {  // one TdnnComponent instance inside the net
   int comp;    // index into comps
   int Di, Do, K;
-  int offsets[2];
+  int offsets[TDNNF_MAX_OFFSETS];
   Grid in, out;
+  // DARTS (TdnnDARTSV3Component): share index, first random draw, coefficient memo [coef(K) | eff(K)] on device
+  bool darts;
+  int share, draw0;
+  float *memo;
   tdnnf_tdnn_indexes ix;
   int rows_in, rows_out;
 };
@@ -50,7 +55,7 @@ struct Tdnn {  // one TdnnComponent instance inside the net
 struct TdnnfLayer {
   int stride, bn;
   Tdnn lin, aff;
-  Grid gin, gout;
+  Grid gin, gout, glin;
   bool perm;  // affine input needs the rho row order
   int bypass_row0, bypass_rowstep;  // rows of the layer input that line up with the output grid
   // activations (arena)
@@ -72,6 +77,11 @@ __global__ __launch_bounds__(256) void make_delta_kernel(float *grads, const flo
   const float lr = tb.lr[c], l2 = tb.l2coef[c];
   for (long long i = b + blockIdx.x * 256LL + threadIdx.x; i < e; i += gridDim.x * 256LL)
     grads[i] = lr * grads[i] + l2 * params[i];
+}
+// W_acc[o][i*Di + d] += coef[i] * G[o][i*Di + d]   (DARTS: fold the unscaled tap gradients into the accumulator)
+__global__ void add_scaled_taps_kernel(const float *G, const float *coef, float *acc, int Do, int KDi, int Di) {
+  const long long total = (long long)Do * KDi;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) acc[e] += coef[(e % KDi) / Di] * G[e];
 }
 __global__ void scale_doubles_kernel(double *x, int n, double s) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -133,6 +143,10 @@ struct tdnnf_net {
   float *prefinal_l_out;
   float *dA, *dB, *dC, *d_small, *d_small2;  // derivative scratch
   float *d_y, *d_xent;
+  float *tapgrad;      // DARTS: unscaled per-tap weight gradients (Do x K*Di) of the component being processed
+  double *tapdots;     // DARTS: s_i = <dW_i, W_i>
+  const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
+  int num_draws;
   void *ws;
   size_t ws_bytes;
   void *chain_ws;
@@ -144,13 +158,17 @@ namespace {
 
 int N_of(const Grid &g, int B) { return g.n * B; }
 
-void make_tdnn(Tdnn *t, int comp, int Di, int Do, int K, int o0, int o1, const Grid &in, const Grid &out, int B) {
+void make_tdnn(Tdnn *t, int comp, int Di, int Do, const std::vector<int> &offs, const Grid &in, const Grid &out, int B) {
+  const int K = (int)offs.size();
   t->comp = comp;
   t->Di = Di;
   t->Do = Do;
   t->K = K;
-  t->offsets[0] = o0;
-  t->offsets[1] = o1;
+  t->darts = false;
+  t->share = 0;
+  t->draw0 = 0;
+  t->memo = nullptr;
+  for (int i = 0; i < K; i++) t->offsets[i] = offs[i];
   t->in = in;
   t->out = out;
   memset(&t->ix, 0, sizeof(t->ix));
@@ -182,8 +200,9 @@ struct Arena {
 };
 
 int add_comp(tdnnf_net *n, const std::string &name, int rows, int cols, int has_bias, float lr_factor, float l2, float mc,
-             float ortho) {
+             float ortho, int num_alpha = 0) {
   CompDesc c;
+  c.num_alpha = num_alpha;
   c.name = name;
   c.begin = n->num_params;
   c.rows = rows;
@@ -202,12 +221,14 @@ int add_comp(tdnnf_net *n, const std::string &name, int rows, int cols, int has_
 float *Wp(const tdnnf_net *n, int comp) { return n->params + n->comps[comp].begin; }
 float *Bp(const tdnnf_net *n, int comp) {
   const CompDesc &c = n->comps[comp];
-  return c.has_bias ? n->params + c.begin + (long long)c.rows * c.cols : nullptr;
+  return c.has_bias ? n->params + c.begin + (long long)c.rows * c.cols + c.num_alpha : nullptr;
 }
+float *Ap(const tdnnf_net *n, int comp) { return n->params + n->comps[comp].begin + (long long)n->comps[comp].rows * n->comps[comp].cols; }
+float *Ag(const tdnnf_net *n, int comp) { return n->grads + n->comps[comp].begin + (long long)n->comps[comp].rows * n->comps[comp].cols; }
 float *Wg(const tdnnf_net *n, int comp) { return n->grads + n->comps[comp].begin; }
 float *Bg(const tdnnf_net *n, int comp) {
   const CompDesc &c = n->comps[comp];
-  return c.has_bias ? n->grads + c.begin + (long long)c.rows * c.cols : nullptr;
+  return c.has_bias ? n->grads + c.begin + (long long)c.rows * c.cols + c.num_alpha : nullptr;
 }
 
 // carve (or, with base == nullptr, just size) every activation buffer
@@ -231,6 +252,8 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     L.relu_out = A.mat(no, Hd);
     L.noop_out = A.mat(no, Hd);
     L.bn_memo = A.take<float>(5 * Hd);
+    L.lin.memo = L.lin.darts ? A.take<float>(2 * TDNNF_MAX_OFFSETS) : nullptr;
+    L.aff.memo = L.aff.darts ? A.take<float>(2 * TDNNF_MAX_OFFSETS) : nullptr;
     L.bn_stats = A.take<double>(1 + 2 * Hd);
     L.relu_stats = A.take<double>(1 + 2 * Hd);
     max_rows = std::max(max_rows, std::max(no, N_of(L.gin, B)));
@@ -259,6 +282,11 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->dC = A.mat(max_rows, Hd);
   n->d_small = A.mat(std::max(max_lin_rows, No), std::max(S, 512));
   n->d_small2 = A.mat(std::max(max_lin_rows, No), std::max(S, 512));
+  size_t tg = 0;
+  for (auto &L : n->layers)
+    if (L.lin.darts) tg = std::max(tg, (size_t)L.bn * L.lin.K * Hd);
+  n->tapgrad = tg ? A.take<float>(tg) : nullptr;
+  n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   // shared workspace: wgrad slabs, column reductions, orthonormal
   size_t ws = 0;
   auto upd = [&](size_t b) { ws = std::max(ws, b); };
@@ -339,6 +367,10 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
   TDNNF_REQUIRE(c.feat_dim > 0 && c.ivector_dim > 0 && c.num_pdfs > 0 && c.hidden_dim > 0 && c.prefinal_small_dim > 0,
                 "net_create: dims must be positive");
   TDNNF_REQUIRE(c.num_layers >= 1 && c.num_layers <= TDNNF_NET_MAX_LAYERS, "net_create: 1..%d tdnnf layers", TDNNF_NET_MAX_LAYERS);
+  TDNNF_REQUIRE(c.darts_num_offsets == 0 || (c.darts_num_offsets >= 2 && c.darts_num_offsets <= TDNNF_MAX_OFFSETS),
+                "net_create: darts_num_offsets must be 0 or 2..%d (the reference assumes K >= 2, nnet-tdnn-component.cc:232)", TDNNF_MAX_OFFSETS);
+  TDNNF_REQUIRE(c.darts_num_offsets == 0 || !(c.darts_flags & TDNNF_DARTS_USE_GUMBEL) || c.darts_temp_proportion > 0,
+                "net_create: gumbel mode needs temp-proportion > 0");
   TDNNF_REQUIRE(c.frame_subsampling >= 1 && c.frames_per_chunk > 0 && c.frames_per_chunk % c.frame_subsampling == 0 && c.num_sequences > 0,
                 "net_create: frames_per_chunk must be a positive multiple of frame_subsampling");
   tdnnf_net *n = new tdnnf_net();
@@ -361,7 +393,19 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     L.gout = g;
     L.perm = false;
     Grid lin = g, in = g;
-    if (L.stride > 0) {
+    const int Kd = c.darts_num_offsets;
+    if (Kd >= 2) {
+      // offset supernet: taps -(K-1)..0 / 0..K-1 at the input frame rate on every layer
+      if (g.step == 1) {
+        lin = Grid{g.t0, 1, g.n + Kd - 1};
+      } else {
+        const int rho = g.step;
+        const int cnt = rho * (g.n - 1) + Kd;
+        lin = Grid{g.t0, 1, ((cnt + rho - 1) / rho) * rho};  // padded to a multiple of rho (:841-843)
+        L.perm = true;
+      }
+      in = Grid{lin.t0 - (Kd - 1), 1, lin.n + Kd - 1};
+    } else if (L.stride > 0) {
       const int s = L.stride;
       if (s % g.step == 0) {
         lin = Grid{g.t0, g.step, g.n + s / g.step};
@@ -373,6 +417,7 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
       TDNNF_REQUIRE(s % lin.step == 0, "net_create: layer %d: unsupported stride combination", l);
       in = Grid{lin.t0 - s, lin.step, lin.n + s / lin.step};
     }
+    L.glin = lin;
     L.gin = in;
     g = in;
   }
@@ -382,20 +427,44 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
   // ---- components, in nnet3 config order
   n->c_lda = add_comp(n, "lda", lda_dim, lda_dim, 1, 0.f, 0.f, 0.f, 0.f);
   const int c_t1 = add_comp(n, "tdnn1.affine", Hd, lda_dim, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f);
-  make_tdnn(&n->tdnn1, c_t1, lda_dim, Hd, 1, 0, 0, n->g_lda, n->g_lda, B);
+  make_tdnn(&n->tdnn1, c_t1, lda_dim, Hd, std::vector<int>{0}, n->g_lda, n->g_lda, B);
+  n->num_draws = 0;
+  n->draws = nullptr;
   for (int l = 0; l < c.num_layers; l++) {
     TdnnfLayer &L = n->layers[l];
-    const int K = L.stride > 0 ? 2 : 1;
+    const int Kd = c.darts_num_offsets;
+    const bool darts = Kd >= 2;
+    const int K = darts ? Kd : (L.stride > 0 ? 2 : 1);
+    std::vector<int> lin_off, aff_off;
+    if (darts) {
+      for (int i = 0; i < K; i++) {
+        lin_off.push_back(-(K - 1) + i);
+        aff_off.push_back(i);
+      }
+    } else if (K == 2) {
+      lin_off = {-L.stride, 0};
+      aff_off = {0, L.stride};
+    } else {
+      lin_off = {0};
+      aff_off = {0};
+    }
     char nm[64];
     snprintf(nm, sizeof(nm), "tdnnf%d.linear", l + 2);
-    const int cl = add_comp(n, nm, L.bn, K * Hd, 0, 1.f, c.l2_hidden, c.max_change_hidden, -1.0f);
+    // DARTS: bias forced on (scripts/generate_config.py:25-26), K logits in front of it, and the orthonormal
+    // constraint is inert because ConstrainOrthonormal does not match TdnnDARTSV3Component (nnet-utils.cc:1047-1061)
+    const int cl = add_comp(n, nm, L.bn, K * Hd, darts ? 1 : 0, 1.f, c.l2_hidden, c.max_change_hidden, darts ? 0.f : -1.0f, darts ? K : 0);
     snprintf(nm, sizeof(nm), "tdnnf%d.affine", l + 2);
-    const int ca = add_comp(n, nm, Hd, K * L.bn, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f);
-    Grid lin_grid = L.gout;
-    if (L.stride > 0) lin_grid = L.perm ? Grid{L.gout.t0, L.stride, (L.gout.step / L.stride) * L.gout.n}
-                                        : Grid{L.gout.t0, L.gout.step, L.gout.n + L.stride / L.gout.step};
-    make_tdnn(&L.lin, cl, Hd, L.bn, K, K == 2 ? -L.stride : 0, 0, L.gin, lin_grid, B);
-    make_tdnn(&L.aff, ca, L.bn, Hd, K, 0, K == 2 ? L.stride : 0, lin_grid, L.gout, B);
+    const int ca = add_comp(n, nm, Hd, K * L.bn, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f, darts ? K : 0);
+    make_tdnn(&L.lin, cl, Hd, L.bn, lin_off, L.gin, L.glin, B);
+    make_tdnn(&L.aff, ca, L.bn, Hd, aff_off, L.glin, L.gout, B);
+    if (darts) {
+      L.lin.darts = L.aff.darts = true;
+      L.lin.share = K - 1;  // time_offsets_[1] < 0  (nnet-tdnn-component.cc:237-240)
+      L.aff.share = 0;      // time_offsets_[1] > 0  (:232-236)
+      L.lin.draw0 = n->num_draws;
+      L.aff.draw0 = n->num_draws + K + 1;
+      n->num_draws += 2 * (K + 1);
+    }
   }
   n->c_prefinal_l = add_comp(n, "prefinal-l", S, Hd, 0, 1.f, c.l2_hidden, c.max_change_hidden, -1.0f);
   const char *hn[2] = {"chain", "xent"};
@@ -468,6 +537,16 @@ int tdnnf_net_component_info(const tdnnf_net *n, int i, char *name_out, long lon
   if (l2) *l2 = c.l2;
   if (max_change) *max_change = c.max_change;
   if (orthonormal) *orthonormal = c.orthonormal;
+  return TDNNF_OK;
+}
+
+int tdnnf_net_component_num_alpha(const tdnnf_net *n, int i) {
+  return n && i >= 0 && i < (int)n->comps.size() ? n->comps[i].num_alpha : 0;
+}
+int tdnnf_net_num_random_draws(const tdnnf_net *n) { return n ? n->num_draws : 0; }
+int tdnnf_net_set_random_draws(tdnnf_net *n, const float *draws) {
+  TDNNF_REQUIRE(n && (draws || n->num_draws == 0), "net_set_random_draws: null argument");
+  n->draws = draws;
   return TDNNF_OK;
 }
 
@@ -548,14 +627,26 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   for (auto &L : n->layers) {
     tdnnf_mat in = M(prev, N_of(L.gin, B), Hd);
     tdnnf_mat lin = M(L.lin_out, L.lin.rows_out, L.bn);
-    CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, nullptr, 2, &lin, s));
+    const float *lin_eff = nullptr, *aff_eff = nullptr;
+    if (L.lin.darts) {  // TdnnDARTSV3Component::Propagate :250-289 for both components of the layer
+      TDNNF_REQUIRE(n->draws, "net_forward_backward: a DARTS net needs net_set_random_draws before every step");
+      for (Tdnn *td : {&L.lin, &L.aff}) {
+        const float *u = n->draws + td->draw0;
+        CK(tdnnf_tdnn_darts_coef(Ap(n, td->comp), td->K, c.darts_flags, c.darts_temp_proportion, u, u + td->K, td->share, td->memo,
+                                 td->memo + TDNNF_MAX_OFFSETS, s));
+      }
+      lin_eff = L.lin.memo + TDNNF_MAX_OFFSETS;
+      aff_eff = L.aff.memo + TDNNF_MAX_OFFSETS;
+    }
+    // (DARTS .linear: bias present but offsets[1] < 0 -> out is zeroed and the bias never added, :237-240)
+    CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, lin_eff, 2, &lin, s));
     tdnnf_mat aff_in = lin;
     if (L.perm) {
       aff_in = M(L.lin_perm, L.lin.rows_out, L.bn);
       CK(tdnnf_reorder_rows(&lin, B, L.aff.ix.row_stride, 1, &aff_in, s));
     }
     tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
-    CK(tdnn_propagate_impl(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), nullptr, 1, 1, &relu, s));
+    CK(tdnn_propagate_impl(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, 1, 1, &relu, s));
     CK(bn_stats(n, L.relu_out, L.aff.rows_out, Hd, L.bn_memo, L.bn_stats, s));
     // noop = Sum(Scale(bypass, input), batchnorm(relu))  in one pass (dropout-proportion 0 -> GeneralDropout is a copy)
     tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
@@ -644,30 +735,48 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : lin;
-    CK(tdnnf_tdnn_update_simple(&L.aff.ix, &aff_in, &d_aff, Hd, L.bn, nullptr, 1.0f, Wg(n, L.aff.comp), L.aff.K * L.bn, nullptr,
-                                n->ws, n->ws_bytes, s));
+    const float *lin_eff = L.lin.darts ? L.lin.memo + TDNNF_MAX_OFFSETS : nullptr;
+    const float *aff_eff = L.aff.darts ? L.aff.memo + TDNNF_MAX_OFFSETS : nullptr;
+    // weight gradient of one Tdnn component.  DARTS in a non-sampling mode also needs the architecture-logit
+    // gradient (UpdateNaturalGradient :516-590): tap gradients are formed unscaled once, s_i = <dW_i, W_i>
+    // replaces the reference's extra forward GEMM per tap, then c_i * dW_i goes into the accumulator.
+    auto tdnn_wgrad = [&](Tdnn &td, tdnnf_mat *x, tdnnf_mat *dy, const float *eff) -> int {
+      const int ldw = td.K * td.Di;
+      if (td.darts && !(c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE)) {
+        TDNNF_HIP(hipMemsetAsync(n->tapgrad, 0, sizeof(float) * (size_t)td.Do * ldw, s));
+        CK(tdnnf_tdnn_update_simple(&td.ix, x, dy, td.Do, td.Di, nullptr, 1.0f, n->tapgrad, ldw, nullptr, n->ws, n->ws_bytes, s));
+        CK(tdnnf_tdnn_darts_alpha_update(n->tapgrad, ldw, Wp(n, td.comp), ldw, td.Do, td.Di, td.K, td.memo, c.darts_flags, td.share,
+                                         c.darts_temp_proportion, 1.0f, Ag(n, td.comp), n->tapdots, s));
+        hipLaunchKernelGGL(add_scaled_taps_kernel, dim3(grid_for((long long)td.Do * ldw, 256)), dim3(256), 0, s, n->tapgrad, eff,
+                           Wg(n, td.comp), td.Do, ldw, td.Di);
+        return TDNNF_OK;
+      }
+      return tdnnf_tdnn_update_simple(&td.ix, x, dy, td.Do, td.Di, eff, 1.0f, Wg(n, td.comp), ldw, nullptr, n->ws, n->ws_bytes, s);
+    };
+    CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff));
     tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
     if (L.perm) {  // rho > 1: some row classes receive no tap -> zero first, then add; un-permute afterwards
       TDNNF_HIP(hipMemsetAsync(d_lin.data, 0, sizeof(float) * (size_t)nl * d_lin.stride, s));
-      CK(tdnnf_tdnn_backprop_data(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, nullptr, &d_lin, s));
+      CK(tdnnf_tdnn_backprop_data(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, aff_eff, &d_lin, s));
       tdnnf_mat un = M(n->d_small2, nl, L.bn);
       CK(tdnnf_reorder_rows(&d_lin, B, L.aff.ix.row_stride, 0, &un, s));
       d_lin = un;
     } else {
-      CK(tdnn_backprop_data_impl(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, nullptr, 1, nullptr, 0.f, 0, &d_lin, s));
+      CK(tdnn_backprop_data_impl(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, aff_eff, 1, nullptr, 0.f, 0, &d_lin, s));
     }
     tdnnf_mat in = M(in_act, ni, Hd);
-    CK(tdnnf_tdnn_update_simple(&L.lin.ix, &in, &d_lin, L.bn, Hd, nullptr, 1.0f, Wg(n, L.lin.comp), L.lin.K * Hd, nullptr, n->ws,
-                                n->ws_bytes, s));
+    CK(tdnn_wgrad(L.lin, &in, &d_lin, lin_eff));
+    if (L.lin.darts)  // the (never added) bias of a DARTS .linear is still updated by the reference (:614); raw-gradient reading
+      TDNNF_HIP(colsum_add(view(&d_lin), 1.0f, Bg(n, L.lin.comp), n->ws, s));
     // deriv w.r.t. the layer input = linear backprop (overwrites) + bypass_scale * d_out on the output-grid rows
     tdnnf_mat d_in = M(d_next, ni, Hd);
     tdnnf_mat d_byp = sub_grid_view(d_next, L.gin, L.gout, B, Hd);
     if (d_byp.rows == d_out.rows) {  // contiguous rows: fused into the GEMM epilogue
       const int row0 = (int)((d_byp.data - d_in.data) / d_in.stride);
-      CK(tdnn_backprop_data_impl(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, 1, &d_out, c.bypass_scale, row0,
+      CK(tdnn_backprop_data_impl(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, lin_eff, 1, &d_out, c.bypass_scale, row0,
                                  &d_in, s));
     } else {
-      CK(tdnn_backprop_data_impl(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, 1, nullptr, 0.f, 0, &d_in, s));
+      CK(tdnn_backprop_data_impl(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, lin_eff, 1, nullptr, 0.f, 0, &d_in, s));
       tdnnf_mat d_o = tdnnf_mat{d_cur, L.gout.n, d_byp.cols, B * ((Hd + 3) & ~3)};
       CK(tdnnf_add_scaled(&d_o, c.bypass_scale, &d_byp, s));
     }

@@ -23,7 +23,10 @@ class NetConfig(C.Structure):
                 ("frame_subsampling", C.c_int), ("leaky_hmm", C.c_float), ("xent_regularize", C.c_float),
                 ("chain_l2_regularize", C.c_float), ("l2_hidden", C.c_float), ("l2_output", C.c_float),
                 ("max_change_hidden", C.c_float), ("max_change_output", C.c_float), ("max_param_change", C.c_float),
-                ("relu_self_repair_scale", C.c_float), ("batchnorm_stats_scale", C.c_float)]
+                ("relu_self_repair_scale", C.c_float), ("batchnorm_stats_scale", C.c_float),
+                ("darts_num_offsets", C.c_int), ("darts_flags", C.c_int), ("darts_temp_proportion", C.c_float)]
+
+DARTS_USE_GUMBEL, DARTS_FREE_SELECT, DARTS_UNIFORM_SAMPLE, DARTS_USE_ENTROPY, DARTS_UPDATE_ALPHA = 1, 2, 4, 8, 16
 
 
 # time strides of the fixed 7q net (run_tdnn_fbk_40_iv_sp_7q.sh:171-184) and of the "manual" variant
@@ -47,6 +50,10 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
     c.max_change_hidden, c.max_change_output, c.max_param_change = 0.75, 1.5, 2.0
     c.relu_self_repair_scale = kw.get("relu_self_repair_scale", 1.0e-5)
     c.batchnorm_stats_scale = kw.get("batchnorm_stats_scale", 0.8)
+    # DARTS offset supernet: run_TDNN_DARTSV3_fbk_stride_pretrain.sh <K> (pretrain flags :124 = uniform-sample)
+    c.darts_num_offsets = kw.get("darts_num_offsets", 0)
+    c.darts_flags = kw.get("darts_flags", DARTS_UNIFORM_SAMPLE if c.darts_num_offsets else 0)
+    c.darts_temp_proportion = kw.get("darts_temp_proportion", 1.0)
     return c
 
 
@@ -72,11 +79,15 @@ class ChainNet:
                                                            C.byref(hb), C.byref(lrf), C.byref(l2), C.byref(mc), C.byref(orth)))
             self.components.append(dict(name=name.value.decode(), begin=begin.value, rows=rows.value, cols=cols.value,
                                         has_bias=hb.value, lr_factor=lrf.value, l2=l2.value, max_change=mc.value,
-                                        orthonormal=orth.value))
+                                        orthonormal=orth.value, num_alpha=self.lib.tdnnf_net_component_num_alpha(self.h, i)))
         nt, t0 = C.c_int(), C.c_int()
         hipabi.check(self.lib.tdnnf_net_input_frames(self.h, C.byref(nt), C.byref(t0)))
         self.num_t_in, self.first_t = nt.value, t0.value
         self.results = torch.zeros(8, dtype=torch.float64, device="cuda")
+        self.num_draws = self.lib.tdnnf_net_num_random_draws(self.h)
+        self.draws = torch.full((max(self.num_draws, 1),), 0.5, dtype=torch.float32, device="cuda")
+        if self.num_draws:
+            hipabi.check(self.lib.tdnnf_net_set_random_draws(self.h, hipabi.ptr(self.draws)))
 
     def close(self):
         if self.h:
@@ -110,9 +121,20 @@ class ChainNet:
                 W = (rng.standard_normal((c["rows"], c["cols"])) / np.sqrt(c["cols"])).astype(np.float32)
                 b = rng.standard_normal(c["rows"]).astype(np.float32)
             p[c["begin"]:c["begin"] + n] = W.ravel()
+            n += c.get("num_alpha", 0)  # architecture logits start at 0 (nnet-tdnn-component.cc:176)
             if c["has_bias"]:
                 p[c["begin"] + n:c["begin"] + n + c["rows"]] = b
         return p
+
+    def set_random_draws(self, draws=None, generator=None):
+        """Uniform(0,1) draws for the DARTS components of the next step (inputs, for reproducibility)."""
+        import torch
+        if not self.num_draws:
+            return
+        if draws is None:
+            self.draws.copy_(torch.rand(self.num_draws, device="cuda", generator=generator).clamp_(1e-6, 1 - 1e-6))
+        else:
+            self.draws.copy_(torch.as_tensor(draws, dtype=torch.float32))
 
     def set_params(self, flat):
         import torch

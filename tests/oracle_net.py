@@ -34,9 +34,20 @@ class OracleNet:
         # grids (t0, step, n), derived backwards from the output grid (0, sub, Tout)
         g = (0, self.sub, self.Tout)
         self.layers = []
+        self.Kd = int(getattr(cfg, "darts_num_offsets", 0))
         for s in reversed(strides):
             out = g
-            if s == 0:
+            if self.Kd >= 2:  # offset supernet: taps -(K-1)..0 / 0..K-1 at the input frame rate
+                K = self.Kd
+                if out[1] == 1:
+                    lin = (out[0], 1, out[2] + K - 1)
+                else:
+                    rho = out[1]
+                    cnt = rho * (out[2] - 1) + K
+                    lin = (out[0], 1, -(-cnt // rho) * rho)
+                inn = (lin[0] - (K - 1), 1, lin[2] + K - 1)
+                s = None
+            elif s == 0:
                 lin = inn = out
             else:
                 if s % out[1] == 0:
@@ -59,8 +70,13 @@ class OracleNet:
 
     def b(self, p, name):
         c = self.comp[name]
-        n = c["rows"] * c["cols"]
+        n = c["rows"] * c["cols"] + c.get("num_alpha", 0)
         return p[c["begin"] + n:c["begin"] + n + c["rows"]] if c["has_bias"] else None
+
+    def alpha(self, p, name):
+        c = self.comp[name]
+        n = c["rows"] * c["cols"]
+        return p[c["begin"] + n:c["begin"] + n + c.get("num_alpha", 0)]
 
     def _indexes(self, offsets, gin, gout):
         rho, ro, rows_in, rows_out = self.pkg.synth.tdnn_indexes(offsets, gout[2], self.B, start_t_in=gin[0], t_step_in=gin[1],
@@ -68,26 +84,45 @@ class OracleNet:
         assert rows_in <= gin[2] * self.B, (rows_in, gin)
         return rho, ro
 
-    def _tdnn_fwd(self, x, W, bias, offsets, gin, gout):
+    def _tdnn_fwd(self, x, W, bias, offsets, gin, gout, eff=None):
         rho, ro = self._indexes(offsets, gin, gout)
         Do, K = W.shape[0], len(offsets)
         Di = W.shape[1] // K
         y = np.zeros((gout[2] * self.B, Do), F)
         self.L.oracle_tdnn_propagate(ora.omat(x), ora.fptr(W), W.shape[1], Do, Di, K, rho, ora.iptr(ro),
-                                     ora.fptr(bias) if bias is not None else None, None, 1 if bias is not None else 2, ora.omat(y))
+                                     ora.fptr(bias) if bias is not None else None, ora.fptr(eff) if eff is not None else None,
+                                     1 if bias is not None else 2, ora.omat(y))
         return y
 
-    def _tdnn_bwd(self, x, dy, W, Wg, bg, offsets, gin, gout, want_dx=True):
+    def _tdnn_bwd(self, x, dy, W, Wg, bg, offsets, gin, gout, want_dx=True, eff=None, darts=None):
         rho, ro = self._indexes(offsets, gin, gout)
         Do, K = W.shape[0], len(offsets)
         Di = W.shape[1] // K
-        self.L.oracle_tdnn_update_simple(ora.omat(x), ora.omat(dy), Do, Di, K, rho, ora.iptr(ro), None, 1.0, ora.fptr(Wg),
+        pe = ora.fptr(eff) if eff is not None else None
+        if darts is not None and not (self.cfg.darts_flags & 4):
+            # architecture-logit update of UpdateNaturalGradient (nnet-tdnn-component.cc:516-590), lr folded in later
+            sdots = np.zeros(K)
+            self.L.oracle_tdnn_darts_tap_dots(ora.omat(x), ora.omat(dy), ora.fptr(W), W.shape[1], Do, Di, K, rho, ora.iptr(ro), ora.dptr(sdots))
+            acc = np.ascontiguousarray(darts["alpha_grad"])
+            self.L.oracle_tdnn_darts_alpha_update(ora.dptr(sdots), ora.fptr(darts["coef"]), K, self.cfg.darts_flags, darts["share"],
+                                                  self.cfg.darts_temp_proportion, 1.0, ora.fptr(acc))
+            darts["alpha_grad"][:] = acc
+        self.L.oracle_tdnn_update_simple(ora.omat(x), ora.omat(dy), Do, Di, K, rho, ora.iptr(ro), pe, 1.0, ora.fptr(Wg),
                                          W.shape[1], ora.fptr(bg) if bg is not None else None)
         if not want_dx:
             return None
         dx = np.zeros_like(x)
-        self.L.oracle_tdnn_backprop_data(ora.omat(dy), ora.fptr(W), W.shape[1], Do, Di, K, rho, ora.iptr(ro), None, ora.omat(dx))
+        self.L.oracle_tdnn_backprop_data(ora.omat(dy), ora.fptr(W), W.shape[1], Do, Di, K, rho, ora.iptr(ro), pe, ora.omat(dx))
         return dx
+
+    def _darts_coef(self, log_alpha, draws, share):
+        K = len(log_alpha)
+        coef, eff = np.zeros(K, F), np.zeros(K, F)
+        la = np.ascontiguousarray(log_alpha, dtype=F)
+        u = np.ascontiguousarray(draws[:K], dtype=F)
+        self.L.oracle_tdnn_darts_coef(ora.fptr(la), K, self.cfg.darts_flags, self.cfg.darts_temp_proportion, ora.fptr(u), float(draws[K]), ora.fptr(coef))
+        self.L.oracle_tdnn_darts_effective_coef(ora.fptr(coef), K, self.cfg.darts_flags, share, ora.fptr(eff))
+        return coef, eff
 
     def _bn_fwd(self, key, x):
         z = np.zeros_like(x)
@@ -117,7 +152,7 @@ class OracleNet:
         return (tau[:, None] * self.B + np.arange(self.B)[None, :]).ravel()
 
     # ------------------------------------------------------------ one minibatch
-    def forward_backward(self, params, feats, ivectors, den, sup, step=0, fixed_xent_post=None, forward_only=False):
+    def forward_backward(self, params, feats, ivectors, den, sup, step=0, fixed_xent_post=None, forward_only=False, draws=None):
         cfg, B, Lb = self.cfg, self.B, self.L
         p = params
         grads = np.zeros_like(p)
@@ -147,18 +182,27 @@ class OracleNet:
             s = Ly["stride"]
             Wlin = np.ascontiguousarray(self.W(p, nm + ".linear"))
             Waff, baff = np.ascontiguousarray(self.W(p, nm + ".affine")), np.ascontiguousarray(self.b(p, nm + ".affine"))
-            lin_off, aff_off = ([-s, 0], [0, s]) if s > 0 else ([0], [0])
-            lin = self._tdnn_fwd(prev, Wlin, None, lin_off, Ly["inn"], Ly["lin"])
+            dl = da = None
+            if self.Kd >= 2:
+                K = self.Kd
+                lin_off, aff_off = list(range(-(K - 1), 1)), list(range(0, K))
+                d0 = 2 * (K + 1) * i
+                cl, el = self._darts_coef(self.alpha(p, nm + ".linear"), draws[d0:d0 + K + 1], K - 1)
+                ca, ea = self._darts_coef(self.alpha(p, nm + ".affine"), draws[d0 + K + 1:d0 + 2 * K + 2], 0)
+                dl, da = dict(coef=cl, eff=el, share=K - 1), dict(coef=ca, eff=ea, share=0)
+            else:
+                lin_off, aff_off = ([-s, 0], [0, s]) if s > 0 else ([0], [0])
+            lin = self._tdnn_fwd(prev, Wlin, None, lin_off, Ly["inn"], Ly["lin"], eff=dl["eff"] if dl else None)
             rho = Ly["out"][1] // Ly["lin"][1]
             aff_in = self._to_rho(lin, rho) if rho > 1 else lin
-            aff = self._tdnn_fwd(aff_in, Waff, baff, aff_off, Ly["lin"], Ly["out"])
+            aff = self._tdnn_fwd(aff_in, Waff, baff, aff_off, Ly["lin"], Ly["out"], eff=da["eff"] if da else None)
             relu = np.maximum(aff, 0)
             bn, memo = self._bn_fwd(nm, relu)
             rows = self._rows_on(Ly["inn"], Ly["out"])
             out = (F(cfg.bypass_scale) * prev[rows] + bn).astype(F)
             acts[nm + ".linear"], acts[nm + ".relu"], acts[nm + ".batchnorm"], acts[nm + ".noop"] = lin, relu, bn, out
             store.append(dict(inp=prev, lin=lin, aff_in=aff_in, relu=relu, bn=bn, memo=memo, rows=rows, rho=rho,
-                              lin_off=lin_off, aff_off=aff_off, Wlin=Wlin, Waff=Waff))
+                              lin_off=lin_off, aff_off=aff_off, Wlin=Wlin, Waff=Waff, dl=dl, da=da))
             prev = out
         No = self.Tout * B
         Wpl = np.ascontiguousarray(self.W(p, "prefinal-l"))
@@ -213,8 +257,13 @@ class OracleNet:
 
         def Gb(name):
             c = self.comp[name]
-            n = c["rows"] * c["cols"]
+            n = c["rows"] * c["cols"] + c.get("num_alpha", 0)
             return grads[c["begin"] + n:c["begin"] + n + c["rows"]] if c["has_bias"] else None
+
+        def Ga(name):
+            c = self.comp[name]
+            n = c["rows"] * c["cols"]
+            return grads[c["begin"] + n:c["begin"] + n + c.get("num_alpha", 0)]
 
         def affine_bwd(x, dyy, W, name, want_dx=True):
             Wg = np.ascontiguousarray(Gw(name))
@@ -261,13 +310,22 @@ class OracleNet:
             d_aff = relu_bwd(nm, st["relu"], d_relu)
             Wg, bgv = np.ascontiguousarray(Gw(nm + ".affine")), Gb(nm + ".affine")
             bg = np.ascontiguousarray(bgv)
-            d_affin = self._tdnn_bwd(st["aff_in"], d_aff, st["Waff"], Wg, bg, st["aff_off"], Ly["lin"], Ly["out"])
+            da, dl = st["da"], st["dl"]
+            if da:
+                da["alpha_grad"] = Ga(nm + ".affine")
+                dl["alpha_grad"] = Ga(nm + ".linear")
+            d_affin = self._tdnn_bwd(st["aff_in"], d_aff, st["Waff"], Wg, bg, st["aff_off"], Ly["lin"], Ly["out"],
+                                     eff=da["eff"] if da else None, darts=da)
             Gw(nm + ".affine")[:] = Wg
             bgv[:] = bg
             d_lin = self._to_rho(d_affin, st["rho"], inverse=True) if st["rho"] > 1 else d_affin
             Wg = np.ascontiguousarray(Gw(nm + ".linear"))
-            d_in = self._tdnn_bwd(st["inp"], d_lin, st["Wlin"], Wg, None, st["lin_off"], Ly["inn"], Ly["lin"])
+            blin = np.ascontiguousarray(Gb(nm + ".linear")) if dl else None  # DARTS .linear: inert bias, still updated
+            d_in = self._tdnn_bwd(st["inp"], d_lin, st["Wlin"], Wg, blin, st["lin_off"], Ly["inn"], Ly["lin"],
+                                  eff=dl["eff"] if dl else None, darts=dl)
             Gw(nm + ".linear")[:] = Wg
+            if dl:
+                Gb(nm + ".linear")[:] = blin
             d_in[st["rows"]] += F(cfg.bypass_scale) * d_cur
             d_cur = d_in
         d_relu = self._bn_bwd(t1_bn, d_cur, t1_memo)

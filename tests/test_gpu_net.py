@@ -22,11 +22,27 @@ CASES = [
 ]
 
 
+# DARTS offset supernet (BASELINE configs[3], run_TDNN_DARTSV3_fbk_stride_pretrain.sh): every coefficient mode
+_D = dict(frames_per_chunk=18, num_sequences=3, strides=[1, 1, 1, 1], bottleneck=16, feat_dim=40, ivector_dim=100,
+          num_pdfs=120, hidden_dim=64, small_dim=32)
+CASES += [
+    ("darts-k7-uniform-pretrain", dict(_D, darts_num_offsets=7, darts_flags=4), 40),
+    ("darts-k7-softmax", dict(_D, darts_num_offsets=7, darts_flags=0), 40),
+    ("darts-k4-gumbel-entropy-updatealpha", dict(_D, darts_num_offsets=4, darts_flags=1 | 8 | 16, darts_temp_proportion=0.7), 40),
+    ("darts-k3-freeselect", dict(_D, darts_num_offsets=3, darts_flags=2), 40),
+]
+
+
 @pytest.mark.parametrize("name,kw,H", CASES, ids=[c[0] for c in CASES])
 def test_net_step_matches_oracle(pkg, name, kw, H):
     cfg = pkg.trainer.make_config(**kw)
     net = pkg.trainer.ChainNet(cfg)
     params = net.init_params_numpy(seed=3, output_stddev=0.3)
+    if cfg.darts_num_offsets:  # non-trivial architecture logits
+        rng = np.random.default_rng(17)
+        for c in net.components:
+            n = c["rows"] * c["cols"]
+            params[c["begin"] + n:c["begin"] + n + c["num_alpha"]] = rng.standard_normal(c["num_alpha"]).astype(np.float32) * 0.5
     net.set_params(params)
     ref = OracleNet(pkg, cfg, net.components)
     assert ref.num_t_in == net.num_t_in
@@ -36,7 +52,9 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
     dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
     fd, ivd = dev(feats), dev(iv)
     for step in (0, 1):  # step 1 exercises ReLU self-repair with stats from step 0
-        res_ref, g_ref, acts = ref.forward_backward(params, feats, iv, den, sup, step=step)
+        draws = np.random.default_rng(100 + step).random(max(net.num_draws, 1)).astype(np.float32)
+        net.set_random_draws(draws)
+        res_ref, g_ref, acts = ref.forward_backward(params, feats, iv, den, sup, step=step, draws=draws)
         net.grads.zero_()
         r = host(net.forward_backward(fd, ivd, dg, ds, step=step))
         for key in ["lda", "tdnn1.batchnorm", "tdnnf2.linear", "tdnnf2.noop", f"tdnnf{cfg.num_layers + 1}.noop", "prefinal-l",
@@ -49,7 +67,7 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
         g = host(net.grads)
         assert rel_l2(g, g_ref) < 1e-3, rel_l2(g, g_ref)
         for c in net.components[1:]:
-            sl = slice(c["begin"], c["begin"] + c["rows"] * c["cols"] + (c["rows"] if c["has_bias"] else 0))
+            sl = slice(c["begin"], c["begin"] + c["rows"] * c["cols"] + c["num_alpha"] + (c["rows"] if c["has_bias"] else 0))
             assert rel_l2(g[sl], g_ref[sl]) < 1e-3, (c["name"], rel_l2(g[sl], g_ref[sl]))
         # optimizer step: L2 + max-change + scheduled orthonormal constraint
         p_ref = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
