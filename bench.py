@@ -85,6 +85,10 @@ def main():
     ap.add_argument("--den-degree", type=float, default=12.0)
     ap.add_argument("--cpu-sequences", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="7q", choices=["7q", "darts-offset"],
+                    help="7q = BASELINE configs[1] (default, the metric's config); darts-offset = configs[3], the K-tap offset "
+                         "supernet of run_TDNN_DARTSV3_fbk_stride_pretrain.sh in pretrain (uniform-sample) mode")
+    ap.add_argument("--darts-offsets", type=int, default=7)
     args = ap.parse_args()
 
     import numpy as np
@@ -105,7 +109,8 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
-    cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch)
+    extra = dict(darts_num_offsets=args.darts_offsets) if args.workload == "darts-offset" else {}
+    cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch, **extra)
     net = pkg.trainer.ChainNet(cfg)
     # identical initial model on every rank (seed), different egs per rank (data parallel over sequences)
     net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
@@ -116,7 +121,11 @@ def main():
     fd, ivd = torch.from_numpy(feats).cuda(), torch.from_numpy(iv).cuda()
     lr = pkg.trainer.learning_rate(0, world, 100, 0, 100)  # 2.5e-4 * num_jobs
 
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(1234)  # same architecture sample on every rank (seed-shared draws)
+
     def step(i):
+        net.set_random_draws(generator=gen)
         net.forward_backward(fd, ivd, dg, ds, step=i)
         net.allreduce_grads()
         # l2 scale: GetNumNvalues * l2_regularize_factor(=1/num_jobs) -> per-GPU sequence count
@@ -167,9 +176,11 @@ def main():
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: run_tdnn_7q fixed TDNN-F (14 tdnnf layers, bottleneck 160, strides 1,1,1,0,3x10, "
-                                   "6034 pdfs, 40-dim fbank + 100-dim ivector), LF-MMI chain objective + xent head, raw-gradient SGD step "
-                                   "with L2, max-change and orthonormal constraint (natural gradient off)",
+            "config": {"workload": ("BASELINE configs[1]: run_tdnn_7q fixed TDNN-F (14 tdnnf layers, bottleneck 160, strides 1,1,1,0,3x10, "
+                                    "6034 pdfs, 40-dim fbank + 100-dim ivector), LF-MMI chain objective + xent head, raw-gradient SGD step "
+                                    "with L2, max-change and orthonormal constraint (natural gradient off)") if args.workload == "7q" else
+                                   (f"BASELINE configs[3]: DARTS offset supernet, {args.darts_offsets} taps per TdnnDARTSV3 component, "
+                                    "pretrain mode (uniform tap sample per layer and minibatch), otherwise as configs[1]"),
                        "frames_per_chunk": args.chunk, "sequences_per_gpu": cfg.num_sequences, "global_batch": world * cfg.num_sequences,
                        "den_graph": {"states": args.den_states, "arcs": int(len(den["src"]))},
                        "parallelism": f"dp{world}", "objf_per_frame": float(res[0] / res[2]) if res[2] else None},

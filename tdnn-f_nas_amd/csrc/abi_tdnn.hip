@@ -187,9 +187,13 @@ size_t tdnnf_tdnn_update_workspace_bytes(int Do, int Di, int K, int num_rows) {
   return wgrad_workspace_bytes(Do, Di, K, num_rows);
 }
 
-int tdnnf_tdnn_update_simple(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int Do,
-                             int Di, const float *eff_coef, float lr, float *W_acc, int ldw, float *bias_acc, void *ws,
-                             size_t ws_bytes, tdnnf_stream stream) {
+}  // extern "C"
+
+namespace tdnnf {
+// active_dev / max_active: optional compacted list of the taps with a non-zero coefficient (gemm_f32.h)
+int tdnn_update_simple_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int Do,
+                            int Di, const float *eff_coef, float lr, float *W_acc, int ldw, float *bias_acc, void *ws,
+                            size_t ws_bytes, const int *active_dev, int max_active, tdnnf_stream stream) {
   TDNNF_REQUIRE(mat_ok(in_value) && mat_ok(out_deriv) && W_acc, "tdnn_update_simple: bad matrices");
   TDNNF_REQUIRE(Do > 0 && Di > 0 && in_value->cols == Di && out_deriv->cols == Do, "tdnn_update_simple: bad dims");
   TDNNF_REQUIRE(tdnn_rows_ok(ix, in_value->rows, out_deriv->rows), "tdnn_update_simple: in_value has too few rows for the time offsets");
@@ -214,8 +218,19 @@ int tdnnf_tdnn_update_simple(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_v
   a.ldg = ldw;
   a.accumulate = 1;
   a.bias_acc = bias_acc;
+  a.active = active_dev;
+  a.max_active = max_active;
   TDNNF_HIP(wgrad(a, ws, ws_bytes, (hipStream_t)stream));
   return TDNNF_OK;
+}
+}  // namespace tdnnf
+
+extern "C" {
+
+int tdnnf_tdnn_update_simple(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int Do,
+                             int Di, const float *eff_coef, float lr, float *W_acc, int ldw, float *bias_acc, void *ws,
+                             size_t ws_bytes, tdnnf_stream stream) {
+  return tdnn_update_simple_impl(ix, in_value, out_deriv, Do, Di, eff_coef, lr, W_acc, ldw, bias_acc, ws, ws_bytes, nullptr, 0, stream);
 }
 
 // AffineComponent::Propagate (nnet-simple-component.cc:1235-1244); bias NULL = LinearComponent :3211-3216

@@ -73,6 +73,9 @@ hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t 
 // trainer-internal variants of the TDNN entry points (abi_tdnn.hip)
 int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
                         const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream);
+int tdnn_update_simple_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int Do, int Di,
+                            const float *eff_coef, float lr, float *W_acc, int ldw, float *bias_acc, void *ws, size_t ws_bytes,
+                            const int *active_dev, int max_active, tdnnf_stream stream);
 int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_deriv, const float *W, int ldw, int Do, int Di,
                             const float *eff_coef, int overwrite, const tdnnf_mat *add, float add_scale, int add_lo,
                             tdnnf_mat *in_deriv, tdnnf_stream stream);

@@ -61,8 +61,12 @@ struct WgradArgs {
   long long ldg;
   int accumulate;     // 1: G += ..., 0: G = ...
   float *bias_acc;    // optional: bias_acc[o] += scale * sum_r dY[r][o]
+  // optional compaction of the taps with a non-zero coefficient (DARTS uniform-sample mode: <= 2 of K taps):
+  // active[0] = count n, active[1..n] = tap ids (device memory); max_active bounds n on the host.
+  const int *active;
+  int max_active;
 };
-size_t wgrad_workspace_bytes(int Do, int Di, int K, int N);
+size_t wgrad_workspace_bytes(int Do, int Di, int K, int N);  // valid for any max_active <= K
 hipError_t wgrad(const WgradArgs &args, void *workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace tdnnf

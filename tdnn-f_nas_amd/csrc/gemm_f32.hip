@@ -552,7 +552,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, 
   int bid = blockIdx.x;  // tile id; blockIdx.y = row split
   (void)tiles;
   const int tile_m = bid % ntm;
-  const int tap = (bid / ntm) / ntn_tap, tile_n = (bid / ntm) % ntn_tap;
+  int tap = (bid / ntm) / ntn_tap;
+  const int tile_n = (bid / ntm) % ntn_tap;
+  if (p.active) {  // compacted tap list: slots beyond the active count have nothing to do
+    if (tap >= p.active[0]) return;
+    tap = p.active[1 + tap];
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int split = blockIdx.y;
   const int r_begin = split * rows_per_split;
@@ -665,6 +670,7 @@ __global__ void wgrad_reduce_kernel(const float *partial, int splits, int Do, in
     float s = 0.f;
     for (int sp = 0; sp < splits; sp++) s += partial[(long long)sp * total + e];
     const float cf = coef ? coef[c / Di] : 1.f;
+    if (cf == 0.f) continue;  // skipped tap: its slab may not have been written
     float *g = G + (long long)o * ldg + c;
     const float v = scale * cf * s;
     *g = accumulate ? *g + v : v;
@@ -728,7 +734,8 @@ int wgrad_slots(int variant) {
 
 // Split the row (reduction) range so that tiles * splits fills whole rounds of resident blocks: every block
 // runs equally long, so a grid of q*slots + r blocks costs q+1 rounds; we want r == 0 (just under a multiple).
-WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots) {
+WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0) {
+  if (ktaps > 0) { WgradPlan p2 = wgrad_plan(Do, Di, ktaps, N, slots); p2.slab_floats = (size_t)p2.splits * Do * K * Di; return p2; }
   WgradPlan pl;
   const WgradTile wt = wgrad_tile(Do, Di);
   const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
@@ -757,8 +764,10 @@ size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
   // sized for the largest split count any device can ask for (4 rounds of 8 blocks on 304 CUs), so the
   // answer does not depend on the GPU being present
   const WgradTile wt = wgrad_tile(Do, Di);
-  const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
-  size_t max_splits = std::max<size_t>(1, std::min<size_t>((N + 255) / 256, (4 * 8 * 304) / tiles + 1));
+  const int tiles = ((Do + wt.BM - 1) / wt.BM) * 1 * ((Di + wt.BN - 1) / wt.BN);  // worst case: one active tap
+  // wgrad_plan picks one round when tiles <= slots/4 (splits = slots/tiles) and at most 4 rounds otherwise (< 16 splits);
+  // slots <= 1024 on any gfx950 part
+  size_t max_splits = std::max<size_t>(1, std::min<size_t>((N + 255) / 256, std::max<size_t>(1024 / tiles + 1, 16)));
   return sizeof(float) * (max_splits * Do * K * Di) + colreduce_bytes(N, Do) + 64;
 }
 
@@ -766,15 +775,16 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   if (a.N <= 0 || a.Do <= 0 || a.Di <= 0) return hipSuccess;
   if (workspace_bytes < wgrad_workspace_bytes(a.Do, a.Di, a.K, a.N)) return hipErrorInvalidValue;
   const WgradTile wt = wgrad_tile(a.Do, a.Di);
-  WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant));
+  const int ktaps = a.active && a.max_active > 0 && a.max_active < a.K ? a.max_active : a.K;
+  WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant), ktaps == a.K ? 0 : ktaps);
   float *partial = reinterpret_cast<float *>(workspace);
   float *cs_partial = partial + pl.slab_floats;
   const bool vec = aligned16(a.dY) && aligned16(a.X) && a.lddy % 4 == 0 && a.ldx % 4 == 0;
   const int ntm = (a.Do + wt.BM - 1) / wt.BM, ntn = (a.Di + wt.BN - 1) / wt.BN;
-  dim3 grid(ntm * a.K * ntn, pl.splits), block(256);
+  dim3 grid(ntm * ktaps * ntn, pl.splits), block(256);
   const size_t lds = sizeof(float) * 2 * (32 * (wt.BM + 4) + 32 * (wt.BN + 4));
   {
-    ProfScope ps(2, 2.0 * a.N * a.Do * a.K * a.Di, s);
+    ProfScope ps(2, 2.0 * a.N * a.Do * ktaps * a.Di, s);
 #define WG_LAUNCH(WM, WN, TM, TN)                                                                                              \
   if (vec) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 4>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial); \
   else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 1>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);

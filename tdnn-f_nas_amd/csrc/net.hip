@@ -48,6 +48,7 @@ struct Tdnn {  // one TdnnComponent instance inside the net
   bool darts;
   int share, draw0;
   float *memo;
+  int *active;  // device: [count, tap ids...] of the non-zero taps (uniform-sample mode)
   tdnnf_tdnn_indexes ix;
   int rows_in, rows_out;
 };
@@ -82,6 +83,14 @@ __global__ __launch_bounds__(256) void make_delta_kernel(float *grads, const flo
 __global__ void add_scaled_taps_kernel(const float *G, const float *coef, float *acc, int Do, int KDi, int Di) {
   const long long total = (long long)Do * KDi;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) acc[e] += coef[(e % KDi) / Di] * G[e];
+}
+// active[0] = number of taps with a non-zero effective coefficient, active[1..] = their ids
+__global__ void active_taps_kernel(const float *eff, int K, int *active) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int n = 0;
+  for (int i = 0; i < K; i++)
+    if (eff[i] != 0.f) active[1 + n++] = i;
+  active[0] = n;
 }
 __global__ void scale_doubles_kernel(double *x, int n, double s) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -168,6 +177,7 @@ void make_tdnn(Tdnn *t, int comp, int Di, int Do, const std::vector<int> &offs, 
   t->share = 0;
   t->draw0 = 0;
   t->memo = nullptr;
+  t->active = nullptr;
   for (int i = 0; i < K; i++) t->offsets[i] = offs[i];
   t->in = in;
   t->out = out;
@@ -254,6 +264,8 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     L.bn_memo = A.take<float>(5 * Hd);
     L.lin.memo = L.lin.darts ? A.take<float>(2 * TDNNF_MAX_OFFSETS) : nullptr;
     L.aff.memo = L.aff.darts ? A.take<float>(2 * TDNNF_MAX_OFFSETS) : nullptr;
+    L.lin.active = L.lin.darts ? A.take<int>(TDNNF_MAX_OFFSETS + 1) : nullptr;
+    L.aff.active = L.aff.darts ? A.take<int>(TDNNF_MAX_OFFSETS + 1) : nullptr;
     L.bn_stats = A.take<double>(1 + 2 * Hd);
     L.relu_stats = A.take<double>(1 + 2 * Hd);
     max_rows = std::max(max_rows, std::max(no, N_of(L.gin, B)));
@@ -634,6 +646,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
         const float *u = n->draws + td->draw0;
         CK(tdnnf_tdnn_darts_coef(Ap(n, td->comp), td->K, c.darts_flags, c.darts_temp_proportion, u, u + td->K, td->share, td->memo,
                                  td->memo + TDNNF_MAX_OFFSETS, s));
+        hipLaunchKernelGGL(active_taps_kernel, dim3(1), dim3(64), 0, s, td->memo + TDNNF_MAX_OFFSETS, td->K, td->active);
       }
       lin_eff = L.lin.memo + TDNNF_MAX_OFFSETS;
       aff_eff = L.aff.memo + TDNNF_MAX_OFFSETS;
@@ -751,7 +764,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                            Wg(n, td.comp), td.Do, ldw, td.Di);
         return TDNNF_OK;
       }
-      return tdnnf_tdnn_update_simple(&td.ix, x, dy, td.Do, td.Di, eff, 1.0f, Wg(n, td.comp), ldw, nullptr, n->ws, n->ws_bytes, s);
+      // uniform-sample mode: only the share tap and the sampled tap are non-zero (:293-304) -> compacted launch
+      const bool compact = td.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && td.K > 2;
+      return tdnn_update_simple_impl(&td.ix, x, dy, td.Do, td.Di, eff, 1.0f, Wg(n, td.comp), ldw, nullptr, n->ws, n->ws_bytes,
+                                     compact ? td.active : nullptr, compact ? 2 : 0, s);
     };
     CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff));
     tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
