@@ -245,10 +245,14 @@ struct SupDev {
 // one wave per sequence.  la/lb: global scratch indexed by global state id.
 __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, MatView xent_out, float *la, float *lb,
                                                        double *num_logprob, double *xent_objf, MatView deriv,
-                                                       MatView xent_deriv, float xent_scale) {
+                                                       MatView xent_deriv, float xent_scale, int phases) {
+  // phases bit 0: forward-backward recursion (la, lb, total) + xent posteriors / objective;
+  //        bit 1: deriv += weight * gamma_num (needs the recursion's la/lb/total, possibly from an earlier launch)
   const int s = blockIdx.x, lane = threadIdx.x, B = sp.B, T = sp.T;
   const int *fsb = sp.frame_state_begin + (size_t)s * (T + 2);
   const int s0 = sp.seq_state_begin[s], s1 = sp.seq_state_begin[s + 1];
+  float tot = -INFINITY;
+  if (phases & 1) {
   for (int i = s0 + lane; i < s1; i += 64) la[i] = (i == s0) ? 0.f : -INFINITY;
   __syncthreads();
   for (int t = 1; t <= T; t++) {  // states entered at time t
@@ -260,7 +264,6 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
     }
     __syncthreads();
   }
-  float tot = -INFINITY;
   for (int st = fsb[T] + lane; st < fsb[T + 1]; st += 64) {
     const float f = sp.final_logprob[st];
     lb[st] = f;
@@ -277,6 +280,10 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
     }
     __syncthreads();
   }
+  } else {
+    tot = (float)num_logprob[s];
+  }
+  const bool do_xent = (phases & 1) != 0, do_deriv = (phases & 2) != 0;
   // posteriors: lane = frame (distinct output rows per lane, fixed arc order -> deterministic)
   double xo = 0.0;
   for (int t = lane; t < T; t += 64) {
@@ -286,15 +293,17 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
         const int pdf = sp.out_pdf[a];
         const float ll = sp.out_lp[a] + y.data[row * y.stride + pdf];
         const float gam = sp.weight * expf(la[st] + ll + lb[sp.out_dst[a]] - tot);
-        if (deriv.data) deriv.data[row * deriv.stride + pdf] += gam;
-        if (xent_deriv.data) xent_deriv.data[row * xent_deriv.stride + pdf] += xent_scale * gam;
-        if (xent_out.data) xo += (double)gam * (double)xent_out.data[row * xent_out.stride + pdf];
+        if (do_deriv && deriv.data) deriv.data[row * deriv.stride + pdf] += gam;
+        if (do_xent && xent_deriv.data) xent_deriv.data[row * xent_deriv.stride + pdf] += xent_scale * gam;
+        if (do_xent && xent_out.data) xo += (double)gam * (double)xent_out.data[row * xent_out.stride + pdf];
       }
   }
-  for (int o = 32; o > 0; o >>= 1) xo += __shfl_xor(xo, o, 64);
-  if (lane == 0) {
-    num_logprob[s] = (double)tot;
-    xent_objf[s] = xo;
+  if (do_xent) {
+    for (int o = 32; o > 0; o >>= 1) xo += __shfl_xor(xo, o, 64);
+    if (lane == 0) {
+      num_logprob[s] = (double)tot;
+      xent_objf[s] = xo;
+    }
   }
 }
 
@@ -578,6 +587,95 @@ size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *g, int B, int T) {
   return sizeof(double) * (3 * (size_t)B + 2) + sizeof(float) * (p.alpha_floats + p.asum_floats + p.gstate_floats + p.la_floats) + 256;
 }
 
+}  // extern "C"
+
+namespace tdnnf {
+namespace {
+struct ChainBufs {
+  ChainPlan p;
+  double *den_lp, *num_lp, *xent, *l2sum;
+  float *alpha, *asum, *gstate, *la, *lb;
+};
+ChainBufs chain_bufs(const tdnnf_den_graph *g, int B, int T, void *ws) {
+  ChainBufs b;
+  b.p = chain_plan(g, B, T, B * 4 * (T + 1));
+  b.den_lp = (double *)ws;
+  b.num_lp = b.den_lp + B;
+  b.xent = b.num_lp + B;
+  b.l2sum = b.xent + B;
+  b.alpha = (float *)(b.l2sum + 2);
+  b.asum = b.alpha + b.p.alpha_floats;
+  b.gstate = b.asum + b.p.asum_floats;
+  b.la = b.gstate + b.p.gstate_floats;
+  b.lb = b.la + b.p.la_floats / 2;
+  return b;
+}
+SupDev sup_dev(const tdnnf_supervision *sp) {
+  return SupDev{sp->B, sp->T, sp->weight, sp->seq_state_begin, sp->frame_state_begin, sp->final_logprob, sp->in_begin, sp->in_src,
+                sp->in_pdf, sp->in_lp, sp->out_begin, sp->out_dst, sp->out_pdf, sp->out_lp};
+}
+}  // namespace
+
+// The three parts of ComputeChainObjfAndDeriv, separately launchable so that the trainer can run the
+// denominator (one workgroup per sequence: half the CUs at 128 sequences) on a second stream beside the xent head.
+// (1) denominator forward + backward: deriv = -weight * gamma_den (whole matrix overwritten), den log-probs -> workspace
+int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws,
+              hipStream_t s) {
+  const int B = sp->B, T = sp->T;
+  ChainBufs b = chain_bufs(g, B, T, ws);
+  DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
+  MatView yv = view(y), dv = view(deriv);
+  if (b.p.lds_state) {
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_bwd));
+    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
+    hipLaunchKernelGGL(den_backward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_bwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, -sp->weight, dv, b.gstate);
+  } else {
+    hipLaunchKernelGGL(den_forward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
+    hipLaunchKernelGGL(den_backward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_bwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, -sp->weight, dv, b.gstate);
+  }
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+// (2) numerator recursion; xent_deriv = xent_regularize * gamma_num, xent objective -> workspace.  Does not touch deriv.
+int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output,
+              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s) {
+  const int B = sp->B, T = sp->T;
+  ChainBufs b = chain_bufs(g, B, T, ws);
+  MatView yv = view(y);
+  MatView xdv = xent_deriv ? view(xent_deriv) : MatView{nullptr, 0, 0, 0};
+  MatView xov = xent_output ? view(xent_output) : MatView{nullptr, 0, 0, 0};
+  if (xent_deriv)
+    hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long long)xdv.rows * xdv.cols, 256)), dim3(256), 0, s, xdv);
+  hipLaunchKernelGGL(numerator_kernel, dim3(B), dim3(64), 0, s, sup_dev(sp), yv, xov, b.la, b.lb, b.num_lp, b.xent, MatView{nullptr, 0, 0, 0},
+                     xdv, xent_regularize, 1);
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+// (3) after (1) and (2): deriv += weight * gamma_num; objective, l2 term, failure handling
+int chain_finish(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float l2_regularize, double *results,
+                 tdnnf_mat *deriv, tdnnf_mat *xent_deriv, void *ws, hipStream_t s) {
+  const int B = sp->B, T = sp->T;
+  ChainBufs b = chain_bufs(g, B, T, ws);
+  MatView yv = view(y), dv = view(deriv);
+  MatView xdv = xent_deriv ? view(xent_deriv) : MatView{nullptr, 0, 0, 0};
+  hipLaunchKernelGGL(numerator_kernel, dim3(B), dim3(64), 0, s, sup_dev(sp), yv, MatView{nullptr, 0, 0, 0}, b.la, b.lb, b.num_lp, b.xent, dv,
+                     MatView{nullptr, 0, 0, 0}, 0.f, 2);
+  if (l2_regularize != 0.f) {
+    TDNNF_HIP(hipMemsetAsync(b.l2sum, 0, sizeof(double), s));
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((long long)yv.rows * yv.cols, 256, 1024)), dim3(256), 0, s, yv, b.l2sum);
+  }
+  hipLaunchKernelGGL(chain_finalize_kernel, dim3(1), dim3(64), 0, s, b.num_lp, b.den_lp, b.xent, l2_regularize != 0.f ? b.l2sum : nullptr,
+                     B, T, sp->weight, l2_regularize, results);
+  hipLaunchKernelGGL(chain_guard_kernel, dim3(grid_for((long long)dv.rows * dv.cols, 256)), dim3(256), 0, s, results, yv,
+                     sp->weight * l2_regularize, dv, xdv);
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+}  // namespace tdnnf
+
+extern "C" {
+
 int tdnnf_chain_objf_and_deriv(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y,
                                const tdnnf_mat *xent_output, float leaky, float l2_regularize, float xent_regularize,
                                double *results, tdnnf_mat *deriv, tdnnf_mat *xent_deriv, void *ws, size_t ws_bytes,
@@ -590,41 +688,10 @@ int tdnnf_chain_objf_and_deriv(const tdnnf_den_graph *g, const tdnnf_supervision
   TDNNF_REQUIRE(sp->num_states <= B * 4 * (T + 1), "chain_objf_and_deriv: supervision has more than 4*(T+1) states per sequence on average");
   TDNNF_REQUIRE(ws && ws_bytes >= tdnnf_chain_workspace_bytes(g, B, T), "chain_objf_and_deriv: workspace too small");
   hipStream_t s = (hipStream_t)stream;
-  ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
-  double *den_lp = (double *)ws, *num_lp = den_lp + B, *xent = num_lp + B, *l2sum = xent + B;
-  float *alpha = (float *)(l2sum + 2);
-  float *asum = alpha + p.alpha_floats;
-  float *gstate = asum + p.asum_floats;
-  float *la = gstate + p.gstate_floats, *lb = la + p.la_floats / 2;
-  DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
-  MatView yv = view(y), dv = view(deriv);
-  MatView xdv = xent_deriv ? view(xent_deriv) : MatView{nullptr, 0, 0, 0};
-  MatView xov = xent_output ? view(xent_output) : MatView{nullptr, 0, 0, 0};
-  if (p.lds_state) {
-    TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_fwd));
-    TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bwd));
-    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), p.lds_fwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, den_lp, gstate);
-    hipLaunchKernelGGL(den_backward_kernel<true>, dim3(B), dim3(kDenThreads), p.lds_bwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, -sp->weight, dv, gstate);
-  } else {
-    hipLaunchKernelGGL(den_forward_kernel<false>, dim3(B), dim3(kDenThreads), p.lds_fwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, den_lp, gstate);
-    hipLaunchKernelGGL(den_backward_kernel<false>, dim3(B), dim3(kDenThreads), p.lds_bwd, s, gd, yv, B, T, leaky, alpha, asum, p.Hs, -sp->weight, dv, gstate);
-  }
-  TDNNF_LAUNCH_CHECK();
-  if (xent_deriv)
-    hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long long)xdv.rows * xdv.cols, 256)), dim3(256), 0, s, xdv);
-  SupDev sd{B, T, sp->weight, sp->seq_state_begin, sp->frame_state_begin, sp->final_logprob, sp->in_begin, sp->in_src,
-            sp->in_pdf, sp->in_lp, sp->out_begin, sp->out_dst, sp->out_pdf, sp->out_lp};
-  hipLaunchKernelGGL(numerator_kernel, dim3(B), dim3(64), 0, s, sd, yv, xov, la, lb, num_lp, xent, dv, xdv, xent_regularize);
-  if (l2_regularize != 0.f) {
-    TDNNF_HIP(hipMemsetAsync(l2sum, 0, sizeof(double), s));
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for((long long)yv.rows * yv.cols, 256, 1024)), dim3(256), 0, s, yv, l2sum);
-  }
-  hipLaunchKernelGGL(chain_finalize_kernel, dim3(1), dim3(64), 0, s, num_lp, den_lp, xent, l2_regularize != 0.f ? l2sum : nullptr,
-                     B, T, sp->weight, l2_regularize, results);
-  hipLaunchKernelGGL(chain_guard_kernel, dim3(grid_for((long long)dv.rows * dv.cols, 256)), dim3(256), 0, s, results, yv,
-                     sp->weight * l2_regularize, dv, xdv);
-  TDNNF_LAUNCH_CHECK();
-  return TDNNF_OK;
+  int rc;
+  if ((rc = chain_den(g, sp, y, leaky, deriv, ws, s))) return rc;
+  if ((rc = chain_num(g, sp, y, xent_output, xent_regularize, xent_deriv, ws, s))) return rc;
+  return chain_finish(g, sp, y, l2_regularize, results, deriv, xent_deriv, ws, s);
 }
 
 }  // extern "C"

@@ -70,6 +70,13 @@ hipError_t colreduce_partial(int kind, MatView a, MatView b, float *partial, hip
 hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s);
 hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s);  // ws: colreduce_bytes(rows, cols)
 
+// the three separately launchable parts of the chain objective (chain.hip)
+int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws, hipStream_t s);
+int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output,
+              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s);
+int chain_finish(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float l2_regularize, double *results,
+                 tdnnf_mat *deriv, tdnnf_mat *xent_deriv, void *ws, hipStream_t s);
+
 // trainer-internal variants of the TDNN entry points (abi_tdnn.hip)
 int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
                         const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream);

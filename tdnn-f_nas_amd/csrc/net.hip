@@ -92,6 +92,12 @@ __global__ void active_taps_kernel(const float *eff, int K, int *active) {
     if (eff[i] != 0.f) active[1 + n++] = i;
   active[0] = n;
 }
+// grads += this minibatch's gradient, unless the chain objective failed (results[5] == 0): then, as in the
+// reference (derivatives set to zero), the minibatch contributes nothing
+__global__ void commit_grads_kernel(float *grads, const float *gtmp, long long n, const double *results) {
+  if (results[5] == 0.0) return;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) grads[i] += gtmp[i];
+}
 __global__ void scale_doubles_kernel(double *x, int n, double s) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= s;
@@ -155,6 +161,9 @@ struct tdnnf_net {
   float *tapgrad;      // DARTS: unscaled per-tap weight gradients (Do x K*Di) of the component being processed
   double *tapdots;     // DARTS: s_i = <dW_i, W_i>
   const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
+  float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
+  hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
+  hipEvent_t ev_fork, ev_den;
   int num_draws;
   void *ws;
   size_t ws_bytes;
@@ -234,11 +243,11 @@ float *Bp(const tdnnf_net *n, int comp) {
   return c.has_bias ? n->params + c.begin + (long long)c.rows * c.cols + c.num_alpha : nullptr;
 }
 float *Ap(const tdnnf_net *n, int comp) { return n->params + n->comps[comp].begin + (long long)n->comps[comp].rows * n->comps[comp].cols; }
-float *Ag(const tdnnf_net *n, int comp) { return n->grads + n->comps[comp].begin + (long long)n->comps[comp].rows * n->comps[comp].cols; }
-float *Wg(const tdnnf_net *n, int comp) { return n->grads + n->comps[comp].begin; }
+float *Ag(const tdnnf_net *n, int comp) { return n->gtmp + n->comps[comp].begin + (long long)n->comps[comp].rows * n->comps[comp].cols; }
+float *Wg(const tdnnf_net *n, int comp) { return n->gtmp + n->comps[comp].begin; }
 float *Bg(const tdnnf_net *n, int comp) {
   const CompDesc &c = n->comps[comp];
-  return c.has_bias ? n->grads + c.begin + (long long)c.rows * c.cols + c.num_alpha : nullptr;
+  return c.has_bias ? n->gtmp + c.begin + (long long)c.rows * c.cols + c.num_alpha : nullptr;
 }
 
 // carve (or, with base == nullptr, just size) every activation buffer
@@ -299,6 +308,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     if (L.lin.darts) tg = std::max(tg, (size_t)L.bn * L.lin.K * Hd);
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
+  n->gtmp = A.take<float>((size_t)n->num_params + 16);
   // shared workspace: wgrad slabs, column reductions, orthonormal
   size_t ws = 0;
   auto upd = [&](size_t b) { ws = std::max(ws, b); };
@@ -498,6 +508,8 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
   n->arena_bytes = sizing.off + 1024;
   n->chain_ws = nullptr;
   n->chain_ws_bytes = 0;
+  n->s2 = nullptr;
+  n->ev_fork = n->ev_den = nullptr;
   if (hipMalloc((void **)&n->arena, n->arena_bytes) != hipSuccess) {
     set_error("net_create: cannot allocate %zu bytes of activations", n->arena_bytes);
     delete n;
@@ -530,6 +542,9 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (!n) return;
   hipFree(n->arena);
   hipFree(n->chain_ws);
+  if (n->s2) hipStreamDestroy(n->s2);
+  if (n->ev_fork) hipEventDestroy(n->ev_fork);
+  if (n->ev_den) hipEventDestroy(n->ev_den);
   delete n;
 }
 
@@ -614,7 +629,11 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   if (!n->chain_ws) {
     n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout);
     TDNNF_HIP(hipMalloc(&n->chain_ws, n->chain_ws_bytes));
+    TDNNF_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
+    TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
+    TDNNF_HIP(hipEventCreateWithFlags(&n->ev_den, hipEventDisableTiming));
   }
+  TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
   TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout), "net_forward_backward: denominator graph changed size");
   // the reference's RandInt()/RandUniform() coin flips, made reproducible: k-th decision of this minibatch
   unsigned long long coin_k = 0;
@@ -674,23 +693,31 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   const int No = n->Tout * B;
   tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
   CK(tdnnf_affine_propagate(&top, Wp(n, n->c_prefinal_l), Hd, nullptr, S, &pl, s));
+  tdnnf_mat y = M(n->head[0].y, No, P), dy = M(n->d_y, No, P), dx = M(n->d_xent, No, P);
+  tdnnf_mat lsm = M(n->xent_logsoftmax, No, P);
   for (int h = 0; h < 2; h++) {
     auto &H = n->head[h];
-    tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), y = M(H.y, No, P);
+    tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), yh = M(H.y, No, P);
     CK(tdnn_propagate_impl(&ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, 1, 1, &ar, s));
     CK(bn_stats(n, H.aff_relu, No, Hd, H.bn1_memo, H.bn1_stats, s));
     TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, none, 0.f, view(&b1), s));
     CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
     CK(bn_fwd(n, H.lin_out, H.bn2_out, No, S, H.bn2_memo, H.bn2_stats, s));
-    CK(tdnnf_affine_propagate(&b2, Wp(n, H.c_output), S, Bp(n, H.c_output), P, &y, s));
+    CK(tdnnf_affine_propagate(&b2, Wp(n, H.c_output), S, Bp(n, H.c_output), P, &yh, s));
+    if (h == 0) {
+      // ====================================================== objective, part 1 (second stream)
+      // The denominator forward-backward (one workgroup per sequence) only needs the chain head's output: it
+      // runs on n->s2 while this stream does the xent head forward, the numerator and the xent head backward.
+      TDNNF_HIP(hipEventRecord(n->ev_fork, s));
+      TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
+      CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2));
+      TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));
+    }
   }
-  tdnnf_mat yx = M(n->head[1].y, No, P), lsm = M(n->xent_logsoftmax, No, P);
+  tdnnf_mat yx = M(n->head[1].y, No, P);
   CK(tdnnf_log_softmax_propagate(&yx, &lsm, s));
-
-  // ============================================================ objective + derivative
-  tdnnf_mat y = M(n->head[0].y, No, P), dy = M(n->d_y, No, P), dx = M(n->d_xent, No, P);
-  CK(tdnnf_chain_objf_and_deriv(den, sup, &y, &lsm, c.leaky_hmm, c.chain_l2_regularize, c.xent_regularize, results, &dy, &dx,
-                                n->chain_ws, n->chain_ws_bytes, s));
+  // objective, part 2: numerator recursion -> xent_deriv = xent_regularize * posteriors, xent objective
+  CK(chain_num(den, sup, &y, &lsm, c.xent_regularize, &dx, n->chain_ws, s));
   // log-softmax backward, in place into d_xent
   CK(tdnnf_log_softmax_backprop(&lsm, &dx, &dx, s));
 
@@ -707,8 +734,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     return TDNNF_OK;
   };
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
-  for (int h = 0; h < 2; h++) {
+  for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
+    if (h == 0) {
+      // objective, part 3: join the denominator stream, d_y += posteriors, objf / failure handling
+      TDNNF_HIP(hipStreamWaitEvent(s, n->ev_den, 0));
+      CK(chain_finish(den, sup, &y, c.chain_l2_regularize, results, &dy, nullptr, n->chain_ws, s));
+    }
     tdnnf_mat dout = h == 0 ? dy : dx;
     tdnnf_mat b2 = M(H.bn2_out, No, S), b1 = M(H.bn1_out, No, Hd);
     tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
@@ -719,7 +751,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
     CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, Bg(n, H.c_affine)));  // dA -> d affine out
     CK(tdnnf_affine_update_simple(&pl, &d_b1, 1.0f, Wg(n, H.c_affine), S, nullptr, n->ws, n->ws_bytes, s));
-    if (h == 0) {
+    if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
     } else {
       tdnnf_mat tmp = M(n->d_small2, No, S);
@@ -803,6 +835,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
     CK(tdnnf_affine_update_simple(&lda_out, &d_aff, 1.0f, Wg(n, n->tdnn1.comp), lda_dim, nullptr, n->ws, n->ws_bytes, s));
   }
+  hipLaunchKernelGGL(commit_grads_kernel, dim3(grid_for(n->num_params, 256)), dim3(256), 0, s, n->grads, n->gtmp, n->num_params, results);
+  TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }
 

@@ -293,7 +293,7 @@ class OracleNet:
             return dd
 
         d_pl = None
-        for h, Hd in enumerate(heads):
+        for h, Hd in reversed(list(enumerate(heads))):  # xent head first (the trainer overlaps it with the denominator)
             dout = dy if h == 0 else dlsm
             d_b2 = affine_bwd(Hd["b2"], dout, Hd["Wo"], Hd["on"])
             d_lo = self._bn_bwd(Hd["b2"], d_b2, Hd["m2"])
