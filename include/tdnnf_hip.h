@@ -292,6 +292,11 @@ typedef struct {
   int darts_num_offsets;
   int darts_flags;
   float darts_temp_proportion;
+  /* != 0: weight gradients go through OnlineNaturalGradient exactly as UpdateNaturalGradient does
+     (nnet-tdnn-component.cc:592-624, nnet-simple-component.cc:2980-3024): spliced input [c_i X_i ..., 1] and the
+     output derivative are preconditioned (rank 20 / 80, alpha 4, history 2000, update period 4), the product of the
+     two scale factors multiplies the update.  0: raw gradients (is_gradient_ / UpdateSimple semantics). */
+  int use_natural_gradient;
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 

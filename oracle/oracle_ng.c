@@ -131,6 +131,109 @@ static void ng_init_default(oracle_ng *ng, int D) {
   ng->t = 0;
 }
 
+/* Gram-Schmidt with a deterministic replacement for (numerically) dependent rows -- stands in for Kaldi's
+   OrthogonalizeRows(), which re-randomises such rows; both the oracle and the product use this exact routine. */
+static void orthogonalize_rows(float *W, int R, int D) {
+  double *row = (double *)malloc(sizeof(double) * D);
+  for (int i = 0; i < R; i++) {
+    int cand = i;
+    for (int attempt = 0;; attempt++) {
+      double n0 = 0;
+      for (int k = 0; k < D; k++) {
+        row[k] = attempt == 0 ? W[(size_t)i * D + k] : (k == cand % D ? 1.0 : 0.0);
+        n0 += row[k] * row[k];
+      }
+      for (int pass = 0; pass < 2; pass++)
+        for (int j = 0; j < i; j++) {
+          double dot = 0;
+          for (int k = 0; k < D; k++) dot += row[k] * W[(size_t)j * D + k];
+          for (int k = 0; k < D; k++) row[k] -= dot * W[(size_t)j * D + k];
+        }
+      double n1 = 0;
+      for (int k = 0; k < D; k++) n1 += row[k] * row[k];
+      if (n0 > 0 && n1 > 1e-8 * n0 && n1 > 1e-30) {
+        const double inv = 1.0 / sqrt(n1);
+        for (int k = 0; k < D; k++) W[(size_t)i * D + k] = (float)(row[k] * inv);
+        break;
+      }
+      cand = attempt == 0 ? i : cand + 1; /* try unit vectors e_i, e_{i+1}, ... */
+    }
+  }
+  free(row);
+}
+
+/* ReorthogonalizeRt1 (UPSTREAM): make R_{t+1} = E_{t+1}^{-1/2} W_{t+1} orthonormal again. */
+static void reorthogonalize(const oracle_ng *ng, const float *d_t1, float rho_t1, float *W1) {
+  const int R = ng->rank, D = ng->D;
+  const float threshold = 1.0e-03f;
+  double d1_sum = 0;
+  for (int i = 0; i < R; i++) d1_sum += d_t1[i];
+  const double beta = rho_t1 * (1.0 + ng->alpha) + ng->alpha * d1_sum / D;
+  double *sqrt_e = malloc(sizeof(double) * R), *inv_sqrt_e = malloc(sizeof(double) * R);
+  for (int i = 0; i < R; i++) {
+    const double e = 1.0 / (beta / d_t1[i] + 1.0);
+    sqrt_e[i] = sqrt(e);
+    inv_sqrt_e[i] = 1.0 / sqrt_e[i];
+  }
+  double *O = malloc(sizeof(double) * R * R), *Cm = calloc((size_t)R * R, sizeof(double));
+  int is_unit = 1;
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j <= i; j++) {
+      double a = 0;
+      for (int k = 0; k < D; k++) a += (double)W1[(size_t)i * D + k] * W1[(size_t)j * D + k];
+      a = (float)a * inv_sqrt_e[i] * inv_sqrt_e[j];
+      O[i * R + j] = O[j * R + i] = a;
+      if (fabs(a - (i == j ? 1.0 : 0.0)) > threshold) is_unit = 0;
+    }
+  if (!is_unit) {
+    /* Cholesky O = C C^T, then C^{-1} */
+    int ok = 1;
+    for (int i = 0; i < R && ok; i++)
+      for (int j = 0; j <= i; j++) {
+        double sum = O[i * R + j];
+        for (int k = 0; k < j; k++) sum -= Cm[i * R + k] * Cm[j * R + k];
+        if (i == j) {
+          if (!(sum > 0.0)) { ok = 0; break; }
+          Cm[i * R + i] = sqrt(sum);
+        } else {
+          Cm[i * R + j] = sum / Cm[j * R + j];
+        }
+      }
+    double *Ci = calloc((size_t)R * R, sizeof(double));
+    double cmax = 0;
+    if (ok) { /* invert the lower-triangular factor */
+      for (int i = 0; i < R; i++) {
+        Ci[i * R + i] = 1.0 / Cm[i * R + i];
+        for (int j = 0; j < i; j++) {
+          double sum = 0;
+          for (int k = j; k < i; k++) sum += Cm[i * R + k] * Ci[k * R + j];
+          Ci[i * R + j] = -sum / Cm[i * R + i];
+        }
+      }
+      for (int i = 0; i < R * R; i++)
+        if (Ci[i] > cmax) cmax = Ci[i];
+      if (!(cmax < 100.0)) ok = 0;
+    }
+    if (!ok) { /* Gram-Schmidt on R_{t+1}' rows, then W = E^{1/2} R */
+      orthogonalize_rows(W1, R, D);
+      for (int i = 0; i < R; i++)
+        for (int k = 0; k < D; k++) W1[(size_t)i * D + k] *= (float)sqrt_e[i];
+    } else { /* W <- E^{1/2} C^{-1} E^{-1/2} W */
+      float *tmp = malloc(sizeof(float) * (size_t)R * D);
+      memcpy(tmp, W1, sizeof(float) * (size_t)R * D);
+      for (int i = 0; i < R; i++)
+        for (int k = 0; k < D; k++) {
+          double a = 0;
+          for (int j = 0; j <= i; j++) a += (float)(Ci[i * R + j] * sqrt_e[i] * inv_sqrt_e[j]) * (double)tmp[(size_t)j * D + k];
+          W1[(size_t)i * D + k] = (float)a;
+        }
+      free(tmp);
+    }
+    free(Ci);
+  }
+  free(sqrt_e); free(inv_sqrt_e); free(O); free(Cm);
+}
+
 static float ng_eta(const oracle_ng *ng, int N) {
   float ans = 1.0f - expf(-(float)N / ng->num_samples_history);
   if (ans > 0.9f) ans = 0.9f;
@@ -219,8 +322,13 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
   double *c = malloc(sizeof(double) * R), *U = malloc(sizeof(double) * R * R);
   sym_eig(Z, R, c, U);
   double c_floor = pow(rho_t * (1.0 - eta), 2);
+  const double condition_threshold = 1.0e+06;
+  int must_reorthogonalize = c[0] > condition_threshold * c[R - 1];
   for (int i = 0; i < R; i++)
-    if (c[i] < c_floor) c[i] = c_floor;
+    if (c[i] < c_floor) {
+      c[i] = c_floor;
+      must_reorthogonalize = 1;
+    }
   double *sqrt_c = malloc(sizeof(double) * R);
   double sqrt_c_sum = 0, sqrt_c_max = 0;
   for (int i = 0; i < R; i++) {
@@ -261,6 +369,7 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
       for (int j = 0; j < R; j++) a += (double)At[i * R + j] * J[(size_t)j * D + k];
       W1[(size_t)i * D + k] = (float)a;
     }
+  if (must_reorthogonalize) reorthogonalize(ng, d_t1, rho_t1, W1);
   memcpy(ng->W, W1, sizeof(float) * (size_t)R * D);
   memcpy(ng->d, d_t1, sizeof(float) * R);
   ng->rho = rho_t1;

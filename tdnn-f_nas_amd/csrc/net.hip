@@ -84,6 +84,37 @@ __global__ void add_scaled_taps_kernel(const float *G, const float *coef, float 
   const long long total = (long long)Do * KDi;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) acc[e] += coef[(e % KDi) / Di] * G[e];
 }
+// in_value_temp of UpdateNaturalGradient (nnet-tdnn-component.cc:482-532): out[r] = [c_0 X_0[r] ... c_{K-1} X_{K-1}[r], 1]
+__global__ void splice_taps_kernel(MatView x, tdnnf_tdnn_indexes ix, const float *eff, int Di, int ones, MatView out) {
+  const int C = out.cols;
+  const long long total = (long long)out.rows * C;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int r = (int)(e / C), c = (int)(e % C);
+    float v = 1.0f;
+    if (!(ones && c == C - 1)) {
+      const int i = c / Di, d = c % Di;
+      const float cf = eff ? eff[i] : 1.0f;
+      v = cf == 0.f ? 0.f : cf * x.data[(size_t)(ix.row_offsets[i] + (long long)r * ix.row_stride) * x.stride + d];
+    }
+    out.data[(size_t)r * out.stride + c] = v;
+  }
+}
+// acc[o] += scale * sum_r dY[r][o] * w[r * ldw]   (bias update with the preconditioned ones column, :610-615)
+__global__ __launch_bounds__(256) void weighted_colsum_kernel(MatView dy, const float *w, long long ldw, int rows_per_chunk, float *partial) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(dy.rows, r0 + rows_per_chunk);
+  if (col >= dy.cols) return;
+  float sacc = 0.f;
+  for (int r = r0; r < r1; r++) sacc += dy.data[(size_t)r * dy.stride + col] * w[(size_t)r * ldw];
+  partial[(size_t)blockIdx.y * dy.cols + col] = sacc;
+}
+__global__ void weighted_colsum_final_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  float sacc = 0.f;
+  for (int c = 0; c < chunks; c++) sacc += partial[(size_t)c * D + d];
+  acc[d] += scale * sacc;
+}
 // active[0] = number of taps with a non-zero effective coefficient, active[1..] = their ids
 __global__ void active_taps_kernel(const float *eff, int K, int *active) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -161,6 +192,8 @@ struct tdnnf_net {
   float *tapgrad;      // DARTS: unscaled per-tap weight gradients (Do x K*Di) of the component being processed
   double *tapdots;     // DARTS: s_i = <dW_i, W_i>
   const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
+  std::vector<tdnnf_ng *> ng_in, ng_out;  // per component (natural gradient)
+  float *ngX, *ngY;    // spliced input / output-derivative copies being preconditioned
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den;
@@ -309,6 +342,19 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
+  n->ngX = n->ngY = nullptr;
+  if (n->cfg.use_natural_gradient) {
+    size_t mx = (size_t)N0 * (lda_dim + 4), my = (size_t)N0 * (Hd + 4);
+    for (auto &L : n->layers) {
+      mx = std::max(mx, (size_t)L.lin.rows_out * (L.lin.K * Hd + 8));
+      mx = std::max(mx, (size_t)L.aff.rows_out * (L.aff.K * L.bn + 8));
+      my = std::max(my, (size_t)L.aff.rows_out * (Hd + 4));
+    }
+    mx = std::max(mx, (size_t)No * (Hd + 8));
+    my = std::max(my, (size_t)No * (P + 8));
+    n->ngX = A.take<float>(mx);
+    n->ngY = A.take<float>(my);
+  }
   // shared workspace: wgrad slabs, column reductions, orthonormal
   size_t ws = 0;
   auto upd = [&](size_t b) { ws = std::max(ws, b); };
@@ -502,6 +548,23 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
                                    c.max_change_output, 0.f);
   }
   TDNNF_REQUIRE(n->comps.size() <= 128, "net_create: too many components");
+  if (c.use_natural_gradient) {
+    // one input-side and one output-side preconditioner per updatable component; configuration of
+    // TdnnDARTSV3Component::InitFromConfig (nnet-tdnn-component.cc:183-210), the same defaults as
+    // NaturalGradientAffineComponent / LinearComponent
+    n->ng_in.assign(n->comps.size(), nullptr);
+    n->ng_out.assign(n->comps.size(), nullptr);
+    for (size_t i = 0; i < n->comps.size(); i++) {
+      const CompDesc &cd = n->comps[i];
+      if (cd.lr_factor == 0.f) continue;  // fixed lda layer
+      const int spliced = cd.cols + (cd.has_bias ? 1 : 0);
+      const int rank_in = std::min(20, (spliced + 1) / 2), rank_out = std::min(80, (cd.rows + 1) / 2);
+      if (tdnnf_ng_create(rank_in, 4, 2000.0f, 4.0f, &n->ng_in[i]) || tdnnf_ng_create(rank_out, 4, 2000.0f, 4.0f, &n->ng_out[i])) {
+        tdnnf_net_destroy(n);
+        return TDNNF_EINVAL;
+      }
+    }
+  }
   // ---- activations
   Arena sizing;
   layout_arena(n, sizing);
@@ -540,6 +603,8 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
 
 void tdnnf_net_destroy(tdnnf_net *n) {
   if (!n) return;
+  for (auto *g : n->ng_in) tdnnf_ng_destroy(g);
+  for (auto *g : n->ng_out) tdnnf_ng_destroy(g);
   hipFree(n->arena);
   hipFree(n->chain_ws);
   if (n->s2) hipStreamDestroy(n->s2);
@@ -733,6 +798,42 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                           n->ws, n->ws_bytes, s));
     return TDNNF_OK;
   };
+  const bool use_ng = c.use_natural_gradient != 0;
+  // Gradient of one component's weights [+ bias] from its input (tap views) and output derivative.
+  //   raw:  W += c_i dY^T X_i, bias += colsum(dY)                      (UpdateSimple, :433-455)
+  //   NG :  X~ = [c_i X_i ..., 1], (X~', a) = NG_in(X~), (dY', b) = NG_out(dY), W += a b dY'^T X~'[:, :K Di],
+  //         bias += a b dY'^T X~'[:, -1]                               (UpdateNaturalGradient, :592-624)
+  // bias_done: the raw bias gradient was already produced by the fused BatchNorm/ReLU backward pass.
+  auto param_grad = [&](int comp, const tdnnf_tdnn_indexes &ix, int K, int Di, int Do, tdnnf_mat *x, tdnnf_mat *dyv, const float *eff,
+                        bool bias_done, const int *active, int max_active) -> int {
+    const int ldw = K * Di;
+    float *bias_acc = Bg(n, comp);
+    if (!use_ng)
+      return tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, Wg(n, comp), ldw, bias_done ? nullptr : bias_acc, n->ws, n->ws_bytes,
+                                     active, max_active, s);
+    const int N = dyv->rows, ones = bias_acc ? 1 : 0;
+    tdnnf_mat X = tdnnf_mat{n->ngX, N, ldw + ones, (ldw + ones + 3) & ~3};
+    tdnnf_mat Y = tdnnf_mat{n->ngY, N, Do, (Do + 3) & ~3};
+    hipLaunchKernelGGL(splice_taps_kernel, dim3(grid_for((long long)N * X.cols, 256)), dim3(256), 0, s, view(x), ix, eff, Di, ones, view(&X));
+    CK(tdnnf_sum_scaled(dyv, 1.0f, nullptr, 0.f, &Y, s));  // CuMatrix out_deriv_temp(out_deriv)  (:592)
+    float in_scale = 1.f, out_scale = 1.f;
+    CK(tdnnf_ng_precondition(n->ng_in[comp], &X, &in_scale, s));
+    CK(tdnnf_ng_precondition(n->ng_out[comp], &Y, &out_scale, s));
+    const float scale = in_scale * out_scale;  // "local_lrate = scale * learning_rate_" (:604-605); lr is applied in net_update
+    tdnnf_tdnn_indexes one;
+    memset(&one, 0, sizeof(one));
+    one.row_stride = 1;
+    one.num_offsets = 1;
+    tdnnf_mat Xw = tdnnf_mat{X.data, N, ldw, X.stride};
+    CK(tdnn_update_simple_impl(&one, &Xw, &Y, Do, ldw, nullptr, scale, Wg(n, comp), ldw, nullptr, n->ws, n->ws_bytes, nullptr, 0, s));
+    if (ones) {
+      const int chunks = (N + 511) / 512;
+      hipLaunchKernelGGL(weighted_colsum_kernel, dim3((Do + 255) / 256, chunks), dim3(256), 0, s, view(&Y), X.data + ldw, (long long)X.stride, 512,
+                         (float *)n->ws);
+      hipLaunchKernelGGL(weighted_colsum_final_kernel, dim3((Do + 255) / 256), dim3(256), 0, s, (const float *)n->ws, chunks, Do, scale, bias_acc);
+    }
+    return TDNNF_OK;
+  };
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
@@ -744,13 +845,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat dout = h == 0 ? dy : dx;
     tdnnf_mat b2 = M(H.bn2_out, No, S), b1 = M(H.bn1_out, No, Hd);
     tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
-    CK(tdnnf_affine_update_simple(&b2, &dout, 1.0f, Wg(n, H.c_output), S, Bg(n, H.c_output), n->ws, n->ws_bytes, s));
+    CK(param_grad(H.c_output, ix1, 1, S, P, &b2, &dout, nullptr, false, nullptr, 0));
     CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
     CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
-    CK(tdnnf_affine_update_simple(&b1, &d_b2, 1.0f, Wg(n, H.c_linear), Hd, nullptr, n->ws, n->ws_bytes, s));
+    CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0));
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
-    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, Bg(n, H.c_affine)));  // dA -> d affine out
-    CK(tdnnf_affine_update_simple(&pl, &d_b1, 1.0f, Wg(n, H.c_affine), S, nullptr, n->ws, n->ws_bytes, s));
+    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, use_ng ? nullptr : Bg(n, H.c_affine)));  // dA -> d affine out
+    CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
     } else {
@@ -759,7 +860,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_add_scaled(&tmp, 1.0f, &d_pl, s));
     }
   }
-  CK(tdnnf_affine_update_simple(&top, &d_pl, 1.0f, Wg(n, n->c_prefinal_l), Hd, nullptr, n->ws, n->ws_bytes, s));
+  CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0));
   float *d_cur = n->dA, *d_next = n->dB;  // d_cur: deriv w.r.t. the current layer's output (noop)
   {
     tdnnf_mat d_top = M(d_cur, No, Hd);
@@ -776,7 +877,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
       tdnnf_mat x = M(L.relu_out, no, Hd);
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, L.relu_stats, store, repair, c.relu_self_repair_scale,
-                            view(&d_aff), Bg(n, L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
+                            view(&d_aff), use_ng ? nullptr : Bg(n, L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
     }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : lin;
@@ -785,23 +886,25 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // weight gradient of one Tdnn component.  DARTS in a non-sampling mode also needs the architecture-logit
     // gradient (UpdateNaturalGradient :516-590): tap gradients are formed unscaled once, s_i = <dW_i, W_i>
     // replaces the reference's extra forward GEMM per tap, then c_i * dW_i goes into the accumulator.
-    auto tdnn_wgrad = [&](Tdnn &td, tdnnf_mat *x, tdnnf_mat *dy, const float *eff) -> int {
+    auto tdnn_wgrad = [&](Tdnn &td, tdnnf_mat *x, tdnnf_mat *dyv, const float *eff, bool bias_done) -> int {
       const int ldw = td.K * td.Di;
       if (td.darts && !(c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE)) {
         TDNNF_HIP(hipMemsetAsync(n->tapgrad, 0, sizeof(float) * (size_t)td.Do * ldw, s));
-        CK(tdnnf_tdnn_update_simple(&td.ix, x, dy, td.Do, td.Di, nullptr, 1.0f, n->tapgrad, ldw, nullptr, n->ws, n->ws_bytes, s));
+        CK(tdnnf_tdnn_update_simple(&td.ix, x, dyv, td.Do, td.Di, nullptr, 1.0f, n->tapgrad, ldw, nullptr, n->ws, n->ws_bytes, s));
         CK(tdnnf_tdnn_darts_alpha_update(n->tapgrad, ldw, Wp(n, td.comp), ldw, td.Do, td.Di, td.K, td.memo, c.darts_flags, td.share,
                                          c.darts_temp_proportion, 1.0f, Ag(n, td.comp), n->tapdots, s));
-        hipLaunchKernelGGL(add_scaled_taps_kernel, dim3(grid_for((long long)td.Do * ldw, 256)), dim3(256), 0, s, n->tapgrad, eff,
-                           Wg(n, td.comp), td.Do, ldw, td.Di);
-        return TDNNF_OK;
+        if (!use_ng) {
+          hipLaunchKernelGGL(add_scaled_taps_kernel, dim3(grid_for((long long)td.Do * ldw, 256)), dim3(256), 0, s, n->tapgrad, eff,
+                             Wg(n, td.comp), td.Do, ldw, td.Di);
+          if (!bias_done) TDNNF_HIP(colsum_add(view(dyv), 1.0f, Bg(n, td.comp), n->ws, s));
+          return TDNNF_OK;
+        }
       }
       // uniform-sample mode: only the share tap and the sampled tap are non-zero (:293-304) -> compacted launch
       const bool compact = td.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && td.K > 2;
-      return tdnn_update_simple_impl(&td.ix, x, dy, td.Do, td.Di, eff, 1.0f, Wg(n, td.comp), ldw, nullptr, n->ws, n->ws_bytes,
-                                     compact ? td.active : nullptr, compact ? 2 : 0, s);
+      return param_grad(td.comp, td.ix, td.K, td.Di, td.Do, x, dyv, eff, bias_done, compact ? td.active : nullptr, compact ? 2 : 0);
     };
-    CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff));
+    CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff, true));
     tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
     if (L.perm) {  // rho > 1: some row classes receive no tap -> zero first, then add; un-permute afterwards
       TDNNF_HIP(hipMemsetAsync(d_lin.data, 0, sizeof(float) * (size_t)nl * d_lin.stride, s));
@@ -813,9 +916,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnn_backprop_data_impl(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, aff_eff, 1, nullptr, 0.f, 0, &d_lin, s));
     }
     tdnnf_mat in = M(in_act, ni, Hd);
-    CK(tdnn_wgrad(L.lin, &in, &d_lin, lin_eff));
-    if (L.lin.darts)  // the (never added) bias of a DARTS .linear is still updated by the reference (:614); raw-gradient reading
-      TDNNF_HIP(colsum_add(view(&d_lin), 1.0f, Bg(n, L.lin.comp), n->ws, s));
+    // (the never-added bias of a DARTS .linear is still updated by the reference, :614 -- Bg() is null for plain layers)
+    CK(tdnn_wgrad(L.lin, &in, &d_lin, lin_eff, false));
     // deriv w.r.t. the layer input = linear backprop (overwrites) + bypass_scale * d_out on the output-grid rows
     tdnnf_mat d_in = M(d_next, ni, Hd);
     tdnnf_mat d_byp = sub_grid_view(d_next, L.gin, L.gout, B, Hd);
@@ -831,9 +933,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     std::swap(d_cur, d_next);
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
-    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, Bg(n, n->tdnn1.comp)));
+    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, use_ng ? nullptr : Bg(n, n->tdnn1.comp)));
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
-    CK(tdnnf_affine_update_simple(&lda_out, &d_aff, 1.0f, Wg(n, n->tdnn1.comp), lda_dim, nullptr, n->ws, n->ws_bytes, s));
+    CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0));
   }
   hipLaunchKernelGGL(commit_grads_kernel, dim3(grid_for(n->num_params, 256)), dim3(256), 0, s, n->grads, n->gtmp, n->num_params, results);
   TDNNF_LAUNCH_CHECK();

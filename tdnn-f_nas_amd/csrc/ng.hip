@@ -102,6 +102,36 @@ void compute_et(const std::vector<float> &d, double beta, std::vector<double> &s
   }
 }
 
+// Gram-Schmidt with a deterministic replacement for (numerically) dependent rows (stand-in for Kaldi's
+// OrthogonalizeRows(), which re-randomises such rows)
+void orthogonalize_rows(std::vector<float> &W, int R, int D) {
+  std::vector<double> row(D);
+  for (int i = 0; i < R; i++) {
+    int cand = i;
+    for (int attempt = 0;; attempt++) {
+      double n0 = 0;
+      for (int k = 0; k < D; k++) {
+        row[k] = attempt == 0 ? W[(size_t)i * D + k] : (k == cand % D ? 1.0 : 0.0);
+        n0 += row[k] * row[k];
+      }
+      for (int pass = 0; pass < 2; pass++)
+        for (int j = 0; j < i; j++) {
+          double dot = 0;
+          for (int k = 0; k < D; k++) dot += row[k] * W[(size_t)j * D + k];
+          for (int k = 0; k < D; k++) row[k] -= dot * W[(size_t)j * D + k];
+        }
+      double n1 = 0;
+      for (int k = 0; k < D; k++) n1 += row[k] * row[k];
+      if (n0 > 0 && n1 > 1e-8 * n0 && n1 > 1e-30) {
+        const double inv = 1.0 / sqrt(n1);
+        for (int k = 0; k < D; k++) W[(size_t)i * D + k] = (float)(row[k] * inv);
+        break;
+      }
+      cand = attempt == 0 ? i : cand + 1;
+    }
+  }
+}
+
 int init_default(tdnnf_ng *ng, int D) {
   if (ng->rank >= D) ng->rank = D - 1;
   const int R = ng->rank;
@@ -227,10 +257,14 @@ int precondition_step(tdnnf_ng *ng, MatView X, float *scale, hipStream_t s) {
       for (int j = 0; j < i; j++) Z[i * R + j] = Z[j * R + i] = 0.5 * (Z[i * R + j] + Z[j * R + i]);
     jacobi_eig(Z, R, c, U);
     const double c_floor = pow(rho_t * (1.0 - eta), 2);
+    bool must_reorthogonalize = c[0] > 1.0e+06 * c[R - 1];  // condition_threshold
     std::vector<double> sqrt_c(R);
     double sqrt_c_sum = 0, sqrt_c_max = 0;
     for (int i = 0; i < R; i++) {
-      if (c[i] < c_floor) c[i] = c_floor;
+      if (c[i] < c_floor) {
+        c[i] = c_floor;
+        must_reorthogonalize = true;
+      }
       sqrt_c[i] = sqrt(c[i]);
       sqrt_c_sum += sqrt_c[i];
       sqrt_c_max = std::max(sqrt_c_max, sqrt_c[i]);
@@ -257,6 +291,73 @@ int precondition_step(tdnnf_ng *ng, MatView X, float *scale, hipStream_t s) {
     w1.A = Ad; w1.lda = R; w1.B = J; w1.ldb = D; w1.C = W1; w1.ldc = D; w1.M = R; w1.N = D; w1.init_mode = 2; w1.nseg = 1;
     w1.seg[0].klen = R; w1.seg[0].m_lo = 0; w1.seg[0].m_hi = R;
     TDNNF_HIP(rows_gemm(w1, false, s));  // W_{t+1} = A_t B_t
+    if (must_reorthogonalize) {  // ReorthogonalizeRt1 (UPSTREAM): R_{t+1} = E_{t+1}^{-1/2} W_{t+1} back to orthonormal rows
+      RowsGemmArgs o;
+      memset(&o, 0, sizeof(o));
+      o.A = W1; o.lda = D; o.B = W1; o.ldb = D; o.C = Kd; o.ldc = R; o.M = R; o.N = R; o.init_mode = 2; o.nseg = 1;
+      o.seg[0].klen = D; o.seg[0].m_lo = 0; o.seg[0].m_hi = R;
+      TDNNF_HIP(rows_gemm(o, true, s));  // O = W W^T
+      std::vector<float> Oh(f_RR);
+      TDNNF_HIP(hipMemcpyAsync(Oh.data(), Kd, sizeof(float) * f_RR, hipMemcpyDeviceToHost, s));
+      TDNNF_HIP(hipStreamSynchronize(s));
+      std::vector<double> O(f_RR), Cm(f_RR, 0.0), Ci(f_RR, 0.0);
+      bool is_unit = true;
+      for (int i = 0; i < R; i++)
+        for (int j = 0; j <= i; j++) {
+          const double a = (double)Oh[i * R + j] * inv_sqrt_e1[i] * inv_sqrt_e1[j];
+          O[i * R + j] = O[j * R + i] = a;
+          if (fabs(a - (i == j ? 1.0 : 0.0)) > 1.0e-03) is_unit = false;
+        }
+      if (!is_unit) {
+        bool ok = true;
+        for (int i = 0; i < R && ok; i++)
+          for (int j = 0; j <= i; j++) {
+            double sum = O[i * R + j];
+            for (int k = 0; k < j; k++) sum -= Cm[i * R + k] * Cm[j * R + k];
+            if (i == j) {
+              if (!(sum > 0.0)) { ok = false; break; }
+              Cm[i * R + i] = sqrt(sum);
+            } else {
+              Cm[i * R + j] = sum / Cm[j * R + j];
+            }
+          }
+        double cmax = 0;
+        if (ok) {
+          for (int i = 0; i < R; i++) {
+            Ci[i * R + i] = 1.0 / Cm[i * R + i];
+            for (int j = 0; j < i; j++) {
+              double sum = 0;
+              for (int k = j; k < i; k++) sum += Cm[i * R + k] * Ci[k * R + j];
+              Ci[i * R + j] = -sum / Cm[i * R + i];
+            }
+          }
+          for (auto v : Ci) cmax = std::max(cmax, v);
+          if (!(cmax < 100.0)) ok = false;
+        }
+        if (!ok) {  // Gram-Schmidt on the host, then W = E^{1/2} R
+          std::vector<float> Wh(f_J);
+          TDNNF_HIP(hipMemcpyAsync(Wh.data(), W1, sizeof(float) * f_J, hipMemcpyDeviceToHost, s));
+          TDNNF_HIP(hipStreamSynchronize(s));
+          orthogonalize_rows(Wh, R, D);
+          for (int i = 0; i < R; i++)
+            for (int k = 0; k < D; k++) Wh[(size_t)i * D + k] *= (float)sqrt_e1[i];
+          TDNNF_HIP(hipMemcpyAsync(W1, Wh.data(), sizeof(float) * f_J, hipMemcpyHostToDevice, s));
+          TDNNF_HIP(hipStreamSynchronize(s));
+        } else {  // W <- (E^{1/2} C^{-1} E^{-1/2}) W
+          std::vector<float> Th(f_RR, 0.f);
+          for (int i = 0; i < R; i++)
+            for (int j = 0; j <= i; j++) Th[i * R + j] = (float)(Ci[i * R + j] * sqrt_e1[i] * inv_sqrt_e1[j]);
+          TDNNF_HIP(hipMemcpyAsync(Ad, Th.data(), sizeof(float) * f_RR, hipMemcpyHostToDevice, s));
+          TDNNF_HIP(hipStreamSynchronize(s));
+          RowsGemmArgs t2;
+          memset(&t2, 0, sizeof(t2));
+          t2.A = Ad; t2.lda = R; t2.B = W1; t2.ldb = D; t2.C = J; t2.ldc = D; t2.M = R; t2.N = D; t2.init_mode = 2; t2.nseg = 1;
+          t2.seg[0].klen = R; t2.seg[0].m_lo = 0; t2.seg[0].m_hi = R;
+          TDNNF_HIP(rows_gemm(t2, false, s));
+          TDNNF_HIP(hipMemcpyAsync(W1, J, sizeof(float) * f_J, hipMemcpyDeviceToDevice, s));
+        }
+      }
+    }
     TDNNF_HIP(hipMemcpyAsync(ng->W, W1, sizeof(float) * f_J, hipMemcpyDeviceToDevice, s));
     TDNNF_HIP(hipStreamSynchronize(s));  // host vectors coeff_h / At go out of scope
     ng->d = d_t1;

@@ -24,7 +24,8 @@ class NetConfig(C.Structure):
                 ("chain_l2_regularize", C.c_float), ("l2_hidden", C.c_float), ("l2_output", C.c_float),
                 ("max_change_hidden", C.c_float), ("max_change_output", C.c_float), ("max_param_change", C.c_float),
                 ("relu_self_repair_scale", C.c_float), ("batchnorm_stats_scale", C.c_float),
-                ("darts_num_offsets", C.c_int), ("darts_flags", C.c_int), ("darts_temp_proportion", C.c_float)]
+                ("darts_num_offsets", C.c_int), ("darts_flags", C.c_int), ("darts_temp_proportion", C.c_float),
+                ("use_natural_gradient", C.c_int)]
 
 DARTS_USE_GUMBEL, DARTS_FREE_SELECT, DARTS_UNIFORM_SAMPLE, DARTS_USE_ENTROPY, DARTS_UPDATE_ALPHA = 1, 2, 4, 8, 16
 
@@ -54,6 +55,7 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
     c.darts_num_offsets = kw.get("darts_num_offsets", 0)
     c.darts_flags = kw.get("darts_flags", DARTS_UNIFORM_SAMPLE if c.darts_num_offsets else 0)
     c.darts_temp_proportion = kw.get("darts_temp_proportion", 1.0)
+    c.use_natural_gradient = int(kw.get("use_natural_gradient", 0))
     return c
 
 

@@ -62,6 +62,31 @@ class OracleNet:
         self.num_t_in = g[2] + 2
         self.bn_stats = {}
         self.relu_stats = {}
+        self.use_ng = bool(getattr(cfg, "use_natural_gradient", 0))
+        self.ng = {}
+        if self.use_ng:  # same configuration as the trainer (nnet-tdnn-component.cc:183-210)
+            for c in components:
+                if c["lr_factor"] == 0.0:
+                    continue
+                spliced = c["cols"] + (1 if c["has_bias"] else 0)
+                self.ng[c["name"]] = (self.L.oracle_ng_create(min(20, (spliced + 1) // 2), 4, 2000.0, 4.0),
+                                      self.L.oracle_ng_create(min(80, (c["rows"] + 1) // 2), 4, 2000.0, 4.0))
+
+    def _ng_grad(self, name, xs, dy, Wg, bg):
+        """UpdateNaturalGradient :592-624: xs = spliced input [c_i X_i ...] (N x K*Di), dy = out_deriv."""
+        N = dy.shape[0]
+        ones = 1 if bg is not None else 0
+        X = np.ones((N, xs.shape[1] + ones), F)
+        X[:, :xs.shape[1]] = xs
+        Y = dy.copy()
+        a, b = C.c_float(1.0), C.c_float(1.0)
+        self.L.oracle_ng_precondition(self.ng[name][0], ora.omat(X), C.byref(a))
+        self.L.oracle_ng_precondition(self.ng[name][1], ora.omat(Y), C.byref(b))
+        scale = F(a.value * b.value)
+        Xw = np.ascontiguousarray(X[:, :xs.shape[1]])
+        self.L.oracle_affine_update_simple(ora.omat(Xw), ora.omat(Y), float(scale), ora.fptr(Wg), Wg.shape[1], None)
+        if ones:
+            bg += (scale * (Y.astype(np.float64) * X[:, -1:].astype(np.float64)).sum(0)).astype(F)
 
     # ----------------------------------------------------------------- helpers
     def W(self, p, name):
@@ -94,7 +119,7 @@ class OracleNet:
                                      1 if bias is not None else 2, ora.omat(y))
         return y
 
-    def _tdnn_bwd(self, x, dy, W, Wg, bg, offsets, gin, gout, want_dx=True, eff=None, darts=None):
+    def _tdnn_bwd(self, x, dy, W, Wg, bg, offsets, gin, gout, want_dx=True, eff=None, darts=None, name=None):
         rho, ro = self._indexes(offsets, gin, gout)
         Do, K = W.shape[0], len(offsets)
         Di = W.shape[1] // K
@@ -107,8 +132,13 @@ class OracleNet:
             self.L.oracle_tdnn_darts_alpha_update(ora.dptr(sdots), ora.fptr(darts["coef"]), K, self.cfg.darts_flags, darts["share"],
                                                   self.cfg.darts_temp_proportion, 1.0, ora.fptr(acc))
             darts["alpha_grad"][:] = acc
-        self.L.oracle_tdnn_update_simple(ora.omat(x), ora.omat(dy), Do, Di, K, rho, ora.iptr(ro), pe, 1.0, ora.fptr(Wg),
-                                         W.shape[1], ora.fptr(bg) if bg is not None else None)
+        if self.use_ng:
+            xs = np.zeros((dy.shape[0], K * Di), F)
+            self.L.oracle_tdnn_splice(ora.omat(x), dy.shape[0], Di, K, rho, ora.iptr(ro), pe, 0, ora.omat(xs))
+            self._ng_grad(name, xs, dy, Wg, bg)
+        else:
+            self.L.oracle_tdnn_update_simple(ora.omat(x), ora.omat(dy), Do, Di, K, rho, ora.iptr(ro), pe, 1.0, ora.fptr(Wg),
+                                             W.shape[1], ora.fptr(bg) if bg is not None else None)
         if not want_dx:
             return None
         dx = np.zeros_like(x)
@@ -269,7 +299,10 @@ class OracleNet:
             Wg = np.ascontiguousarray(Gw(name))
             bgv = Gb(name)
             bg = np.ascontiguousarray(bgv) if bgv is not None else None
-            Lb.oracle_affine_update_simple(ora.omat(x), ora.omat(dyy), 1.0, ora.fptr(Wg), W.shape[1], ora.fptr(bg) if bg is not None else None)
+            if self.use_ng:
+                self._ng_grad(name, x, dyy, Wg, bg)
+            else:
+                Lb.oracle_affine_update_simple(ora.omat(x), ora.omat(dyy), 1.0, ora.fptr(Wg), W.shape[1], ora.fptr(bg) if bg is not None else None)
             Gw(name)[:] = Wg
             if bg is not None:
                 bgv[:] = bg
@@ -315,14 +348,14 @@ class OracleNet:
                 da["alpha_grad"] = Ga(nm + ".affine")
                 dl["alpha_grad"] = Ga(nm + ".linear")
             d_affin = self._tdnn_bwd(st["aff_in"], d_aff, st["Waff"], Wg, bg, st["aff_off"], Ly["lin"], Ly["out"],
-                                     eff=da["eff"] if da else None, darts=da)
+                                     eff=da["eff"] if da else None, darts=da, name=nm + ".affine")
             Gw(nm + ".affine")[:] = Wg
             bgv[:] = bg
             d_lin = self._to_rho(d_affin, st["rho"], inverse=True) if st["rho"] > 1 else d_affin
             Wg = np.ascontiguousarray(Gw(nm + ".linear"))
             blin = np.ascontiguousarray(Gb(nm + ".linear")) if dl else None  # DARTS .linear: inert bias, still updated
             d_in = self._tdnn_bwd(st["inp"], d_lin, st["Wlin"], Wg, blin, st["lin_off"], Ly["inn"], Ly["lin"],
-                                  eff=dl["eff"] if dl else None, darts=dl)
+                                  eff=dl["eff"] if dl else None, darts=dl, name=nm + ".linear")
             Gw(nm + ".linear")[:] = Wg
             if dl:
                 Gb(nm + ".linear")[:] = blin

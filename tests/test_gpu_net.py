@@ -30,6 +30,13 @@ CASES += [
     ("darts-k7-softmax", dict(_D, darts_num_offsets=7, darts_flags=0), 40),
     ("darts-k4-gumbel-entropy-updatealpha", dict(_D, darts_num_offsets=4, darts_flags=1 | 8 | 16, darts_temp_proportion=0.7), 40),
     ("darts-k3-freeselect", dict(_D, darts_num_offsets=3, darts_flags=2), 40),
+    # natural-gradient update (UpdateNaturalGradient / NaturalGradientAffineComponent::Update), plain and DARTS
+    # (more rows than the preconditioner ranks everywhere: with fewer rows than rank the low-rank update is
+    #  degenerate and the reference itself falls back to a randomised Gram-Schmidt)
+    ("7q-shape-small-NG", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=24, feat_dim=40,
+                               ivector_dim=100, num_pdfs=150, hidden_dim=96, small_dim=48, use_natural_gradient=1), 60),
+    ("darts-k4-softmax-NG", dict(frames_per_chunk=36, num_sequences=6, strides=[1, 1, 1], bottleneck=16, feat_dim=40, ivector_dim=100,
+                                 num_pdfs=64, hidden_dim=64, small_dim=32, darts_num_offsets=4, darts_flags=0, use_natural_gradient=1), 40),
 ]
 
 
@@ -65,15 +72,17 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
         assert abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"]), (r[0], res_ref["objf"])
         assert abs(r[6] - res_ref["xent_objf"]) < 1e-4 * abs(res_ref["xent_objf"])
         g = host(net.grads)
-        assert rel_l2(g, g_ref) < 1e-3, rel_l2(g, g_ref)
+        # natural gradient: the low-rank state is refreshed from an eigen-decomposition -> small differences feed back
+        gtol = 5e-3 if cfg.use_natural_gradient else 1e-3
+        assert rel_l2(g, g_ref) < gtol, rel_l2(g, g_ref)
         for c in net.components[1:]:
             sl = slice(c["begin"], c["begin"] + c["rows"] * c["cols"] + c["num_alpha"] + (c["rows"] if c["has_bias"] else 0))
-            assert rel_l2(g[sl], g_ref[sl]) < 1e-3, (c["name"], rel_l2(g[sl], g_ref[sl]))
+            assert rel_l2(g[sl], g_ref[sl]) < 2 * gtol, (c["name"], rel_l2(g[sl], g_ref[sl]))
         # optimizer step: L2 + max-change + scheduled orthonormal constraint
         p_ref = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
         net.update(1e-3, step=step)
         p = host(net.params)
-        assert rel_l2(p - params, p_ref - params) < 2e-3, rel_l2(p - params, p_ref - params)
+        assert rel_l2(p - params, p_ref - params) < (1e-2 if cfg.use_natural_gradient else 2e-3), rel_l2(p - params, p_ref - params)
         assert not host(net.grads).any()
         params = p_ref
         net.set_params(params)
