@@ -228,8 +228,9 @@ int tdnnf_chain_objf_and_deriv(const tdnnf_den_graph *, const tdnnf_supervision 
 typedef struct tdnnf_ng tdnnf_ng;
 int tdnnf_ng_create(int rank, int update_period, float num_samples_history, float alpha, tdnnf_ng **out);
 void tdnnf_ng_destroy(tdnnf_ng *);
-/* X is modified in place; *scale_host receives the scalar (this call synchronises the stream on the
-   steps where the low-rank state is refreshed, as the reference does for its R x R eig on the host). */
+/* X is modified in place; *scale_host (may be NULL) receives the scalar, which costs a stream synchronisation.
+   The R x R eigen-problem of a refresh step is solved on a host worker thread and W_{t+1} is installed at the
+   next call on the same object, so a call with scale_host == NULL never blocks.  rank <= 128. */
 int tdnnf_ng_precondition(tdnnf_ng *, tdnnf_mat *X, float *scale_host, tdnnf_stream);
 
 /* ========================================================================== A9
@@ -332,7 +333,7 @@ int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, in
 /* ======================================================================== profiling
  * Optional per-launch timing of the MFMA GEMM kernels with HIP events recorded on the launch stream
  * (bench.py's live roofline measurement).  Classes: 0 = rows_gemm 128x128 tile, 1 = rows_gemm 128x160 tile,
- * 2 = wgrad.  tdnnf_profile_read synchronises the recorded events and returns totals since enable. */
+ * 2 = wgrad, 3 = the skinny GEMMs of the natural-gradient statistics.  tdnnf_profile_read synchronises the recorded events and returns totals since enable. */
 int tdnnf_profile_enable(int on);
 int tdnnf_profile_read(int kernel_class, double *launches, double *total_ms, double *total_flops);
 const char *tdnnf_profile_class_name(int kernel_class);

@@ -39,9 +39,23 @@ struct RowsGemmArgs {
   int ksplit;       // 0/1: no split
   int kchunk;       // multiple of the kernel's K step
   float *partial;
+  // optional: sumsq[block] = sum over this block's rows of sum_s coef[s]^2 * |A_s row|^2 (the Frobenius norm of the
+  // scaled, spliced A operand, a by-product of staging it).  Needs N to fit one column tile (every A element is
+  // then staged exactly once): rows_gemm() fails otherwise.  One double per 128-row block: rows_gemm_sumsq_blocks(M).
+  double *sumsq;
   int nseg;
   GemmSeg seg[kMaxSeg];
 };
+
+// Event-timing class of the launches made while one of these is alive (tdnnf_profile_*: 0 rows_gemm 128x128,
+// 1 rows_gemm 128x160, 2 wgrad, 3 natural-gradient skinny GEMMs).
+struct ProfClassOverride {
+  int prev;
+  explicit ProfClassOverride(int cls);
+  ~ProfClassOverride();
+};
+
+inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128; }
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).
 hipError_t rows_gemm(const RowsGemmArgs &args, bool b_kcontig, hipStream_t stream);

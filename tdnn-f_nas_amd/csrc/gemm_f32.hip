@@ -34,8 +34,11 @@ struct ProfClass {
   size_t used = 0;
   double flops = 0;
 };
-static ProfClass g_prof[3] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32"}};
+static ProfClass g_prof[4] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32"}, {"ng_skinny_gemm_f32"}};
 static bool g_prof_on = false;
+static int g_prof_override = -1;
+ProfClassOverride::ProfClassOverride(int cls) : prev(g_prof_override) { g_prof_override = cls; }
+ProfClassOverride::~ProfClassOverride() { g_prof_override = prev; }
 constexpr size_t kProfMaxLaunches = 1 << 15;
 
 struct ProfScope {
@@ -43,7 +46,7 @@ struct ProfScope {
   hipStream_t s;
   ProfScope(int cls, double flops, hipStream_t stream) : s(stream) {
     if (!g_prof_on) return;
-    ProfClass &p = g_prof[cls];
+    ProfClass &p = g_prof[g_prof_override >= 0 ? g_prof_override : cls];
     if (p.used + 2 > p.ev.size()) return;
     c = &p;
     p.flops += flops;
@@ -144,6 +147,13 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
   next_seg();
 
   float4 ra[A_F4], rb[B_F4];
+  float ssq = 0.f;  // p.sumsq: running sum of (coef * a)^2 over everything this thread stages
+  auto add_ssq = [&]() {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) q += ra[j].x * ra[j].x + ra[j].y * ra[j].y + ra[j].z * ra[j].z + ra[j].w * ra[j].w;
+    ssq += cf * cf * q;
+  };
   // Per-segment, per-thread source pointers for the fast path (full K-step inside the segment, float4 loads):
   // rows/columns that are out of range read 16 zero bytes instead of branching.
   const float *aptr[A_F4], *bptr[B_F4];
@@ -190,6 +200,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
         v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
         rb[j] = v;
       }
+      if (p.sumsq) add_ssq();
       return;
     }
     const GemmSeg sg = p.seg[seg];
@@ -229,6 +240,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
         rb[j] = v;
       }
     }
+    if (p.sumsq) add_ssq();
   };
   auto store_tile = [&](int buf) {  // registers -> LDS
     float *as = As + buf * A_TILE, *bs = Bs + buf * B_TILE;
@@ -308,6 +320,15 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
   float *Cs = smem;
   const bool cvec = p.c_vec != 0;
   __syncthreads();
+  if (p.sumsq) {  // block total through LDS (the staging buffers are free now)
+    double v = ssq;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    double *red = reinterpret_cast<double *>(smem);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (t == 0) p.sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
 #pragma unroll
   for (int pass = 0; pass < BM / HALF; pass++) {
     if ((wm * TM * 32) / HALF == pass) {
@@ -367,20 +388,27 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
 }
 
 template <int WM, int WN, int TM, int TN, int BK>
+void rows_attr() {  // > 64 KiB of dynamic LDS must be opted into, once per instantiation
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  const size_t lds_kc = sizeof(float) * 2 * (BM * (BK + 4) + BN * (BK + 4));
+  const size_t lds_nc = sizeof(float) * 2 * (BM * (BK + 4) + BK * (BN + 4));
+  static bool attr_done = false;
+  if (attr_done) return;
+  hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kc);
+  hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kc);
+  hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
+  hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
+  attr_done = true;
+}
+
+template <int WM, int WN, int TM, int TN, int BK>
 hipError_t launch_rows(const RowsGemmArgs &a, bool b_kc, bool vec, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   const size_t lds_kc = sizeof(float) * 2 * (BM * (BK + 4) + BN * (BK + 4));
   const size_t lds_nc = sizeof(float) * 2 * (BM * (BK + 4) + BK * (BN + 4));
   dim3 grid(ntm * ntn), block(256);
-  static bool attr_done = false;  // > 64 KiB of dynamic LDS must be opted into, once per instantiation
-  if (!attr_done) {
-    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kc);
-    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kc);
-    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
-    hipFuncSetAttribute((const void *)rows_gemm_kernel<WM, WN, TM, TN, BK, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_nc);
-    attr_done = true;
-  }
+  rows_attr<WM, WN, TM, TN, BK>();
   if (b_kc) {
     if (vec) hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 4>), grid, block, lds_kc, s, a, ntm, ntn);
     else hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 1>), grid, block, lds_kc, s, a, ntm, ntn);
@@ -459,6 +487,36 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   // half full, finish the last rows with a split-K launch that spreads them over every CU instead.
   const int main_mt = (q * slots) / ntn;  // full tile rows handled by the plain launch
   float *scratch = nullptr;
+  // A handful of tiles with a long reduction (the R x D products of the natural-gradient state, P = M M^T of the
+  // orthonormal constraint): one block per tile would crawl through K at load latency on a few CUs, so split K
+  // over the idle ones.
+  if (tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch())) {
+    const long long kt = (ktot + BK - 1) / BK;
+    int S = slots / tiles;
+    if (S > kt / 4) S = (int)(kt / 4);
+    const size_t need = sizeof(float) * (size_t)S * a.M * ((a.N + 3) & ~3);
+    if (S >= 2 && need <= kScratchBytes) {
+      RowsGemmArgs at = a;
+      at.kchunk = (int)(((kt + S - 1) / S) * BK);
+      at.ksplit = (int)((ktot + at.kchunk - 1) / at.kchunk);
+      at.partial = scratch;
+      ProfScope ps(cls, flops, s);
+      constexpr size_t lds_kc = sizeof(float) * 2 * (BM * (BK + 4) + BN * (BK + 4));
+      constexpr size_t lds_nc = sizeof(float) * 2 * (BM * (BK + 4) + BK * (BN + 4));
+      rows_attr<WM, WN, TM, TN, BK>();
+      dim3 grid(tiles * at.ksplit), block(256);
+      if (b_kc) {
+        if (vec) hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 4>), grid, block, lds_kc, s, at, ntm, ntn);
+        else hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, true, 1>), grid, block, lds_kc, s, at, ntm, ntn);
+      } else {
+        if (vec) hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, false, 4>), grid, block, lds_nc, s, at, ntm, ntn);
+        else hipLaunchKernelGGL((rows_gemm_kernel<WM, WN, TM, TN, BK, false, 1>), grid, block, lds_nc, s, at, ntm, ntn);
+      }
+      const long long total = (long long)at.M * at.N;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, at);
+      return hipGetLastError();
+    }
+  }
   if (q >= 1 && r > 0 && 2 * r <= slots && main_mt > 0 && main_mt < ntm && k4 && ktot >= 8 * BK && (scratch = splitk_scratch())) {
     const int m_main = main_mt * BM;
     RowsGemmArgs am = a;
@@ -528,6 +586,18 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   for (int i = 0; i < a.nseg; i++) {
     const int lo = a.seg[i].m_lo > 0 ? a.seg[i].m_lo : 0, hi = a.seg[i].m_hi < a.M ? a.seg[i].m_hi : a.M;
     if (hi > lo) flops += 2.0 * (hi - lo) * a.N * a.seg[i].klen;
+  }
+  if (a.sumsq) {  // one column tile, no split-K tail: block b owns rows [128 b, 128 b + 128)
+    if (a.N > 128) return hipErrorInvalidValue;
+    ProfScope ps(0, flops, s);
+    if (a.N <= 32) return launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    return launch_rows<2, 2, 2, 2, 32>(a, b_kc, vec, s);
+  }
+  // skinny outputs (the natural-gradient projections X W^T, rank <= 32): a 128x32 tile wastes no MFMA columns and
+  // keeps three blocks per CU resident to pull the A operand at HBM rate
+  if (a.N <= 32 && a.M >= 1024) {
+    ProfScope ps(0, flops, s);
+    return launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
   }
   if (waste160 < waste128) return launch_rows_balanced<4, 1, 1, 5, 16>(a, b_kc, vec, 1, flops, s);
   return launch_rows_balanced<2, 2, 2, 2, 32>(a, b_kc, vec, 0, flops, s);
@@ -677,6 +747,30 @@ __global__ void wgrad_reduce_kernel(const float *partial, int splits, int Do, in
   }
 }
 
+// The same for small outputs (the R x R products of the natural-gradient statistics: one tile, hundreds of row
+// splits): 16 split groups per element so the serial chain is splits/16 loads long.
+__global__ __launch_bounds__(256) void wgrad_reduce_small_kernel(const float *partial, int splits, int Do, int KDi, int Di, const float *coef,
+                                                                 float scale, float *G, long long ldg, int accumulate) {
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const long long total = (long long)Do * KDi, e = blockIdx.x * 16LL + el;
+  float s = 0.f;
+  if (e < total)
+    for (int sp = grp; sp < splits; sp += 16) s += partial[(long long)sp * total + e];
+  red[grp][el] = s;
+  __syncthreads();
+  if (grp != 0 || e >= total) return;
+  s = 0.f;
+#pragma unroll
+  for (int g = 0; g < 16; g++) s += red[g][el];
+  const int o = (int)(e / KDi), c = (int)(e % KDi);
+  const float cf = coef ? coef[c / Di] : 1.f;
+  if (cf == 0.f) return;
+  float *g = G + (long long)o * ldg + c;
+  const float v = scale * cf * s;
+  *g = accumulate ? *g + v : v;
+}
+
 // column sums of dY in two deterministic stages: partial[chunk][col] then bias_acc[col] += scale*sum
 __global__ void colsum_partial_kernel(const float *Y, long long ld, int rows, int cols, int rows_per_chunk,
                                       float *partial) {
@@ -702,10 +796,11 @@ struct WgradPlan {
 
 // tile shape of the weight-gradient kernel: 160-wide variants for the TDNN-F bottleneck dimension
 struct WgradTile {
-  int BM, BN, variant;  // variant 0: 128x128, 1: 160x128 (Do == 160-ish), 2: 128x160 (Di == 160-ish)
+  int BM, BN, variant;  // variant 0: 128x128, 1: 160x128 (Do == 160-ish), 2: 128x160 (Di == 160-ish), 3: 32x128 (Do <= 32)
 };
 inline int waste_of(int n, int t) { return ((n + t - 1) / t) * t - n; }
 WgradTile wgrad_tile(int Do, int Di) {
+  if (Do <= 32) return {32, 128, 3};  // J = H^T X of a rank <= 32 preconditioner: HBM-bound on X, no wasted MFMA rows
   if (waste_of(Do, 160) * 128 < waste_of(Do, 128) * 160 && waste_of(Do, 160) < waste_of(Do, 128)) return {160, 128, 1};
   if (waste_of(Di, 160) < waste_of(Di, 128)) return {128, 160, 2};
   return {128, 128, 0};
@@ -723,13 +818,14 @@ int wgrad_slots_of() {
     hipFuncSetAttribute((const void *)wgrad_kernel<WM, WN, TM, TN, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipFuncSetAttribute((const void *)wgrad_kernel<WM, WN, TM, TN, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)wgrad_kernel<WM, WN, TM, TN, 4>, 256, lds) != hipSuccess || occ < 1) occ = 2;
-    slots = occ * cus;
+    slots = std::min(occ * cus, 1024);  // wgrad_workspace_bytes() assumes at most 1024 resident blocks
     (void)hipGetLastError();
   }
   return slots;
 }
 int wgrad_slots(int variant) {
-  return variant == 1 ? wgrad_slots_of<1, 4, 5, 1>() : variant == 2 ? wgrad_slots_of<4, 1, 1, 5>() : wgrad_slots_of<2, 2, 2, 2>();
+  return variant == 1 ? wgrad_slots_of<1, 4, 5, 1>() : variant == 2 ? wgrad_slots_of<4, 1, 1, 5>() : variant == 3 ? wgrad_slots_of<1, 4, 1, 1>()
+                                                                                                   : wgrad_slots_of<2, 2, 2, 2>();
 }
 
 // Split the row (reduction) range so that tiles * splits fills whole rounds of resident blocks: every block
@@ -777,6 +873,7 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   const WgradTile wt = wgrad_tile(a.Do, a.Di);
   const int ktaps = a.active && a.max_active > 0 && a.max_active < a.K ? a.max_active : a.K;
   WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant), ktaps == a.K ? 0 : ktaps);
+  if (sizeof(float) * pl.slab_floats > workspace_bytes) return hipErrorInvalidValue;
   float *partial = reinterpret_cast<float *>(workspace);
   float *cs_partial = partial + pl.slab_floats;
   const bool vec = aligned16(a.dY) && aligned16(a.X) && a.lddy % 4 == 0 && a.ldx % 4 == 0;
@@ -790,6 +887,7 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 1>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);
     if (wt.variant == 1) { WG_LAUNCH(1, 4, 5, 1) }
     else if (wt.variant == 2) { WG_LAUNCH(4, 1, 1, 5) }
+    else if (wt.variant == 3) { WG_LAUNCH(1, 4, 1, 1) }
     else { WG_LAUNCH(2, 2, 2, 2) }
 #undef WG_LAUNCH
   }
@@ -798,8 +896,12 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   const long long total = (long long)a.Do * a.K * a.Di;
   int rb = (int)((total + 255) / 256);
   if (rb > 2048) rb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, pl.splits, a.Do, a.K * a.Di, a.Di, a.coef,
-                     a.scale, a.G, a.ldg, a.accumulate);
+  if (total <= 32768 && pl.splits >= 8)
+    hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, partial, pl.splits, a.Do, a.K * a.Di,
+                       a.Di, a.coef, a.scale, a.G, a.ldg, a.accumulate);
+  else
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, pl.splits, a.Do, a.K * a.Di, a.Di, a.coef,
+                       a.scale, a.G, a.ldg, a.accumulate);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.bias_acc) {
@@ -830,7 +932,7 @@ int tdnnf_profile_enable(int on) {
 }
 int tdnnf_profile_read(int cls, double *launches, double *total_ms, double *total_flops) {
   using namespace tdnnf;
-  if (cls < 0 || cls > 2) return TDNNF_EINVAL;
+  if (cls < 0 || cls > 3) return TDNNF_EINVAL;
   ProfClass &p = g_prof[cls];
   double ms = 0;
   for (size_t i = 0; i + 1 < p.used; i += 2) {
@@ -844,5 +946,5 @@ int tdnnf_profile_read(int cls, double *launches, double *total_ms, double *tota
   if (total_flops) *total_flops = p.flops;
   return TDNNF_OK;
 }
-const char *tdnnf_profile_class_name(int cls) { return cls >= 0 && cls <= 2 ? tdnnf::g_prof[cls].name : ""; }
+const char *tdnnf_profile_class_name(int cls) { return cls >= 0 && cls <= 3 ? tdnnf::g_prof[cls].name : ""; }
 }

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "fused.h"
 #include "gemm_f32.h"
+#include "ng.h"
 
 namespace tdnnf {
 namespace {
@@ -84,36 +85,30 @@ __global__ void add_scaled_taps_kernel(const float *G, const float *coef, float 
   const long long total = (long long)Do * KDi;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) acc[e] += coef[(e % KDi) / Di] * G[e];
 }
-// in_value_temp of UpdateNaturalGradient (nnet-tdnn-component.cc:482-532): out[r] = [c_0 X_0[r] ... c_{K-1} X_{K-1}[r], 1]
-__global__ void splice_taps_kernel(MatView x, tdnnf_tdnn_indexes ix, const float *eff, int Di, int ones, MatView out) {
-  const int C = out.cols;
-  const long long total = (long long)out.rows * C;
+// T[o][c] = coef[c / Di] * G[o][c]   (raw gradient of the spliced, coefficient-scaled input from the unscaled tap gradients)
+__global__ void scaled_taps_to_kernel(const float *G, const float *coef, int Do, int KDi, int Di, float *T, int ldT) {
+  const long long total = (long long)Do * KDi;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
-    const int r = (int)(e / C), c = (int)(e % C);
-    float v = 1.0f;
-    if (!(ones && c == C - 1)) {
-      const int i = c / Di, d = c % Di;
-      const float cf = eff ? eff[i] : 1.0f;
-      v = cf == 0.f ? 0.f : cf * x.data[(size_t)(ix.row_offsets[i] + (long long)r * ix.row_stride) * x.stride + d];
-    }
-    out.data[(size_t)r * out.stride + c] = v;
+    const int o = (int)(e / KDi), c = (int)(e % KDi);
+    T[(size_t)o * ldT + c] = (coef ? coef[c / Di] : 1.0f) * G[e];
   }
 }
-// acc[o] += scale * sum_r dY[r][o] * w[r * ldw]   (bias update with the preconditioned ones column, :610-615)
-__global__ __launch_bounds__(256) void weighted_colsum_kernel(MatView dy, const float *w, long long ldw, int rows_per_chunk, float *partial) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(dy.rows, r0 + rows_per_chunk);
-  if (col >= dy.cols) return;
-  float sacc = 0.f;
-  for (int r = r0; r < r1; r++) sacc += dy.data[(size_t)r * dy.stride + col] * w[(size_t)r * ldw];
-  partial[(size_t)blockIdx.y * dy.cols + col] = sacc;
+__global__ void set_column_kernel(const float *v, int rows, float *T, int ldT, int col) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) T[(size_t)r * ldT + col] = v[r];
 }
-__global__ void weighted_colsum_final_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
-  float sacc = 0.f;
-  for (int c = 0; c < chunks; c++) sacc += partial[(size_t)c * D + d];
-  acc[d] += scale * sacc;
+// W_acc[o][c] += a b T[o][c] (c < ldw), bias_acc[o] += a b T[o][ldw]: "local_lrate = scale * learning_rate_"
+// (nnet-tdnn-component.cc:604-624); a, b are the two preconditioners' scales, still on the device
+__global__ void ng_commit_kernel(const float *T, int ldT, int Do, int ldw, const float *sa, const float *sb, float *W_acc, float *bias_acc) {
+  const float sc = sa[0] * sb[0];
+  const int C = ldw + (bias_acc ? 1 : 0);
+  const long long total = (long long)Do * C;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int o = (int)(e / C), c = (int)(e % C);
+    const float v = sc * T[(size_t)o * ldT + c];
+    if (c < ldw) W_acc[(size_t)o * ldw + c] += v;
+    else bias_acc[o] += v;
+  }
 }
 // active[0] = number of taps with a non-zero effective coefficient, active[1..] = their ids
 __global__ void active_taps_kernel(const float *eff, int K, int *active) {
@@ -193,7 +188,7 @@ struct tdnnf_net {
   double *tapdots;     // DARTS: s_i = <dW_i, W_i>
   const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
   std::vector<tdnnf_ng *> ng_in, ng_out;  // per component (natural gradient)
-  float *ngX, *ngY;    // spliced input / output-derivative copies being preconditioned
+  float *ngH, *ngT, *ngTmp, *ngBias;  // natural gradient: H = X W^T scratch, raw gradient [W | b], projection temporaries, raw bias gradient
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den;
@@ -342,18 +337,35 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
-  n->ngX = n->ngY = nullptr;
+  n->ngH = n->ngT = n->ngTmp = n->ngBias = nullptr;
+  size_t ng_ws = 0;
   if (n->cfg.use_natural_gradient) {
-    size_t mx = (size_t)N0 * (lda_dim + 4), my = (size_t)N0 * (Hd + 4);
+    size_t mt = 0, mtmp = 0, mb = 0;
+    auto comp_ng = [&](int comp, int K, int rows) {  // rows = N of the component's output grid
+      const CompDesc &cd = n->comps[comp];
+      if (cd.lr_factor == 0.f) return;
+      const int Dx = cd.cols + (cd.has_bias ? 1 : 0), ldT = (Dx + 3) & ~3;
+      const int rank_in = std::min(20, (Dx + 1) / 2), rank_out = std::min(80, (cd.rows + 1) / 2);
+      mt = std::max(mt, (size_t)cd.rows * ldT);
+      mtmp = std::max(mtmp, std::max((size_t)cd.rows * ((rank_in + 3) & ~3), (size_t)((rank_out + 3) & ~3) * ldT));
+      mb = std::max(mb, (size_t)cd.rows);
+      ng_ws = std::max(ng_ws, std::max(ng_stats_workspace_bytes(rank_in, Dx, K, rows), ng_stats_workspace_bytes(rank_out, cd.rows, 1, rows)));
+    };
+    comp_ng(n->tdnn1.comp, 1, N0);
     for (auto &L : n->layers) {
-      mx = std::max(mx, (size_t)L.lin.rows_out * (L.lin.K * Hd + 8));
-      mx = std::max(mx, (size_t)L.aff.rows_out * (L.aff.K * L.bn + 8));
-      my = std::max(my, (size_t)L.aff.rows_out * (Hd + 4));
+      comp_ng(L.lin.comp, L.lin.K, L.lin.rows_out);
+      comp_ng(L.aff.comp, L.aff.K, L.aff.rows_out);
     }
-    mx = std::max(mx, (size_t)No * (Hd + 8));
-    my = std::max(my, (size_t)No * (P + 8));
-    n->ngX = A.take<float>(mx);
-    n->ngY = A.take<float>(my);
+    comp_ng(n->c_prefinal_l, 1, No);
+    for (int h = 0; h < 2; h++) {
+      comp_ng(n->head[h].c_affine, 1, No);
+      comp_ng(n->head[h].c_linear, 1, No);
+      comp_ng(n->head[h].c_output, 1, No);
+    }
+    n->ngH = A.take<float>((size_t)std::max(std::max(max_rows, N0), No) * 80 + 64);
+    n->ngT = A.take<float>(mt + 16);
+    n->ngTmp = A.take<float>(mtmp + 64);
+    n->ngBias = A.take<float>(mb + 16);
   }
   // shared workspace: wgrad slabs, column reductions, orthonormal
   size_t ws = 0;
@@ -372,6 +384,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   upd(colreduce_bytes(No, P));
   upd(tdnnf_constrain_orthonormal_workspace_bytes(S, Hd));
   upd(tdnnf_max_change_workspace_bytes((int)n->comps.size()));
+  upd(ng_ws);
   n->ws_bytes = ws + 256;
   n->ws = A.take<char>(n->ws_bytes);
 }
@@ -803,35 +816,46 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   //   raw:  W += c_i dY^T X_i, bias += colsum(dY)                      (UpdateSimple, :433-455)
   //   NG :  X~ = [c_i X_i ..., 1], (X~', a) = NG_in(X~), (dY', b) = NG_out(dY), W += a b dY'^T X~'[:, :K Di],
   //         bias += a b dY'^T X~'[:, -1]                               (UpdateNaturalGradient, :592-624)
-  // bias_done: the raw bias gradient was already produced by the fused BatchNorm/ReLU backward pass.
+  //         computed as a b (I - Wy^T Wy) [raw gradient] (I - Wx^T Wx): see ng.h.
+  // bias_done: the raw bias gradient was already produced by the fused BatchNorm/ReLU backward pass (into Bg(), or
+  // into n->ngBias when natural gradient is on).  tapgrad: unscaled per-tap gradients already in n->tapgrad.
+  auto bias_target = [&](int comp) -> float * {  // where a fused backward pass should accumulate the raw bias gradient
+    if (!use_ng) return Bg(n, comp);
+    (void)hipMemsetAsync(n->ngBias, 0, sizeof(float) * n->comps[comp].rows, s);
+    return n->ngBias;
+  };
   auto param_grad = [&](int comp, const tdnnf_tdnn_indexes &ix, int K, int Di, int Do, tdnnf_mat *x, tdnnf_mat *dyv, const float *eff,
-                        bool bias_done, const int *active, int max_active) -> int {
+                        bool bias_done, const int *active, int max_active, bool from_tapgrad) -> int {
     const int ldw = K * Di;
     float *bias_acc = Bg(n, comp);
     if (!use_ng)
       return tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, Wg(n, comp), ldw, bias_done ? nullptr : bias_acc, n->ws, n->ws_bytes,
                                      active, max_active, s);
-    const int N = dyv->rows, ones = bias_acc ? 1 : 0;
-    tdnnf_mat X = tdnnf_mat{n->ngX, N, ldw + ones, (ldw + ones + 3) & ~3};
-    tdnnf_mat Y = tdnnf_mat{n->ngY, N, Do, (Do + 3) & ~3};
-    hipLaunchKernelGGL(splice_taps_kernel, dim3(grid_for((long long)N * X.cols, 256)), dim3(256), 0, s, view(x), ix, eff, Di, ones, view(&X));
-    CK(tdnnf_sum_scaled(dyv, 1.0f, nullptr, 0.f, &Y, s));  // CuMatrix out_deriv_temp(out_deriv)  (:592)
-    float in_scale = 1.f, out_scale = 1.f;
-    CK(tdnnf_ng_precondition(n->ng_in[comp], &X, &in_scale, s));
-    CK(tdnnf_ng_precondition(n->ng_out[comp], &Y, &out_scale, s));
-    const float scale = in_scale * out_scale;  // "local_lrate = scale * learning_rate_" (:604-605); lr is applied in net_update
-    tdnnf_tdnn_indexes one;
-    memset(&one, 0, sizeof(one));
-    one.row_stride = 1;
-    one.num_offsets = 1;
-    tdnnf_mat Xw = tdnnf_mat{X.data, N, ldw, X.stride};
-    CK(tdnn_update_simple_impl(&one, &Xw, &Y, Do, ldw, nullptr, scale, Wg(n, comp), ldw, nullptr, n->ws, n->ws_bytes, nullptr, 0, s));
+    const int N = dyv->rows, ones = bias_acc ? 1 : 0, Dx = ldw + ones, ldT = (Dx + 3) & ~3;
+    float *T = n->ngT;
+    TDNNF_HIP(hipMemsetAsync(T, 0, sizeof(float) * (size_t)Do * ldT, s));
+    if (from_tapgrad)
+      hipLaunchKernelGGL(scaled_taps_to_kernel, dim3(grid_for((long long)Do * ldw, 256)), dim3(256), 0, s, n->tapgrad, eff, Do, ldw, Di, T, ldT);
+    else
+      CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, T, ldT, nullptr, n->ws, n->ws_bytes, active, max_active, s));
     if (ones) {
-      const int chunks = (N + 511) / 512;
-      hipLaunchKernelGGL(weighted_colsum_kernel, dim3((Do + 255) / 256, chunks), dim3(256), 0, s, view(&Y), X.data + ldw, (long long)X.stride, 512,
-                         (float *)n->ws);
-      hipLaunchKernelGGL(weighted_colsum_final_kernel, dim3((Do + 255) / 256), dim3(256), 0, s, (const float *)n->ws, chunks, Do, scale, bias_acc);
+      if (!bias_done) {
+        TDNNF_HIP(hipMemsetAsync(n->ngBias, 0, sizeof(float) * Do, s));
+        TDNNF_HIP(colsum_add(view(dyv), 1.0f, n->ngBias, n->ws, s));
+      }
+      hipLaunchKernelGGL(set_column_kernel, dim3((Do + 255) / 256), dim3(256), 0, s, n->ngBias, Do, T, ldT, ldw);
     }
+    NgInput xin;
+    memset(&xin, 0, sizeof(xin));
+    xin.x = view(x); xin.ix = ix; xin.Di = Di; xin.ones = ones; xin.N = N; xin.eff = eff; xin.active = active; xin.max_active = max_active;
+    CK(ng_stats_step(n->ng_in[comp], xin, n->ngH, n->ws, n->ws_bytes, s));
+    NgInput yin;
+    memset(&yin, 0, sizeof(yin));
+    yin.x = view(dyv); yin.ix.row_stride = 1; yin.ix.num_offsets = 1; yin.Di = Do; yin.N = N;
+    CK(ng_stats_step(n->ng_out[comp], yin, n->ngH, n->ws, n->ws_bytes, s));
+    CK(ng_project(n->ng_in[comp], n->ng_out[comp], T, Do, Dx, ldT, n->ngTmp, s));
+    hipLaunchKernelGGL(ng_commit_kernel, dim3(grid_for((long long)Do * Dx, 256)), dim3(256), 0, s, T, ldT, Do, ldw, ng_scale_dev(n->ng_in[comp]),
+                       ng_scale_dev(n->ng_out[comp]), Wg(n, comp), bias_acc);
     return TDNNF_OK;
   };
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
@@ -845,13 +869,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat dout = h == 0 ? dy : dx;
     tdnnf_mat b2 = M(H.bn2_out, No, S), b1 = M(H.bn1_out, No, Hd);
     tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
-    CK(param_grad(H.c_output, ix1, 1, S, P, &b2, &dout, nullptr, false, nullptr, 0));
+    CK(param_grad(H.c_output, ix1, 1, S, P, &b2, &dout, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
     CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
-    CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0));
+    CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
-    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, use_ng ? nullptr : Bg(n, H.c_affine)));  // dA -> d affine out
-    CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0));
+    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine)));  // dA -> d affine out
+    CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
     } else {
@@ -860,7 +884,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_add_scaled(&tmp, 1.0f, &d_pl, s));
     }
   }
-  CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0));
+  CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0, false));
   float *d_cur = n->dA, *d_next = n->dB;  // d_cur: deriv w.r.t. the current layer's output (noop)
   {
     tdnnf_mat d_top = M(d_cur, No, Hd);
@@ -877,7 +901,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
       tdnnf_mat x = M(L.relu_out, no, Hd);
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, L.relu_stats, store, repair, c.relu_self_repair_scale,
-                            view(&d_aff), use_ng ? nullptr : Bg(n, L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
+                            view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
     }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : lin;
@@ -888,7 +912,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // replaces the reference's extra forward GEMM per tap, then c_i * dW_i goes into the accumulator.
     auto tdnn_wgrad = [&](Tdnn &td, tdnnf_mat *x, tdnnf_mat *dyv, const float *eff, bool bias_done) -> int {
       const int ldw = td.K * td.Di;
+      bool tap_ready = false;
       if (td.darts && !(c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE)) {
+        tap_ready = true;
         TDNNF_HIP(hipMemsetAsync(n->tapgrad, 0, sizeof(float) * (size_t)td.Do * ldw, s));
         CK(tdnnf_tdnn_update_simple(&td.ix, x, dyv, td.Do, td.Di, nullptr, 1.0f, n->tapgrad, ldw, nullptr, n->ws, n->ws_bytes, s));
         CK(tdnnf_tdnn_darts_alpha_update(n->tapgrad, ldw, Wp(n, td.comp), ldw, td.Do, td.Di, td.K, td.memo, c.darts_flags, td.share,
@@ -902,7 +928,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       }
       // uniform-sample mode: only the share tap and the sampled tap are non-zero (:293-304) -> compacted launch
       const bool compact = td.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && td.K > 2;
-      return param_grad(td.comp, td.ix, td.K, td.Di, td.Do, x, dyv, eff, bias_done, compact ? td.active : nullptr, compact ? 2 : 0);
+      return param_grad(td.comp, td.ix, td.K, td.Di, td.Do, x, dyv, eff, bias_done, compact ? td.active : nullptr, compact ? 2 : 0, tap_ready);
     };
     CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff, true));
     tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
@@ -933,9 +959,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     std::swap(d_cur, d_next);
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
-    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, use_ng ? nullptr : Bg(n, n->tdnn1.comp)));
+    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp)));
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
-    CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0));
+    CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }
   hipLaunchKernelGGL(commit_grads_kernel, dim3(grid_for(n->num_params, 256)), dim3(256), 0, s, n->grads, n->gtmp, n->num_params, results);
   TDNNF_LAUNCH_CHECK();

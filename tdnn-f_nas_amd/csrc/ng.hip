@@ -2,94 +2,159 @@
 // nnet3/natural-gradient-online.{h,cc}; call sites /root/reference/src/nnet3/nnet-tdnn-component.cc:598-599,
 // nnet-simple-component.cc:3001-3002; configuration :183-210).  SURVEY.md 8(a) row A8.
 //
-// The N x D work (H = X W^T, X_hat = X - H W, J = H^T X, L = H^T H, K = J J^T) runs on the f32 MFMA
-// GEMM kernels; the R x R symmetric eigen-problem (R <= 80) is solved on the host in double, exactly
-// where the reference does it, on the steps where the low-rank state is refreshed.
+// Fisher model F ~ R^T D R + rho I of rank R; the preconditioned directions are X^ = X - (X W^T) W with
+// W = E^{1/2} R, returned with scale = sqrt(tr(X X^T) / tr(X^ X^^T)).  What is N-sized (N = frames x sequences):
+//   every call   H = X W^T                         one pass over X on the MFMA rows-GEMM (128x32 tile for R <= 32);
+//                tr(X X^T)                         by-product of staging X in that GEMM
+//                L = H^T H,  tr(X^ X^^T) = tr(XX^T) - 2 tr(L) + <L, W W^T>      (R x R, no second pass over X)
+//   refresh call J = H^T X, K = J J^T              second pass (first 10 calls, then every update_period-th)
+// The R x R symmetric eigen-problem of the refresh is solved on the host in double, where the reference solves it,
+// but off the critical path: K, L and tr(XX^T) are copied to pinned memory, a stream callback hands them to a
+// worker thread, and W_{t+1} = A_t (J + diag(c) W_t) is formed on the device the next time this object is used
+// (W_{t+1} is not needed earlier).  X itself is only rewritten by tdnnf_ng_precondition (the component-level entry
+// point); the trainer never materialises X^ (ng.h).
+#include "ng.h"
+
 #include <math.h>
 #include <string.h>
 
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
-#include "common.h"
 #include "gemm_f32.h"
+#include "host_linalg.h"
 
 struct tdnnf_ng {
-  int rank, update_period, t, D, frozen;
+  int rank, Rp, update_period, t, D, Dp, frozen;
   float num_samples_history, alpha, epsilon, delta, rho;
-  float *W;  // device R x D
   std::vector<float> d;
+  // device state (one allocation)
+  float *dev;
+  float *W, *WT, *WWT, *wlast, *J, *W1, *Kd, *Ld, *Ad, *coeff, *tmpR, *neg_one, *scale_f;
+  double *scal;  // [0] tr(X X^T)  [1] tr(X^ X^^T)
+  // pinned host staging
+  float *pin;
+  float *h_K, *h_L, *h_At, *h_coeff, *h_scale;
+  double *h_tr0;
+  // scratch of the component-level entry point
   float *scratch;
   size_t scratch_floats;
-  float *neg_one;  // device constant {-1}
+  // deferred refresh
+  int pending, job_done, job_N;
+  std::vector<float> d_next;
+  float rho_next;
+  bool must_reorth;
+  std::vector<double> sqrt_e1, inv_sqrt_e1;
 };
 
 namespace tdnnf {
 namespace {
 
-constexpr int kSumBlocks = 256;
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(MatView x, double *partial) {
-  __shared__ double red[4];
-  double s = 0;
-  const long long total = (long long)x.rows * x.cols;
-  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += kSumBlocks * 256LL) {
-    const double v = x.data[(size_t)(e / x.cols) * x.stride + e % x.cols];
-    s += v * v;
-  }
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-}
+inline int pad4(int x) { return (x + 3) & ~3; }
+inline size_t pad4z(size_t x) { return (x + 3) & ~(size_t)3; }
+
+// ------------------------------------------------------------------ small device kernels
 __global__ void add_diag_rows_kernel(float *J, const float *W, const float *coeff, int R, int D) {
   const long long total = (long long)R * D;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) J[e] += coeff[e / D] * W[e];
 }
-
-// cyclic Jacobi for a symmetric n x n matrix (row-major), eigenvalues sorted descending, eigenvectors in columns of U
-void jacobi_eig(std::vector<double> &A, int n, std::vector<double> &c, std::vector<double> &U) {
-  U.assign((size_t)n * n, 0.0);
-  for (int i = 0; i < n; i++) U[i * n + i] = 1.0;
-  for (int sweep = 0; sweep < 100; sweep++) {
-    double off = 0;
-    for (int i = 0; i < n; i++)
-      for (int j = i + 1; j < n; j++) off += A[i * n + j] * A[i * n + j];
-    if (off < 1e-300) break;
-    for (int p = 0; p < n; p++)
-      for (int q = p + 1; q < n; q++) {
-        const double apq = A[p * n + q];
-        if (fabs(apq) < 1e-300) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / sqrt(tt * tt + 1.0), sn = tt * cs;
-        for (int k = 0; k < n; k++) {
-          const double x = A[k * n + p], y = A[k * n + q];
-          A[k * n + p] = cs * x - sn * y;
-          A[k * n + q] = sn * x + cs * y;
-        }
-        for (int k = 0; k < n; k++) {
-          const double x = A[p * n + k], y = A[q * n + k];
-          A[p * n + k] = cs * x - sn * y;
-          A[q * n + k] = sn * x + cs * y;
-        }
-        for (int k = 0; k < n; k++) {
-          const double x = U[k * n + p], y = U[k * n + q];
-          U[k * n + p] = cs * x - sn * y;
-          U[k * n + q] = sn * x + cs * y;
-        }
-      }
-  }
-  c.resize(n);
-  for (int i = 0; i < n; i++) c[i] = A[i * n + i];
-  for (int i = 0; i < n; i++) {
-    int m = i;
-    for (int j = i + 1; j < n; j++)
-      if (c[j] > c[m]) m = j;
-    if (m != i) {
-      std::swap(c[i], c[m]);
-      for (int k = 0; k < n; k++) std::swap(U[k * n + i], U[k * n + m]);
-    }
+// WT[d][r] = W[r][d];  wlast[r] = W[r][D-1]
+__global__ void derive_kernel(const float *W, int Rp, int D, int Dp, float *WT, float *wlast) {
+  const long long total = (long long)D * Rp;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int dd = (int)(e / Rp), r = (int)(e % Rp);
+    const float v = W[(size_t)r * Dp + dd];
+    WT[e] = v;
+    if (dd == D - 1) wlast[r] = v;
   }
 }
+__global__ void scatter_col_kernel(const float *v, int R, float *J, int ld, int col) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < R) J[(size_t)r * ld + col] = v[r];
+}
+// tr0 = sum partial + ones_term;  tr1 = tr0 - 2 tr(L) + <L, WWT>;  scale = sqrt(tr0 / tr1)
+__global__ __launch_bounds__(256) void ng_scalars_kernel(const double *partial, int nb, double ones_term, const float *L, const float *WWT,
+                                                         int Rp, double *scal, float *scale_f) {
+  __shared__ double red[3][4];
+  double a = 0, b = 0, c = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
+  for (int i = threadIdx.x; i < Rp * Rp; i += 256) {
+    const double l = L[i];
+    c += l * (double)WWT[i];
+    if (i / Rp == i % Rp) b += l;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+    c += __shfl_xor(c, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = b;
+    red[2][threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tr0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) + ones_term;
+    const double trL = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    const double trLW = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    const double tr1 = tr0 - 2.0 * trL + trLW;
+    scal[0] = tr0;
+    scal[1] = tr1;
+    *scale_f = (tr0 <= 0.0 || !(tr1 > 0.0)) ? 1.0f : (float)sqrt(tr0 / tr1);
+  }
+}
+
+// ------------------------------------------------------------------ worker pool for the host part of a refresh
+void host_update(tdnnf_ng *ng);
+
+struct NgPool {
+  std::mutex mu;
+  std::condition_variable cv_job, cv_done;
+  std::deque<tdnnf_ng *> q;
+  bool started = false;
+  void start() {
+    unsigned hw = std::thread::hardware_concurrency();
+    int n = hw >= 16 ? 8 : (hw >= 4 ? (int)hw / 2 : 1);
+    for (int i = 0; i < n; i++) std::thread([this]() { run(); }).detach();
+    started = true;
+  }
+  void push(tdnnf_ng *ng) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!started) start();
+    q.push_back(ng);
+    cv_job.notify_one();
+  }
+  void run() {
+    for (;;) {
+      tdnnf_ng *ng;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_job.wait(lk, [this]() { return !q.empty(); });
+        ng = q.front();
+        q.pop_front();
+      }
+      host_update(ng);
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        ng->job_done = 1;
+      }
+      cv_done.notify_all();
+    }
+  }
+  void wait(tdnnf_ng *ng) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv_done.wait(lk, [ng]() { return ng->job_done != 0; });
+  }
+};
+NgPool &pool() {
+  static NgPool *p = new NgPool();  // never destroyed: worker threads outlive static destruction
+  return *p;
+}
+void enqueue_cb(void *p) { pool().push((tdnnf_ng *)p); }
 
 void compute_et(const std::vector<float> &d, double beta, std::vector<double> &sqrt_e, std::vector<double> &inv_sqrt_e) {
   const int R = (int)d.size();
@@ -102,272 +167,370 @@ void compute_et(const std::vector<float> &d, double beta, std::vector<double> &s
   }
 }
 
-// Gram-Schmidt with a deterministic replacement for (numerically) dependent rows (stand-in for Kaldi's
-// OrthogonalizeRows(), which re-randomises such rows)
-void orthogonalize_rows(std::vector<float> &W, int R, int D) {
-  std::vector<double> row(D);
-  for (int i = 0; i < R; i++) {
-    int cand = i;
-    for (int attempt = 0;; attempt++) {
-      double n0 = 0;
-      for (int k = 0; k < D; k++) {
-        row[k] = attempt == 0 ? W[(size_t)i * D + k] : (k == cand % D ? 1.0 : 0.0);
-        n0 += row[k] * row[k];
-      }
-      for (int pass = 0; pass < 2; pass++)
-        for (int j = 0; j < i; j++) {
-          double dot = 0;
-          for (int k = 0; k < D; k++) dot += row[k] * W[(size_t)j * D + k];
-          for (int k = 0; k < D; k++) row[k] -= dot * W[(size_t)j * D + k];
-        }
-      double n1 = 0;
-      for (int k = 0; k < D; k++) n1 += row[k] * row[k];
-      if (n0 > 0 && n1 > 1e-8 * n0 && n1 > 1e-30) {
-        const double inv = 1.0 / sqrt(n1);
-        for (int k = 0; k < D; k++) W[(size_t)i * D + k] = (float)(row[k] * inv);
-        break;
-      }
-      cand = attempt == 0 ? i : cand + 1;
+// Z_t, its eigen-decomposition, d_{t+1}, rho_{t+1} and the R x R factor A_t of W_{t+1} = A_t B_t (UPSTREAM
+// PreconditionDirectionsInternal, updating branch).  Reads only host memory; runs on a pool thread.
+void host_update(tdnnf_ng *ng) {
+  const int R = ng->rank, Rp = ng->Rp, D = ng->D, N = ng->job_N;
+  const float *Kh = ng->h_K, *Lh = ng->h_L;
+  const double tr0 = *ng->h_tr0;
+  float eta = 1.0f - expf(-(float)N / ng->num_samples_history);
+  if (eta > 0.9f) eta = 0.9f;
+  const float rho_t = ng->rho, alpha = ng->alpha;
+  double d_sum = 0;
+  for (int i = 0; i < R; i++) d_sum += ng->d[i];
+  const double beta_t = rho_t * (1.0 + alpha) + alpha * d_sum / D;
+  std::vector<double> sqrt_e, inv_sqrt_e;
+  compute_et(ng->d, beta_t, sqrt_e, inv_sqrt_e);
+  std::vector<double> Z((size_t)R * R), c, U;
+  const double eN = (double)eta / N, eN1 = eN * (1.0 - eta);
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j < R; j++) {
+      const double di = ng->d[i] + rho_t, dj = ng->d[j] + rho_t;
+      double z = eN * eN * inv_sqrt_e[i] * Kh[i * Rp + j] * inv_sqrt_e[j] + eN1 * inv_sqrt_e[i] * Lh[i * Rp + j] * inv_sqrt_e[j] * (di + dj);
+      if (i == j) z += (1.0 - eta) * (1.0 - eta) * di * di;
+      Z[(size_t)i * R + j] = z;
     }
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j < i; j++) Z[(size_t)i * R + j] = Z[(size_t)j * R + i] = 0.5 * (Z[(size_t)i * R + j] + Z[(size_t)j * R + i]);
+  hostla::sym_eig(Z, R, c, U);
+  const double c_floor = pow(rho_t * (1.0 - eta), 2);
+  bool must_reorthogonalize = c[0] > 1.0e+06 * c[R - 1];  // condition_threshold
+  std::vector<double> sqrt_c(R);
+  double sqrt_c_sum = 0, sqrt_c_max = 0;
+  for (int i = 0; i < R; i++) {
+    if (c[i] < c_floor) {
+      c[i] = c_floor;
+      must_reorthogonalize = true;
+    }
+    sqrt_c[i] = sqrt(c[i]);
+    sqrt_c_sum += sqrt_c[i];
+    sqrt_c_max = std::max(sqrt_c_max, sqrt_c[i]);
   }
+  float rho_t1 = (float)(1.0 / (D - R) * (eta / N * tr0 + (1 - eta) * (D * rho_t + d_sum) - sqrt_c_sum));
+  const float floor_val = std::max(ng->epsilon, ng->delta * (float)sqrt_c_max);
+  ng->d_next.resize(R);
+  for (int i = 0; i < R; i++) ng->d_next[i] = std::max((float)sqrt_c[i] - rho_t1, floor_val);
+  if (rho_t1 < floor_val) rho_t1 = floor_val;
+  ng->rho_next = rho_t1;
+  double d1_sum = 0;
+  for (int i = 0; i < R; i++) d1_sum += ng->d_next[i];
+  const double beta_t1 = rho_t1 * (1.0 + alpha) + alpha * d1_sum / D;
+  compute_et(ng->d_next, beta_t1, ng->sqrt_e1, ng->inv_sqrt_e1);
+  memset(ng->h_coeff, 0, sizeof(float) * Rp);
+  memset(ng->h_At, 0, sizeof(float) * (size_t)Rp * Rp);
+  for (int r = 0; r < R; r++) ng->h_coeff[r] = (float)((1.0 - eta) / (eta / N) * (ng->d[r] + rho_t));
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j < R; j++)
+      ng->h_At[(size_t)i * Rp + j] = (float)(U[(size_t)j * R + i] * (eta / N) * ng->sqrt_e1[i] / sqrt_c[i] * inv_sqrt_e[j]);
+  ng->must_reorth = must_reorthogonalize;
 }
 
-int init_default(tdnnf_ng *ng, int D) {
+// ------------------------------------------------------------------ device state
+int alloc_state(tdnnf_ng *ng, int D) {
   if (ng->rank >= D) ng->rank = D - 1;
-  const int R = ng->rank;
+  const int R = ng->rank, Rp = pad4(std::max(R, 1)), Dp = pad4(D);
   ng->D = D;
-  if (ng->W) hipFree(ng->W);
-  ng->W = nullptr;
+  ng->Dp = Dp;
+  ng->Rp = Rp;
+  const size_t fRD = (size_t)Rp * Dp, fRR = (size_t)Rp * Rp;
+  const size_t floats = 3 * fRD + pad4z((size_t)D * Rp) + 4 * fRR + 3 * Rp + 8 + 8;
+  TDNNF_HIP(hipMalloc((void **)&ng->dev, sizeof(float) * floats));
+  TDNNF_HIP(hipMemset(ng->dev, 0, sizeof(float) * floats));
+  float *p = ng->dev;
+  ng->W = p; p += fRD;
+  ng->J = p; p += fRD;
+  ng->W1 = p; p += fRD;
+  ng->WT = p; p += pad4z((size_t)D * Rp);
+  ng->WWT = p; p += fRR;
+  ng->Kd = p; p += fRR;
+  ng->Ld = p; p += fRR;
+  ng->Ad = p; p += fRR;
+  ng->wlast = p; p += Rp;
+  ng->coeff = p; p += Rp;
+  ng->tmpR = p; p += Rp;
+  ng->neg_one = p; p += 4;
+  ng->scale_f = p; p += 4;
+  ng->scal = (double *)p;
+  const size_t pin_floats = 3 * fRR + Rp + 4 + 4;
+  TDNNF_HIP(hipHostMalloc((void **)&ng->pin, sizeof(float) * pin_floats, hipHostMallocDefault));
+  memset(ng->pin, 0, sizeof(float) * pin_floats);
+  float *h = ng->pin;
+  ng->h_K = h; h += fRR;
+  ng->h_L = h; h += fRR;
+  ng->h_At = h; h += fRR;
+  ng->h_coeff = h; h += Rp;
+  ng->h_scale = h; h += 4;
+  ng->h_tr0 = (double *)h;
+  const float consts[8] = {-1.0f, 0, 0, 0, 1.0f, 0, 0, 0};  // neg_one, scale_f
+  TDNNF_HIP(hipMemcpy(ng->neg_one, consts, sizeof(consts), hipMemcpyHostToDevice));
+  return TDNNF_OK;
+}
+
+int derive(tdnnf_ng *ng, hipStream_t s) {  // W^T, W W^T and the last column of W after W changed
+  const int Rp = ng->Rp, D = ng->D, Dp = ng->Dp;
+  hipLaunchKernelGGL(derive_kernel, dim3(grid_for((long long)D * Rp, 256)), dim3(256), 0, s, ng->W, Rp, D, Dp, ng->WT, ng->wlast);
+  RowsGemmArgs k;
+  memset(&k, 0, sizeof(k));
+  k.A = ng->W; k.lda = Dp; k.B = ng->W; k.ldb = Dp; k.C = ng->WWT; k.ldc = Rp; k.M = Rp; k.N = Rp; k.init_mode = 2; k.nseg = 1;
+  k.seg[0].klen = Dp; k.seg[0].m_lo = 0; k.seg[0].m_hi = Rp;
+  TDNNF_HIP(rows_gemm(k, true, s));
+  return TDNNF_OK;
+}
+
+int init_default(tdnnf_ng *ng, int D, hipStream_t s) {  // InitDefault (UPSTREAM)
+  int rc = alloc_state(ng, D);
+  if (rc) return rc;
+  const int R = ng->rank, Dp = ng->Dp;
   ng->d.assign(R, ng->epsilon);
   ng->rho = ng->epsilon;
   ng->t = 0;
   if (R == 0) return TDNNF_OK;
-  std::vector<float> W((size_t)R * D, 0.f);
+  std::vector<float> W((size_t)ng->Rp * Dp, 0.f);
   const float first_elem = 1.1f;
+  const float E_tii = 1.0f / (2.0f + (D + R) * ng->alpha / D);
   for (int r = 0; r < R; r++) {  // InitOrthonormalSpecial
     int ncols = 0;
     for (int c = r; c < D; c += R) ncols++;
     const float normalizer = 1.0f / sqrtf(first_elem * first_elem + ncols - 1);
     int i = 0;
-    for (int c = r; c < D; c += R, i++) W[(size_t)r * D + c] = normalizer * (i == 0 ? first_elem : 1.0f);
+    for (int c = r; c < D; c += R, i++) W[(size_t)r * Dp + c] = normalizer * (i == 0 ? first_elem : 1.0f) * sqrtf(E_tii);
   }
-  const float E_tii = 1.0f / (2.0f + (D + R) * ng->alpha / D);
-  for (auto &w : W) w *= sqrtf(E_tii);
-  TDNNF_HIP(hipMalloc((void **)&ng->W, sizeof(float) * (size_t)R * D));
-  TDNNF_HIP(hipMemcpy(ng->W, W.data(), sizeof(float) * W.size(), hipMemcpyHostToDevice));
-  return TDNNF_OK;
+  TDNNF_HIP(hipMemcpyAsync(ng->W, W.data(), sizeof(float) * W.size(), hipMemcpyHostToDevice, s));
+  TDNNF_HIP(hipStreamSynchronize(s));
+  return derive(ng, s);
 }
 
 bool updating(const tdnnf_ng *ng) {
   return !ng->frozen && (ng->t <= 10 || (ng->t - 10) % ng->update_period == 0);
 }
 
-int ensure_scratch(tdnnf_ng *ng, size_t floats) {
-  if (ng->scratch_floats >= floats) return TDNNF_OK;
-  if (ng->scratch) hipFree(ng->scratch);
-  ng->scratch = nullptr;
-  ng->scratch_floats = 0;
-  TDNNF_HIP(hipMalloc((void **)&ng->scratch, sizeof(float) * floats));
-  ng->scratch_floats = floats;
-  return TDNNF_OK;
-}
-
-int sumsq_host(MatView x, double *partial_dev, hipStream_t s, double *out) {
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(kSumBlocks), dim3(256), 0, s, x, partial_dev);
-  double h[kSumBlocks];
-  TDNNF_HIP(hipMemcpyAsync(h, partial_dev, sizeof(h), hipMemcpyDeviceToHost, s));
+// ReorthogonalizeRt1 (UPSTREAM): bring R_{t+1} = E_{t+1}^{-1/2} W_{t+1} back to orthonormal rows.  Rare; synchronous.
+int reorthogonalize(tdnnf_ng *ng, hipStream_t s) {
+  const int R = ng->rank, Rp = ng->Rp, D = ng->D, Dp = ng->Dp;
+  const size_t fRR = (size_t)Rp * Rp, fRD = (size_t)Rp * Dp;
+  RowsGemmArgs o;
+  memset(&o, 0, sizeof(o));
+  o.A = ng->W1; o.lda = Dp; o.B = ng->W1; o.ldb = Dp; o.C = ng->Kd; o.ldc = Rp; o.M = Rp; o.N = Rp; o.init_mode = 2; o.nseg = 1;
+  o.seg[0].klen = Dp; o.seg[0].m_lo = 0; o.seg[0].m_hi = Rp;
+  TDNNF_HIP(rows_gemm(o, true, s));  // O = W W^T
+  std::vector<float> Oh(fRR);
+  TDNNF_HIP(hipMemcpyAsync(Oh.data(), ng->Kd, sizeof(float) * fRR, hipMemcpyDeviceToHost, s));
   TDNNF_HIP(hipStreamSynchronize(s));
-  double t = 0;
-  for (int i = 0; i < kSumBlocks; i++) t += h[i];
-  *out = t;
+  std::vector<double> O((size_t)R * R), Cm, Ci;
+  bool is_unit = true;
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j <= i; j++) {
+      const double a = (double)Oh[(size_t)i * Rp + j] * ng->inv_sqrt_e1[i] * ng->inv_sqrt_e1[j];
+      O[(size_t)i * R + j] = O[(size_t)j * R + i] = a;
+      if (fabs(a - (i == j ? 1.0 : 0.0)) > 1.0e-03) is_unit = false;
+    }
+  if (is_unit) return TDNNF_OK;
+  bool ok = hostla::cholesky_inverse(O, R, Cm, Ci);
+  if (ok) {
+    double cmax = 0;
+    for (auto v : Ci) cmax = std::max(cmax, v);
+    if (!(cmax < 100.0)) ok = false;
+  }
+  if (!ok) {  // Gram-Schmidt on the host, then W = E^{1/2} R
+    std::vector<float> Wh(fRD);
+    TDNNF_HIP(hipMemcpyAsync(Wh.data(), ng->W1, sizeof(float) * fRD, hipMemcpyDeviceToHost, s));
+    TDNNF_HIP(hipStreamSynchronize(s));
+    hostla::orthogonalize_rows(Wh, R, D, Dp);
+    for (int i = 0; i < R; i++)
+      for (int k = 0; k < D; k++) Wh[(size_t)i * Dp + k] *= (float)ng->sqrt_e1[i];
+    TDNNF_HIP(hipMemcpyAsync(ng->W1, Wh.data(), sizeof(float) * fRD, hipMemcpyHostToDevice, s));
+    TDNNF_HIP(hipStreamSynchronize(s));
+    return TDNNF_OK;
+  }
+  std::vector<float> Th(fRR, 0.f);  // W <- (E^{1/2} C^{-1} E^{-1/2}) W
+  for (int i = 0; i < R; i++)
+    for (int j = 0; j <= i; j++) Th[(size_t)i * Rp + j] = (float)(Ci[(size_t)i * R + j] * ng->sqrt_e1[i] * ng->inv_sqrt_e1[j]);
+  TDNNF_HIP(hipMemcpyAsync(ng->Ad, Th.data(), sizeof(float) * fRR, hipMemcpyHostToDevice, s));
+  TDNNF_HIP(hipStreamSynchronize(s));
+  RowsGemmArgs t2;
+  memset(&t2, 0, sizeof(t2));
+  t2.A = ng->Ad; t2.lda = Rp; t2.B = ng->W1; t2.ldb = Dp; t2.C = ng->J; t2.ldc = Dp; t2.M = Rp; t2.N = Dp; t2.init_mode = 2; t2.nseg = 1;
+  t2.seg[0].klen = Rp; t2.seg[0].m_lo = 0; t2.seg[0].m_hi = Rp;
+  TDNNF_HIP(rows_gemm(t2, false, s));
+  TDNNF_HIP(hipMemcpyAsync(ng->W1, ng->J, sizeof(float) * fRD, hipMemcpyDeviceToDevice, s));
   return TDNNF_OK;
 }
 
-// one PreconditionDirections step on X (state must be initialised); increments t
-int precondition_step(tdnnf_ng *ng, MatView X, float *scale, hipStream_t s) {
-  const int N = X.rows, D = X.cols, R = ng->rank;
-  const bool upd = updating(ng);
-  const size_t wg_bytes = std::max(wgrad_workspace_bytes(R, D, 1, N), wgrad_workspace_bytes(R, R, 1, N));
-  const size_t f_H = (size_t)N * R, f_J = (size_t)R * D, f_RR = (size_t)R * R;
-  const size_t need = f_H + 2 * f_J + 3 * f_RR + R + 2 * kSumBlocks * 2 + wg_bytes / 4 + 64;
-  int rc = ensure_scratch(ng, need);
-  if (rc) return rc;
-  float *H = ng->scratch, *J = H + ((f_H + 3) & ~(size_t)3), *W1 = J + ((f_J + 3) & ~(size_t)3);
-  float *Kd = W1 + ((f_J + 3) & ~(size_t)3), *Ld = Kd + ((f_RR + 3) & ~(size_t)3), *Ad = Ld + ((f_RR + 3) & ~(size_t)3);
-  float *coeff = Ad + ((f_RR + 3) & ~(size_t)3);
-  double *partial = (double *)(coeff + ((R + 3) & ~3) + 2);
-  partial = (double *)(((uintptr_t)partial + 15) & ~(uintptr_t)15);
-  void *wg_ws = (void *)(partial + 2 * kSumBlocks);
-  double tr0;
-  if ((rc = sumsq_host(X, partial, s, &tr0))) return rc;
+// Second half of a refresh: wait for the host part, then W_{t+1} = A_t (J + diag(coeff) W_t) on the device.
+int finalize(tdnnf_ng *ng, hipStream_t s) {
+  if (!ng->pending) return TDNNF_OK;
+  pool().wait(ng);
+  ng->pending = 0;
+  const int Rp = ng->Rp, Dp = ng->Dp;
+  const size_t fRR = (size_t)Rp * Rp, fRD = (size_t)Rp * Dp;
+  TDNNF_HIP(hipMemcpyAsync(ng->coeff, ng->h_coeff, sizeof(float) * Rp, hipMemcpyHostToDevice, s));
+  TDNNF_HIP(hipMemcpyAsync(ng->Ad, ng->h_At, sizeof(float) * fRR, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(add_diag_rows_kernel, dim3(grid_for((long long)fRD, 256)), dim3(256), 0, s, ng->J, ng->W, ng->coeff, Rp, Dp);
+  RowsGemmArgs w1;
+  memset(&w1, 0, sizeof(w1));
+  w1.A = ng->Ad; w1.lda = Rp; w1.B = ng->J; w1.ldb = Dp; w1.C = ng->W1; w1.ldc = Dp; w1.M = Rp; w1.N = Dp; w1.init_mode = 2; w1.nseg = 1;
+  w1.seg[0].klen = Rp; w1.seg[0].m_lo = 0; w1.seg[0].m_hi = Rp;
+  TDNNF_HIP(rows_gemm(w1, false, s));
+  if (ng->must_reorth) {
+    int rc = reorthogonalize(ng, s);
+    if (rc) return rc;
+  }
+  TDNNF_HIP(hipMemcpyAsync(ng->W, ng->W1, sizeof(float) * fRD, hipMemcpyDeviceToDevice, s));
+  ng->d = ng->d_next;
+  ng->rho = ng->rho_next;
+  return derive(ng, s);
+}
+
+size_t stats_ws_bytes(int Rp, int Di, int K, int N) {
+  const size_t part = ((size_t)rows_gemm_sumsq_blocks(N) * sizeof(double) + 63) & ~(size_t)63;
+  return part + std::max(wgrad_workspace_bytes(Rp, Rp, 1, N), wgrad_workspace_bytes(Rp, Di, K, N));
+}
+
+// H, traces, scale [+ J, K and the hand-off to the host on a refresh]; W_t is left untouched
+int stats_core(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_bytes, bool upd, hipStream_t s) {
+  const int N = in.N, K = in.ix.num_offsets, Di = in.Di, Rp = ng->Rp, Dp = ng->Dp, D = ng->D;
+  TDNNF_REQUIRE(ws && ws_bytes >= stats_ws_bytes(Rp, Di, K, N), "ng: workspace too small");
+  const int nb = rows_gemm_sumsq_blocks(N);
+  double *part = (double *)ws;
+  const size_t part_bytes = ((size_t)nb * sizeof(double) + 63) & ~(size_t)63;
+  void *wg_ws = (char *)ws + part_bytes;
+  const size_t wg_bytes = ws_bytes - part_bytes;
 
   RowsGemmArgs a;
   memset(&a, 0, sizeof(a));
-  a.A = X.data; a.lda = X.stride; a.B = ng->W; a.ldb = D; a.C = H; a.ldc = R; a.M = N; a.N = R; a.init_mode = 2; a.nseg = 1;
-  a.seg[0].klen = D; a.seg[0].m_lo = 0; a.seg[0].m_hi = N;
-  TDNNF_HIP(rows_gemm(a, true, s));  // H = X W^T
-  std::vector<float> Kh, Lh;
-  if (upd) {
-    WgradArgs w;
-    memset(&w, 0, sizeof(w));
-    w.dY = H; w.lddy = R; w.X = X.data; w.ldx = X.stride; w.Do = R; w.Di = D; w.K = 1; w.N = N; w.row_stride = 1;
-    w.scale = 1.f; w.G = J; w.ldg = D; w.accumulate = 0;
-    TDNNF_HIP(wgrad(w, wg_ws, wg_bytes, s));  // J = H^T X
-    w.X = H; w.ldx = R; w.Di = R; w.G = Ld; w.ldg = R;
-    TDNNF_HIP(wgrad(w, wg_ws, wg_bytes, s));  // L = H^T H
-    RowsGemmArgs k;
-    memset(&k, 0, sizeof(k));
-    k.A = J; k.lda = D; k.B = J; k.ldb = D; k.C = Kd; k.ldc = R; k.M = R; k.N = R; k.init_mode = 2; k.nseg = 1;
-    k.seg[0].klen = D; k.seg[0].m_lo = 0; k.seg[0].m_hi = R;
-    TDNNF_HIP(rows_gemm(k, true, s));  // K = J J^T
-    Kh.resize(f_RR);
-    Lh.resize(f_RR);
-    TDNNF_HIP(hipMemcpyAsync(Kh.data(), Kd, sizeof(float) * f_RR, hipMemcpyDeviceToHost, s));
-    TDNNF_HIP(hipMemcpyAsync(Lh.data(), Ld, sizeof(float) * f_RR, hipMemcpyDeviceToHost, s));
+  a.A = in.x.data; a.lda = (long long)in.x.stride * in.ix.row_stride; a.B = ng->W; a.ldb = Dp; a.C = H; a.ldc = Rp; a.M = N; a.N = Rp;
+  a.bias = in.ones ? ng->wlast : nullptr;
+  a.init_mode = in.ones ? 1 : 2;
+  a.coef = in.eff;
+  a.sumsq = part;
+  a.nseg = K;
+  for (int i = 0; i < K; i++) {
+    a.seg[i].a_off = (long long)in.ix.row_offsets[i] * in.x.stride;
+    a.seg[i].b_off = (long long)i * Di;
+    a.seg[i].klen = Di;
+    a.seg[i].m_lo = 0;
+    a.seg[i].m_hi = N;
   }
-  RowsGemmArgs b;
-  memset(&b, 0, sizeof(b));
-  b.A = H; b.lda = R; b.B = ng->W; b.ldb = D; b.C = X.data; b.ldc = X.stride; b.M = N; b.N = D; b.init_mode = 0; b.nseg = 1;
-  b.coef = ng->neg_one;
-  b.seg[0].klen = R; b.seg[0].m_lo = 0; b.seg[0].m_hi = N;
-  TDNNF_HIP(rows_gemm(b, false, s));  // X_hat = X - H W
-  double tr1;
-  if ((rc = sumsq_host(X, partial, s, &tr1))) return rc;  // also completes the K/L copies
-  if (scale) *scale = tr0 <= 0.0 ? 1.0f : (float)sqrt(tr0 / tr1);
+  TDNNF_HIP(rows_gemm(a, true, s));  // H = X W^T (+ ||X||_F^2 per block)
 
-  if (upd) {
-    float eta = 1.0f - expf(-(float)N / ng->num_samples_history);
-    if (eta > 0.9f) eta = 0.9f;
-    const float rho_t = ng->rho, alpha = ng->alpha;
-    double d_sum = 0;
-    for (int i = 0; i < R; i++) d_sum += ng->d[i];
-    const double beta_t = rho_t * (1.0 + alpha) + alpha * d_sum / D;
-    std::vector<double> sqrt_e, inv_sqrt_e;
-    compute_et(ng->d, beta_t, sqrt_e, inv_sqrt_e);
-    std::vector<double> Z(f_RR), c, U;
-    const double eN = (double)eta / N, eN1 = eN * (1.0 - eta);
-    for (int i = 0; i < R; i++)
-      for (int j = 0; j < R; j++) {
-        const double di = ng->d[i] + rho_t, dj = ng->d[j] + rho_t;
-        double z = eN * eN * inv_sqrt_e[i] * Kh[i * R + j] * inv_sqrt_e[j] + eN1 * inv_sqrt_e[i] * Lh[i * R + j] * inv_sqrt_e[j] * (di + dj);
-        if (i == j) z += (1.0 - eta) * (1.0 - eta) * di * di;
-        Z[i * R + j] = z;
-      }
-    for (int i = 0; i < R; i++)
-      for (int j = 0; j < i; j++) Z[i * R + j] = Z[j * R + i] = 0.5 * (Z[i * R + j] + Z[j * R + i]);
-    jacobi_eig(Z, R, c, U);
-    const double c_floor = pow(rho_t * (1.0 - eta), 2);
-    bool must_reorthogonalize = c[0] > 1.0e+06 * c[R - 1];  // condition_threshold
-    std::vector<double> sqrt_c(R);
-    double sqrt_c_sum = 0, sqrt_c_max = 0;
-    for (int i = 0; i < R; i++) {
-      if (c[i] < c_floor) {
-        c[i] = c_floor;
-        must_reorthogonalize = true;
-      }
-      sqrt_c[i] = sqrt(c[i]);
-      sqrt_c_sum += sqrt_c[i];
-      sqrt_c_max = std::max(sqrt_c_max, sqrt_c[i]);
-    }
-    float rho_t1 = (float)(1.0 / (D - R) * (eta / N * tr0 + (1 - eta) * (D * rho_t + d_sum) - sqrt_c_sum));
-    const float floor_val = std::max(ng->epsilon, ng->delta * (float)sqrt_c_max);
-    std::vector<float> d_t1(R);
-    for (int i = 0; i < R; i++) d_t1[i] = std::max((float)sqrt_c[i] - rho_t1, floor_val);
-    if (rho_t1 < floor_val) rho_t1 = floor_val;
-    double d1_sum = 0;
-    for (int i = 0; i < R; i++) d1_sum += d_t1[i];
-    const double beta_t1 = rho_t1 * (1.0 + alpha) + alpha * d1_sum / D;
-    std::vector<double> sqrt_e1, inv_sqrt_e1;
-    compute_et(d_t1, beta_t1, sqrt_e1, inv_sqrt_e1);
-    std::vector<float> coeff_h(R), At(f_RR);
-    for (int r = 0; r < R; r++) coeff_h[r] = (float)((1.0 - eta) / (eta / N) * (ng->d[r] + rho_t));
-    for (int i = 0; i < R; i++)
-      for (int j = 0; j < R; j++) At[i * R + j] = (float)(U[j * R + i] * (eta / N) * sqrt_e1[i] / sqrt_c[i] * inv_sqrt_e[j]);
-    TDNNF_HIP(hipMemcpyAsync(coeff, coeff_h.data(), sizeof(float) * R, hipMemcpyHostToDevice, s));
-    TDNNF_HIP(hipMemcpyAsync(Ad, At.data(), sizeof(float) * f_RR, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(add_diag_rows_kernel, dim3(grid_for((long long)R * D, 256)), dim3(256), 0, s, J, ng->W, coeff, R, D);
-    RowsGemmArgs w1;
-    memset(&w1, 0, sizeof(w1));
-    w1.A = Ad; w1.lda = R; w1.B = J; w1.ldb = D; w1.C = W1; w1.ldc = D; w1.M = R; w1.N = D; w1.init_mode = 2; w1.nseg = 1;
-    w1.seg[0].klen = R; w1.seg[0].m_lo = 0; w1.seg[0].m_hi = R;
-    TDNNF_HIP(rows_gemm(w1, false, s));  // W_{t+1} = A_t B_t
-    if (must_reorthogonalize) {  // ReorthogonalizeRt1 (UPSTREAM): R_{t+1} = E_{t+1}^{-1/2} W_{t+1} back to orthonormal rows
-      RowsGemmArgs o;
-      memset(&o, 0, sizeof(o));
-      o.A = W1; o.lda = D; o.B = W1; o.ldb = D; o.C = Kd; o.ldc = R; o.M = R; o.N = R; o.init_mode = 2; o.nseg = 1;
-      o.seg[0].klen = D; o.seg[0].m_lo = 0; o.seg[0].m_hi = R;
-      TDNNF_HIP(rows_gemm(o, true, s));  // O = W W^T
-      std::vector<float> Oh(f_RR);
-      TDNNF_HIP(hipMemcpyAsync(Oh.data(), Kd, sizeof(float) * f_RR, hipMemcpyDeviceToHost, s));
-      TDNNF_HIP(hipStreamSynchronize(s));
-      std::vector<double> O(f_RR), Cm(f_RR, 0.0), Ci(f_RR, 0.0);
-      bool is_unit = true;
-      for (int i = 0; i < R; i++)
-        for (int j = 0; j <= i; j++) {
-          const double a = (double)Oh[i * R + j] * inv_sqrt_e1[i] * inv_sqrt_e1[j];
-          O[i * R + j] = O[j * R + i] = a;
-          if (fabs(a - (i == j ? 1.0 : 0.0)) > 1.0e-03) is_unit = false;
-        }
-      if (!is_unit) {
-        bool ok = true;
-        for (int i = 0; i < R && ok; i++)
-          for (int j = 0; j <= i; j++) {
-            double sum = O[i * R + j];
-            for (int k = 0; k < j; k++) sum -= Cm[i * R + k] * Cm[j * R + k];
-            if (i == j) {
-              if (!(sum > 0.0)) { ok = false; break; }
-              Cm[i * R + i] = sqrt(sum);
-            } else {
-              Cm[i * R + j] = sum / Cm[j * R + j];
-            }
-          }
-        double cmax = 0;
-        if (ok) {
-          for (int i = 0; i < R; i++) {
-            Ci[i * R + i] = 1.0 / Cm[i * R + i];
-            for (int j = 0; j < i; j++) {
-              double sum = 0;
-              for (int k = j; k < i; k++) sum += Cm[i * R + k] * Ci[k * R + j];
-              Ci[i * R + j] = -sum / Cm[i * R + i];
-            }
-          }
-          for (auto v : Ci) cmax = std::max(cmax, v);
-          if (!(cmax < 100.0)) ok = false;
-        }
-        if (!ok) {  // Gram-Schmidt on the host, then W = E^{1/2} R
-          std::vector<float> Wh(f_J);
-          TDNNF_HIP(hipMemcpyAsync(Wh.data(), W1, sizeof(float) * f_J, hipMemcpyDeviceToHost, s));
-          TDNNF_HIP(hipStreamSynchronize(s));
-          orthogonalize_rows(Wh, R, D);
-          for (int i = 0; i < R; i++)
-            for (int k = 0; k < D; k++) Wh[(size_t)i * D + k] *= (float)sqrt_e1[i];
-          TDNNF_HIP(hipMemcpyAsync(W1, Wh.data(), sizeof(float) * f_J, hipMemcpyHostToDevice, s));
-          TDNNF_HIP(hipStreamSynchronize(s));
-        } else {  // W <- (E^{1/2} C^{-1} E^{-1/2}) W
-          std::vector<float> Th(f_RR, 0.f);
-          for (int i = 0; i < R; i++)
-            for (int j = 0; j <= i; j++) Th[i * R + j] = (float)(Ci[i * R + j] * sqrt_e1[i] * inv_sqrt_e1[j]);
-          TDNNF_HIP(hipMemcpyAsync(Ad, Th.data(), sizeof(float) * f_RR, hipMemcpyHostToDevice, s));
-          TDNNF_HIP(hipStreamSynchronize(s));
-          RowsGemmArgs t2;
-          memset(&t2, 0, sizeof(t2));
-          t2.A = Ad; t2.lda = R; t2.B = W1; t2.ldb = D; t2.C = J; t2.ldc = D; t2.M = R; t2.N = D; t2.init_mode = 2; t2.nseg = 1;
-          t2.seg[0].klen = R; t2.seg[0].m_lo = 0; t2.seg[0].m_hi = R;
-          TDNNF_HIP(rows_gemm(t2, false, s));
-          TDNNF_HIP(hipMemcpyAsync(W1, J, sizeof(float) * f_J, hipMemcpyDeviceToDevice, s));
-        }
-      }
-    }
-    TDNNF_HIP(hipMemcpyAsync(ng->W, W1, sizeof(float) * f_J, hipMemcpyDeviceToDevice, s));
-    TDNNF_HIP(hipStreamSynchronize(s));  // host vectors coeff_h / At go out of scope
-    ng->d = d_t1;
-    ng->rho = rho_t1;
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  w.dY = H; w.lddy = Rp; w.X = H; w.ldx = Rp; w.Do = Rp; w.Di = Rp; w.K = 1; w.N = N; w.row_stride = 1; w.scale = 1.f;
+  w.G = ng->Ld; w.ldg = Rp; w.accumulate = 0;
+  TDNNF_HIP(wgrad(w, wg_ws, wg_bytes, s));  // L = H^T H
+  hipLaunchKernelGGL(ng_scalars_kernel, dim3(1), dim3(256), 0, s, part, nb, in.ones ? (double)N : 0.0, ng->Ld, ng->WWT, Rp, ng->scal, ng->scale_f);
+  if (!upd) return TDNNF_OK;
+
+  TDNNF_HIP(hipMemsetAsync(ng->J, 0, sizeof(float) * (size_t)Rp * Dp, s));
+  if (in.ones) TDNNF_HIP(hipMemsetAsync(ng->tmpR, 0, sizeof(float) * Rp, s));
+  WgradArgs j;
+  memset(&j, 0, sizeof(j));
+  j.dY = H; j.lddy = Rp; j.X = in.x.data; j.ldx = in.x.stride; j.Do = Rp; j.Di = Di; j.K = K; j.N = N; j.row_stride = in.ix.row_stride;
+  for (int i = 0; i < K; i++) j.row_offsets[i] = in.ix.row_offsets[i];
+  j.coef = in.eff; j.scale = 1.f; j.G = ng->J; j.ldg = Dp; j.accumulate = 1; j.bias_acc = in.ones ? ng->tmpR : nullptr;
+  j.active = in.active; j.max_active = in.max_active;
+  TDNNF_HIP(wgrad(j, wg_ws, wg_bytes, s));  // J = H^T X  (last column: column sums of H)
+  if (in.ones) hipLaunchKernelGGL(scatter_col_kernel, dim3((Rp + 63) / 64), dim3(64), 0, s, ng->tmpR, Rp, ng->J, Dp, D - 1);
+  RowsGemmArgs k;
+  memset(&k, 0, sizeof(k));
+  k.A = ng->J; k.lda = Dp; k.B = ng->J; k.ldb = Dp; k.C = ng->Kd; k.ldc = Rp; k.M = Rp; k.N = Rp; k.init_mode = 2; k.nseg = 1;
+  k.seg[0].klen = Dp; k.seg[0].m_lo = 0; k.seg[0].m_hi = Rp;
+  TDNNF_HIP(rows_gemm(k, true, s));  // K = J J^T
+  const size_t fRR = (size_t)Rp * Rp;
+  TDNNF_HIP(hipMemcpyAsync(ng->h_K, ng->Kd, sizeof(float) * fRR, hipMemcpyDeviceToHost, s));
+  TDNNF_HIP(hipMemcpyAsync(ng->h_L, ng->Ld, sizeof(float) * fRR, hipMemcpyDeviceToHost, s));
+  TDNNF_HIP(hipMemcpyAsync(ng->h_tr0, ng->scal, sizeof(double), hipMemcpyDeviceToHost, s));
+  ng->job_N = N;
+  ng->job_done = 0;
+  ng->pending = 1;
+  if (hipLaunchHostFunc(s, enqueue_cb, ng) != hipSuccess) {  // no stream callbacks: do the host part here
+    (void)hipGetLastError();
+    TDNNF_HIP(hipStreamSynchronize(s));
+    host_update(ng);
+    ng->job_done = 1;
   }
-  ng->t += 1;
   return TDNNF_OK;
 }
 
 }  // namespace
+
+size_t ng_stats_workspace_bytes(int rank, int D, int K, int N) {
+  const int Rp = pad4(std::max(1, std::min(rank, D - 1)));
+  const int Di = K > 0 ? D / K : D;
+  return stats_ws_bytes(Rp, Di, std::max(K, 1), N) + 64;
+}
+int ng_h_ld(const tdnnf_ng *ng) { return ng->Rp; }
+int ng_dim(const tdnnf_ng *ng) { return ng->D; }
+const float *ng_scale_dev(const tdnnf_ng *ng) { return ng->scale_f; }
+const float *ng_w_dev(const tdnnf_ng *ng) { return ng->W; }
+int ng_w_ld(const tdnnf_ng *ng) { return ng->Dp; }
+
+int ng_stats_step(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_bytes, hipStream_t s) {
+  const int K = in.ix.num_offsets, D = K * in.Di + (in.ones ? 1 : 0);
+  TDNNF_REQUIRE(ng && H && in.N > 0 && K >= 1 && K <= kMaxSeg && in.Di > 0, "ng_stats_step: bad arguments");
+  ProfClassOverride prof_as_ng(3);
+  if (ng->D == 0) {  // Init(): default state, then self-training on this minibatch (3 refreshes from the same data)
+    int rc = init_default(ng, D, s);
+    if (rc) return rc;
+    if (ng->rank > 0) {
+      const int iters = in.N <= ng->rank ? 1 : 3;
+      for (int i = 0; i < iters; i++) {
+        if ((rc = stats_core(ng, in, H, ws, ws_bytes, true, s))) return rc;
+        if ((rc = finalize(ng, s))) return rc;
+      }
+    }
+    ng->t = 0;
+  }
+  TDNNF_REQUIRE(ng->D == D, "ng: dimension changed from %d to %d", ng->D, D);
+  if (ng->rank == 0) return TDNNF_OK;
+  int rc = finalize(ng, s);  // a refresh started by the previous call on this object
+  if (rc) return rc;
+  rc = stats_core(ng, in, H, ws, ws_bytes, updating(ng), s);
+  ng->t += 1;
+  return rc;
+}
+
+size_t ng_project_tmp_floats(const tdnnf_ng *in, const tdnnf_ng *out, int Do, int ldT) {
+  const size_t q = in ? (size_t)Do * in->Rp : 0, p = out ? (size_t)out->Rp * ldT : 0;
+  return std::max(q, p) + 16;
+}
+
+int ng_project(tdnnf_ng *in, tdnnf_ng *out, float *T, int Do, int Dx, int ldT, float *tmp, hipStream_t s) {
+  TDNNF_REQUIRE(T && tmp && ldT % 4 == 0 && ldT >= Dx, "ng_project: bad arguments");
+  ProfClassOverride prof_as_ng(3);
+  if (in && in->rank > 0) {
+    TDNNF_REQUIRE(in->D == Dx && in->Dp == ldT, "ng_project: input-side dimension mismatch");
+    const int Rp = in->Rp;
+    RowsGemmArgs q;
+    memset(&q, 0, sizeof(q));
+    q.A = T; q.lda = ldT; q.B = in->W; q.ldb = in->Dp; q.C = tmp; q.ldc = Rp; q.M = Do; q.N = Rp; q.init_mode = 2; q.nseg = 1;
+    q.seg[0].klen = ldT; q.seg[0].m_lo = 0; q.seg[0].m_hi = Do;
+    TDNNF_HIP(rows_gemm(q, true, s));  // Q = T Wx^T
+    RowsGemmArgs c;
+    memset(&c, 0, sizeof(c));
+    c.A = tmp; c.lda = Rp; c.B = in->W; c.ldb = in->Dp; c.C = T; c.ldc = ldT; c.M = Do; c.N = ldT; c.init_mode = 0; c.nseg = 1;
+    c.coef = in->neg_one;
+    c.seg[0].klen = Rp; c.seg[0].m_lo = 0; c.seg[0].m_hi = Do;
+    TDNNF_HIP(rows_gemm(c, false, s));  // T -= Q Wx
+  }
+  if (out && out->rank > 0) {
+    TDNNF_REQUIRE(out->D == Do, "ng_project: output-side dimension mismatch");
+    const int Rp = out->Rp;
+    RowsGemmArgs p;
+    memset(&p, 0, sizeof(p));
+    p.A = out->W; p.lda = out->Dp; p.B = T; p.ldb = ldT; p.C = tmp; p.ldc = ldT; p.M = Rp; p.N = ldT; p.init_mode = 2; p.nseg = 1;
+    p.seg[0].klen = Do; p.seg[0].m_lo = 0; p.seg[0].m_hi = Rp;
+    TDNNF_HIP(rows_gemm(p, false, s));  // P = Wy T
+    RowsGemmArgs c;
+    memset(&c, 0, sizeof(c));
+    c.A = out->WT; c.lda = Rp; c.B = tmp; c.ldb = ldT; c.C = T; c.ldc = ldT; c.M = Do; c.N = ldT; c.init_mode = 0; c.nseg = 1;
+    c.coef = out->neg_one;
+    c.seg[0].klen = Rp; c.seg[0].m_lo = 0; c.seg[0].m_hi = Do;
+    TDNNF_HIP(rows_gemm(c, false, s));  // T -= Wy^T P
+  }
+  return TDNNF_OK;
+}
+
 }  // namespace tdnnf
 
 using namespace tdnnf;
@@ -378,73 +541,84 @@ int tdnnf_ng_create(int rank, int update_period, float num_samples_history, floa
   TDNNF_REQUIRE(out && rank >= 0 && update_period >= 1 && num_samples_history > 0 && alpha >= 0, "ng_create: bad configuration");
   tdnnf_ng *ng = new tdnnf_ng();
   ng->rank = rank;
+  ng->Rp = 0;
   ng->update_period = update_period;
   ng->t = 0;
-  ng->D = 0;
+  ng->D = ng->Dp = 0;
   ng->frozen = 0;
   ng->num_samples_history = num_samples_history;
   ng->alpha = alpha;
   ng->epsilon = 1.0e-10f;
   ng->delta = 5.0e-04f;
   ng->rho = 0;
-  ng->W = nullptr;
+  ng->dev = nullptr;
+  ng->pin = nullptr;
   ng->scratch = nullptr;
   ng->scratch_floats = 0;
-  ng->neg_one = nullptr;
+  ng->pending = 0;
+  ng->job_done = 0;
+  ng->must_reorth = false;
   *out = ng;
   return TDNNF_OK;
 }
 
 void tdnnf_ng_destroy(tdnnf_ng *ng) {
   if (!ng) return;
-  hipFree(ng->W);
+  if (ng->pending) pool().wait(ng);  // the worker still reads this object's pinned buffers
+  hipFree(ng->dev);
+  hipHostFree(ng->pin);
   hipFree(ng->scratch);
-  hipFree(ng->neg_one);
   delete ng;
 }
 
+// Component-level entry point: X (N x D, device) is replaced by X^; *scale_host (optional) receives the scale,
+// which costs a stream synchronisation.
 int tdnnf_ng_precondition(tdnnf_ng *ng, tdnnf_mat *X, float *scale_host, tdnnf_stream stream) {
   TDNNF_REQUIRE(ng && mat_ok(X) && X->rows > 0 && X->cols > 0, "ng_precondition: bad arguments");
   hipStream_t s = (hipStream_t)stream;
+  ProfClassOverride prof_as_ng(3);
   if (X->cols == 1) {  // preconditioning one column is pointless (UPSTREAM)
     if (scale_host) *scale_host = 1.0f;
     return TDNNF_OK;
   }
-  if (!ng->neg_one) {
-    const float m1 = -1.0f;
-    TDNNF_HIP(hipMalloc((void **)&ng->neg_one, 16));
-    TDNNF_HIP(hipMemcpy(ng->neg_one, &m1, sizeof(float), hipMemcpyHostToDevice));
+  const int N = X->rows, D = X->cols;
+  const int Rp = pad4(std::max(1, std::min(ng->rank, D - 1)));
+  const size_t ws_bytes = stats_ws_bytes(Rp, D, 1, N) + 64;
+  const size_t need = (size_t)N * Rp + ws_bytes / sizeof(float) + 64;
+  if (ng->scratch_floats < need) {
+    if (ng->scratch) hipFree(ng->scratch);
+    ng->scratch = nullptr;
+    ng->scratch_floats = 0;
+    TDNNF_HIP(hipMalloc((void **)&ng->scratch, sizeof(float) * need));
+    ng->scratch_floats = need;
   }
-  MatView xv = view(X);
-  if (ng->t == 0 && ng->W == nullptr && ng->D == 0) {  // Init(): default state + self-training on this minibatch
-    int rc = init_default(ng, X->cols);
-    if (rc) return rc;
-    if (ng->rank > 0) {
-      const int iters = X->rows <= ng->rank ? 1 : 3;
-      float *copy = nullptr;
-      TDNNF_HIP(hipMalloc((void **)&copy, sizeof(float) * (size_t)X->rows * X->cols));
-      const int was_frozen = ng->frozen;
-      ng->frozen = 0;
-      ng->t = 1;
-      for (int i = 0; i < iters && rc == 0; i++) {
-        hipMemcpy2DAsync(copy, sizeof(float) * X->cols, X->data, sizeof(float) * X->stride, sizeof(float) * X->cols, X->rows,
-                         hipMemcpyDeviceToDevice, s);
-        float sc;
-        rc = precondition_step(ng, MatView{copy, X->rows, X->cols, X->cols}, &sc, s);
-      }
-      hipStreamSynchronize(s);
-      hipFree(copy);
-      ng->frozen = was_frozen;
-      ng->t = 0;
-      if (rc) return rc;
-    }
-  }
-  TDNNF_REQUIRE(ng->D == X->cols, "ng_precondition: dimension changed from %d to %d", ng->D, X->cols);
+  float *H = ng->scratch;
+  void *ws = (void *)(((uintptr_t)(H + (size_t)N * Rp) + 63) & ~(uintptr_t)63);
+  NgInput in;
+  memset(&in, 0, sizeof(in));
+  in.x = view(X);
+  in.ix.row_stride = 1;
+  in.ix.num_offsets = 1;
+  in.Di = D;
+  in.N = N;
+  int rc = ng_stats_step(ng, in, H, ws, ws_bytes - 64, s);
+  if (rc) return rc;
   if (ng->rank == 0) {
     if (scale_host) *scale_host = 1.0f;
     return TDNNF_OK;
   }
-  return precondition_step(ng, xv, scale_host, s);
+  RowsGemmArgs b;
+  memset(&b, 0, sizeof(b));
+  b.A = H; b.lda = ng->Rp; b.B = ng->W; b.ldb = ng->Dp; b.C = X->data; b.ldc = X->stride; b.M = N; b.N = D; b.init_mode = 0; b.nseg = 1;
+  b.coef = ng->neg_one;
+  b.seg[0].klen = ng->Rp; b.seg[0].m_lo = 0; b.seg[0].m_hi = N;
+  TDNNF_HIP(rows_gemm(b, false, s));  // X^ = X - H W
+  if (scale_host) {
+    TDNNF_HIP(hipMemcpyAsync(ng->h_scale, ng->scale_f, sizeof(float), hipMemcpyDeviceToHost, s));
+    TDNNF_HIP(hipStreamSynchronize(s));
+    *scale_host = *ng->h_scale;
+  }
+  return TDNNF_OK;
 }
 
 }  // extern "C"
