@@ -298,6 +298,23 @@ typedef struct {
      output derivative are preconditioned (rank 20 / 80, alpha 4, history 2000, update period 4), the product of the
      two scale factors multiplies the update.  0: raw gradients (is_gradient_ / UpdateSimple semantics). */
   int use_natural_gradient;
+  /* Bottleneck-dimension search supernet (run_TDNNf_DARTS_mod_fbk_bottleneckCBshare_95onehottrain.sh:151-176 +
+     scripts/generate_bottleneckCB8share_onehottrain_config.py:8-102; cv-update: scripts/add_flopsconstraint.py:18-30).
+     bn_num_choices = C in 2..8 turns every tdnnf layer into: X.linear (-> sum of bn_choice_dims, must equal
+     bottleneck_dim[]) split into C column blocks of widths bn_choice_dims[k]; block k is multiplied (ElementwiseProduct)
+     by CopyN(Sum(p_k..p_{C-1})) where p (C values, the same for every row) comes from
+       bn_mode 0: OnehotFunctionComponent "X.softmax" (one uniform draw per layer and minibatch; its C-vector
+                  output_ is updated with lr * colsum(deriv) although nothing reads it, nnet-simple-component.cc:9521-9552)
+       bn_mode 1: ConstantFunctionComponent "X.alpha" (C logits, update 5 * lr * colsum, :2636) -> SoftmaxFlopsComponent
+       bn_mode 2: the same through GumbelSoftmaxFlopsComponent (C uniform draws, bn_temp_proportion)
+     and X.affine reads the masked blocks.  The FLOPs penalty of modes 1/2 adds bn_flops_scale / (rows * C) * flops_k to
+     every row of d p with flops_k = -(bn_choice_dims[0] + ... + bn_choice_dims[k]) (the reference hard-codes
+     -25 ... -240, :10006-10017).  0 = off.  Not combinable with darts_num_offsets. */
+  int bn_num_choices;
+  int bn_choice_dims[8];
+  int bn_mode;
+  float bn_flops_scale;
+  float bn_temp_proportion;
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 

@@ -37,6 +37,7 @@ struct CompDesc {
   int rows, cols, has_bias;
   float lr_factor, l2, max_change, orthonormal;
   int num_alpha;  // DARTS: K architecture logits between the weights and the bias
+  bool plain = false;  // updated without natural gradient (OnehotFunction / ConstantFunction output_ vectors)
   long long size() const { return (long long)rows * cols + num_alpha + (has_bias ? rows : 0); }
 };
 
@@ -64,6 +65,10 @@ struct TdnnfLayer {
   float *lin_out, *lin_perm, *relu_out, *noop_out;
   float *bn_memo;
   double *bn_stats, *relu_stats;
+  // bottleneck-dimension supernet: component of the C-vector (X.softmax / X.alpha), first random draw, choice
+  // probabilities p (C) and the column mask (bn), masked linear output
+  int c_arch, arch_draw0;
+  float *arch_p, *arch_mask, *lin_masked;
 };
 
 // per-component table for the update kernels
@@ -110,6 +115,96 @@ __global__ void ng_commit_kernel(const float *T, int ldT, int Do, int ldw, const
     else bias_acc[o] += v;
   }
 }
+// ---- bottleneck-dimension supernet (scripts/generate_bottleneckCB8share_onehottrain_config.py:10-85).
+struct BnChoice {
+  int C, mode;
+  int cum[8];  // cumulative block widths: candidate bottleneck dims
+  float flops_scale, temp;
+};
+// p (C): choice probabilities, identical for every row -- mode 0 OnehotFunctionComponent::Propagate
+// (nnet-simple-component.cc:9504-9519), 1 SoftmaxFlops :9968-9981 on the ConstantFunction output, 2 GumbelSoftmaxFlops
+// :10088-10113 (one noise vector shared by all rows).  mask[c] = sum_{j >= block(c)} p_j: CopyN of Sum(p_k..p_{C-1}).
+__global__ void bn_choice_forward_kernel(BnChoice bc, const float *alpha, const float *u, float *p, float *mask) {
+  __shared__ float sp[8];
+  if (threadIdx.x == 0) {
+    const int C = bc.C;
+    if (bc.mode == 0) {
+      for (int i = 0; i < C; i++) sp[i] = (u[0] >= (float)i / C && u[0] < (float)(i + 1) / C) ? 1.0f : 0.0f;
+    } else {
+      float v[8], mx = -INFINITY;
+      for (int i = 0; i < C; i++) {
+        v[i] = bc.mode == 2 ? (alpha[i] + -logf(-logf(u[i]))) * (1.0f / bc.temp) : alpha[i];
+        mx = fmaxf(mx, v[i]);
+      }
+      double sum = 0;
+      for (int i = 0; i < C; i++) sum += exp((double)v[i] - mx);
+      for (int i = 0; i < C; i++) {
+        const float q = (float)(exp((double)v[i] - mx) / sum);
+        sp[i] = q < 1.0e-20f ? 1.0e-20f : q;  // ApplyFloor(1e-20)
+      }
+    }
+    for (int i = 0; i < C; i++) p[i] = sp[i];
+  }
+  __syncthreads();
+  const int bn = bc.cum[bc.C - 1];
+  for (int c = threadIdx.x; c < bn; c += blockDim.x) {
+    int k = 0;
+    while (c >= bc.cum[k]) k++;
+    float m = 0.f;
+    for (int j = k; j < bc.C; j++) m += sp[j];  // Sum(softmax_k, ..., softmax_{C-1}) descriptor
+    mask[c] = m;
+  }
+}
+// out[r][c] = in[r][c] * mask[c]   (ElementwiseProductComponent :256-274 / :276-299 with a row-constant factor)
+__global__ void col_scale_kernel(MatView in, const float *mask, MatView out) {
+  const int C = in.cols;
+  const long long total = (long long)in.rows * C;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int r = (int)(e / C), c = (int)(e % C);
+    out.data[(size_t)r * out.stride + c] = in.data[(size_t)r * in.stride + c] * mask[c];
+  }
+}
+// Gradient of the C-vector.  partial[chunk][c] = sum over the chunk's rows of lin[r][c] * d_masked[r][c]
+// (ElementwiseProduct backprop w.r.t. the CopyN factor), E_j = sum_{c < cum[j]} (CopyN backprop + Sum descriptor).
+//   mode 0: grad_j += E_j                                                    (OnehotFunction :9539-9548)
+//   mode 1/2: e_j = E_j + flops_scale / C * (-cum[j]);  grad_j += 5 * p_j (e_j - <p, e>) / temp
+//             ((Gumbel)SoftmaxFlops backprop summed over rows, then ConstantFunction :2636)
+__global__ void bn_choice_backward_kernel(BnChoice bc, const float *partial, int chunks, const float *p, float *grad) {
+  __shared__ double dm[512];
+  const int bn = bc.cum[bc.C - 1];
+  for (int c = threadIdx.x; c < bn; c += blockDim.x) {
+    double sacc = 0;
+    for (int k = 0; k < chunks; k++) sacc += partial[(size_t)k * bn + c];
+    dm[c] = sacc;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double E[8], run = 0;
+  int c = 0;
+  for (int j = 0; j < bc.C; j++) {
+    for (; c < bc.cum[j]; c++) run += dm[c];
+    E[j] = run;
+  }
+  if (bc.mode == 0) {
+    for (int j = 0; j < bc.C; j++) grad[j] += (float)E[j];
+    return;
+  }
+  double pe = 0;
+  for (int j = 0; j < bc.C; j++) {
+    E[j] += (double)bc.flops_scale / bc.C * -(double)bc.cum[j];
+    pe += (double)p[j] * E[j];
+  }
+  for (int j = 0; j < bc.C; j++) grad[j] += 5.0f * (float)(p[j] * (E[j] - pe)) * (1.0f / bc.temp);
+}
+// partial[chunk][c] = sum_{r in chunk} a[r][c] * b[r][c]
+__global__ __launch_bounds__(256) void colsum_prod_partial_kernel(MatView a, MatView b, int rows_per_chunk, float *partial) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(a.rows, r0 + rows_per_chunk);
+  if (col >= a.cols) return;
+  float sacc = 0.f;
+  for (int r = r0; r < r1; r++) sacc += a.data[(size_t)r * a.stride + col] * b.data[(size_t)r * b.stride + col];
+  partial[(size_t)blockIdx.y * a.cols + col] = sacc;
+}
 // active[0] = number of taps with a non-zero effective coefficient, active[1..] = their ids
 __global__ void active_taps_kernel(const float *eff, int K, int *active) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -123,6 +218,14 @@ __global__ void active_taps_kernel(const float *eff, int K, int *active) {
 __global__ void commit_grads_kernel(float *grads, const float *gtmp, long long n, const double *results) {
   if (results[5] == 0.0) return;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) grads[i] += gtmp[i];
+}
+// out (cols x rows) = in (rows x cols)^T, both dense
+__global__ void transpose_kernel(const float *in, int rows, int cols, float *out) {
+  const long long total = (long long)rows * cols;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int r = (int)(e / cols), c = (int)(e % cols);
+    out[(size_t)c * rows + r] = in[e];
+  }
 }
 __global__ void scale_doubles_kernel(double *x, int n, double s) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -188,6 +291,7 @@ struct tdnnf_net {
   double *tapdots;     // DARTS: s_i = <dW_i, W_i>
   const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
   std::vector<tdnnf_ng *> ng_in, ng_out;  // per component (natural gradient)
+  float *orthoT;       // transpose of a constrained matrix with more rows than columns (null when there is none)
   float *ngH, *ngT, *ngTmp, *ngBias;  // natural gradient: H = X W^T scratch, raw gradient [W | b], projection temporaries, raw bias gradient
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
@@ -296,6 +400,12 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     const int nl = N_of(L.lin.out, B), no = N_of(L.gout, B);
     L.lin_out = A.mat(nl, L.bn);
     L.lin_perm = L.perm ? A.mat(nl, L.bn) : nullptr;
+    L.arch_p = L.arch_mask = L.lin_masked = nullptr;
+    if (L.c_arch >= 0) {
+      L.arch_p = A.take<float>(8);
+      L.arch_mask = A.take<float>(L.bn + 4);
+      L.lin_masked = A.mat(nl, L.bn);
+    }
     L.relu_out = A.mat(no, Hd);
     L.noop_out = A.mat(no, Hd);
     L.bn_memo = A.take<float>(5 * Hd);
@@ -338,12 +448,19 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
   n->ngH = n->ngT = n->ngTmp = n->ngBias = nullptr;
+  size_t tall = 0, tall_ws = 0;
+  for (auto &cd : n->comps)
+    if (cd.orthonormal != 0.f && cd.rows > cd.cols) {
+      tall = std::max(tall, (size_t)cd.rows * cd.cols);
+      tall_ws = std::max(tall_ws, tdnnf_constrain_orthonormal_workspace_bytes(cd.cols, cd.rows));
+    }
+  n->orthoT = tall ? A.take<float>(tall + 16) : nullptr;
   size_t ng_ws = 0;
   if (n->cfg.use_natural_gradient) {
     size_t mt = 0, mtmp = 0, mb = 0;
     auto comp_ng = [&](int comp, int K, int rows) {  // rows = N of the component's output grid
       const CompDesc &cd = n->comps[comp];
-      if (cd.lr_factor == 0.f) return;
+      if (cd.lr_factor == 0.f || cd.plain) return;
       const int Dx = cd.cols + (cd.has_bias ? 1 : 0), ldT = (Dx + 3) & ~3;
       const int rank_in = std::min(20, (Dx + 1) / 2), rank_out = std::min(80, (cd.rows + 1) / 2);
       mt = std::max(mt, (size_t)cd.rows * ldT);
@@ -385,6 +502,8 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   upd(tdnnf_constrain_orthonormal_workspace_bytes(S, Hd));
   upd(tdnnf_max_change_workspace_bytes((int)n->comps.size()));
   upd(ng_ws);
+  upd(tall_ws);
+  if (n->cfg.bn_num_choices > 0) upd(sizeof(float) * (size_t)((max_lin_rows + 511) / 512 + 1) * 512);
   n->ws_bytes = ws + 256;
   n->ws = A.take<char>(n->ws_bytes);
 }
@@ -450,6 +569,19 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
   TDNNF_REQUIRE(c.num_layers >= 1 && c.num_layers <= TDNNF_NET_MAX_LAYERS, "net_create: 1..%d tdnnf layers", TDNNF_NET_MAX_LAYERS);
   TDNNF_REQUIRE(c.darts_num_offsets == 0 || (c.darts_num_offsets >= 2 && c.darts_num_offsets <= TDNNF_MAX_OFFSETS),
                 "net_create: darts_num_offsets must be 0 or 2..%d (the reference assumes K >= 2, nnet-tdnn-component.cc:232)", TDNNF_MAX_OFFSETS);
+  if (c.bn_num_choices != 0) {
+    TDNNF_REQUIRE(c.bn_num_choices >= 2 && c.bn_num_choices <= 8 && c.bn_mode >= 0 && c.bn_mode <= 2, "net_create: bn_num_choices must be 2..8, bn_mode 0..2");
+    TDNNF_REQUIRE(c.darts_num_offsets == 0, "net_create: the bottleneck and the offset supernet cannot be combined");
+    TDNNF_REQUIRE(c.bn_mode != 2 || c.bn_temp_proportion > 0, "net_create: bn_temp_proportion must be > 0");
+    int sum = 0;
+    for (int k = 0; k < c.bn_num_choices; k++) {
+      TDNNF_REQUIRE(c.bn_choice_dims[k] > 0, "net_create: bn_choice_dims must be positive");
+      sum += c.bn_choice_dims[k];
+    }
+    TDNNF_REQUIRE(sum <= 512, "net_create: bottleneck supernet wider than 512");
+    for (int l = 0; l < c.num_layers; l++)
+      TDNNF_REQUIRE(c.bottleneck_dim[l] == sum, "net_create: bottleneck_dim[%d] = %d but the choice blocks sum to %d", l, c.bottleneck_dim[l], sum);
+  }
   TDNNF_REQUIRE(c.darts_num_offsets == 0 || !(c.darts_flags & TDNNF_DARTS_USE_GUMBEL) || c.darts_temp_proportion > 0,
                 "net_create: gumbel mode needs temp-proportion > 0");
   TDNNF_REQUIRE(c.frame_subsampling >= 1 && c.frames_per_chunk > 0 && c.frames_per_chunk % c.frame_subsampling == 0 && c.num_sequences > 0,
@@ -530,6 +662,17 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
       aff_off = {0};
     }
     char nm[64];
+    L.c_arch = -1;
+    L.arch_draw0 = 0;
+    if (c.bn_num_choices > 0) {
+      // X.softmax (OnehotFunctionComponent, is-updatable=true use-natural-gradient=false) or X.alpha
+      // (ConstantFunctionComponent, same flags): a C-vector, no l2, no per-component max-change
+      snprintf(nm, sizeof(nm), c.bn_mode == 0 ? "tdnnf%d.softmax" : "tdnnf%d.alpha", l + 2);
+      L.c_arch = add_comp(n, nm, c.bn_num_choices, 1, 0, 1.f, 0.f, 0.f, 0.f);
+      n->comps[L.c_arch].plain = true;
+      L.arch_draw0 = n->num_draws;
+      n->num_draws += c.bn_mode == 0 ? 1 : (c.bn_mode == 2 ? c.bn_num_choices : 0);
+    }
     snprintf(nm, sizeof(nm), "tdnnf%d.linear", l + 2);
     // DARTS: bias forced on (scripts/generate_config.py:25-26), K logits in front of it, and the orthonormal
     // constraint is inert because ConstrainOrthonormal does not match TdnnDARTSV3Component (nnet-utils.cc:1047-1061)
@@ -569,7 +712,7 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     n->ng_out.assign(n->comps.size(), nullptr);
     for (size_t i = 0; i < n->comps.size(); i++) {
       const CompDesc &cd = n->comps[i];
-      if (cd.lr_factor == 0.f) continue;  // fixed lda layer
+      if (cd.lr_factor == 0.f || cd.plain) continue;  // fixed lda layer; vectors updated without natural gradient
       const int spliced = cd.cols + (cd.has_bias ? 1 : 0);
       const int rank_in = std::min(20, (spliced + 1) / 2), rank_out = std::min(80, (cd.rows + 1) / 2);
       if (tdnnf_ng_create(rank_in, 4, 2000.0f, 4.0f, &n->ng_in[i]) || tdnnf_ng_create(rank_out, 4, 2000.0f, 4.0f, &n->ng_out[i])) {
@@ -606,6 +749,8 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     name(p + ".relu", L.relu_out, L.aff.rows_out, Hd);
     name(p + ".noop", L.noop_out, L.aff.rows_out, Hd);
   }
+  if (!n->layers.empty() && !n->layers[0].perm)  // what the last backward step left: d objective / d tdnnf2.linear (debugging aid)
+    name("tdnnf2.linear.deriv", n->d_small, n->layers[0].lin.rows_out, n->layers[0].bn);
   name("prefinal-l", n->prefinal_l_out, n->Tout * B, S);
   name("output", n->head[0].y, n->Tout * B, P);
   name("output-xent", n->xent_logsoftmax, n->Tout * B, P);
@@ -694,6 +839,21 @@ int tdnnf_net_get_activation(const tdnnf_net *n, const char *name, tdnnf_mat *ou
   return TDNNF_EINVAL;
 }
 
+static BnChoice bn_choice(const tdnnf_net_config &c) {
+  BnChoice bc;
+  memset(&bc, 0, sizeof(bc));
+  bc.C = c.bn_num_choices;
+  bc.mode = c.bn_mode;
+  int run = 0;
+  for (int k = 0; k < 8; k++) {
+    if (k < bc.C) run += c.bn_choice_dims[k];
+    bc.cum[k] = run;
+  }
+  bc.flops_scale = c.bn_flops_scale;
+  bc.temp = c.bn_mode == 2 ? c.bn_temp_proportion : 1.0f;
+  return bc;
+}
+
 int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *den,
                                const tdnnf_supervision *sup, double *results, long long step, tdnnf_stream stream) {
   TDNNF_REQUIRE(n && n->params && n->grads, "net_forward_backward: call net_set_buffers first");
@@ -751,9 +911,17 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // (DARTS .linear: bias present but offsets[1] < 0 -> out is zeroed and the bias never added, :237-240)
     CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, lin_eff, 2, &lin, s));
     tdnnf_mat aff_in = lin;
+    if (L.c_arch >= 0) {  // bottleneck supernet: column blocks of the linear output times CopyN(Sum(p_k..))
+      TDNNF_REQUIRE(n->draws || c.bn_mode == 1, "net_forward_backward: the bottleneck supernet needs net_set_random_draws before every step");
+      hipLaunchKernelGGL(bn_choice_forward_kernel, dim3(1), dim3(256), 0, s, bn_choice(c), Wp(n, L.c_arch),
+                         n->draws ? n->draws + L.arch_draw0 : nullptr, L.arch_p, L.arch_mask);
+      aff_in = M(L.lin_masked, L.lin.rows_out, L.bn);
+      hipLaunchKernelGGL(col_scale_kernel, dim3(grid_for((long long)lin.rows * L.bn, 256)), dim3(256), 0, s, view(&lin), L.arch_mask, view(&aff_in));
+    }
     if (L.perm) {
+      tdnnf_mat src = aff_in;
       aff_in = M(L.lin_perm, L.lin.rows_out, L.bn);
-      CK(tdnnf_reorder_rows(&lin, B, L.aff.ix.row_stride, 1, &aff_in, s));
+      CK(tdnnf_reorder_rows(&src, B, L.aff.ix.row_stride, 1, &aff_in, s));
     }
     tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
     CK(tdnn_propagate_impl(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, 1, 1, &relu, s));
@@ -904,7 +1072,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                             view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
     }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
-    tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : lin;
+    tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : (L.c_arch >= 0 ? M(L.lin_masked, nl, L.bn) : lin);
     const float *lin_eff = L.lin.darts ? L.lin.memo + TDNNF_MAX_OFFSETS : nullptr;
     const float *aff_eff = L.aff.darts ? L.aff.memo + TDNNF_MAX_OFFSETS : nullptr;
     // weight gradient of one Tdnn component.  DARTS in a non-sampling mode also needs the architecture-logit
@@ -940,6 +1108,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       d_lin = un;
     } else {
       CK(tdnn_backprop_data_impl(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, aff_eff, 1, nullptr, 0.f, 0, &d_lin, s));
+    }
+    if (L.c_arch >= 0) {
+      // d_lin is the derivative w.r.t. the masked blocks: the CopyN factor receives colsum(lin * d) (-> gradient of the
+      // C-vector), the linear output receives d * mask (ElementwiseProductComponent::Backprop :276-299)
+      const int chunks = (nl + 511) / 512;
+      hipLaunchKernelGGL(colsum_prod_partial_kernel, dim3((L.bn + 255) / 256, chunks), dim3(256), 0, s, view(&lin), view(&d_lin), 512, (float *)n->ws);
+      hipLaunchKernelGGL(bn_choice_backward_kernel, dim3(1), dim3(256), 0, s, bn_choice(c), (const float *)n->ws, chunks, L.arch_p, Wg(n, L.c_arch));
+      hipLaunchKernelGGL(col_scale_kernel, dim3(grid_for((long long)nl * L.bn, 256)), dim3(256), 0, s, view(&d_lin), L.arch_mask, view(&d_lin));
     }
     tdnnf_mat in = M(in_act, ni, Hd);
     // (the never-added bias of a DARTS .linear is still updated by the reference, :614 -- Bg() is null for plain layers)
@@ -1009,8 +1185,15 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
     const CompDesc &c = n->comps[i];
     if (c.orthonormal == 0.f) continue;
     if (::tdnnf::tdnnf_decision((unsigned long long)step, 2 * (unsigned long long)i + 1) % 4 != 0) continue;  // RandInt(0,3) != 0
-    TDNNF_REQUIRE(c.rows <= c.cols, "net_update: constrained matrix %s has rows > cols", c.name.c_str());
-    CK(tdnnf_constrain_orthonormal(c.orthonormal, n->params + c.begin, c.rows, c.cols, c.cols, n->ws, n->ws_bytes, s));
+    if (c.rows <= c.cols) {
+      CK(tdnnf_constrain_orthonormal(c.orthonormal, n->params + c.begin, c.rows, c.cols, c.cols, n->ws, n->ws_bytes, s));
+    } else {  // tall matrix: constrain the transpose (nnet-utils.cc:1068-1075)
+      TDNNF_REQUIRE(n->orthoT, "net_update: no transpose buffer for %s", c.name.c_str());
+      const long long total = (long long)c.rows * c.cols;
+      hipLaunchKernelGGL(transpose_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, n->params + c.begin, c.rows, c.cols, n->orthoT);
+      CK(tdnnf_constrain_orthonormal(c.orthonormal, n->orthoT, c.cols, c.rows, c.rows, n->ws, n->ws_bytes, s));
+      hipLaunchKernelGGL(transpose_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, n->orthoT, c.cols, c.rows, n->params + c.begin);
+    }
   }
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;

@@ -25,7 +25,9 @@ class NetConfig(C.Structure):
                 ("max_change_hidden", C.c_float), ("max_change_output", C.c_float), ("max_param_change", C.c_float),
                 ("relu_self_repair_scale", C.c_float), ("batchnorm_stats_scale", C.c_float),
                 ("darts_num_offsets", C.c_int), ("darts_flags", C.c_int), ("darts_temp_proportion", C.c_float),
-                ("use_natural_gradient", C.c_int)]
+                ("use_natural_gradient", C.c_int),
+                ("bn_num_choices", C.c_int), ("bn_choice_dims", C.c_int * 8), ("bn_mode", C.c_int),
+                ("bn_flops_scale", C.c_float), ("bn_temp_proportion", C.c_float)]
 
 DARTS_USE_GUMBEL, DARTS_FREE_SELECT, DARTS_UNIFORM_SAMPLE, DARTS_USE_ENTROPY, DARTS_UPDATE_ALPHA = 1, 2, 4, 8, 16
 
@@ -33,6 +35,10 @@ DARTS_USE_GUMBEL, DARTS_FREE_SELECT, DARTS_UNIFORM_SAMPLE, DARTS_USE_ENTROPY, DA
 # time strides of the fixed 7q net (run_tdnn_fbk_40_iv_sp_7q.sh:171-184) and of the "manual" variant
 STRIDES_7Q = [1, 1, 1, 0] + [3] * 10
 STRIDES_MANUAL_OFFSET6 = [1, 1, 1, 0] + [6] * 10   # run_tdnn_7q_fbk_40_manual.sh --offset 6
+# block widths of the bottleneck-dimension supernet (generate_bottleneckCB8share_onehottrain_config.py:24-38):
+# candidate bottleneck dims 25, 50, 80, 100, 120, 160, 200, 240
+BN_CHOICE_DIMS = [25, 25, 30, 20, 20, 40, 40, 40]
+BN_ONEHOT, BN_SOFTMAX_FLOPS, BN_GUMBEL_SOFTMAX_FLOPS = 0, 1, 2
 
 
 def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck=160, feat_dim=40, ivector_dim=100,
@@ -56,6 +62,18 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
     c.darts_flags = kw.get("darts_flags", DARTS_UNIFORM_SAMPLE if c.darts_num_offsets else 0)
     c.darts_temp_proportion = kw.get("darts_temp_proportion", 1.0)
     c.use_natural_gradient = int(kw.get("use_natural_gradient", 0))
+    # bottleneck-dimension supernet: bn_choice_dims = block widths (their sum is every layer's linear output dim)
+    dims = kw.get("bn_choice_dims")
+    if dims:
+        assert 2 <= len(dims) <= 8
+        c.bn_num_choices = len(dims)
+        for i, d in enumerate(dims):
+            c.bn_choice_dims[i] = int(d)
+        for i in range(len(strides)):
+            c.bottleneck_dim[i] = int(sum(dims))
+        c.bn_mode = int(kw.get("bn_mode", BN_ONEHOT))
+        c.bn_flops_scale = float(kw.get("bn_flops_scale", 0.0))
+        c.bn_temp_proportion = float(kw.get("bn_temp_proportion", 1.0))
     return c
 
 
@@ -115,6 +133,8 @@ class ChainNet:
             if c["name"] == "lda":
                 q = np.linalg.qr(rng.standard_normal((c["rows"], c["cols"])))[0]
                 W, b = q.astype(np.float32), np.zeros(c["rows"], np.float32)
+            elif c["name"].endswith((".softmax", ".alpha")):  # ConstantFunction / Onehot output_: zeros (InitFromConfig)
+                W, b = np.zeros((c["rows"], c["cols"]), np.float32), None
             elif c["name"].startswith("output"):
                 sd = 0.0 if output_stddev is None else output_stddev
                 W = (rng.standard_normal((c["rows"], c["cols"])) * sd).astype(np.float32)

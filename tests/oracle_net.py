@@ -62,11 +62,13 @@ class OracleNet:
         self.num_t_in = g[2] + 2
         self.bn_stats = {}
         self.relu_stats = {}
+        self.bnC = int(getattr(cfg, "bn_num_choices", 0))
+        self.bn_dims = [cfg.bn_choice_dims[k] for k in range(self.bnC)]
         self.use_ng = bool(getattr(cfg, "use_natural_gradient", 0))
         self.ng = {}
         if self.use_ng:  # same configuration as the trainer (nnet-tdnn-component.cc:183-210)
             for c in components:
-                if c["lr_factor"] == 0.0:
+                if c["lr_factor"] == 0.0 or c["name"].endswith((".softmax", ".alpha")):
                     continue
                 spliced = c["cols"] + (1 if c["has_bias"] else 0)
                 self.ng[c["name"]] = (self.L.oracle_ng_create(min(20, (spliced + 1) // 2), 4, 2000.0, 4.0),
@@ -154,6 +156,61 @@ class OracleNet:
         self.L.oracle_tdnn_darts_effective_coef(ora.fptr(coef), K, self.cfg.darts_flags, share, ora.fptr(eff))
         return coef, eff
 
+    # ---- bottleneck-dimension supernet, node by node as generate_bottleneckCB8share_onehottrain_config.py:10-85 wires it
+    def _arch_fwd(self, p, nm, lin, draws, d0):
+        cfg, Lb, Cn = self.cfg, self.L, self.bnC
+        nl = lin.shape[0]
+        P = np.zeros((nl, Cn), F)
+        if cfg.bn_mode == 0:  # X.softmax = OnehotFunctionComponent
+            Lb.oracle_onehot_propagate(float(draws[d0]), ora.omat(P))
+        else:  # X.alpha = ConstantFunctionComponent -> X.softmax = (Gumbel)SoftmaxFlopsComponent
+            alpha = np.ascontiguousarray(self.W(p, nm + ".alpha").ravel())
+            A = np.zeros((nl, Cn), F)
+            Lb.oracle_constant_function_propagate(ora.fptr(alpha), ora.omat(A))
+            u = np.ascontiguousarray(draws[d0:d0 + Cn], dtype=F) if cfg.bn_mode == 2 else None
+            Lb.oracle_softmax_flops_propagate(ora.omat(A), ora.fptr(u) if u is not None else None,
+                                              cfg.bn_temp_proportion if cfg.bn_mode == 2 else 1.0, ora.omat(P))
+        masked, ew_ins, c0 = np.zeros_like(lin), [], 0
+        for k, d in enumerate(self.bn_dims):
+            sk = np.zeros((nl, 1), F)
+            for j in range(k, Cn):  # Sum(softmax_k, ..., softmax_{C-1})
+                sk[:, 0] += P[:, j]
+            cop = np.zeros((nl, d), F)
+            Lb.oracle_copyn_propagate(ora.omat(sk), 1.0, ora.omat(cop))
+            ew_in = np.ascontiguousarray(np.concatenate([cop, lin[:, c0:c0 + d]], axis=1))  # Append(Xk.copyn, Xk.linear)
+            out = np.zeros((nl, d), F)
+            Lb.oracle_elementwise_product_propagate(ora.omat(ew_in), d, ora.omat(out))
+            masked[:, c0:c0 + d] = out
+            ew_ins.append(ew_in)
+            c0 += d
+        return masked, dict(P=P, ew_ins=ew_ins)
+
+    def _arch_bwd(self, nm, st, d_masked, grad_vec):
+        cfg, Lb, Cn = self.cfg, self.L, self.bnC
+        nl = d_masked.shape[0]
+        d_P, d_lin, c0 = np.zeros((nl, Cn), F), np.zeros_like(d_masked), 0
+        for k, d in enumerate(self.bn_dims):
+            ind = np.zeros((nl, 2 * d), F)
+            od = np.ascontiguousarray(d_masked[:, c0:c0 + d])
+            Lb.oracle_elementwise_product_backprop(ora.omat(st["ew_ins"][k]), ora.omat(od), d, ora.omat(ind))
+            d_lin[:, c0:c0 + d] = ind[:, d:]
+            dsk, d_cop = np.zeros((nl, 1), F), np.ascontiguousarray(ind[:, :d])  # (named: omat() keeps no reference)
+            Lb.oracle_copyn_backprop(ora.omat(d_cop), 1.0, ora.omat(dsk))
+            for j in range(k, Cn):
+                d_P[:, j] += dsk[:, 0]
+            c0 += d
+        g = np.ascontiguousarray(grad_vec)
+        if cfg.bn_mode == 0:  # OnehotFunctionComponent::Backprop :9539-9548: output_.AddRowSumMat(lr, out_deriv)
+            g += d_P.astype(np.float64).sum(0).astype(F)
+        else:
+            flops = (-np.cumsum(self.bn_dims)).astype(F)
+            d_A = np.zeros((nl, Cn), F)
+            Lb.oracle_softmax_flops_backprop(ora.omat(st["P"]), ora.omat(d_P), cfg.bn_flops_scale, ora.fptr(flops), Cn,
+                                             cfg.bn_temp_proportion if cfg.bn_mode == 2 else 1.0, ora.omat(d_A))
+            Lb.oracle_constant_function_backprop(ora.omat(d_A), 1.0, ora.fptr(g))
+        grad_vec[:] = g
+        return d_lin
+
     def _bn_fwd(self, key, x):
         z = np.zeros_like(x)
         memo = np.zeros((5, x.shape[1]), F)
@@ -224,7 +281,12 @@ class OracleNet:
                 lin_off, aff_off = ([-s, 0], [0, s]) if s > 0 else ([0], [0])
             lin = self._tdnn_fwd(prev, Wlin, None, lin_off, Ly["inn"], Ly["lin"], eff=dl["eff"] if dl else None)
             rho = Ly["out"][1] // Ly["lin"][1]
-            aff_in = self._to_rho(lin, rho) if rho > 1 else lin
+            arch = None
+            lin_used = lin
+            if self.bnC:
+                per = 1 if cfg.bn_mode == 0 else (self.bnC if cfg.bn_mode == 2 else 0)
+                lin_used, arch = self._arch_fwd(p, nm, lin, draws, per * i)
+            aff_in = self._to_rho(lin_used, rho) if rho > 1 else lin_used
             aff = self._tdnn_fwd(aff_in, Waff, baff, aff_off, Ly["lin"], Ly["out"], eff=da["eff"] if da else None)
             relu = np.maximum(aff, 0)
             bn, memo = self._bn_fwd(nm, relu)
@@ -232,7 +294,7 @@ class OracleNet:
             out = (F(cfg.bypass_scale) * prev[rows] + bn).astype(F)
             acts[nm + ".linear"], acts[nm + ".relu"], acts[nm + ".batchnorm"], acts[nm + ".noop"] = lin, relu, bn, out
             store.append(dict(inp=prev, lin=lin, aff_in=aff_in, relu=relu, bn=bn, memo=memo, rows=rows, rho=rho,
-                              lin_off=lin_off, aff_off=aff_off, Wlin=Wlin, Waff=Waff, dl=dl, da=da))
+                              lin_off=lin_off, aff_off=aff_off, Wlin=Wlin, Waff=Waff, dl=dl, da=da, arch=arch))
             prev = out
         No = self.Tout * B
         Wpl = np.ascontiguousarray(self.W(p, "prefinal-l"))
@@ -352,6 +414,9 @@ class OracleNet:
             Gw(nm + ".affine")[:] = Wg
             bgv[:] = bg
             d_lin = self._to_rho(d_affin, st["rho"], inverse=True) if st["rho"] > 1 else d_affin
+            if st["arch"] is not None:
+                an = nm + (".softmax" if cfg.bn_mode == 0 else ".alpha")
+                d_lin = self._arch_bwd(nm, st["arch"], d_lin, Gw(an).reshape(-1))
             Wg = np.ascontiguousarray(Gw(nm + ".linear"))
             blin = np.ascontiguousarray(Gb(nm + ".linear")) if dl else None  # DARTS .linear: inert bias, still updated
             d_in = self._tdnn_bwd(st["inp"], d_lin, st["Wlin"], Wg, blin, st["lin_off"], Ly["inn"], Ly["lin"],
@@ -395,6 +460,11 @@ class OracleNet:
             if c["orthonormal"] == 0.0 or decision(step, 2 * i + 1) % 4 != 0:
                 continue
             M = np.ascontiguousarray(p[c["begin"]:c["begin"] + c["rows"] * c["cols"]].reshape(c["rows"], c["cols"]))
-            Lb.oracle_constrain_orthonormal(c["orthonormal"], ora.fptr(M), c["rows"], c["cols"], c["cols"])
+            if c["rows"] <= c["cols"]:
+                Lb.oracle_constrain_orthonormal(c["orthonormal"], ora.fptr(M), c["rows"], c["cols"], c["cols"])
+            else:  # nnet-utils.cc:1068-1075: constrain the transpose
+                Mt = np.ascontiguousarray(M.T)
+                Lb.oracle_constrain_orthonormal(c["orthonormal"], ora.fptr(Mt), c["cols"], c["rows"], c["rows"])
+                M = np.ascontiguousarray(Mt.T)
             p[c["begin"]:c["begin"] + c["rows"] * c["cols"]] = M.ravel()
         return p

@@ -39,6 +39,16 @@ CASES += [
                                  num_pdfs=64, hidden_dim=64, small_dim=32, darts_num_offsets=4, darts_flags=0, use_natural_gradient=1), 40),
 ]
 
+# bottleneck-dimension supernet (BASELINE configs[4]; run_TDNNf_DARTS_mod_fbk_bottleneckCBshare_95onehottrain.sh and the
+# cv-update wiring of scripts/add_flopsconstraint.py): the reference's 8 candidate dims and a 4-way set, all three modes
+_B = dict(frames_per_chunk=24, num_sequences=3, strides=[1, 1, 0, 3], feat_dim=40, ivector_dim=100, num_pdfs=120, hidden_dim=128, small_dim=32)
+CASES += [
+    ("bn-supernet-onehot-pretrain", dict(_B, bn_choice_dims=[25, 25, 30, 20, 20, 40, 40, 40], bn_mode=0), 40),
+    ("bn-supernet-softmax-flops", dict(_B, bn_choice_dims=[8, 8, 16, 32], bn_mode=1, bn_flops_scale=2.0), 40),
+    ("bn-supernet-gumbel-flops-NG", dict(_B, frames_per_chunk=48, num_sequences=6, bn_choice_dims=[8, 8, 16, 32], bn_mode=2,
+                                         bn_flops_scale=0.5, bn_temp_proportion=0.8, use_natural_gradient=1), 40),
+]
+
 
 @pytest.mark.parametrize("name,kw,H", CASES, ids=[c[0] for c in CASES])
 def test_net_step_matches_oracle(pkg, name, kw, H):
@@ -50,6 +60,11 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
         for c in net.components:
             n = c["rows"] * c["cols"]
             params[c["begin"] + n:c["begin"] + n + c["num_alpha"]] = rng.standard_normal(c["num_alpha"]).astype(np.float32) * 0.5
+    if cfg.bn_num_choices:
+        rng = np.random.default_rng(19)
+        for c in net.components:
+            if c["name"].endswith((".alpha", ".softmax")):
+                params[c["begin"]:c["begin"] + c["rows"]] = rng.standard_normal(c["rows"]).astype(np.float32) * 0.7
     net.set_params(params)
     ref = OracleNet(pkg, cfg, net.components)
     assert ref.num_t_in == net.num_t_in
@@ -59,7 +74,7 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
     dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
     fd, ivd = dev(feats), dev(iv)
     for step in (0, 1):  # step 1 exercises ReLU self-repair with stats from step 0
-        draws = np.random.default_rng(100 + step).random(max(net.num_draws, 1)).astype(np.float32)
+        draws = np.random.default_rng(100 + step).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(np.float32)
         net.set_random_draws(draws)
         res_ref, g_ref, acts = ref.forward_backward(params, feats, iv, den, sup, step=step, draws=draws)
         net.grads.zero_()
@@ -106,6 +121,30 @@ def test_net_gradients_accumulate_and_are_reproducible(pkg):
     net.grads.zero_()
     net.forward_backward(fd, ivd, dg, ds, step=0)
     assert torch.equal(net.grads, g1)  # bitwise reproducible
+    net.close()
+
+
+def test_net_update_constrains_tall_matrices_through_their_transpose(pkg):
+    """ConstrainOrthonormal on a matrix with more rows than columns works on the transpose (nnet-utils.cc:1068-1075):
+    the stride-0 layer of the bottleneck supernet (240 x hidden) is such a matrix when hidden < 240."""
+    from tests.oracle_net import decision
+    cfg = pkg.trainer.make_config(**dict(_B, bn_choice_dims=[25, 25, 30, 20, 20, 40, 40, 40], bn_mode=0))
+    net = pkg.trainer.ChainNet(cfg)
+    params = net.init_params_numpy(seed=5, output_stddev=0.3)
+    i = [k for k, c in enumerate(net.components) if c["name"] == "tdnnf4.linear"][0]
+    assert net.components[i]["rows"] > net.components[i]["cols"]
+    step = next(s for s in range(1000) if decision(s, 2 * i + 1) % 4 == 0)
+    net.set_params(params)
+    net.grads.zero_()
+    ref = OracleNet(pkg, cfg, net.components)
+    p_ref = ref.update(params, np.zeros_like(params), 1e-3, float(cfg.num_sequences), step)
+    net.update(1e-3, step=step)
+    p = host(net.params)
+    c = net.components[i]
+    sl = slice(c["begin"], c["begin"] + c["rows"] * c["cols"])
+    assert (p_ref[sl] != params[sl]).any()
+    assert rel_l2(p[sl] - params[sl], p_ref[sl] - params[sl]) < 2e-3
+    assert rel_l2(p - params, p_ref - params) < 2e-3
     net.close()
 
 

@@ -14,6 +14,7 @@ def tiny_setup(pkg, strides=(1, 1, 0, 3, 3), T=12, B=2, seed=0, **kw):
     comps, begin = [], 0
     lda_dim = 3 * 8 + 4
     Kd = cfg.darts_num_offsets
+    bnC, bn = cfg.bn_num_choices, cfg.bottleneck_dim[0]
 
     def add(name, rows, cols, hb, lrf=1.0, l2=0.01, mc=0.75, orth=0.0, na=0):
         nonlocal begin
@@ -25,8 +26,10 @@ def tiny_setup(pkg, strides=(1, 1, 0, 3, 3), T=12, B=2, seed=0, **kw):
     add("tdnn1.affine", 32, lda_dim, 1)
     for i, s in enumerate(strides):
         K = Kd if Kd else (2 if s > 0 else 1)
-        add(f"tdnnf{i + 2}.linear", 8, K * 32, 1 if Kd else 0, orth=0.0 if Kd else -1.0, na=Kd)
-        add(f"tdnnf{i + 2}.affine", 32, K * 8, 1, na=Kd)
+        if bnC:  # X.softmax (Onehot) / X.alpha (ConstantFunction): C-vector, no l2, no max-change
+            add(f"tdnnf{i + 2}" + (".softmax" if cfg.bn_mode == 0 else ".alpha"), bnC, 1, 0, l2=0.0, mc=0.0)
+        add(f"tdnnf{i + 2}.linear", bn, K * 32, 1 if Kd else 0, orth=0.0 if Kd else -1.0, na=Kd)
+        add(f"tdnnf{i + 2}.affine", 32, K * bn, 1, na=Kd)
     add("prefinal-l", 16, 32, 0, orth=-1.0)
     for hn in ("chain", "xent"):
         add(f"prefinal-{hn}.affine", 32, 16, 1)
@@ -41,6 +44,8 @@ def tiny_setup(pkg, strides=(1, 1, 0, 3, 3), T=12, B=2, seed=0, **kw):
         params[c["begin"] + n:c["begin"] + n + na] = rng.standard_normal(na).astype(np.float32) * 0.5
         if c["has_bias"]:
             params[c["begin"] + n + na:c["begin"] + n + na + c["rows"]] = rng.standard_normal(c["rows"]).astype(np.float32) * 0.3
+        if c["name"].endswith((".softmax", ".alpha")):
+            params[c["begin"]:c["begin"] + n] = rng.standard_normal(n).astype(np.float32) * 0.5
     net = OracleNet(pkg, cfg, comps)
     feats = rng.standard_normal((net.num_t_in * B, 8)).astype(np.float32)
     iv = rng.standard_normal((B, 4)).astype(np.float32)
@@ -130,3 +135,73 @@ def test_oracle_darts_net_alpha_gradient_by_finite_differences(pkg, flags):
             if not ok_any:
                 print(c["name"], k, fd, grads[i])
     assert checked == 18 and bad <= 2, (bad, checked)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_oracle_bottleneck_supernet_alpha_gradient_by_finite_differences(pkg, mode):
+    """Bottleneck-dimension supernet, cv-update wiring (ConstantFunction -> (Gumbel)SoftmaxFlops -> Sum -> CopyN ->
+    ElementwiseProduct with the linear blocks): the accumulated update of X.alpha equals
+    5 x d(objective + flops penalty)/d(alpha), the penalty being scale / C * <p, flops> summed over rows / rows."""
+    dims = [2, 1, 3, 2]
+    cfg, comps, params, net, feats, iv, den, sup = tiny_setup(pkg, strides=(1, 0, 3), T=12, relu_self_repair_scale=0.0,
+                                                              bn_choice_dims=dims, bn_mode=mode, bn_flops_scale=0.3, bn_temp_proportion=0.7)
+    draws = np.random.default_rng(4).uniform(0.05, 0.95, 3 * 4).astype(np.float32)
+    res, grads, acts = net.forward_backward(params, feats, iv, den, sup, draws=draws)
+    post = acts["xent.post"]
+    flops = -np.cumsum(dims).astype(np.float64)
+
+    def penalty(p):
+        tot = 0.0
+        for i in range(3):
+            c = net.comp[f"tdnnf{i + 2}.alpha"]
+            a = p[c["begin"]:c["begin"] + 4].astype(np.float64)
+            if mode == 2:
+                a = (a - np.log(-np.log(draws[4 * i:4 * i + 4].astype(np.float64)))) / 0.7
+            q = np.exp(a - a.max())
+            q /= q.sum()
+            tot += 0.3 / 4 * float(q @ flops)
+        return tot
+
+    def total(p):
+        r, _, _ = net.forward_backward(p, feats, iv, den, sup, fixed_xent_post=post, forward_only=True, draws=draws)
+        return r["objf"] + r["l2_term"] + cfg.xent_regularize * r["xent_objf"] + penalty(p)
+
+    bad = checked = 0
+    for i in range(3):
+        c = net.comp[f"tdnnf{i + 2}.alpha"]
+        for k in range(4):
+            j = c["begin"] + k
+            ok_any = False
+            for eps in (4e-3, 1e-3):
+                pp, pm = params.copy(), params.copy()
+                pp[j] += eps
+                pm[j] -= eps
+                fd = 5.0 * (total(pp) - total(pm)) / (2 * eps)
+                if abs(fd - grads[j]) <= 3e-2 * max(abs(fd), abs(grads[j])) + 2e-2:
+                    ok_any = True
+            checked += 1
+            bad += 0 if ok_any else 1
+            if not ok_any:
+                print(c["name"], k, fd, grads[j])
+    assert checked == 12 and bad <= 1, (bad, checked)
+
+
+def test_oracle_bottleneck_supernet_onehot_is_a_truncated_bottleneck(pkg):
+    """Pretrain wiring (OnehotFunction): with choice j sampled the layer equals a TDNN-F layer whose bottleneck is the
+    first cum[j] columns; the Onehot component's own vector still collects colsum of its output derivative."""
+    dims = [2, 1, 3, 2]
+    cfg, comps, params, net, feats, iv, den, sup = tiny_setup(pkg, strides=(1, 0, 3), T=12, relu_self_repair_scale=0.0,
+                                                              bn_choice_dims=dims, bn_mode=0)
+    draws = np.asarray([0.30, 0.80, 0.55], np.float32)  # choices 1, 3, 2 -> bottlenecks 3, 8, 6
+    res, grads, acts = net.forward_backward(params, feats, iv, den, sup, draws=draws)
+    assert res["ok"] == 1
+    cum = np.cumsum(dims)
+    for i, j in enumerate([1, 3, 2]):
+        cl, ca = net.comp[f"tdnnf{i + 2}.linear"], net.comp[f"tdnnf{i + 2}.affine"]
+        gl = grads[cl["begin"]:cl["begin"] + cl["rows"] * cl["cols"]].reshape(cl["rows"], cl["cols"])
+        assert not gl[cum[j]:].any() and gl[:cum[j]].any()       # masked-out rows of the linear weights get no gradient
+        ga = grads[ca["begin"]:ca["begin"] + ca["rows"] * ca["cols"]].reshape(ca["rows"], -1, cl["rows"])
+        assert not ga[:, :, cum[j]:].any() and ga[:, :, :cum[j]].any()
+        cs = net.comp[f"tdnnf{i + 2}.softmax"]
+        g = grads[cs["begin"]:cs["begin"] + 4]
+        assert np.all(np.isfinite(g)) and g.any()
