@@ -315,6 +315,12 @@ typedef struct {
   int bn_mode;
   float bn_flops_scale;
   float bn_temp_proportion;
+  /* != 0: cross-validation architecture update (run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-142,
+     run_TDNNf_DARTS_mod_fbk_bottleneckCBshare_cvupdate_flopsconstraint.sh:136-139): every BatchNormComponent becomes a
+     BatchNormTestComponent (scale / offset from the stored statistics: load them with tdnnf_net_set_stats, nothing is
+     accumulated or rescaled), learning-rate factor 0 on every component (no model derivative is computed for them)
+     except 1e-4 on the TdnnDARTSV3Components and 1 on the X.alpha vectors of the bottleneck supernet. */
+  int cv_update;
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 
@@ -343,6 +349,13 @@ int tdnnf_net_forward_backward(tdnnf_net *, const tdnnf_mat *feats, const tdnnf_
 /* delta = lr_c*(grad) - 2*l2_scale*lr_c*l2_c*params; max-change; params += delta; grads = 0; orthonormal
    constraint on the scheduled quarter of the constrained matrices; batchnorm stats *= batchnorm_stats_scale. */
 int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale, long long step, tdnnf_stream);
+/* Model state outside the parameter vector, as doubles in network order (tdnn1, tdnnf2.., prefinal-chain, prefinal-xent):
+   per BatchNorm [count, stats_sum[D], stats_sumsq[D]] (BatchNormComponent::StoreStats, nnet-normalize-component.cc:551-589)
+   and per ReLU [count, value_sum[D], deriv_sum[D]] (NonlinearComponent::StoreStatsInternal, nnet-component-itf.cc:433);
+   block order per unit: batchnorm, relu (heads: batchnorm1, relu, batchnorm2).  Host buffers; both calls synchronise. */
+long long tdnnf_net_stats_size(const tdnnf_net *);
+int tdnnf_net_get_stats(const tdnnf_net *, double *stats_host, tdnnf_stream);
+int tdnnf_net_set_stats(tdnnf_net *, const double *stats_host, tdnnf_stream);
 /* debugging / parity: copy an internal activation by name ("tdnnf2.linear", "output", ...) into out */
 int tdnnf_net_get_activation(const tdnnf_net *, const char *name, tdnnf_mat *out, tdnnf_stream);
 int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, int *cols);

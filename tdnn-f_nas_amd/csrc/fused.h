@@ -9,7 +9,8 @@ hipError_t bn_apply_bypass(MatView x, const float *memo, int D, MatView prev, fl
 
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols);
 // BatchNorm backward + ReLU backward (+ self-repair, ReLU statistics, bias-gradient column sums) in two passes.
-hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, double *relu_stats, bool store_relu_stats,
+// bn_test_mode: the BatchNorm is a BatchNormTestComponent (memo rows 0 and 2 hold the stored mean / scale): dX = dZ * scale.
+hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
                        void *ws, size_t ws_bytes, hipStream_t s);
 

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
 // memo rows 3 (var_deriv_mod) and 4 (temp) from the partials (nnet-normalize-component.cc:520-526);
 // optionally the ReLU statistics [count, value_sum[D], deriv_sum[D]] (StoreStatsInternal).
 __global__ __launch_bounds__(256) void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms,
-                                                                   float *memo, double *relu_stats) {
+                                                                   float *memo, double *relu_stats, int test_mode) {
   __shared__ double red[4][4][64];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
   if (relu_stats && blockIdx.x == 0 && threadIdx.x == 0) relu_stats[0] += (double)N;
@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_finalize_kernel(const float *
   if (tr != 0 || d >= D) return;
   for (int k = 0; k < 4; k++) q[k] = (red[k][0][tc] + red[k][1][tc]) + (red[k][2][tc] + red[k][3][tc]);
   const float coeff = -1.0f / (target_rms * target_rms * N);
-  memo[3 * D + d] = (float)(coeff * q[0]) * memo[2 * D + d];
-  memo[4 * D + d] = (float)(-q[1] / N);
+  // test mode (BatchNormTestComponent::Backprop, nnet-normalize-component.cc:879-922): in_deriv = out_deriv * scale
+  memo[3 * D + d] = test_mode ? 0.f : (float)(coeff * q[0]) * memo[2 * D + d];
+  memo[4 * D + d] = test_mode ? 0.f : (float)(-q[1] / N);
   if (relu_stats) {
     relu_stats[1 + d] += q[2];
     relu_stats[1 + D + d] += q[3];
@@ -211,7 +212,7 @@ size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
 
 // x: ReLU output (= BatchNorm input), dz: derivative w.r.t. the BatchNorm output, memo: forward memo (rows 0-2
 // valid).  Writes d_aff (may alias dz) and adds lr_scale * colsum(d_aff) into bias_acc (may be null).
-hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, double *relu_stats, bool store_relu_stats,
+hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
                        void *ws, size_t ws_bytes, hipStream_t s) {
   if (x.rows == 0) return hipSuccess;
@@ -233,7 +234,7 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, dou
     else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
   }
   hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(256), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
-                     store_relu_stats ? relu_stats : (double *)nullptr);
+                     store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0);
   const double *rep = self_repair ? relu_stats : nullptr;
   if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);
   else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);

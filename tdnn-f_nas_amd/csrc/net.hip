@@ -523,13 +523,42 @@ tdnnf_mat sub_grid_view(float *data, const Grid &g, const Grid &sub, int B, int 
   return tdnnf_mat{data + (size_t)tau0 * B * stride, sub.n, B * stride - (stride - cols), ratio * B * stride};
 }
 
+// BatchNormTestComponent (cv-update): memo rows 0 (mean) and 2 (scale) from the stored statistics, ComputeDerived
+// nnet-normalize-component.cc:682-715; rows 3 and 4 (backward terms of the train-mode component) are zero
+__global__ void bn_test_memo_kernel(const double *stats, int D, float epsilon, float target_rms, float *memo) {
+  const int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= D) return;
+  const double count = stats[0];
+  const float off = (float)(stats[1 + d] * (-1.0 / count));
+  float sc = (float)(stats[1 + D + d] * (1.0 / count));
+  sc += -1.0f * off * off;
+  memo[D + d] = sc;
+  sc = fmaxf(sc, 0.f) + epsilon;
+  sc = target_rms / sqrtf(sc);
+  memo[d] = -off;
+  memo[2 * D + d] = sc;
+  memo[3 * D + d] = 0.f;
+  memo[4 * D + d] = 0.f;
+}
+int bn_test_memo(float *memo, const double *stats, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(bn_test_memo_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, stats, cols, 1.0e-3f, 1.0f, memo);
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
 int bn_fwd(tdnnf_net *n, float *in, float *out, int rows, int cols, float *memo, double *stats, hipStream_t s) {
   tdnnf_mat a = M(in, rows, cols), o = M(out, rows, cols);
+  if (n->cfg.cv_update) {
+    CK(bn_test_memo(memo, stats, cols, s));
+    const MatView none{nullptr, 0, 0, 0};
+    TDNNF_HIP(bn_apply_bypass(view(&a), memo, cols, none, 0.f, view(&o), s));
+    return TDNNF_OK;
+  }
   CK(tdnnf_batchnorm_propagate(&a, 1.0e-3f, 1.0f, &o, memo, n->ws, n->ws_bytes, s));
   return tdnnf_batchnorm_store_stats(memo, cols, rows, stats, s);  // StoreStats runs on every minibatch
 }
 // statistics of BatchNorm(x) only; the normalisation itself is applied by a fused pass
 int bn_stats(tdnnf_net *n, float *x, int rows, int cols, float *memo, double *stats, hipStream_t s) {
+  if (n->cfg.cv_update) return bn_test_memo(memo, stats, cols, s);
   tdnnf_mat a = M(x, rows, cols);
   TDNNF_HIP(batchnorm_stats(view(&a), 1.0e-3f, 1.0f, memo, n->ws, s));
   return tdnnf_batchnorm_store_stats(memo, cols, rows, stats, s);
@@ -704,6 +733,13 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
                                    c.max_change_output, 0.f);
   }
   TDNNF_REQUIRE(n->comps.size() <= 128, "net_create: too many components");
+  if (c.cv_update) {
+    // cross-validation architecture update (run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-142,
+    // run_TDNNf_DARTS_mod_fbk_bottleneckCBshare_cvupdate_flopsconstraint.sh:136-139): "set-learning-rate-factor 0" on
+    // everything, 1e-4 on the TdnnDARTSV3Components (theta is frozen only by that factor, the logits are compensated by
+    // update-alpha's x10000), the freshly added X.alpha vectors keep factor 1.
+    for (auto &cd : n->comps) cd.lr_factor = cd.plain ? 1.0f : (cd.num_alpha > 0 ? 1.0e-4f : 0.0f);
+  }
   if (c.use_natural_gradient) {
     // one input-side and one output-side preconditioner per updatable component; configuration of
     // TdnnDARTSV3Component::InitFromConfig (nnet-tdnn-component.cc:183-210), the same defaults as
@@ -790,6 +826,53 @@ int tdnnf_net_component_info(const tdnnf_net *n, int i, char *name_out, long lon
   return TDNNF_OK;
 }
 
+// model statistics outside the parameter vector: [count, sum[D], sumsq[D]] of every BatchNorm and
+// [count, value_sum[D], deriv_sum[D]] of every ReLU, in network order
+static void stat_blocks(const tdnnf_net *n, std::vector<std::pair<double *, int>> &out) {
+  const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
+  out.push_back({n->t1_bn_stats, Hd});
+  out.push_back({n->t1_relu_stats, Hd});
+  for (auto &L : n->layers) {
+    out.push_back({L.bn_stats, Hd});
+    out.push_back({L.relu_stats, Hd});
+  }
+  for (int h = 0; h < 2; h++) {
+    out.push_back({n->head[h].bn1_stats, Hd});
+    out.push_back({n->head[h].relu_stats, Hd});
+    out.push_back({n->head[h].bn2_stats, S});
+  }
+}
+long long tdnnf_net_stats_size(const tdnnf_net *n) {
+  if (!n) return 0;
+  std::vector<std::pair<double *, int>> b;
+  stat_blocks(n, b);
+  long long t = 0;
+  for (auto &x : b) t += 1 + 2 * x.second;
+  return t;
+}
+int tdnnf_net_get_stats(const tdnnf_net *n, double *host_out, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && host_out, "net_get_stats: null argument");
+  std::vector<std::pair<double *, int>> b;
+  stat_blocks(n, b);
+  TDNNF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  for (auto &x : b) {
+    TDNNF_HIP(hipMemcpy(host_out, x.first, sizeof(double) * (1 + 2 * x.second), hipMemcpyDeviceToHost));
+    host_out += 1 + 2 * x.second;
+  }
+  return TDNNF_OK;
+}
+int tdnnf_net_set_stats(tdnnf_net *n, const double *host_in, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && host_in, "net_set_stats: null argument");
+  std::vector<std::pair<double *, int>> b;
+  stat_blocks(n, b);
+  TDNNF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  for (auto &x : b) {
+    TDNNF_HIP(hipMemcpy(x.first, host_in, sizeof(double) * (1 + 2 * x.second), hipMemcpyHostToDevice));
+    host_in += 1 + 2 * x.second;
+  }
+  return TDNNF_OK;
+}
+
 int tdnnf_net_component_num_alpha(const tdnnf_net *n, int i) {
   return n && i >= 0 && i < (int)n->comps.size() ? n->comps[i].num_alpha : 0;
 }
@@ -864,6 +947,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                 n->g_feat.n * B, c.feat_dim);
   TDNNF_REQUIRE(ivectors->rows == B && ivectors->cols == c.ivector_dim, "net_forward_backward: ivectors must be %d x %d", B, c.ivector_dim);
   hipStream_t s = (hipStream_t)stream;
+  const bool cv = c.cv_update != 0;  // BatchNorm components are BatchNormTestComponents
   if (!n->chain_ws) {
     n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout);
     TDNNF_HIP(hipMalloc(&n->chain_ws, n->chain_ws_bytes));
@@ -975,7 +1059,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const bool store = coin() || step == 0;
     const bool repair = c.relu_self_repair_scale > 0.f && coin();
     tdnnf_mat x = M(relu_out, rows, Hd), d = M(d_io, rows, Hd);
-    TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
+    TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, cv, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
                           n->ws, n->ws_bytes, s));
     return TDNNF_OK;
   };
@@ -988,6 +1072,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // bias_done: the raw bias gradient was already produced by the fused BatchNorm/ReLU backward pass (into Bg(), or
   // into n->ngBias when natural gradient is on).  tapgrad: unscaled per-tap gradients already in n->tapgrad.
   auto bias_target = [&](int comp) -> float * {  // where a fused backward pass should accumulate the raw bias gradient
+    if (n->comps[comp].lr_factor == 0.f) return nullptr;  // "if (to_update && learning_rate != 0)": no model derivative
     if (!use_ng) return Bg(n, comp);
     (void)hipMemsetAsync(n->ngBias, 0, sizeof(float) * n->comps[comp].rows, s);
     return n->ngBias;
@@ -996,6 +1081,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                         bool bias_done, const int *active, int max_active, bool from_tapgrad) -> int {
     const int ldw = K * Di;
     float *bias_acc = Bg(n, comp);
+    if (n->comps[comp].lr_factor == 0.f) return TDNNF_OK;  // frozen component (cv-update): the reference skips its update
     if (!use_ng)
       return tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, Wg(n, comp), ldw, bias_done ? nullptr : bias_acc, n->ws, n->ws_bytes,
                                      active, max_active, s);
@@ -1039,7 +1125,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
     CK(param_grad(H.c_output, ix1, 1, S, P, &b2, &dout, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
-    CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
+    if (cv) CK(tdnnf_batchnorm_test_backprop(&d_b2, H.bn2_memo + 2 * S, &d_b2, s));
+    else CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
     CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
     CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine)));  // dA -> d affine out
@@ -1068,7 +1155,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const bool store = coin() || step == 0;
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
       tdnnf_mat x = M(L.relu_out, no, Hd);
-      TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, L.relu_stats, store, repair, c.relu_self_repair_scale,
+      TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
                             view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
     }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
@@ -1167,7 +1254,7 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
   CK(tdnnf_update_with_max_change(n->params, n->grads, nc, begin.data(), mc.data(), n->cfg.max_param_change, 1.0f, 1.0f, 1,
                                   n->ws, n->ws_bytes, nullptr, s));
   // ScaleBatchnormStats
-  if (n->cfg.batchnorm_stats_scale != 1.0f) {
+  if (n->cfg.batchnorm_stats_scale != 1.0f && !n->cfg.cv_update) {  // (BatchNormTestComponents are not scaled)
     const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
     auto sc = [&](double *st, int D) {
       hipLaunchKernelGGL(scale_doubles_kernel, dim3((1 + 2 * D + 255) / 256), dim3(256), 0, s, st, 1 + 2 * D,

@@ -27,7 +27,7 @@ class NetConfig(C.Structure):
                 ("darts_num_offsets", C.c_int), ("darts_flags", C.c_int), ("darts_temp_proportion", C.c_float),
                 ("use_natural_gradient", C.c_int),
                 ("bn_num_choices", C.c_int), ("bn_choice_dims", C.c_int * 8), ("bn_mode", C.c_int),
-                ("bn_flops_scale", C.c_float), ("bn_temp_proportion", C.c_float)]
+                ("bn_flops_scale", C.c_float), ("bn_temp_proportion", C.c_float), ("cv_update", C.c_int)]
 
 DARTS_USE_GUMBEL, DARTS_FREE_SELECT, DARTS_UNIFORM_SAMPLE, DARTS_USE_ENTROPY, DARTS_UPDATE_ALPHA = 1, 2, 4, 8, 16
 
@@ -74,6 +74,7 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
         c.bn_mode = int(kw.get("bn_mode", BN_ONEHOT))
         c.bn_flops_scale = float(kw.get("bn_flops_scale", 0.0))
         c.bn_temp_proportion = float(kw.get("bn_temp_proportion", 1.0))
+    c.cv_update = int(kw.get("cv_update", 0))
     return c
 
 
@@ -157,6 +158,17 @@ class ChainNet:
             self.draws.copy_(torch.rand(self.num_draws, device="cuda", generator=generator).clamp_(1e-6, 1 - 1e-6))
         else:
             self.draws.copy_(torch.as_tensor(draws, dtype=torch.float32))
+
+    def get_stats(self):
+        """BatchNorm / ReLU statistics of the model as one float64 vector (layout: include/tdnnf_hip.h, tdnnf_net_get_stats)."""
+        out = np.zeros(int(self.lib.tdnnf_net_stats_size(self.h)), np.float64)
+        hipabi.check(self.lib.tdnnf_net_get_stats(self.h, out.ctypes.data_as(C.POINTER(C.c_double)), hipabi.stream()))
+        return out
+
+    def set_stats(self, stats):
+        st = np.ascontiguousarray(stats, dtype=np.float64)
+        assert st.size == int(self.lib.tdnnf_net_stats_size(self.h))
+        hipabi.check(self.lib.tdnnf_net_set_stats(self.h, st.ctypes.data_as(C.POINTER(C.c_double)), hipabi.stream()))
 
     def set_params(self, flat):
         import torch

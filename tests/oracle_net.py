@@ -62,6 +62,7 @@ class OracleNet:
         self.num_t_in = g[2] + 2
         self.bn_stats = {}
         self.relu_stats = {}
+        self.cv = bool(getattr(cfg, "cv_update", 0))
         self.bnC = int(getattr(cfg, "bn_num_choices", 0))
         self.bn_dims = [cfg.bn_choice_dims[k] for k in range(self.bnC)]
         self.use_ng = bool(getattr(cfg, "use_natural_gradient", 0))
@@ -134,7 +135,9 @@ class OracleNet:
             self.L.oracle_tdnn_darts_alpha_update(ora.dptr(sdots), ora.fptr(darts["coef"]), K, self.cfg.darts_flags, darts["share"],
                                                   self.cfg.darts_temp_proportion, 1.0, ora.fptr(acc))
             darts["alpha_grad"][:] = acc
-        if self.use_ng:
+        if name is not None and self.comp[name]["lr_factor"] == 0.0:
+            pass  # "if (to_update && learning_rate != 0)": no model derivative for a frozen component
+        elif self.use_ng:
             xs = np.zeros((dy.shape[0], K * Di), F)
             self.L.oracle_tdnn_splice(ora.omat(x), dy.shape[0], Di, K, rho, ora.iptr(ro), pe, 0, ora.omat(xs))
             self._ng_grad(name, xs, dy, Wg, bg)
@@ -212,15 +215,65 @@ class OracleNet:
         return d_lin
 
     def _bn_fwd(self, key, x):
+        D = x.shape[1]
         z = np.zeros_like(x)
-        memo = np.zeros((5, x.shape[1]), F)
+        st = self.bn_stats.setdefault(key, dict(count=0.0, sum=np.zeros(D), sumsq=np.zeros(D)))
+        if self.cv:  # BatchNormTestComponent: ComputeDerived :682-715 + Propagate :843-877 from the stored statistics
+            scale, offset = np.zeros(D, F), np.zeros(D, F)
+            self.L.oracle_batchnorm_compute_derived(st["count"], ora.dptr(st["sum"]), ora.dptr(st["sumsq"]), D, 1e-3, 1.0,
+                                                    ora.fptr(scale), ora.fptr(offset))
+            self.L.oracle_batchnorm_test_propagate(ora.omat(x), ora.fptr(scale), ora.fptr(offset), ora.omat(z))
+            return z, scale
+        memo = np.zeros((5, D), F)
         self.L.oracle_batchnorm_propagate(ora.omat(x), 1e-3, 1.0, ora.omat(z), ora.fptr(memo))
+        cnt = C.c_double(st["count"])  # StoreStats :551-589 runs on every minibatch
+        self.L.oracle_batchnorm_store_stats(ora.fptr(memo), D, x.shape[0], C.byref(cnt), ora.dptr(st["sum"]), ora.dptr(st["sumsq"]))
+        st["count"] = cnt.value
         return z, memo
 
     def _bn_bwd(self, z, dz, memo):
         dx = np.zeros_like(z)
+        if self.cv:  # :879-922
+            self.L.oracle_batchnorm_test_backprop(ora.omat(dz), ora.fptr(memo), ora.omat(dx))
+            return dx
         self.L.oracle_batchnorm_backprop(ora.omat(z), ora.omat(dz), 1.0, ora.fptr(memo), ora.omat(dx))
         return dx
+
+    # model statistics in the trainer's order (include/tdnnf_hip.h: tdnnf_net_get_stats)
+    def _stat_keys(self):
+        keys = [("bn", "tdnn1"), ("relu", "tdnn1")]
+        for i in range(len(self.layers)):
+            keys += [("bn", f"tdnnf{i + 2}"), ("relu", f"tdnnf{i + 2}")]
+        for hn in ("chain", "xent"):
+            keys += [("bn", hn + "1"), ("relu", "head" + hn), ("bn", hn + "2")]
+        return keys
+
+    def _stat_dim(self, kind, key):
+        return self.cfg.prefinal_small_dim if (kind == "bn" and key.endswith("2") and not key.startswith("tdnn")) else self.cfg.hidden_dim
+
+    def get_stats(self):
+        out = []
+        for kind, key in self._stat_keys():
+            D = self._stat_dim(kind, key)
+            if kind == "bn":
+                st = self.bn_stats.get(key, dict(count=0.0, sum=np.zeros(D), sumsq=np.zeros(D)))
+                out += [[st["count"]], st["sum"], st["sumsq"]]
+            else:
+                st = self.relu_stats.get(key, dict(count=0.0, vs=np.zeros(D), ds=np.zeros(D)))
+                out += [[st["count"]], st["vs"], st["ds"]]
+        return np.concatenate([np.asarray(a, np.float64) for a in out])
+
+    def set_stats(self, flat):
+        o = 0
+        for kind, key in self._stat_keys():
+            D = self._stat_dim(kind, key)
+            cnt, a, b = float(flat[o]), np.array(flat[o + 1:o + 1 + D], np.float64), np.array(flat[o + 1 + D:o + 1 + 2 * D], np.float64)
+            o += 1 + 2 * D
+            if kind == "bn":
+                self.bn_stats[key] = dict(count=cnt, sum=a, sumsq=b)
+            else:
+                self.relu_stats[key] = dict(count=cnt, vs=a, ds=b)
+        assert o == len(flat)
 
     def _to_rho(self, x, rho, inverse=False):
         n = x.shape[0] // self.B
@@ -361,7 +414,9 @@ class OracleNet:
             Wg = np.ascontiguousarray(Gw(name))
             bgv = Gb(name)
             bg = np.ascontiguousarray(bgv) if bgv is not None else None
-            if self.use_ng:
+            if self.comp[name]["lr_factor"] == 0.0:
+                pass
+            elif self.use_ng:
                 self._ng_grad(name, x, dyy, Wg, bg)
             else:
                 Lb.oracle_affine_update_simple(ora.omat(x), ora.omat(dyy), 1.0, ora.fptr(Wg), W.shape[1], ora.fptr(bg) if bg is not None else None)
@@ -455,6 +510,11 @@ class OracleNet:
             c = self.comp[n]
             if ok.value:
                 p[c["begin"]:end] += sf[i] * delta[n]
+        if not self.cv and cfg.batchnorm_stats_scale != 1.0:  # ScaleBatchnormStats (UPSTREAM trainer)
+            for st in self.bn_stats.values():
+                st["count"] *= float(cfg.batchnorm_stats_scale)
+                st["sum"] *= float(cfg.batchnorm_stats_scale)
+                st["sumsq"] *= float(cfg.batchnorm_stats_scale)
         for i, n in enumerate(names):
             c = self.comp[n]
             if c["orthonormal"] == 0.0 or decision(step, 2 * i + 1) % 4 != 0:

@@ -124,6 +124,88 @@ def test_net_gradients_accumulate_and_are_reproducible(pkg):
     net.close()
 
 
+CV_CASES = [
+    # offset supernet: uniform-sample pretrain, then the Gumbel cv-update (run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-134)
+    ("darts-k4-gumbel", dict(_D, darts_num_offsets=4, darts_flags=4),
+     dict(_D, darts_num_offsets=4, darts_flags=1 | 16, darts_temp_proportion=0.9, cv_update=1)),
+    # bottleneck supernet: Onehot pretrain, then ConstantFunction + SoftmaxFlops with the FLOPs penalty
+    ("bn-supernet-softmax-flops", dict(_B, bn_choice_dims=[8, 8, 16, 32], bn_mode=0),
+     dict(_B, bn_choice_dims=[8, 8, 16, 32], bn_mode=1, bn_flops_scale=1.5, cv_update=1)),
+]
+
+
+@pytest.mark.parametrize("name,pre_kw,cv_kw", CV_CASES, ids=[c[0] for c in CV_CASES])
+def test_net_cv_update_after_pretrain_matches_oracle(pkg, name, pre_kw, cv_kw):
+    """pretrain -> cv-update hand-over: BatchNorm / ReLU statistics accumulated by two training steps agree with the
+    oracle's, then a net in cv-update mode (BatchNormTest from those statistics, everything frozen but the architecture
+    parameters) matches the oracle on objective, gradients and update."""
+    den = sup = None
+
+    def egs(net, cfg):
+        nonlocal den, sup
+        feats, iv = pkg.trainer.synthetic_egs(net, seed=4)
+        den = pkg.synth.make_den_graph(40, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+        sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+        return feats, iv, pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+
+    cfg = pkg.trainer.make_config(**pre_kw)
+    net = pkg.trainer.ChainNet(cfg)
+    params = net.init_params_numpy(seed=3, output_stddev=0.3)
+    ref = OracleNet(pkg, cfg, net.components)
+    feats, iv, dg, ds = egs(net, cfg)
+    fd, ivd = dev(feats), dev(iv)
+    for step in (0, 1):
+        draws = np.random.default_rng(300 + step).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(np.float32)
+        net.set_params(params)
+        net.set_random_draws(draws)
+        net.grads.zero_()
+        net.forward_backward(fd, ivd, dg, ds, step=step)
+        net.update(1e-3, step=step)
+        _, g_ref, _ = ref.forward_backward(params, feats, iv, den, sup, step=step, draws=draws)
+        params = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
+    st_gpu, st_ref = net.get_stats(), ref.get_stats()
+    assert st_gpu.shape == st_ref.shape and st_ref[0] > 0
+    assert rel_l2(st_gpu, st_ref) < 1e-5, rel_l2(st_gpu, st_ref)
+    net.close()
+
+    cfg2 = pkg.trainer.make_config(**cv_kw)
+    net2 = pkg.trainer.ChainNet(cfg2)
+    assert [c["begin"] for c in net2.components] == [c["begin"] for c in ref.comp.values()]
+    rng = np.random.default_rng(23)
+    for c in net2.components:  # fresh X.alpha vectors (change.config) / trained-looking offset logits
+        if c["name"].endswith(".alpha"):
+            params[c["begin"]:c["begin"] + c["rows"]] = rng.standard_normal(c["rows"]).astype(np.float32) * 0.5
+        n = c["rows"] * c["cols"]
+        params[c["begin"] + n:c["begin"] + n + c["num_alpha"]] = rng.standard_normal(c["num_alpha"]).astype(np.float32) * 0.5
+    lrf = {c["name"]: c["lr_factor"] for c in net2.components}
+    assert lrf["tdnn1.affine"] == 0.0 and lrf["output.affine"] == 0.0
+    ref2 = OracleNet(pkg, cfg2, net2.components)
+    net2.set_stats(st_gpu)
+    ref2.set_stats(st_ref)
+    for step in (0, 1):
+        draws = np.random.default_rng(400 + step).uniform(1e-3, 1 - 1e-3, max(net2.num_draws, 1)).astype(np.float32)
+        net2.set_params(params)
+        net2.set_random_draws(draws)
+        net2.grads.zero_()
+        r = host(net2.forward_backward(fd, ivd, dg, ds, step=step))
+        res_ref, g_ref, acts = ref2.forward_backward(params, feats, iv, den, sup, step=step, draws=draws)
+        for key in ["tdnn1.batchnorm", "tdnnf2.noop", "output", "output-xent"]:
+            assert rel_l2(host(net2.activation(key)), acts[key]) < 1e-4, key
+        assert abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"]), (r[0], res_ref["objf"])
+        g = host(net2.grads)
+        assert np.linalg.norm(g_ref) > 0 and rel_l2(g, g_ref) < 1e-3, rel_l2(g, g_ref)
+        for c in net2.components:
+            if c["lr_factor"] == 0.0:
+                end = c["begin"] + c["rows"] * c["cols"] + c["num_alpha"] + (c["rows"] if c["has_bias"] else 0)
+                assert not g[c["begin"]:end].any(), c["name"]
+        p_ref = ref2.update(params, g_ref, 1e-3, float(cfg2.num_sequences), step)
+        net2.update(1e-3, step=step)
+        assert rel_l2(host(net2.params) - params, p_ref - params) < 2e-3
+        params = p_ref
+    assert np.array_equal(net2.get_stats()[:1 + 2 * cfg2.hidden_dim], st_gpu[:1 + 2 * cfg2.hidden_dim])  # BatchNormTest: stats untouched
+    net2.close()
+
+
 def test_net_update_constrains_tall_matrices_through_their_transpose(pkg):
     """ConstrainOrthonormal on a matrix with more rows than columns works on the transpose (nnet-utils.cc:1068-1075):
     the stride-0 layer of the bottleneck supernet (240 x hidden) is such a matrix when hidden < 240."""
