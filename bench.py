@@ -3,8 +3,8 @@
 
 One "step" = one minibatch of nnet3-chain-train on synthetic egs already resident in HBM:
 forward through every component, chain objective (denominator + numerator forward-backward),
-backward with raw-gradient accumulation, [RCCL all-reduce of the gradient buffer when N > 1],
-L2 + max-change + parameter update + scheduled orthonormal constraint.
+backward with gradient accumulation (OnlineNaturalGradient-preconditioned, as the reference's recipes train),
+[RCCL all-reduce of the gradient buffer when N > 1], L2 + max-change + parameter update + scheduled orthonormal constraint.
 
   python bench.py --gpus 1 --steps 5 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -34,7 +34,7 @@ def cpu_baseline(pkg, args):
     box's host cores on a bounded sample: same net, chunk 150, a few sequences."""
     from tests.oracle_net import OracleNet
     B, T = args.cpu_sequences, 150
-    cfg = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B)
+    cfg = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B, use_natural_gradient=args.natural_gradient)
     comps, begin = [], 0
     # component table without touching the GPU: same layout rule as the trainer (16-byte aligned blocks)
     lda_dim = 3 * cfg.feat_dim + cfg.ivector_dim
@@ -69,28 +69,63 @@ def cpu_baseline(pkg, args):
     net.update(params, grads, 1e-3, float(B), 0)
     dt = time.time() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": round(B * T / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"one full training step of the same 7q net on {B} sequences x {T} frames ({dt:.1f} s), "
-                      f"CPU restatement of the reference path (oracle/, OpenMP float build), not Kaldi"}
+    out = {"value": round(B * T / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"one full training step (natural gradient {'on' if args.natural_gradient else 'off'}) of the same 7q net on {B} sequences x "
+                     f"{T} frames ({dt:.1f} s), CPU restatement of the reference path (oracle/, OpenMP float build), not Kaldi"}
+    # stock Kaldi CPU nnet3 runs one thread per job ("nnet3 does not yet support multiple threads", train.py:251-252)
+    try:
+        gomp = C.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        B1 = 1
+        cfg1 = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B1, use_natural_gradient=args.natural_gradient)
+        net1 = OracleNet(pkg, cfg1, comps, fast=True)
+        f1 = rng.standard_normal((net1.num_t_in * B1, cfg1.feat_dim)).astype(np.float32)
+        sup1 = pkg.synth.make_supervision_from_den(den, B1, T // 3, num_paths=2, seed=3)
+        t0 = time.time()
+        _, g1, _ = net1.forward_backward(params, f1, iv[:B1], den, sup1, step=0)
+        net1.update(params, g1, 1e-3, float(B1), 0)
+        dt1 = time.time() - t0
+        gomp.omp_set_num_threads(cores)
+        out["single_thread"] = {"value": round(B1 * T / dt1, 2), "unit": "frames/s", "cores": 1,
+                                "sample": f"the same step on {B1} sequences x {T} frames, one thread ({dt1:.1f} s)"}
+    except OSError:
+        pass
+    return out
+
+
+def workload_text(args):
+    ng = "OnlineNaturalGradient-preconditioned" if args.natural_gradient else "raw-gradient (natural gradient off)"
+    tail = (f"LF-MMI chain objective + xent head, {ng} SGD step with L2, max-change and the scheduled orthonormal constraint")
+    if args.workload == "7q":
+        return ("BASELINE configs[1]: run_tdnn_7q fixed TDNN-F (14 tdnnf layers, bottleneck 160, strides 1,1,1,0,3x10, 6034 pdfs, "
+                "40-dim fbank + 100-dim ivector), " + tail)
+    if args.workload == "darts-offset":
+        return (f"BASELINE configs[3]: DARTS offset supernet, {args.darts_offsets} taps per TdnnDARTSV3 component, pretrain mode "
+                "(uniform tap sample per layer and minibatch), otherwise as configs[1]; " + tail)
+    return ("BASELINE configs[4]: bottleneck-dimension supernet (candidate dims 25..240 in 8 blocks, Onehot sample per layer and "
+            "minibatch), otherwise as configs[1]; " + tail)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=12,
+                    help="untimed steps; 12 takes the natural-gradient state past its first 10 minibatches, which refresh every step")
     ap.add_argument("--chunk", type=int, default=1500, help="frames per chunk (north_star: 1500-frame chunks)")
     ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--den-states", type=int, default=4000)
     ap.add_argument("--den-degree", type=float, default=12.0)
     ap.add_argument("--cpu-sequences", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="7q", choices=["7q", "darts-offset"],
+    ap.add_argument("--workload", default="7q", choices=["7q", "darts-offset", "bn-supernet"],
                     help="7q = BASELINE configs[1] (default, the metric's config); darts-offset = configs[3], the K-tap offset "
-                         "supernet of run_TDNN_DARTSV3_fbk_stride_pretrain.sh in pretrain (uniform-sample) mode")
+                         "supernet of run_TDNN_DARTSV3_fbk_stride_pretrain.sh in pretrain (uniform-sample) mode; bn-supernet = "
+                         "configs[4], the bottleneck-dimension supernet (8 candidate dims up to 240) in Onehot pretrain mode")
     ap.add_argument("--darts-offsets", type=int, default=7)
-    ap.add_argument("--natural-gradient", type=int, default=0, choices=[0, 1],
-                    help="1 = OnlineNaturalGradient preconditioning of every updatable component's gradient (Kaldi's default)")
+    ap.add_argument("--natural-gradient", type=int, default=1, choices=[0, 1],
+                    help="1 (default, what the reference's recipes train with) = OnlineNaturalGradient preconditioning of every "
+                         "updatable component's gradient; 0 = raw-gradient SGD step")
     args = ap.parse_args()
 
     import numpy as np
@@ -111,7 +146,11 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
-    extra = dict(darts_num_offsets=args.darts_offsets) if args.workload == "darts-offset" else {}
+    extra = {}
+    if args.workload == "darts-offset":
+        extra = dict(darts_num_offsets=args.darts_offsets)
+    elif args.workload == "bn-supernet":
+        extra = dict(bn_choice_dims=pkg.trainer.BN_CHOICE_DIMS, bn_mode=pkg.trainer.BN_ONEHOT)
     cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch,
                                   use_natural_gradient=args.natural_gradient, **extra)
     net = pkg.trainer.ChainNet(cfg)
@@ -179,14 +218,12 @@ def main():
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: run_tdnn_7q fixed TDNN-F (14 tdnnf layers, bottleneck 160, strides 1,1,1,0,3x10, "
-                                    "6034 pdfs, 40-dim fbank + 100-dim ivector), LF-MMI chain objective + xent head, raw-gradient SGD step "
-                                    "with L2, max-change and orthonormal constraint (natural gradient " + ("on" if args.natural_gradient else "off") + ")") if args.workload == "7q" else
-                                   (f"BASELINE configs[3]: DARTS offset supernet, {args.darts_offsets} taps per TdnnDARTSV3 component, "
-                                    "pretrain mode (uniform tap sample per layer and minibatch), otherwise as configs[1]; natural gradient "
-                                    + ("on" if args.natural_gradient else "off")),
+            "config": {"workload": workload_text(args),
                        "frames_per_chunk": args.chunk, "sequences_per_gpu": cfg.num_sequences, "global_batch": world * cfg.num_sequences,
                        "den_graph": {"states": args.den_states, "arcs": int(len(den["src"]))},
+                       "natural_gradient": {"on": bool(args.natural_gradient), "rank_in": 20, "rank_out": 80, "update_period": 4,
+                                            "refresh_steps_in_timed_region": sum(1 for t in range(args.warmup, args.warmup + args.steps)
+                                                                                 if t <= 10 or (t - 10) % 4 == 0) if args.natural_gradient else 0},
                        "parallelism": f"dp{world}", "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,

@@ -55,6 +55,14 @@ struct ProfClassOverride {
   ~ProfClassOverride();
 };
 
+// Scales the algorithmic FLOPs recorded for the launches made while alive: the host cannot see device-side tap
+// coefficients, so a caller that knows only `active` of K taps are non-zero (DARTS uniform-sample mode) says so.
+struct ProfFlopsScale {
+  double prev;
+  explicit ProfFlopsScale(double f);
+  ~ProfFlopsScale();
+};
+
 inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128; }
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).

@@ -992,6 +992,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       lin_eff = L.lin.memo + TDNNF_MAX_OFFSETS;
       aff_eff = L.aff.memo + TDNNF_MAX_OFFSETS;
     }
+    // uniform-sample mode runs at most two taps of K (share + sampled): tell the FLOP accounting of the profiler
+    ProfFlopsScale taps_active(L.lin.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && L.lin.K > 2 ? 2.0 / L.lin.K : 1.0);
     // (DARTS .linear: bias present but offsets[1] < 0 -> out is zeroed and the bias never added, :237-240)
     CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, lin_eff, 2, &lin, s));
     tdnnf_mat aff_in = lin;
@@ -1162,6 +1164,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : (L.c_arch >= 0 ? M(L.lin_masked, nl, L.bn) : lin);
     const float *lin_eff = L.lin.darts ? L.lin.memo + TDNNF_MAX_OFFSETS : nullptr;
     const float *aff_eff = L.aff.darts ? L.aff.memo + TDNNF_MAX_OFFSETS : nullptr;
+    ProfFlopsScale taps_active(L.lin.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && L.lin.K > 2 ? 2.0 / L.lin.K : 1.0);
     // weight gradient of one Tdnn component.  DARTS in a non-sampling mode also needs the architecture-logit
     // gradient (UpdateNaturalGradient :516-590): tap gradients are formed unscaled once, s_i = <dW_i, W_i>
     // replaces the reference's extra forward GEMM per tap, then c_i * dW_i goes into the accumulator.
