@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--den-states", type=int, default=4000)
     ap.add_argument("--den-degree", type=float, default=12.0)
-    ap.add_argument("--cpu-sequences", type=int, default=32)
+    ap.add_argument("--cpu-sequences", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="7q", choices=["7q", "darts-offset", "bn-supernet"],
                     help="7q = BASELINE configs[1] (default, the metric's config); darts-offset = configs[3], the K-tap offset "

@@ -261,6 +261,7 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
   float *W = ng->W;
   /* H = X W^T */
   float *H = (float *)malloc(sizeof(float) * (size_t)N * R);
+#pragma omp parallel for schedule(static)
   for (int n = 0; n < N; n++)
     for (int r = 0; r < R; r++) {
       double a = 0;
@@ -271,14 +272,20 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
   double *Kt = NULL, *Lt = NULL;
   if (updating) {
     J = (float *)malloc(sizeof(float) * (size_t)R * D);
-    for (int r = 0; r < R; r++)
-      for (int k = 0; k < D; k++) {
-        double a = 0;
-        for (int n = 0; n < N; n++) a += (double)H[(size_t)n * R + r] * X->data[(long)X->stride * n + k];
-        J[(size_t)r * D + k] = (float)a; /* J = H^T X */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int r = 0; r < R; r++) { /* J = H^T X, one row of J per thread, X walked row by row */
+      double *acc = (double *)calloc(D, sizeof(double));
+      for (int n = 0; n < N; n++) {
+        const double h = H[(size_t)n * R + r];
+        const float *x = X->data + (long)X->stride * n;
+        for (int k = 0; k < D; k++) acc[k] += h * x[k];
       }
+      for (int k = 0; k < D; k++) J[(size_t)r * D + k] = (float)acc[k];
+      free(acc);
+    }
     Kt = (double *)malloc(sizeof(double) * R * R);
     Lt = (double *)malloc(sizeof(double) * R * R);
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < R; i++)
       for (int j = 0; j < R; j++) {
         double k = 0, l = 0;
@@ -289,12 +296,18 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
       }
   }
   /* X_hat = X - H W  (uses W_t, before it is replaced) */
-  for (int n = 0; n < N; n++)
-    for (int k = 0; k < D; k++) {
-      double a = 0;
-      for (int r = 0; r < R; r++) a += (double)H[(size_t)n * R + r] * W[(size_t)r * D + k];
-      X->data[(long)X->stride * n + k] = (float)((double)X->data[(long)X->stride * n + k] - a);
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; n++) {
+    double *acc = (double *)calloc(D, sizeof(double));
+    for (int r = 0; r < R; r++) {
+      const double h = H[(size_t)n * R + r];
+      const float *w = W + (size_t)r * D;
+      for (int k = 0; k < D; k++) acc[k] += h * w[k];
     }
+    float *x = X->data + (long)X->stride * n;
+    for (int k = 0; k < D; k++) x[k] = (float)((double)x[k] - acc[k]);
+    free(acc);
+  }
   free(H);
   if (!updating) return;
 
