@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "tdnnf_hip.h"
@@ -152,12 +153,16 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
   next_seg();
 
   float4 ra[A_F4], rb[B_F4];
-  float ssq = 0.f;  // p.sumsq: running sum of (coef * a)^2 over everything this thread stages
+  // The tap coefficient (and the sum of squares of p.sumsq) is applied when a staged tile goes to LDS, not when it is
+  // loaded: anything that touches ra/rb right after the loads would wait for them in front of the MFMAs they are
+  // supposed to overlap with.
+  float cf_tile = 1.f;  // coefficient of the segment the tile in ra/rb was loaded from
+  float ssq = 0.f;      // p.sumsq: running sum of (coef * a)^2 over everything this thread stages
   auto add_ssq = [&]() {
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < A_F4; j++) q += ra[j].x * ra[j].x + ra[j].y * ra[j].y + ra[j].z * ra[j].z + ra[j].w * ra[j].w;
-    ssq += cf * cf * q;
+    ssq += cf_tile * cf_tile * q;
   };
   // Per-segment, per-thread source pointers for the fast path (full K-step inside the segment, float4 loads):
   // rows/columns that are out of range read 16 zero bytes instead of branching.
@@ -200,12 +205,8 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
 #pragma unroll
       for (int j = 0; j < A_F4; j++) ra[j] = *reinterpret_cast<const float4 *>(aptr[j] + (long long)kc * astep[j]);
 #pragma unroll
-      for (int j = 0; j < B_F4; j++) {
-        float4 v = *reinterpret_cast<const float4 *>(bptr[j] + (long long)kc * bstep[j]);
-        v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
-        rb[j] = v;
-      }
-      if (p.sumsq) add_ssq();
+      for (int j = 0; j < B_F4; j++) rb[j] = *reinterpret_cast<const float4 *>(bptr[j] + (long long)kc * bstep[j]);
+      cf_tile = cf;
       return;
     }
     const GemmSeg sg = p.seg[seg];
@@ -228,9 +229,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
         const int n = n0 + row;
         const bool rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n < p.N;
         const float *ptr = Bb + (long long)n * p.ldb + k;
-        float4 v = ld4(ptr, rv && k < klen, rv && k + 1 < klen, rv && k + 2 < klen, rv && k + 3 < klen, VEC == 4);
-        v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
-        rb[j] = v;
+        rb[j] = ld4(ptr, rv && k < klen, rv && k + 1 < klen, rv && k + 2 < klen, rv && k + 3 < klen, VEC == 4);
       }
     } else {
       constexpr int NF4 = BN / 4;
@@ -240,15 +239,20 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
         const int kr = idx / NF4, n = n0 + (idx % NF4) * 4;
         const bool rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && kc + kr < klen;
         const float *ptr = Bb + (long long)(kc + kr) * p.ldb + n;
-        float4 v = ld4(ptr, rv && n < p.N, rv && n + 1 < p.N, rv && n + 2 < p.N, rv && n + 3 < p.N, VEC == 4);
-        v.x *= cf; v.y *= cf; v.z *= cf; v.w *= cf;
-        rb[j] = v;
+        rb[j] = ld4(ptr, rv && n < p.N, rv && n + 1 < p.N, rv && n + 2 < p.N, rv && n + 3 < p.N, VEC == 4);
       }
     }
-    if (p.sumsq) add_ssq();
+    cf_tile = cf;
   };
   auto store_tile = [&](int buf) {  // registers -> LDS
     float *as = As + buf * A_TILE, *bs = Bs + buf * B_TILE;
+    if (p.sumsq) add_ssq();
+    if (p.coef) {
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) {
+        rb[j].x *= cf_tile; rb[j].y *= cf_tile; rb[j].z *= cf_tile; rb[j].w *= cf_tile;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < A_F4; j++) {
       const int idx = t + 256 * j;
@@ -305,12 +309,14 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       kc += BK;
       if (kc >= klen) next_seg();
       const bool more = seg < p.nseg;
-      if (more) load_tile();  // in flight while the MFMAs run
+      if (more && p.dbg == 0) load_tile();  // in flight while the MFMAs run
       compute(buf);
       if (!more) break;
-      store_tile(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
+      if (p.dbg < 2) {
+        store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
     }
   }
 
@@ -574,6 +580,11 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
 hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   if (a_in.M <= 0 || a_in.N <= 0 || a_in.nseg <= 0) return hipSuccess;
   RowsGemmArgs a = a_in;
+  {
+    static int dbg = -1;
+    if (dbg < 0) dbg = getenv("TDNNF_GEMM_DEBUG") ? atoi(getenv("TDNNF_GEMM_DEBUG")) : 0;
+    a.dbg = dbg;
+  }
   a.c_vec = aligned16(a.C) && a.ldc % 4 == 0 && (a.init_mode != 1 || aligned16(a.bias)) && (!a.add || (aligned16(a.add) && a.ldadd % 4 == 0));
   // float4 path needs 16-byte aligned rows and segment starts; ragged tails fall back per float4
   bool vec = aligned16(a.A) && aligned16(a.B) && a.lda % 4 == 0 && a.ldb % 4 == 0;
