@@ -657,7 +657,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, 
   const long long xrow = (long long)p.row_stride * p.ldx;
 
   float4 ra[A_F4], rb[B_F4];
+  // Fast path (whole K-step inside the split, 16-byte accesses, Do and Di multiples of 4): per-thread source pointers
+  // set up once; a column group that is out of range reads 16 zero bytes with step 0 instead of branching, which
+  // keeps the steady-state loop a single basic block (accumulators stay in AGPRs).
+  const bool fast_ok = VEC == 4 && p.Do % 4 == 0 && p.Di % 4 == 0;
+  const float *aptr[A_F4], *bptr[B_F4];
+  long long astep[A_F4], bstep[B_F4];
+  {
+    const float *zero = reinterpret_cast<const float *>(&g_zero4);
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j, kr = idx / (BM / 4), m = m0 + (idx % (BM / 4)) * 4;
+      const bool v = (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) && m < p.Do;
+      aptr[j] = v ? p.dY + (long long)kr * p.lddy + m : zero;
+      astep[j] = v ? p.lddy : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; j++) {
+      const int idx = t + 256 * j, kr = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+      const bool v = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n < p.Di;
+      bptr[j] = v ? Xb + (long long)kr * xrow + n : zero;
+      bstep[j] = v ? xrow : 0;
+    }
+  }
   auto load_tile = [&](int r0) {
+    if (fast_ok && r0 + BK <= r_end) {
+#pragma unroll
+      for (int j = 0; j < A_F4; j++) ra[j] = *reinterpret_cast<const float4 *>(aptr[j] + (long long)r0 * astep[j]);
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) rb[j] = *reinterpret_cast<const float4 *>(bptr[j] + (long long)r0 * bstep[j]);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < A_F4; j++) {
       const int idx = t + 256 * j;
@@ -693,27 +723,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, 
   auto compute = [&](int buf) {
     const float *as = As + buf * A_TILE + lh * LDAS + wm * TM * 32 + li;
     const float *bs = Bs + buf * B_TILE + lh * LDBS + wn * TN * 32 + li;
+    // fragments of k-pair k2 + 1 are requested before the MFMAs of k-pair k2 are issued (two register sets), so the
+    // LDS latency hides behind TM * TN MFMAs instead of stalling every other one
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) a[0][i] = as[i * 32];
+#pragma unroll
+    for (int i = 0; i < TN; i++) b[0][i] = bs[i * 32];
 #pragma unroll
     for (int k2 = 0; k2 < BK / 2; k2++) {
-      float a[TM], b[TN];
+      const int cur = k2 & 1, nxt = cur ^ 1;
+      if (k2 + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; i++) a[i] = as[(2 * k2) * LDAS + i * 32];
+        for (int i = 0; i < TM; i++) a[nxt][i] = as[(2 * k2 + 2) * LDAS + i * 32];
 #pragma unroll
-      for (int i = 0; i < TN; i++) b[i] = bs[(2 * k2) * LDBS + i * 32];
+        for (int i = 0; i < TN; i++) b[nxt][i] = bs[(2 * k2 + 2) * LDBS + i * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
   };
 
-  if (cf != 0.f && r_begin < r_end) {
-    load_tile(r_begin);
-    store_tile(0);
-    __syncthreads();
+  // partial slab [split][Do][K*Di]
+  float *P = partial + (long long)split * p.Do * (p.K * p.Di);
+  if (cf == 0.f) return;  // skipped tap: the reduce kernel does not read its slab
+  if (r_begin >= r_end) {  // (cannot happen with the host's split plan; keep the slab defined anyway)
+    for (int e = t; e < BM * BN; e += 256) {
+      const int m = m0 + e / BN, n = n0 + e % BN;
+      if (m < p.Do && n < p.Di) P[(long long)m * (p.K * p.Di) + tap * p.Di + n] = 0.f;
+    }
+    return;
+  }
+  // straight-line prologue / loop / epilogue: with the loop under a condition the register allocator kept the 64-80
+  // accumulators in VGPRs across the back edge and copied them to AGPRs every K-step (288 registers, one wave per SIMD)
+  load_tile(r_begin);
+  store_tile(0);
+  __syncthreads();
+  {
     int buf = 0;
-    for (int r0 = r_begin; r0 < r_end; r0 += BK) {
+    for (int r0 = r_begin;; r0 += BK) {
       const bool more = r0 + BK < r_end;
       if (more) load_tile(r0 + BK);
       compute(buf);
@@ -723,8 +774,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, 
       buf ^= 1;
     }
   }
-  // partial slab [split][Do][K*Di]
-  float *P = partial + (long long)split * p.Do * (p.K * p.Di);
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
