@@ -21,6 +21,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 
@@ -466,16 +467,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RowsGemmArgs p
 }
 
 template <int WM, int WN, int TM, int TN, int BK>
-int rows_slots() {  // resident blocks on the chip for this tile variant
-  // 2 blocks per CU for both variants: the 128x128 tile is LDS-bound (73.7 KiB of 160), the 128x160 tile is
-  // register-bound (91 VGPR + 80 AGPR -> 176 allocated -> 2 waves per SIMD).  The occupancy API answers 3 for
-  // the latter (MI355X_MICROARCH.md: it can over-report), measured residency is 2 (511 vs 513 tiles).
+int rows_slots(bool b_kc) {  // resident blocks on the chip for this tile variant
+  // Blocks per CU are MEASURED (tools/residency_probe.py: time of a plain launch steps up when one more tile needs one
+  // more round), not queried: hipOccupancyMaxActiveBlocksPerMultiprocessor answers 3 for the 128x160 tile (168
+  // registers, 46 KiB LDS) where the steps sit at 513 and 1025 tiles, i.e. 2 per CU (MI355X_MICROARCH.md warns that the
+  // query can over-report).  128x128 BK 32: 2 (73.7 KiB LDS); 128x128 BK 16: 3 (41 KiB, 154 registers; steps at 513,
+  // 769, 1025); 128x160: 2.
+  (void)b_kc;
   static int slots = 0;
   if (slots == 0) {
     int dev = 0, cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    slots = 2 * cus;
+    const int per_cu = (WM * TM == 4 && WN * TN == 4 && BK == 16) ? 3 : 2;
+    slots = per_cu * cus;
     (void)hipGetLastError();
   }
   return slots;
@@ -498,7 +503,12 @@ template <int WM, int WN, int TM, int TN, int BK>
 hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int cls, double flops, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  const int tiles = ntm * ntn, slots = rows_slots<WM, WN, TM, TN, BK>();
+  static const bool nobal = getenv("TDNNF_GEMM_NOBAL") != nullptr;  // experiments: plain launch, no split-K balancing
+  if (nobal) {
+    ProfScope ps(cls, flops, s);
+    return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
+  }
+  const int tiles = ntm * ntn, slots = rows_slots<WM, WN, TM, TN, BK>(b_kc);
   const int q = tiles / slots, r = tiles % slots;
   long long ktot = 0;
   bool k4 = true;
@@ -609,6 +619,13 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     return launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
   }
   if (waste160 < waste128) return launch_rows_balanced<4, 1, 1, 5, 16>(a, b_kc, vec, 1, flops, s);
+  {
+    // short reductions (K <= 512: affine forward, linear backward, prefinal layers): BK 16 halves the LDS footprint,
+    // three blocks per CU cover each other's prologue / epilogue (+6..13 % measured); long reductions keep BK 32
+    long long kt = 0;
+    for (int i = 0; i < a.nseg; i++) kt += a.seg[i].klen;
+    if (kt <= 512) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
+  }
   return launch_rows_balanced<2, 2, 2, 2, 32>(a, b_kc, vec, 0, flops, s);
 }
 
