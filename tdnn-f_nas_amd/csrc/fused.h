@@ -4,8 +4,9 @@
 
 namespace tdnnf {
 
-// out = (x - memo.mean) * memo.scale + bypass * prev  (prev.data may be null); memo = 5 x D BatchNorm memo
-hipError_t bn_apply_bypass(MatView x, const float *memo, int D, MatView prev, float bypass, MatView out, hipStream_t s);
+// out = (x - memo.mean) * memo.scale + bypass * prev  (prev.data may be null); memo = 5 x D BatchNorm memo.
+// x / prev / out may be "super row" views (cols > D): runs of D-column rows, each `period` elements apart.
+hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s);
 
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols);
 // BatchNorm backward + ReLU backward (+ self-repair, ReLU statistics, bias-gradient column sums) in two passes.

@@ -195,9 +195,9 @@ __global__ __launch_bounds__(256) void colsum_add_kernel(const float *partial, i
 
 }  // namespace
 
-hipError_t bn_apply_bypass(MatView x, const float *memo, int D, MatView prev, float bypass, MatView out, hipStream_t s) {
+hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s) {
   if (x.rows == 0) return hipSuccess;
-  const int period = (D + 3) & ~3;  // a super row (cols > D) is a run of rows of D values padded to a multiple of 4
+  // period: a super row (cols > D) is a run of rows of D values, each padded to `period` (the plain rows' stride)
   const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0;
   const long long work = (long long)x.rows * (vec ? x.cols / 4 : x.cols);
   if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out);

@@ -335,7 +335,11 @@ void make_tdnn(Tdnn *t, int comp, int Di, int Do, const std::vector<int> &offs, 
   t->rows_out = out.n * B;
 }
 
-tdnnf_mat M(float *p, int rows, int cols) { return tdnnf_mat{p, rows, cols, (cols + 3) & ~3}; }
+// Row stride of every activation matrix of the trainer: a multiple of 32 floats, so that rows start on 128-byte lines.
+// (With the 16-byte minimum, the 6034-wide output matrices ran their GEMMs at 80 instead of 120 TFLOP/s: every 128-byte
+// row segment a tile load fetches straddled two cache lines.)
+inline int ldpad(int cols) { return (cols + 31) & ~31; }
+tdnnf_mat M(float *p, int rows, int cols) { return tdnnf_mat{p, rows, cols, ldpad(cols)}; }
 
 struct Arena {
   size_t off = 0;
@@ -347,7 +351,7 @@ struct Arena {
     off += sizeof(T) * n;
     return p;
   }
-  float *mat(int rows, int cols) { return take<float>((size_t)rows * ((cols + 3) & ~3)); }
+  float *mat(int rows, int cols) { return take<float>((size_t)rows * ldpad(cols)); }
 };
 
 int add_comp(tdnnf_net *n, const std::string &name, int rows, int cols, int has_bias, float lr_factor, float l2, float mc,
@@ -516,7 +520,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
 
 // view of the rows of a t-major matrix (grid g, B sequences, `cols` wide) that lie on a coarser grid `sub`
 tdnnf_mat sub_grid_view(float *data, const Grid &g, const Grid &sub, int B, int cols) {
-  const int stride = (cols + 3) & ~3;
+  const int stride = ldpad(cols);
   const int tau0 = (sub.t0 - g.t0) / g.step, ratio = sub.step / g.step;
   if (ratio == 1) return tdnnf_mat{data + (size_t)tau0 * B * stride, sub.n * B, cols, stride};
   // every ratio-th block of B rows: n "super rows" of B*stride elements
@@ -550,7 +554,7 @@ int bn_fwd(tdnnf_net *n, float *in, float *out, int rows, int cols, float *memo,
   if (n->cfg.cv_update) {
     CK(bn_test_memo(memo, stats, cols, s));
     const MatView none{nullptr, 0, 0, 0};
-    TDNNF_HIP(bn_apply_bypass(view(&a), memo, cols, none, 0.f, view(&o), s));
+    TDNNF_HIP(bn_apply_bypass(view(&a), memo, cols, ldpad(cols), none, 0.f, view(&o), s));
     return TDNNF_OK;
   }
   CK(tdnnf_batchnorm_propagate(&a, 1.0e-3f, 1.0f, &o, memo, n->ws, n->ws_bytes, s));
@@ -975,7 +979,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // tdnn1: affine (+bias, ReLU in the GEMM epilogue) -> BatchNorm
   CK(tdnn_propagate_impl(&ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, 1, 1, &t1r, s));
   CK(bn_stats(n, n->t1_relu, N0, Hd, n->t1_bn_memo, n->t1_bn_stats, s));
-  TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, none, 0.f, view(&t1b), s));
+  TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, ldpad(Hd), none, 0.f, view(&t1b), s));
   float *prev = n->t1_bn;
   for (auto &L : n->layers) {
     tdnnf_mat in = M(prev, N_of(L.gin, B), Hd);
@@ -1016,10 +1020,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
     tdnnf_mat x = relu, out = M(L.noop_out, L.aff.rows_out, Hd);
     if (byp.rows != out.rows) {  // strided bypass rows: view everything as (n, B*stride) super rows
-      x = tdnnf_mat{L.relu_out, L.gout.n, byp.cols, B * ((Hd + 3) & ~3)};
-      out = tdnnf_mat{L.noop_out, L.gout.n, byp.cols, B * ((Hd + 3) & ~3)};
+      x = tdnnf_mat{L.relu_out, L.gout.n, byp.cols, B * ldpad(Hd)};
+      out = tdnnf_mat{L.noop_out, L.gout.n, byp.cols, B * ldpad(Hd)};
     }
-    TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, view(&byp), c.bypass_scale, view(&out), s));
+    TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, ldpad(Hd), view(&byp), c.bypass_scale, view(&out), s));
     prev = L.noop_out;
   }
   const int No = n->Tout * B;
@@ -1032,7 +1036,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), yh = M(H.y, No, P);
     CK(tdnn_propagate_impl(&ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, 1, 1, &ar, s));
     CK(bn_stats(n, H.aff_relu, No, Hd, H.bn1_memo, H.bn1_stats, s));
-    TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, none, 0.f, view(&b1), s));
+    TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, ldpad(Hd), none, 0.f, view(&b1), s));
     CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
     CK(bn_fwd(n, H.lin_out, H.bn2_out, No, S, H.bn2_memo, H.bn2_stats, s));
     CK(tdnnf_affine_propagate(&b2, Wp(n, H.c_output), S, Bp(n, H.c_output), P, &yh, s));
@@ -1219,7 +1223,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                                  &d_in, s));
     } else {
       CK(tdnn_backprop_data_impl(&L.lin.ix, &d_lin, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, lin_eff, 1, nullptr, 0.f, 0, &d_in, s));
-      tdnnf_mat d_o = tdnnf_mat{d_cur, L.gout.n, d_byp.cols, B * ((Hd + 3) & ~3)};
+      tdnnf_mat d_o = tdnnf_mat{d_cur, L.gout.n, d_byp.cols, B * ldpad(Hd)};
       CK(tdnnf_add_scaled(&d_o, c.bypass_scale, &d_byp, s));
     }
     std::swap(d_cur, d_next);

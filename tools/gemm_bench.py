@@ -67,5 +67,8 @@ run("prefinal.affine", [0], 500, B, 256, 1536)
 run("prefinal.linear", [0], 500, B, 1536, 256)
 run("output.affine", [0], 500, B, 256, 6034)
 run("config1.linear", [-1, 0, 1], 150, B, 40, 160)
+run("outprobe K6016", [0], 500, B, 256, 6016)
+run("outprobe K6144", [0], 500, B, 256, 6144)
+run("outprobe K6034 N4096->", [0], 500, B, 4096, 6034)
 run("probe160 longK 1round", [-1, 0], 512, B, 1536, 160)
 run("probe128 longK", [-1, 0], 512, B, 1536, 1536)
