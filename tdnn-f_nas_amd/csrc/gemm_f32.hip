@@ -514,7 +514,7 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   bool k4 = true;
   for (int i = 0; i < a.nseg; i++) {
     ktot += a.seg[i].klen;
-    k4 = k4 && a.seg[i].klen % 4 == 0;
+    k4 = k4 && (a.seg[i].klen % 4 == 0 || a.nseg == 1);  // one segment: only the very end of K is ragged (slow path of the last chunk)
   }
   // All blocks run equally long, so q*slots + r tiles cost q+1 rounds.  When the last round would be less than
   // half full, finish the last rows with a split-K launch that spreads them over every CU instead.

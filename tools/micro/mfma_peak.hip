@@ -27,13 +27,13 @@ int main(int argc, char **argv) {
   const int wps = argc > 1 ? atoi(argv[1]) : 2, ch = argc > 2 ? atoi(argv[2]) : 4;
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
-  const int cus = prop.multiProcessorCount, blocks = cus * wps, iters = 20000;
+  const int cus = prop.multiProcessorCount, blocks = cus * wps, iters = argc > 3 ? atoi(argv[3]) : 20000;
   float *out;
   hipMalloc(&out, sizeof(float) * blocks * 256);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  for (int rep = 0; rep < 3; rep++) {
+  for (int rep = 0; rep < (argc > 4 ? atoi(argv[4]) : 3); rep++) {
     hipEventRecord(e0);
     if (ch == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f, 1e-3f);
     else if (ch == 8) hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f, 1e-3f);
