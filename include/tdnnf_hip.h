@@ -356,6 +356,15 @@ int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale
 long long tdnnf_net_stats_size(const tdnnf_net *);
 int tdnnf_net_get_stats(const tdnnf_net *, double *stats_host, tdnnf_stream);
 int tdnnf_net_set_stats(tdnnf_net *, const double *stats_host, tdnnf_stream);
+/* nnet3 "raw" model files of the network (what nnet3-copy reads and writes): "<Nnet3>", the config lines of the graph,
+   "<NumComponents>" and every component in the token order of the reference's Write() functions (csrc/model_io.hip
+   cites each one); binary != 0 writes Kaldi's binary encoding ("\0B" header, "FM"/"FV" blobs).  Parameters come from /
+   go to the buffers of tdnnf_net_set_buffers, BatchNorm / ReLU statistics from / to the net (as tdnnf_net_get_stats).
+   learning_rate is what the "<LearningRate>" tokens record (times each component's factor).  read_model matches
+   components by name, checks dimensions and fails if a parameterised component of the net is missing from the file;
+   both text and binary files are accepted.  Both calls synchronise the stream. */
+int tdnnf_net_write_model(const tdnnf_net *, const char *path, int binary, float learning_rate, tdnnf_stream);
+int tdnnf_net_read_model(tdnnf_net *, const char *path, tdnnf_stream);
 /* debugging / parity: copy an internal activation by name ("tdnnf2.linear", "output", ...) into out */
 int tdnnf_net_get_activation(const tdnnf_net *, const char *name, tdnnf_mat *out, tdnnf_stream);
 int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, int *cols);

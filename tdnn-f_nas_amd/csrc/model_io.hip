@@ -1,0 +1,1011 @@
+// model_io.hip -- nnet3 "raw" model files (text and binary) for the graphs the trainer runs.
+//
+// Writes / reads what `nnet3-copy [--binary=false]` would hold for the network: "<Nnet3>", the config lines of the
+// graph, "<NumComponents>", and every component in the token order of the reference's own Write() functions:
+//   UpdatableComponent::WriteUpdatableCommon        /root/reference/src/nnet3/nnet-component-itf.cc:390-414
+//   NonlinearComponent::Write (ReLU, LogSoftmax)    nnet-component-itf.cc:630-686
+//   TdnnDARTSV3Component::Write                     nnet-tdnn-component.cc:659-700  (plain TdnnComponent: UPSTREAM, the
+//                                                   same without the seven DARTS tokens)
+//   BatchNormComponent / BatchNormTestComponent     nnet-normalize-component.cc:616-642, :956-982
+//   NaturalGradientAffine / Linear / FixedAffine    nnet-simple-component.cc:2935-2958, :3161-3188, :3408-3415
+//   NoOp / ConstantFunction / OnehotFunction        :476-483, :2683-2694, :9593-9604
+//   (Gumbel)SoftmaxFlops / CopyN / ElementwiseProduct :10037-10044, :10178-10187, :4824-4833, :310-317
+// GeneralDropoutComponent, Nnet::Write/Read and the matrix / vector / basic-type encodings are UPSTREAM (not shipped);
+// they are restated from Kaldi's documented on-disk format.  Graph text: the xconfig output of
+// local/chain_NAS/run_tdnn_fbk_40_iv_sp_7q.sh:160-186 (composite_layers.py:135-215, :1283-1331), generate_config.py for
+// the offset supernet and generate_bottleneckCB8share_onehottrain_config.py:10-102 for the bottleneck supernet.
+// Text mode prints floats with 9 significant digits (Kaldi prints 6; its reader takes either), so text round trips
+// are lossless here.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "net.h"
+
+namespace tdnnf {
+namespace {
+
+// ------------------------------------------------------------------------------------------------ Kaldi encodings
+struct Out {
+  std::ostream &os;
+  bool bin;
+  void token(const std::string &t) { os << t << " "; }
+  void i32(int v) {
+    if (bin) {
+      os.put((char)sizeof(int));
+      os.write((const char *)&v, sizeof(v));
+    } else {
+      os << v << " ";
+    }
+  }
+  void f32(float v) {
+    if (bin) {
+      os.put((char)sizeof(float));
+      os.write((const char *)&v, sizeof(v));
+    } else {
+      char buf[40];
+      snprintf(buf, sizeof(buf), "%.9g ", (double)v);
+      os << buf;
+    }
+  }
+  void f64(double v) {
+    if (bin) {
+      os.put((char)sizeof(double));
+      os.write((const char *)&v, sizeof(v));
+    } else {
+      char buf[48];
+      snprintf(buf, sizeof(buf), "%.17g ", v);
+      os << buf;
+    }
+  }
+  void boolean(bool b) {
+    os << (b ? "T" : "F");
+    if (!bin) os << " ";
+  }
+  void vec(const float *v, int n) {  // Vector<BaseFloat>::Write
+    if (bin) {
+      token("FV");
+      i32(n);
+      os.write((const char *)v, sizeof(float) * (size_t)n);
+    } else {
+      os << " [ ";
+      for (int i = 0; i < n; i++) f32(v[i]);
+      os << "]\n";
+    }
+  }
+  void mat(const float *m, int rows, int cols, long long ld) {  // Matrix<BaseFloat>::Write
+    if (bin) {
+      token("FM");
+      i32(rows);
+      i32(cols);
+      for (int r = 0; r < rows; r++) os.write((const char *)(m + (long long)r * ld), sizeof(float) * (size_t)cols);
+    } else if (cols == 0 || rows == 0) {
+      os << " [ ]\n";
+    } else {
+      os << " [";
+      for (int r = 0; r < rows; r++) {
+        os << "\n  ";
+        for (int c = 0; c < cols; c++) f32(m[(long long)r * ld + c]);
+      }
+      os << "]\n";
+    }
+  }
+  void intvec(const std::vector<int> &v) {  // WriteIntegerVector<int32>
+    if (bin) {
+      os.put((char)sizeof(int));
+      const int n = (int)v.size();
+      os.write((const char *)&n, sizeof(n));
+      if (n) os.write((const char *)v.data(), sizeof(int) * (size_t)n);
+    } else {
+      os << "[ ";
+      for (int x : v) os << x << " ";
+      os << "]\n";
+    }
+  }
+};
+
+struct In {
+  std::istream &is;
+  bool bin;
+  std::string err;
+  bool fail(const std::string &m) {
+    if (err.empty()) err = m;
+    return false;
+  }
+  bool token(std::string *t) {
+    if (!bin) is >> std::ws;
+    if (!(is >> *t)) return fail("unexpected end of file while reading a token");
+    if (!isspace(is.peek())) return fail("token " + *t + " is not followed by white space");
+    is.get();
+    return true;
+  }
+  bool expect(const std::string &want) {
+    std::string t;
+    if (!token(&t)) return false;
+    return t == want ? true : fail("expected token " + want + ", got " + t);
+  }
+  int peek_letter() {  // first letter of the next token (after '<'), without consuming it: PeekToken()
+    if (!bin) is >> std::ws;
+    const std::streampos p = is.tellg();
+    int c = is.get();
+    if (c == '<') c = is.get();
+    is.seekg(p);
+    return c;
+  }
+  bool i32(int *v) {
+    if (bin) {
+      const int sz = is.get();
+      if (sz != (int)sizeof(int)) return fail("binary integer of unexpected size");
+      is.read((char *)v, sizeof(int));
+    } else {
+      is >> *v;
+    }
+    return is.good() || is.eof() ? true : fail("bad integer");
+  }
+  bool real(double *v) {  // BaseFloat or double on disk (ReadBasicType accepts either width)
+    if (bin) {
+      const int sz = is.get();
+      if (sz == (int)sizeof(float)) {
+        float f;
+        is.read((char *)&f, sizeof(f));
+        *v = f;
+      } else if (sz == (int)sizeof(double)) {
+        is.read((char *)v, sizeof(double));
+      } else {
+        return fail("binary float of unexpected size");
+      }
+      return is.good() ? true : fail("truncated float");
+    }
+    std::string t;
+    is >> t;
+    if (t.empty()) return fail("bad float");
+    if (t == "inf" || t == "Inf" || t == "infinity") *v = INFINITY;
+    else if (t == "-inf" || t == "-Inf") *v = -INFINITY;
+    else if (t == "nan" || t == "NaN" || t == "-nan") *v = NAN;
+    else *v = strtod(t.c_str(), nullptr);
+    return true;
+  }
+  bool f32(float *v) {
+    double d;
+    if (!real(&d)) return false;
+    *v = (float)d;
+    return true;
+  }
+  bool boolean(bool *b) {
+    if (!bin) is >> std::ws;
+    const int c = is.get();
+    if (c != 'T' && c != 'F') return fail("expected T or F");
+    *b = c == 'T';
+    return true;
+  }
+  bool vec(std::vector<float> *v) {
+    if (bin) {
+      std::string t;
+      if (!token(&t)) return false;
+      if (t != "FV" && t != "DV") return fail("expected a vector, got " + t);
+      int n;
+      if (!i32(&n) || n < 0) return fail("bad vector size");
+      v->resize(n);
+      if (t == "FV") {
+        is.read((char *)v->data(), sizeof(float) * (size_t)n);
+      } else {
+        std::vector<double> d(n);
+        is.read((char *)d.data(), sizeof(double) * (size_t)n);
+        for (int i = 0; i < n; i++) (*v)[i] = (float)d[i];
+      }
+      return is.good() ? true : fail("truncated vector");
+    }
+    std::string t;
+    is >> t;
+    if (t != "[") return fail("expected [ at the start of a vector, got " + t);
+    v->clear();
+    for (;;) {
+      is >> t;
+      if (!is) return fail("unterminated vector");
+      if (t == "]") break;
+      v->push_back((float)strtod(t.c_str(), nullptr));
+    }
+    return true;
+  }
+  bool mat(std::vector<float> *m, int *rows, int *cols) {
+    if (bin) {
+      std::string t;
+      if (!token(&t)) return false;
+      if (t != "FM" && t != "DM") return fail("expected a matrix, got " + t + " (compressed matrices are not supported)");
+      if (!i32(rows) || !i32(cols) || *rows < 0 || *cols < 0) return fail("bad matrix size");
+      const size_t n = (size_t)*rows * *cols;
+      m->resize(n);
+      if (t == "FM") {
+        is.read((char *)m->data(), sizeof(float) * n);
+      } else {
+        std::vector<double> d(n);
+        is.read((char *)d.data(), sizeof(double) * n);
+        for (size_t i = 0; i < n; i++) (*m)[i] = (float)d[i];
+      }
+      return is.good() ? true : fail("truncated matrix");
+    }
+    std::string t;
+    is >> t;
+    if (t != "[") return fail("expected [ at the start of a matrix, got " + t);
+    m->clear();
+    *rows = 0;
+    *cols = 0;
+    int cur = 0;
+    std::string num;
+    auto flush_num = [&]() {
+      if (!num.empty()) {
+        m->push_back((float)strtod(num.c_str(), nullptr));
+        cur++;
+        num.clear();
+      }
+    };
+    auto end_row = [&]() -> bool {
+      if (cur == 0) return true;
+      if (*cols == 0) *cols = cur;
+      else if (cur != *cols) return fail("ragged matrix");
+      (*rows)++;
+      cur = 0;
+      return true;
+    };
+    for (;;) {
+      const int c = is.get();
+      if (c == EOF) return fail("unterminated matrix");
+      if (c == ']') {
+        flush_num();
+        if (!end_row()) return false;
+        break;
+      }
+      if (c == '\n' || c == ';') {
+        flush_num();
+        if (!end_row()) return false;
+      } else if (isspace(c)) {
+        flush_num();
+      } else {
+        num.push_back((char)c);
+      }
+    }
+    return true;
+  }
+  bool intvec(std::vector<int> *v) {
+    if (bin) {
+      const int sz = is.get();
+      if (sz != (int)sizeof(int)) return fail("integer vector of unexpected element size");
+      int n;
+      is.read((char *)&n, sizeof(n));
+      if (n < 0) return fail("bad integer vector size");
+      v->resize(n);
+      if (n) is.read((char *)v->data(), sizeof(int) * (size_t)n);
+      return is.good() ? true : fail("truncated integer vector");
+    }
+    std::string t;
+    is >> t;
+    if (t != "[") return fail("expected [ at the start of an integer vector");
+    v->clear();
+    for (;;) {
+      is >> t;
+      if (!is) return fail("unterminated integer vector");
+      if (t == "]") break;
+      v->push_back(atoi(t.c_str()));
+    }
+    return true;
+  }
+};
+
+// ------------------------------------------------------------------------------------------- host copy of the net
+struct HostNet {
+  std::vector<float> params;
+  std::vector<double> stats;
+  std::map<std::string, size_t> stat_off;  // "tdnn1.batchnorm" -> offset of [count, a[D], b[D]] in stats
+  std::map<std::string, int> stat_dim;
+};
+
+void stat_layout(const tdnnf_net *n, HostNet *h) {  // the order of tdnnf_net_get_stats (net.hip: stat_blocks)
+  const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
+  size_t off = 0;
+  auto add = [&](const std::string &name, int D) {
+    h->stat_off[name] = off;
+    h->stat_dim[name] = D;
+    off += 1 + 2 * (size_t)D;
+  };
+  add("tdnn1.batchnorm", Hd);
+  add("tdnn1.relu", Hd);
+  for (size_t l = 0; l < n->layers.size(); l++) {
+    const std::string p = "tdnnf" + std::to_string(l + 2);
+    add(p + ".batchnorm", Hd);
+    add(p + ".relu", Hd);
+  }
+  const char *hn[2] = {"chain", "xent"};
+  for (int k = 0; k < 2; k++) {
+    const std::string p = std::string("prefinal-") + hn[k];
+    add(p + ".batchnorm1", Hd);
+    add(p + ".relu", Hd);
+    add(p + ".batchnorm2", S);
+  }
+}
+
+std::string layer_name(int l) { return "tdnnf" + std::to_string(l + 2); }
+
+// ------------------------------------------------------------------------------------------------- config lines
+std::vector<std::string> config_lines(const tdnnf_net *n) {
+  const tdnnf_net_config &c = n->cfg;
+  std::vector<std::string> L;
+  char buf[512];
+  auto add = [&](const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    L.push_back(buf);
+  };
+  auto cn = [&](const std::string &name, const std::string &input) { add("component-node name=%s component=%s input=%s", name.c_str(), name.c_str(), input.c_str()); };
+  add("input-node name=ivector dim=%d", c.ivector_dim);
+  add("input-node name=input dim=%d", c.feat_dim);
+  cn("lda", "Append(Offset(input, -1), input, Offset(input, 1), ReplaceIndex(ivector, t, 0))");
+  cn("tdnn1.affine", "lda");
+  cn("tdnn1.relu", "tdnn1.affine");
+  cn("tdnn1.batchnorm", "tdnn1.relu");
+  cn("tdnn1.dropout", "tdnn1.batchnorm");
+  std::string prev = "tdnn1.dropout";
+  for (size_t l = 0; l < n->layers.size(); l++) {
+    const std::string p = layer_name((int)l);
+    std::string aff_in = p + ".linear";
+    if (c.bn_num_choices > 0) {  // generate_bottleneckCB8share_onehottrain_config.py:10-85 / add_flopsconstraint.py:18-30
+      const int C = c.bn_num_choices;
+      if (c.bn_mode != 0) cn(p + ".alpha", "lda");
+      cn(p + ".softmax", c.bn_mode == 0 ? "lda" : p + ".alpha");
+      for (int k = 0; k < C; k++) add("dim-range-node name=%s.softmax%d input-node=%s.softmax dim-offset=%d dim=1", p.c_str(), k, p.c_str(), k);
+      for (int k = 0; k < C; k++) {
+        std::string sum;
+        for (int j = k; j < C; j++) sum += (j > k ? "," : "") + p + ".softmax" + std::to_string(j);
+        const std::string nm = p + std::to_string(k) + ".copyn";
+        cn(nm, k + 1 < C ? "Sum(" + sum + ")" : sum);
+      }
+      cn(p + ".linear", prev);
+      int off = 0;
+      for (int k = 0; k < C; k++) {
+        add("dim-range-node name=%s%d.linear input-node=%s.linear dim-offset=%d dim=%d", p.c_str(), k, p.c_str(), off, c.bn_choice_dims[k]);
+        off += c.bn_choice_dims[k];
+      }
+      aff_in = "Append(";
+      for (int k = 0; k < C; k++) {
+        const std::string pk = p + std::to_string(k);
+        cn(pk + ".output", "Append(" + pk + ".copyn, " + pk + ".linear)");
+        aff_in += (k ? "," : "") + pk + ".output";
+      }
+      aff_in += ")";
+    } else {
+      cn(p + ".linear", prev);
+    }
+    cn(p + ".affine", aff_in);
+    cn(p + ".relu", p + ".affine");
+    cn(p + ".batchnorm", p + ".relu");
+    cn(p + ".dropout", p + ".batchnorm");
+    snprintf(buf, sizeof(buf), "Sum(Scale(%g, %s), %s.dropout)", c.bypass_scale, prev.c_str(), p.c_str());
+    cn(p + ".noop", buf);
+    prev = p + ".noop";
+  }
+  cn("prefinal-l", prev);
+  const char *hn[2] = {"chain", "xent"};
+  for (int k = 0; k < 2; k++) {
+    const std::string p = std::string("prefinal-") + hn[k], o = k == 0 ? "output" : "output-xent";
+    cn(p + ".affine", "prefinal-l");
+    cn(p + ".relu", p + ".affine");
+    cn(p + ".batchnorm1", p + ".relu");
+    cn(p + ".linear", p + ".batchnorm1");
+    cn(p + ".batchnorm2", p + ".linear");
+    cn(o + ".affine", p + ".batchnorm2");
+    if (k == 1) cn(o + ".log-softmax", o + ".affine");
+    add("output-node name=%s input=%s objective=linear", o.c_str(), k == 0 ? "output.affine" : "output-xent.log-softmax");
+  }
+  return L;
+}
+
+// -------------------------------------------------------------------------------------------- component writers
+struct Ctx {
+  const tdnnf_net *n;
+  const HostNet *h;
+  Out *o;
+  float lr;
+};
+
+void updatable_common(Ctx &x, const char *type, const CompDesc &cd) {  // WriteUpdatableCommon
+  Out &o = *x.o;
+  o.token(std::string("<") + type + ">");
+  if (cd.lr_factor != 1.0f) {
+    o.token("<LearningRateFactor>");
+    o.f32(cd.lr_factor);
+  }
+  if (cd.max_change > 0.f) {
+    o.token("<MaxChange>");
+    o.f32(cd.max_change);
+  }
+  if (cd.l2 > 0.f) {
+    o.token("<L2Regularize>");
+    o.f32(cd.l2);
+  }
+  o.token("<LearningRate>");
+  o.f32(x.lr * cd.lr_factor);
+}
+
+const float *pW(Ctx &x, const CompDesc &cd) { return x.h->params.data() + cd.begin; }
+
+void ng_ranks(const CompDesc &cd, int *rank_in, int *rank_out) {  // nnet-tdnn-component.cc:183-210 defaults
+  const int spliced = cd.cols + (cd.has_bias ? 1 : 0);
+  *rank_in = std::min(20, (spliced + 1) / 2);
+  *rank_out = std::min(80, (cd.rows + 1) / 2);
+}
+
+void write_ng_affine(Ctx &x, const CompDesc &cd) {  // nnet-simple-component.cc:2935-2958
+  Out &o = *x.o;
+  updatable_common(x, "NaturalGradientAffineComponent", cd);
+  o.token("<LinearParams>");
+  o.mat(pW(x, cd), cd.rows, cd.cols, cd.cols);
+  o.token("<BiasParams>");
+  o.vec(pW(x, cd) + (long long)cd.rows * cd.cols, cd.rows);
+  int ri, ro;
+  ng_ranks(cd, &ri, &ro);
+  o.token("<RankIn>");
+  o.i32(ri);
+  o.token("<RankOut>");
+  o.i32(ro);
+  if (cd.orthonormal != 0.f) {
+    o.token("<OrthonormalConstraint>");
+    o.f32(cd.orthonormal);
+  }
+  o.token("<UpdatePeriod>");
+  o.i32(4);
+  o.token("<NumSamplesHistory>");
+  o.f32(2000.0f);
+  o.token("<Alpha>");
+  o.f32(4.0f);
+  o.token("</NaturalGradientAffineComponent>");
+}
+
+void write_linear(Ctx &x, const CompDesc &cd) {  // :3161-3188
+  Out &o = *x.o;
+  updatable_common(x, "LinearComponent", cd);
+  o.token("<Params>");
+  o.mat(pW(x, cd), cd.rows, cd.cols, cd.cols);
+  if (cd.orthonormal != 0.f) {
+    o.token("<OrthonormalConstraint>");
+    o.f32(cd.orthonormal);
+  }
+  o.token("<UseNaturalGradient>");
+  o.boolean(true);
+  int ri, ro;
+  ng_ranks(cd, &ri, &ro);
+  o.token("<RankInOut>");
+  o.i32(ri);
+  o.i32(ro);
+  o.token("<Alpha>");
+  o.f32(4.0f);
+  o.token("<NumSamplesHistory>");
+  o.f32(2000.0f);
+  o.token("<UpdatePeriod>");
+  o.i32(4);
+  o.token("</LinearComponent>");
+}
+
+void write_tdnn(Ctx &x, const CompDesc &cd, const Tdnn &t) {  // nnet-tdnn-component.cc:659-700
+  Out &o = *x.o;
+  const tdnnf_net_config &c = x.n->cfg;
+  const char *type = t.darts ? "TdnnDARTSV3Component" : "TdnnComponent";
+  updatable_common(x, type, cd);
+  if (t.darts) {
+    o.token("<use-gumbel>");
+    o.boolean(c.darts_flags & TDNNF_DARTS_USE_GUMBEL);
+    o.token("<use-entropy>");
+    o.boolean(c.darts_flags & TDNNF_DARTS_USE_ENTROPY);
+    o.token("<free-select>");
+    o.boolean(c.darts_flags & TDNNF_DARTS_FREE_SELECT);
+    o.token("<update-alpha>");
+    o.boolean(c.darts_flags & TDNNF_DARTS_UPDATE_ALPHA);
+    o.token("<update-theta>");
+    o.boolean(!c.cv_update);
+    o.token("<uniform-sample>");
+    o.boolean(c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE);
+    o.token("<Temp-Proportion>");
+    o.f32(c.darts_temp_proportion);
+  }
+  o.token("<TimeOffsets>");
+  o.intvec(std::vector<int>(t.offsets, t.offsets + t.K));
+  o.token("<LinearParams>");
+  o.mat(pW(x, cd), cd.rows, cd.cols, cd.cols);
+  o.token("<BiasParams>");  // DARTS: [K architecture logits | Do biases] (nnet-tdnn-component.cc:176); no bias: empty vector
+  o.vec(pW(x, cd) + (long long)cd.rows * cd.cols, cd.num_alpha + (cd.has_bias ? cd.rows : 0));
+  o.token("<OrthonormalConstraint>");
+  o.f32(cd.orthonormal);
+  o.token("<UseNaturalGradient>");
+  o.boolean(true);
+  int ri, ro;
+  ng_ranks(cd, &ri, &ro);
+  o.token("<NumSamplesHistory>");
+  o.f32(2000.0f);
+  o.token("<AlphaInOut>");
+  o.f32(4.0f);
+  o.f32(4.0f);
+  o.token("<RankInOut>");
+  o.i32(ri);
+  o.i32(ro);
+  o.token(std::string("</") + type + ">");
+}
+
+void write_batchnorm(Ctx &x, const std::string &name) {  // nnet-normalize-component.cc:616-642 / :956-982
+  Out &o = *x.o;
+  const bool test = x.n->cfg.cv_update != 0;
+  const char *type = test ? "BatchNormTestComponent" : "BatchNormComponent";
+  const int D = x.h->stat_dim.at(name);
+  const double *st = x.h->stats.data() + x.h->stat_off.at(name);
+  o.token(std::string("<") + type + ">");
+  o.token("<Dim>");
+  o.i32(D);
+  o.token("<BlockDim>");
+  o.i32(D);
+  o.token("<Epsilon>");
+  o.f32(1.0e-3f);
+  o.token("<TargetRms>");
+  o.f32(1.0f);
+  o.token("<TestMode>");
+  o.boolean(test);
+  o.token("<Count>");
+  o.f64(st[0]);  // double count_ (nnet-normalize-component.h:282)
+  std::vector<float> mean(D), var(D);
+  for (int d = 0; d < D; d++) {
+    if (st[0] != 0) {
+      const double m = st[1 + d] / st[0];
+      mean[d] = (float)m;
+      var[d] = (float)(st[1 + D + d] / st[0] - m * m);
+    } else {
+      mean[d] = (float)st[1 + d];
+      var[d] = (float)st[1 + D + d];
+    }
+  }
+  o.token("<StatsMean>");
+  o.vec(mean.data(), D);
+  o.token("<StatsVar>");
+  o.vec(var.data(), D);
+  o.token(std::string("</") + type + ">");
+}
+
+void write_nonlinear(Ctx &x, const char *type, int D, const std::string &stat_name, float self_repair_scale) {  // itf.cc:630-686
+  Out &o = *x.o;
+  o.token(std::string("<") + type + ">");
+  o.token("<Dim>");
+  o.i32(D);
+  std::vector<float> va, da;
+  double count = 0;
+  if (!stat_name.empty()) {
+    const double *st = x.h->stats.data() + x.h->stat_off.at(stat_name);
+    count = st[0];
+    va.resize(D);
+    da.resize(D);
+    for (int d = 0; d < D; d++) {
+      va[d] = (float)(count != 0 ? st[1 + d] / count : st[1 + d]);
+      da[d] = (float)(count != 0 ? st[1 + D + d] / count : st[1 + D + d]);
+    }
+  }
+  o.token("<ValueAvg>");
+  o.vec(va.data(), (int)va.size());
+  o.token("<DerivAvg>");
+  o.vec(da.data(), (int)da.size());
+  o.token("<Count>");
+  o.f64(count);
+  o.token("<OderivRms>");
+  o.vec(nullptr, 0);
+  o.token("<OderivCount>");
+  o.f64(0.0);
+  o.token("<NumDimsSelfRepaired>");
+  o.f64(0.0);
+  o.token("<NumDimsProcessed>");
+  o.f64(0.0);
+  if (self_repair_scale != 0.f) {
+    o.token("<SelfRepairScale>");
+    o.f32(self_repair_scale);
+  }
+  o.token(std::string("</") + type + ">");
+}
+
+void write_dropout(Ctx &x, int D) {  // GeneralDropoutComponent (UPSTREAM): dropout-proportion 0, continuous
+  Out &o = *x.o;
+  o.token("<GeneralDropoutComponent>");
+  o.token("<Dim>");
+  o.i32(D);
+  o.token("<BlockDim>");
+  o.i32(D);
+  o.token("<TimePeriod>");
+  o.i32(0);
+  o.token("<DropoutProportion>");
+  o.f32(0.0f);
+  o.token("<Continuous>");
+  o.token("</GeneralDropoutComponent>");
+}
+
+void write_constant_like(Ctx &x, const char *type, const CompDesc &cd, int input_dim) {  // :2683-2694 / :9593-9604
+  Out &o = *x.o;
+  updatable_common(x, type, cd);
+  o.token("<InputDim>");
+  o.i32(input_dim);
+  o.token("<Output>");
+  o.vec(pW(x, cd), cd.rows);
+  o.token("<IsUpdatable>");
+  o.boolean(true);
+  o.token("<UseNaturalGradient>");
+  o.boolean(false);
+  o.token(std::string("</") + type + ">");
+}
+
+int write_components(Ctx &x, bool count_only) {
+  const tdnnf_net *n = x.n;
+  const tdnnf_net_config &c = n->cfg;
+  Out &o = *x.o;
+  const int Hd = c.hidden_dim, S = c.prefinal_small_dim, lda_dim = 3 * c.feat_dim + c.ivector_dim;
+  int count = 0;
+  auto begin = [&](const std::string &name) -> bool {
+    count++;
+    if (count_only) return false;
+    o.token("<ComponentName>");
+    o.token(name);
+    return true;
+  };
+  auto end = [&]() {
+    if (!o.bin) o.os << "\n";
+  };
+  if (begin("lda")) {  // FixedAffineComponent :3408-3415
+    const CompDesc &cd = n->comps[n->c_lda];
+    o.token("<FixedAffineComponent>");
+    o.token("<LinearParams>");
+    o.mat(pW(x, cd), cd.rows, cd.cols, cd.cols);
+    o.token("<BiasParams>");
+    o.vec(pW(x, cd) + (long long)cd.rows * cd.cols, cd.rows);
+    o.token("</FixedAffineComponent>");
+    end();
+  }
+  (void)lda_dim;
+  auto relu_bn_dropout = [&](const std::string &p, const std::string &bn_suffix, int D) {
+    if (begin(p + ".relu")) {
+      write_nonlinear(x, "RectifiedLinearComponent", D, p + ".relu", c.relu_self_repair_scale);
+      end();
+    }
+    if (begin(p + bn_suffix)) {
+      write_batchnorm(x, p + bn_suffix);
+      end();
+    }
+  };
+  if (begin("tdnn1.affine")) {
+    write_ng_affine(x, n->comps[n->tdnn1.comp]);
+    end();
+  }
+  relu_bn_dropout("tdnn1", ".batchnorm", Hd);
+  if (begin("tdnn1.dropout")) {
+    write_dropout(x, Hd);
+    end();
+  }
+  for (size_t l = 0; l < n->layers.size(); l++) {
+    const TdnnfLayer &L = n->layers[l];
+    const std::string p = layer_name((int)l);
+    if (L.c_arch >= 0) {
+      const CompDesc &ca = n->comps[L.c_arch];
+      const int C = c.bn_num_choices;
+      if (c.bn_mode == 0) {
+        if (begin(p + ".softmax")) {
+          write_constant_like(x, "OnehotFunctionComponent", ca, lda_dim);
+          end();
+        }
+      } else {
+        if (begin(p + ".alpha")) {
+          write_constant_like(x, "ConstantFunctionComponent", ca, lda_dim);
+          end();
+        }
+        if (begin(p + ".softmax")) {
+          const char *type = c.bn_mode == 2 ? "GumbelSoftmaxFlopsComponent" : "SoftmaxFlopsComponent";
+          o.token(std::string("<") + type + ">");
+          o.token("<Dim>");
+          o.i32(C);
+          o.token("<Scale>");
+          o.f32(c.bn_flops_scale);
+          if (c.bn_mode == 2) {
+            o.token("<TempProportion>");
+            o.f32(c.bn_temp_proportion);
+          }
+          o.token(std::string("</") + type + ">");
+          end();
+        }
+      }
+      for (int k = 0; k < C; k++)
+        if (begin(p + std::to_string(k) + ".copyn")) {  // :4824-4833
+          o.token("<CopyNComponent>");
+          o.token("<InputDim>");
+          o.i32(1);
+          o.token("<OutputDim>");
+          o.i32(c.bn_choice_dims[k]);
+          o.token("<Scale>");
+          o.f32(1.0f);
+          o.token("</CopyNComponent>");
+          end();
+        }
+    }
+    if (begin(p + ".linear")) {
+      write_tdnn(x, n->comps[L.lin.comp], L.lin);
+      end();
+    }
+    if (L.c_arch >= 0)
+      for (int k = 0; k < c.bn_num_choices; k++)
+        if (begin(p + std::to_string(k) + ".output")) {  // :310-317
+          o.token("<ElementwiseProductComponent>");
+          o.token("<InputDim>");
+          o.i32(2 * c.bn_choice_dims[k]);
+          o.token("<OutputDim>");
+          o.i32(c.bn_choice_dims[k]);
+          o.token("</ElementwiseProductComponent>");
+          end();
+        }
+    if (begin(p + ".affine")) {
+      write_tdnn(x, n->comps[L.aff.comp], L.aff);
+      end();
+    }
+    relu_bn_dropout(p, ".batchnorm", Hd);
+    if (begin(p + ".dropout")) {
+      write_dropout(x, Hd);
+      end();
+    }
+    if (begin(p + ".noop")) {  // :476-483
+      o.token("<NoOpComponent>");
+      o.token("<Dim>");
+      o.i32(Hd);
+      o.token("<BackpropScale>");
+      o.f32(1.0f);
+      o.token("</NoOpComponent>");
+      end();
+    }
+  }
+  if (begin("prefinal-l")) {
+    write_linear(x, n->comps[n->c_prefinal_l]);
+    end();
+  }
+  const char *hn[2] = {"chain", "xent"};
+  for (int k = 0; k < 2; k++) {
+    const std::string p = std::string("prefinal-") + hn[k], out = k == 0 ? "output" : "output-xent";
+    if (begin(p + ".affine")) {
+      write_ng_affine(x, n->comps[n->head[k].c_affine]);
+      end();
+    }
+    relu_bn_dropout(p, ".batchnorm1", Hd);
+    if (begin(p + ".linear")) {
+      write_linear(x, n->comps[n->head[k].c_linear]);
+      end();
+    }
+    if (begin(p + ".batchnorm2")) {
+      write_batchnorm(x, p + ".batchnorm2");
+      end();
+    }
+    if (begin(out + ".affine")) {
+      write_ng_affine(x, n->comps[n->head[k].c_output]);
+      end();
+    }
+    if (k == 1 && begin(out + ".log-softmax")) {
+      write_nonlinear(x, "LogSoftmaxComponent", c.num_pdfs, "", 0.f);
+      end();
+    }
+  }
+  (void)S;
+  return count;
+}
+
+// --------------------------------------------------------------------------------------------- component readers
+struct Parsed {  // what one component block contributed
+  std::string type;
+  std::vector<float> W, b, out_vec, mean, var, value_avg, deriv_avg;
+  int rows = 0, cols = 0;
+  double count = 0;
+  std::vector<int> offsets;
+  bool have_stats = false;
+};
+
+// Reads the tokens of one component after its opening tag up to and including the closing tag.  `kinds` says how the
+// value after each known token is encoded: i int, f float/double, b bool, v vector, m matrix, I integer vector,
+// 2 two floats, J two ints, - no value.
+bool read_block(In &in, const std::string &type, Parsed *p) {
+  static const std::map<std::string, char> kinds = {
+      {"<LearningRateFactor>", 'f'}, {"<IsGradient>", 'b'}, {"<MaxChange>", 'f'}, {"<L2Regularize>", 'f'}, {"<LearningRate>", 'f'},
+      {"<use-gumbel>", 'b'}, {"<use-entropy>", 'b'}, {"<free-select>", 'b'}, {"<update-alpha>", 'b'}, {"<update-theta>", 'b'},
+      {"<uniform-sample>", 'b'}, {"<Temp-Proportion>", 'f'}, {"<TimeOffsets>", 'I'}, {"<LinearParams>", 'm'}, {"<Params>", 'm'},
+      {"<BiasParams>", 'v'}, {"<OrthonormalConstraint>", 'f'}, {"<UseNaturalGradient>", 'b'}, {"<NumSamplesHistory>", 'f'},
+      {"<AlphaInOut>", '2'}, {"<RankInOut>", 'J'}, {"<RankIn>", 'i'}, {"<RankOut>", 'i'}, {"<UpdatePeriod>", 'i'}, {"<Alpha>", 'f'},
+      {"<Dim>", 'i'}, {"<BlockDim>", 'i'}, {"<Epsilon>", 'f'}, {"<TargetRms>", 'f'}, {"<TestMode>", 'b'}, {"<Count>", 'f'},
+      {"<StatsMean>", 'v'}, {"<StatsVar>", 'v'}, {"<ValueAvg>", 'v'}, {"<DerivAvg>", 'v'}, {"<OderivRms>", 'v'}, {"<OderivCount>", 'f'},
+      {"<NumDimsSelfRepaired>", 'f'}, {"<NumDimsProcessed>", 'f'}, {"<SelfRepairLowerThreshold>", 'f'},
+      {"<SelfRepairUpperThreshold>", 'f'}, {"<SelfRepairScale>", 'f'}, {"<TimePeriod>", 'i'}, {"<DropoutProportion>", 'f'},
+      {"<Continuous>", '-'}, {"<SpecAugmentMaxProportion>", 'f'}, {"<SpecAugmentMaxRegions>", 'i'}, {"<BackpropScale>", 'f'},
+      {"<InputDim>", 'i'}, {"<OutputDim>", 'i'}, {"<Output>", 'v'}, {"<IsUpdatable>", 'b'}, {"<Scale>", 'f'}, {"<TempProportion>", 'f'}};
+  const std::string closing = "</" + type + ">";
+  p->type = type;
+  // BatchNorm and GeneralDropout write "<TestMode>" differently: a bool value in the former, a bare flag in the latter
+  const bool flag_testmode = type == "GeneralDropoutComponent";
+  for (;;) {
+    std::string t;
+    if (!in.token(&t)) return false;
+    if (t == closing) return true;
+    auto it = kinds.find(t);
+    if (it == kinds.end()) return in.fail("component " + type + ": unknown token " + t);
+    char kind = it->second;
+    if (t == "<TestMode>" && flag_testmode) kind = '-';
+    double f, f2;
+    int i, i2;
+    bool b;
+    std::vector<float> v;
+    switch (kind) {
+      case '-':
+        break;
+      case 'i':
+        if (!in.i32(&i)) return false;
+        break;
+      case 'J':
+        if (!in.i32(&i) || !in.i32(&i2)) return false;
+        break;
+      case 'f':
+        if (!in.real(&f)) return false;
+        if (t == "<Count>") p->count = f;
+        break;
+      case '2':
+        if (!in.real(&f) || !in.real(&f2)) return false;
+        break;
+      case 'b':
+        if (!in.boolean(&b)) return false;
+        break;
+      case 'I':
+        if (!in.intvec(&p->offsets)) return false;
+        break;
+      case 'm':
+        if (!in.mat(&p->W, &p->rows, &p->cols)) return false;
+        break;
+      case 'v':
+        if (!in.vec(&v)) return false;
+        if (t == "<BiasParams>") p->b = v;
+        else if (t == "<Output>") p->out_vec = v;
+        else if (t == "<StatsMean>") { p->mean = v; p->have_stats = true; }
+        else if (t == "<StatsVar>") p->var = v;
+        else if (t == "<ValueAvg>") { p->value_avg = v; p->have_stats = true; }
+        else if (t == "<DerivAvg>") p->deriv_avg = v;
+        break;
+    }
+  }
+}
+
+}  // namespace
+}  // namespace tdnnf
+
+using namespace tdnnf;
+
+extern "C" {
+
+int tdnnf_net_write_model(const tdnnf_net *n, const char *path, int binary, float learning_rate, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && n->params && path, "net_write_model: bad arguments (call net_set_buffers first)");
+  HostNet h;
+  stat_layout(n, &h);
+  h.params.resize((size_t)n->num_params);
+  h.stats.resize((size_t)tdnnf_net_stats_size(n));
+  TDNNF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  TDNNF_HIP(hipMemcpy(h.params.data(), n->params, sizeof(float) * h.params.size(), hipMemcpyDeviceToHost));
+  int rc = tdnnf_net_get_stats(n, h.stats.data(), stream);
+  if (rc) return rc;
+  std::ofstream os(path, std::ios::out | std::ios::binary);
+  TDNNF_REQUIRE(os.good(), "net_write_model: cannot open %s", path);
+  if (binary) os.write("\0B", 2);  // Kaldi binary-mode header
+  Out o{os, binary != 0};
+  Ctx x{n, &h, &o, learning_rate};
+  o.token("<Nnet3>");
+  os << "\n";
+  for (const std::string &line : config_lines(n)) os << line << "\n";
+  os << "\n";
+  o.token("<NumComponents>");
+  o.i32(write_components(x, true));
+  if (!binary) os << "\n";
+  write_components(x, false);
+  o.token("</Nnet3>");
+  os.flush();
+  TDNNF_REQUIRE(os.good(), "net_write_model: write to %s failed", path);
+  return TDNNF_OK;
+}
+
+int tdnnf_net_read_model(tdnnf_net *n, const char *path, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && n->params && path, "net_read_model: bad arguments (call net_set_buffers first)");
+  std::ifstream is(path, std::ios::in | std::ios::binary);
+  TDNNF_REQUIRE(is.good(), "net_read_model: cannot open %s", path);
+  bool binary = false;
+  if (is.peek() == '\0') {
+    is.get();
+    TDNNF_REQUIRE(is.get() == 'B', "net_read_model: %s: bad binary header", path);
+    binary = true;
+  }
+  In in{is, binary, ""};
+  HostNet h;
+  stat_layout(n, &h);
+  h.params.resize((size_t)n->num_params);
+  h.stats.resize((size_t)tdnnf_net_stats_size(n));
+  TDNNF_HIP(hipStreamSynchronize((hipStream_t)stream));
+  TDNNF_HIP(hipMemcpy(h.params.data(), n->params, sizeof(float) * h.params.size(), hipMemcpyDeviceToHost));
+  int rc = tdnnf_net_get_stats(n, h.stats.data(), stream);
+  if (rc) return rc;
+  // name -> component of the trainer
+  std::map<std::string, int> by_name;
+  for (size_t i = 0; i < n->comps.size(); i++) by_name[n->comps[i].name] = (int)i;
+  std::map<std::string, int> seen;
+  TDNNF_REQUIRE(in.expect("<Nnet3>"), "net_read_model: %s: %s", path, in.err.c_str());
+  std::string line;
+  std::getline(is, line);  // rest of the "<Nnet3>" line
+  int num_config_lines = 0;
+  while (std::getline(is, line)) {  // the config section ends with an empty line
+    if (line.empty() || line == "\r") break;
+    num_config_lines++;
+  }
+  int num = 0;
+  TDNNF_REQUIRE(in.expect("<NumComponents>") && in.i32(&num) && num > 0, "net_read_model: %s: %s", path, in.err.c_str());
+  for (int k = 0; k < num; k++) {
+    std::string name, type;
+    TDNNF_REQUIRE(in.expect("<ComponentName>") && in.token(&name) && in.token(&type), "net_read_model: %s: %s", path, in.err.c_str());
+    TDNNF_REQUIRE(type.size() > 2 && type[0] == '<' && type.back() == '>', "net_read_model: %s: component %s: bad type token %s", path,
+                  name.c_str(), type.c_str());
+    type = type.substr(1, type.size() - 2);
+    Parsed p;
+    TDNNF_REQUIRE(read_block(in, type, &p), "net_read_model: %s: component %s: %s", path, name.c_str(), in.err.c_str());
+    seen[name]++;
+    // ---- parameters
+    std::string pname = name;
+    auto it = by_name.find(pname);
+    if (it != by_name.end()) {
+      const CompDesc &cd = n->comps[it->second];
+      float *dst = h.params.data() + cd.begin;
+      if (!p.out_vec.empty()) {  // OnehotFunction / ConstantFunction output_
+        TDNNF_REQUIRE((int)p.out_vec.size() == cd.rows && cd.cols == 1, "net_read_model: %s: <Output> of %s has %d entries, expected %d", path,
+                      name.c_str(), (int)p.out_vec.size(), cd.rows);
+        memcpy(dst, p.out_vec.data(), sizeof(float) * cd.rows);
+      } else {
+        TDNNF_REQUIRE(p.rows == cd.rows && p.cols == cd.cols, "net_read_model: %s: %s is %d x %d in the file, %d x %d in the net", path,
+                      name.c_str(), p.rows, p.cols, cd.rows, cd.cols);
+        memcpy(dst, p.W.data(), sizeof(float) * (size_t)cd.rows * cd.cols);
+        const int nb = cd.num_alpha + (cd.has_bias ? cd.rows : 0);
+        TDNNF_REQUIRE((int)p.b.size() == nb || (nb == 0 && p.b.empty()), "net_read_model: %s: bias vector of %s has %d entries, expected %d", path,
+                      name.c_str(), (int)p.b.size(), nb);
+        if (nb) memcpy(dst + (size_t)cd.rows * cd.cols, p.b.data(), sizeof(float) * nb);
+      }
+    }
+    // ---- statistics
+    auto st = h.stat_off.find(name);
+    if (st != h.stat_off.end() && p.have_stats) {
+      const int D = h.stat_dim[name];
+      double *dstat = h.stats.data() + st->second;
+      if (!p.mean.empty()) {  // BatchNorm[Test]Component: Read() rebuilds the sums (nnet-normalize-component.cc:591-614)
+        TDNNF_REQUIRE((int)p.mean.size() == D && (int)p.var.size() == D, "net_read_model: %s: %s statistics have the wrong dimension", path,
+                      name.c_str());
+        dstat[0] = p.count;
+        for (int d = 0; d < D; d++) {
+          dstat[1 + d] = (double)p.mean[d] * p.count;
+          dstat[1 + D + d] = ((double)p.var[d] + (double)p.mean[d] * p.mean[d]) * p.count;
+        }
+      } else if (!p.value_avg.empty()) {  // NonlinearComponent::Read: value_sum_ = avg * count (itf.cc:566-596)
+        TDNNF_REQUIRE((int)p.value_avg.size() == D && (int)p.deriv_avg.size() == D, "net_read_model: %s: %s statistics have the wrong dimension",
+                      path, name.c_str());
+        dstat[0] = p.count;
+        for (int d = 0; d < D; d++) {
+          dstat[1 + d] = (double)p.value_avg[d] * p.count;
+          dstat[1 + D + d] = (double)p.deriv_avg[d] * p.count;
+        }
+      }
+    }
+  }
+  TDNNF_REQUIRE(in.expect("</Nnet3>"), "net_read_model: %s: %s", path, in.err.c_str());
+  for (size_t i = 0; i < n->comps.size(); i++)
+    TDNNF_REQUIRE(seen.count(n->comps[i].name), "net_read_model: %s has no component named %s (%d config lines, %d components read)", path,
+                  n->comps[i].name.c_str(), num_config_lines, num);
+  TDNNF_HIP(hipMemcpy(n->params, h.params.data(), sizeof(float) * h.params.size(), hipMemcpyHostToDevice));
+  return tdnnf_net_set_stats(n, h.stats.data(), stream);
+}
+
+}  // extern "C"

@@ -21,55 +21,11 @@
 #include "common.h"
 #include "fused.h"
 #include "gemm_f32.h"
+#include "net.h"
 #include "ng.h"
 
 namespace tdnnf {
 namespace {
-
-struct Grid {
-  int t0, step, n;
-  int last() const { return t0 + step * (n - 1); }
-};
-
-struct CompDesc {
-  std::string name;
-  long long begin;
-  int rows, cols, has_bias;
-  float lr_factor, l2, max_change, orthonormal;
-  int num_alpha;  // DARTS: K architecture logits between the weights and the bias
-  bool plain = false;  // updated without natural gradient (OnehotFunction / ConstantFunction output_ vectors)
-  long long size() const { return (long long)rows * cols + num_alpha + (has_bias ? rows : 0); }
-};
-
-struct Tdnn {  // one TdnnComponent instance inside the net
-  int comp;    // index into comps
-  int Di, Do, K;
-  int offsets[TDNNF_MAX_OFFSETS];
-  Grid in, out;
-  // DARTS (TdnnDARTSV3Component): share index, first random draw, coefficient memo [coef(K) | eff(K)] on device
-  bool darts;
-  int share, draw0;
-  float *memo;
-  int *active;  // device: [count, tap ids...] of the non-zero taps (uniform-sample mode)
-  tdnnf_tdnn_indexes ix;
-  int rows_in, rows_out;
-};
-
-struct TdnnfLayer {
-  int stride, bn;
-  Tdnn lin, aff;
-  Grid gin, gout, glin;
-  bool perm;  // affine input needs the rho row order
-  int bypass_row0, bypass_rowstep;  // rows of the layer input that line up with the output grid
-  // activations (arena)
-  float *lin_out, *lin_perm, *relu_out, *noop_out;
-  float *bn_memo;
-  double *bn_stats, *relu_stats;
-  // bottleneck-dimension supernet: component of the C-vector (X.softmax / X.alpha), first random draw, choice
-  // probabilities p (C) and the column mask (bn), masked linear output
-  int c_arch, arch_draw0;
-  float *arch_p, *arch_mask, *lin_masked;
-};
 
 // per-component table for the update kernels
 struct UpdTable {
@@ -260,49 +216,6 @@ __global__ void reorder_rows_kernel(MatView in, int B, int rho, int to_rho, MatV
 
 using namespace tdnnf;
 
-struct tdnnf_net {
-  tdnnf_net_config cfg;
-  std::vector<CompDesc> comps;
-  long long num_params;
-  float *params, *grads;
-  int B, T, Tout;
-  // graph
-  Grid g_lda, g_feat;
-  Tdnn tdnn1;  // affine 220 -> hidden on g_lda
-  std::vector<TdnnfLayer> layers;
-  int c_lda, c_prefinal_l;
-  struct Head {
-    int c_affine, c_linear, c_output;
-    float *aff_relu, *bn1_out, *lin_out, *bn2_out, *y;
-    float *bn1_memo, *bn2_memo;
-    double *bn1_stats, *bn2_stats, *relu_stats;
-  } head[2];  // 0 chain, 1 xent
-  float *xent_logsoftmax;
-  // arena
-  char *arena;
-  size_t arena_bytes;
-  float *lda_in, *lda_out, *t1_relu, *t1_bn;
-  float *t1_bn_memo;
-  double *t1_bn_stats, *t1_relu_stats;
-  float *prefinal_l_out;
-  float *dA, *dB, *dC, *d_small, *d_small2;  // derivative scratch
-  float *d_y, *d_xent;
-  float *tapgrad;      // DARTS: unscaled per-tap weight gradients (Do x K*Di) of the component being processed
-  double *tapdots;     // DARTS: s_i = <dW_i, W_i>
-  const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
-  std::vector<tdnnf_ng *> ng_in, ng_out;  // per component (natural gradient)
-  float *orthoT;       // transpose of a constrained matrix with more rows than columns (null when there is none)
-  float *ngH, *ngT, *ngTmp, *ngBias;  // natural gradient: H = X W^T scratch, raw gradient [W | b], projection temporaries, raw bias gradient
-  float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
-  hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
-  hipEvent_t ev_fork, ev_den;
-  int num_draws;
-  void *ws;
-  size_t ws_bytes;
-  void *chain_ws;
-  size_t chain_ws_bytes;
-  std::vector<std::pair<std::string, tdnnf_mat>> named;
-};
 
 namespace {
 

@@ -170,6 +170,13 @@ class ChainNet:
         assert st.size == int(self.lib.tdnnf_net_stats_size(self.h))
         hipabi.check(self.lib.tdnnf_net_set_stats(self.h, st.ctypes.data_as(C.POINTER(C.c_double)), hipabi.stream()))
 
+    def write_model(self, path, binary=True, learning_rate=0.0):
+        """nnet3 raw model file (text or binary) of this net: parameters + BatchNorm / ReLU statistics."""
+        hipabi.check(self.lib.tdnnf_net_write_model(self.h, str(path).encode(), int(bool(binary)), float(learning_rate), hipabi.stream()))
+
+    def read_model(self, path):
+        hipabi.check(self.lib.tdnnf_net_read_model(self.h, str(path).encode(), hipabi.stream()))
+
     def set_params(self, flat):
         import torch
         self.params.copy_(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)))
