@@ -140,10 +140,17 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # rehearsal of the multi-rank path on a one-GPU box (never used by the driver): every rank on device 0, gloo collective
+    rehearse = os.environ.get("TDNNF_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
     extra = {}
@@ -174,9 +181,10 @@ def main():
         net.update(lr, l2_regularize_scale=float(cfg.num_sequences), step=i)
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         step(i)
