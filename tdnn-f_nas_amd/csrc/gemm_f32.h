@@ -64,6 +64,15 @@ struct ProfFlopsScale {
   ~ProfFlopsScale();
 };
 
+// rows_gemm() keeps one process-wide scratch buffer for its split-K partial tiles, which is only safe for launches that
+// are ordered on one stream.  Launches made on another stream while one of these is alive use `buf` instead.
+struct SplitKScratchOverride {
+  float *prev_buf;
+  size_t prev_bytes;
+  SplitKScratchOverride(float *buf, size_t bytes);
+  ~SplitKScratchOverride();
+};
+
 inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128; }
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).

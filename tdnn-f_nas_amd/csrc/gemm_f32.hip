@@ -42,6 +42,18 @@ static int g_prof_override = -1;
 static double g_prof_flops_scale = 1.0;
 ProfFlopsScale::ProfFlopsScale(double f) : prev(g_prof_flops_scale) { g_prof_flops_scale = f; }
 ProfFlopsScale::~ProfFlopsScale() { g_prof_flops_scale = prev; }
+namespace {
+extern float *g_scratch_override;
+extern size_t g_scratch_override_bytes;
+}  // namespace
+SplitKScratchOverride::SplitKScratchOverride(float *buf, size_t bytes) : prev_buf(g_scratch_override), prev_bytes(g_scratch_override_bytes) {
+  g_scratch_override = buf;
+  g_scratch_override_bytes = bytes;
+}
+SplitKScratchOverride::~SplitKScratchOverride() {
+  g_scratch_override = prev_buf;
+  g_scratch_override_bytes = prev_bytes;
+}
 ProfClassOverride::ProfClassOverride(int cls) : prev(g_prof_override) { g_prof_override = cls; }
 ProfClassOverride::~ProfClassOverride() { g_prof_override = prev; }
 constexpr size_t kProfMaxLaunches = 1 << 15;
@@ -487,15 +499,22 @@ int rows_slots(bool b_kc) {  // resident blocks on the chip for this tile varian
 }
 
 // scratch for split-K partial tiles: allocated once, on first use (64 MiB covers slots x BM x BN floats)
-constexpr size_t kScratchBytes = 64u << 20;
-float *splitk_scratch() {
+constexpr size_t kScratchDefaultBytes = 64u << 20;
+float *g_scratch_override = nullptr;
+size_t g_scratch_override_bytes = 0;
+float *splitk_scratch(size_t *bytes) {
+  if (g_scratch_override) {
+    *bytes = g_scratch_override_bytes;
+    return g_scratch_override;
+  }
   static float *buf = nullptr;
   static bool tried = false;
   if (!tried) {
     tried = true;
-    if (hipMalloc((void **)&buf, kScratchBytes) != hipSuccess) buf = nullptr;
+    if (hipMalloc((void **)&buf, kScratchDefaultBytes) != hipSuccess) buf = nullptr;
     (void)hipGetLastError();
   }
+  *bytes = kScratchDefaultBytes;
   return buf;
 }
 
@@ -520,15 +539,16 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   // half full, finish the last rows with a split-K launch that spreads them over every CU instead.
   const int main_mt = (q * slots) / ntn;  // full tile rows handled by the plain launch
   float *scratch = nullptr;
+  size_t scratch_bytes = 0;
   // A handful of tiles with a long reduction (the R x D products of the natural-gradient state, P = M M^T of the
   // orthonormal constraint): one block per tile would crawl through K at load latency on a few CUs, so split K
   // over the idle ones.
-  if (tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch())) {
+  if (tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
     const long long kt = (ktot + BK - 1) / BK;
     int S = slots / tiles;
     if (S > kt / 4) S = (int)(kt / 4);
     const size_t need = sizeof(float) * (size_t)S * a.M * ((a.N + 3) & ~3);
-    if (S >= 2 && need <= kScratchBytes) {
+    if (S >= 2 && need <= scratch_bytes) {
       RowsGemmArgs at = a;
       at.kchunk = (int)(((kt + S - 1) / S) * BK);
       at.ksplit = (int)((ktot + at.kchunk - 1) / at.kchunk);
@@ -540,7 +560,7 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
       return hipGetLastError();
     }
   }
-  if (q >= 1 && r > 0 && 2 * r <= slots && main_mt > 0 && main_mt < ntm && k4 && ktot >= 8 * BK && (scratch = splitk_scratch())) {
+  if (q >= 1 && r > 0 && 2 * r <= slots && main_mt > 0 && main_mt < ntm && k4 && ktot >= 8 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
     const int m_main = main_mt * BM;
     RowsGemmArgs am = a;
     am.M = m_main;
@@ -564,7 +584,7 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
     int S = slots / tail_tiles;
     if (S > kt / 2) S = (int)(kt / 2);
     const size_t need = sizeof(float) * (size_t)S * at.M * ((a.N + 3) & ~3);
-    if (S >= 2 && need <= kScratchBytes) {
+    if (S >= 2 && need <= scratch_bytes) {
       at.kchunk = (int)(((kt + S - 1) / S) * BK);
       at.ksplit = (int)((ktot + at.kchunk - 1) / at.kchunk);
       at.partial = scratch;

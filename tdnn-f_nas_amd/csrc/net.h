@@ -90,7 +90,23 @@ struct tdnnf_net {
   const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
   std::vector<tdnnf_ng *> ng_in, ng_out;  // per component (natural gradient)
   float *orthoT;       // transpose of a constrained matrix with more rows than columns (null when there is none)
-  float *ngH, *ngT, *ngTmp, *ngBias;  // natural gradient: H = X W^T scratch, raw gradient [W | b], projection temporaries, raw bias gradient
+  float *ngBias;       // natural gradient: raw bias gradient of the component being processed
+  // Natural gradient, per component: the N-sized passes (raw gradient, H = X W^T, J) run on the caller's stream, the
+  // latency-bound rest (L, traces, the rank-R projections of the raw gradient, commit; K and the host hand-off on a
+  // refresh) on stream s3, fed through a ring of buffer sets so that it trails the backward pass instead of stalling it.
+  struct NgSet {
+    float *H_in, *H_out, *T, *Tmp;
+    double *part_in, *part_out;
+    void *ws;
+    hipEvent_t ready, done;
+    bool used;
+  } ngset[4];
+  size_t ngset_ws_bytes;
+  unsigned ng_next;
+  hipStream_t s3;
+  hipEvent_t ev_s3;
+  float *s3_scratch;   // split-K scratch of the GEMMs launched on s3
+  size_t s3_scratch_bytes;
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den;

@@ -364,7 +364,10 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
-  n->ngH = n->ngT = n->ngTmp = n->ngBias = nullptr;
+  n->ngBias = nullptr;
+  n->s3_scratch = nullptr;
+  n->s3_scratch_bytes = 0;
+  for (auto &S : n->ngset) S.H_in = S.H_out = S.T = S.Tmp = nullptr;
   size_t tall = 0, tall_ws = 0;
   for (auto &cd : n->comps)
     if (cd.orthonormal != 0.f && cd.rows > cd.cols) {
@@ -396,9 +399,19 @@ void layout_arena(tdnnf_net *n, Arena &A) {
       comp_ng(n->head[h].c_linear, 1, No);
       comp_ng(n->head[h].c_output, 1, No);
     }
-    n->ngH = A.take<float>((size_t)std::max(std::max(max_rows, N0), No) * 80 + 64);
-    n->ngT = A.take<float>(mt + 16);
-    n->ngTmp = A.take<float>(mtmp + 64);
+    const size_t maxN = (size_t)std::max(std::max(max_rows, N0), No);
+    n->ngset_ws_bytes = wgrad_workspace_bytes(80, 80, 1, (int)maxN) + 256;
+    for (auto &S : n->ngset) {
+      S.H_in = A.take<float>(maxN * 80 + 64);
+      S.H_out = A.take<float>(maxN * 80 + 64);
+      S.T = A.take<float>(mt + 16);
+      S.Tmp = A.take<float>(mtmp + 64);
+      S.part_in = A.take<double>(maxN / 128 + 8);
+      S.part_out = A.take<double>(maxN / 128 + 8);
+      S.ws = A.take<char>(n->ngset_ws_bytes);
+    }
+    n->s3_scratch_bytes = 16u << 20;
+    n->s3_scratch = A.take<float>(n->s3_scratch_bytes / sizeof(float));
     n->ngBias = A.take<float>(mb + 16);
   }
   // shared workspace: wgrad slabs, column reductions, orthonormal
@@ -682,6 +695,13 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
   n->chain_ws_bytes = 0;
   n->s2 = nullptr;
   n->ev_fork = n->ev_den = nullptr;
+  n->s3 = nullptr;
+  n->ev_s3 = nullptr;
+  n->ng_next = 0;
+  for (auto &S : n->ngset) {
+    S.ready = S.done = nullptr;
+    S.used = false;
+  }
   if (hipMalloc((void **)&n->arena, n->arena_bytes) != hipSuccess) {
     set_error("net_create: cannot allocate %zu bytes of activations", n->arena_bytes);
     delete n;
@@ -714,6 +734,8 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
 
 void tdnnf_net_destroy(tdnnf_net *n) {
   if (!n) return;
+  if (n->s3) hipStreamSynchronize(n->s3);  // its kernels use the preconditioners' buffers
+  if (n->s2) hipStreamSynchronize(n->s2);
   for (auto *g : n->ng_in) tdnnf_ng_destroy(g);
   for (auto *g : n->ng_out) tdnnf_ng_destroy(g);
   hipFree(n->arena);
@@ -721,6 +743,12 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->s2) hipStreamDestroy(n->s2);
   if (n->ev_fork) hipEventDestroy(n->ev_fork);
   if (n->ev_den) hipEventDestroy(n->ev_den);
+  for (auto &S : n->ngset) {
+    if (S.ready) hipEventDestroy(S.ready);
+    if (S.done) hipEventDestroy(S.done);
+  }
+  if (n->ev_s3) hipEventDestroy(n->ev_s3);
+  if (n->s3) hipStreamDestroy(n->s3);
   delete n;
 }
 
@@ -871,6 +899,12 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_den, hipEventDisableTiming));
+    TDNNF_HIP(hipStreamCreateWithFlags(&n->s3, hipStreamNonBlocking));
+    TDNNF_HIP(hipEventCreateWithFlags(&n->ev_s3, hipEventDisableTiming));
+    for (auto &S : n->ngset) {
+      TDNNF_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
+      TDNNF_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
+    }
   }
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
   TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout), "net_forward_backward: denominator graph changed size");
@@ -1005,7 +1039,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       return tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, Wg(n, comp), ldw, bias_done ? nullptr : bias_acc, n->ws, n->ws_bytes,
                                      active, max_active, s);
     const int N = dyv->rows, ones = bias_acc ? 1 : 0, Dx = ldw + ones, ldT = (Dx + 3) & ~3;
-    float *T = n->ngT;
+    auto &S = n->ngset[n->ng_next++ % 4];
+    if (S.used) TDNNF_HIP(hipStreamWaitEvent(s, S.done, 0));  // the side stream still owned this set four components ago
+    float *T = S.T;
     TDNNF_HIP(hipMemsetAsync(T, 0, sizeof(float) * (size_t)Do * ldT, s));
     if (from_tapgrad)
       hipLaunchKernelGGL(scaled_taps_to_kernel, dim3(grid_for((long long)Do * ldw, 256)), dim3(256), 0, s, n->tapgrad, eff, Do, ldw, Di, T, ldT);
@@ -1018,17 +1054,28 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       }
       hipLaunchKernelGGL(set_column_kernel, dim3((Do + 255) / 256), dim3(256), 0, s, n->ngBias, Do, T, ldT, ldw);
     }
+    // ---- the passes over the N-sized operands, on this stream
     NgInput xin;
     memset(&xin, 0, sizeof(xin));
     xin.x = view(x); xin.ix = ix; xin.Di = Di; xin.ones = ones; xin.N = N; xin.eff = eff; xin.active = active; xin.max_active = max_active;
-    CK(ng_stats_step(n->ng_in[comp], xin, n->ngH, n->ws, n->ws_bytes, s));
+    CK(ng_stats_main(n->ng_in[comp], xin, S.H_in, S.part_in, n->ws, n->ws_bytes, s));
     NgInput yin;
     memset(&yin, 0, sizeof(yin));
     yin.x = view(dyv); yin.ix.row_stride = 1; yin.ix.num_offsets = 1; yin.Di = Do; yin.N = N;
-    CK(ng_stats_step(n->ng_out[comp], yin, n->ngH, n->ws, n->ws_bytes, s));
-    CK(ng_project(n->ng_in[comp], n->ng_out[comp], T, Do, Dx, ldT, n->ngTmp, s));
-    hipLaunchKernelGGL(ng_commit_kernel, dim3(grid_for((long long)Do * Dx, 256)), dim3(256), 0, s, T, ldT, Do, ldw, ng_scale_dev(n->ng_in[comp]),
+    CK(ng_stats_main(n->ng_out[comp], yin, S.H_out, S.part_out, n->ws, n->ws_bytes, s));
+    // ---- the R x R work, the projections of the raw gradient and the commit, on the side stream
+    TDNNF_HIP(hipEventRecord(S.ready, s));
+    TDNNF_HIP(hipStreamWaitEvent(n->s3, S.ready, 0));
+    {
+      SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
+      CK(ng_stats_side(n->ng_in[comp], S.H_in, S.part_in, S.ws, n->ngset_ws_bytes, n->s3));
+      CK(ng_stats_side(n->ng_out[comp], S.H_out, S.part_out, S.ws, n->ngset_ws_bytes, n->s3));
+      CK(ng_project(n->ng_in[comp], n->ng_out[comp], T, Do, Dx, ldT, S.Tmp, n->s3));
+    }
+    hipLaunchKernelGGL(ng_commit_kernel, dim3(grid_for((long long)Do * Dx, 256)), dim3(256), 0, n->s3, T, ldT, Do, ldw, ng_scale_dev(n->ng_in[comp]),
                        ng_scale_dev(n->ng_out[comp]), Wg(n, comp), bias_acc);
+    TDNNF_HIP(hipEventRecord(S.done, n->s3));
+    S.used = true;
     return TDNNF_OK;
   };
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
@@ -1145,6 +1192,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp)));
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
+  }
+  if (use_ng) {  // join the side stream: every component's preconditioned gradient is in gtmp
+    TDNNF_HIP(hipEventRecord(n->ev_s3, n->s3));
+    TDNNF_HIP(hipStreamWaitEvent(s, n->ev_s3, 0));
   }
   hipLaunchKernelGGL(commit_grads_kernel, dim3(grid_for(n->num_params, 256)), dim3(256), 0, s, n->grads, n->gtmp, n->num_params, results);
   TDNNF_LAUNCH_CHECK();

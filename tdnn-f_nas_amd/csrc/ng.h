@@ -30,6 +30,13 @@ size_t ng_stats_workspace_bytes(int rank, int D, int K, int N);
 // tr(X^ X^^T) and the scale on the device; on refresh steps also J, K, L and the (asynchronous) host update that
 // produces W_{t+1}.  Increments t.
 int ng_stats_step(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_bytes, hipStream_t s);
+// The same in two halves, so that the latency-bound R x R half can run on a side stream: ng_stats_main (the caller's
+// main stream) installs a pending refresh, forms H and the per-block ||X||^2 partials (`part`:
+// rows_gemm_sumsq_blocks(N) doubles) and, on refresh steps, J; ng_stats_side (any stream ordered after it) forms L, the
+// traces and the scale, on refresh steps K and the hand-off to the host, and increments t.  ws of ng_stats_main must hold
+// ng_stats_workspace_bytes(); ws of ng_stats_side wgrad_workspace_bytes(rank_padded, rank_padded, 1, N).
+int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *ws, size_t ws_bytes, hipStream_t s);
+int ng_stats_side(tdnnf_ng *ng, const float *H, const double *part, void *ws, size_t ws_bytes, hipStream_t s);
 int ng_h_ld(const tdnnf_ng *ng);        // leading dimension (padded rank) of H, W W^T, ...
 int ng_dim(const tdnnf_ng *ng);         // D (0 before the first call)
 const float *ng_scale_dev(const tdnnf_ng *ng);  // device float: sqrt(tr(XX^T)/tr(X^X^^T)) of the last call

@@ -44,6 +44,8 @@ struct tdnnf_ng {
   size_t scratch_floats;
   // deferred refresh
   int pending, job_done, job_N;
+  bool cur_upd;  // the call in flight between ng_stats_main and ng_stats_side
+  int cur_N, cur_ones;
   std::vector<float> d_next;
   float rho_next;
   bool must_reorth;
@@ -386,16 +388,10 @@ size_t stats_ws_bytes(int Rp, int Di, int K, int N) {
   return part + std::max(wgrad_workspace_bytes(Rp, Rp, 1, N), wgrad_workspace_bytes(Rp, Di, K, N));
 }
 
-// H, traces, scale [+ J, K and the hand-off to the host on a refresh]; W_t is left untouched
-int stats_core(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_bytes, bool upd, hipStream_t s) {
+// First half of one PreconditionDirections call, everything N x D sized: H = X W_t^T (with ||X||^2 per block into
+// `part`) and, on a refresh, J = H^T X.  W_t is left untouched.
+int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg_ws, size_t wg_bytes, bool upd, hipStream_t s) {
   const int N = in.N, K = in.ix.num_offsets, Di = in.Di, Rp = ng->Rp, Dp = ng->Dp, D = ng->D;
-  TDNNF_REQUIRE(ws && ws_bytes >= stats_ws_bytes(Rp, Di, K, N), "ng: workspace too small");
-  const int nb = rows_gemm_sumsq_blocks(N);
-  double *part = (double *)ws;
-  const size_t part_bytes = ((size_t)nb * sizeof(double) + 63) & ~(size_t)63;
-  void *wg_ws = (char *)ws + part_bytes;
-  const size_t wg_bytes = ws_bytes - part_bytes;
-
   RowsGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = in.x.data; a.lda = (long long)in.x.stride * in.ix.row_stride; a.B = ng->W; a.ldb = Dp; a.C = H; a.ldc = Rp; a.M = N; a.N = Rp;
@@ -412,15 +408,11 @@ int stats_core(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_by
     a.seg[i].m_hi = N;
   }
   TDNNF_HIP(rows_gemm(a, true, s));  // H = X W^T (+ ||X||_F^2 per block)
-
-  WgradArgs w;
-  memset(&w, 0, sizeof(w));
-  w.dY = H; w.lddy = Rp; w.X = H; w.ldx = Rp; w.Do = Rp; w.Di = Rp; w.K = 1; w.N = N; w.row_stride = 1; w.scale = 1.f;
-  w.G = ng->Ld; w.ldg = Rp; w.accumulate = 0;
-  TDNNF_HIP(wgrad(w, wg_ws, wg_bytes, s));  // L = H^T H
-  hipLaunchKernelGGL(ng_scalars_kernel, dim3(1), dim3(256), 0, s, part, nb, in.ones ? (double)N : 0.0, ng->Ld, ng->WWT, Rp, ng->scal, ng->scale_f);
+  ng->cur_upd = upd;
+  ng->cur_N = N;
+  ng->cur_ones = in.ones;
   if (!upd) return TDNNF_OK;
-
+  TDNNF_REQUIRE(wg_ws && wg_bytes >= wgrad_workspace_bytes(Rp, Di, K, N), "ng: workspace too small");
   TDNNF_HIP(hipMemsetAsync(ng->J, 0, sizeof(float) * (size_t)Rp * Dp, s));
   if (in.ones) TDNNF_HIP(hipMemsetAsync(ng->tmpR, 0, sizeof(float) * Rp, s));
   WgradArgs j;
@@ -431,6 +423,22 @@ int stats_core(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_by
   j.active = in.active; j.max_active = in.max_active;
   TDNNF_HIP(wgrad(j, wg_ws, wg_bytes, s));  // J = H^T X  (last column: column sums of H)
   if (in.ones) hipLaunchKernelGGL(scatter_col_kernel, dim3((Rp + 63) / 64), dim3(64), 0, s, ng->tmpR, Rp, ng->J, Dp, D - 1);
+  return TDNNF_OK;
+}
+
+// Second half, R x R sized and latency bound: L = H^T H, traces and scale; on a refresh K = J J^T and the hand-off to the
+// host worker.  May run on another stream than stats_main as long as it is ordered after it.
+int stats_side(tdnnf_ng *ng, const float *H, const double *part, void *wg_ws, size_t wg_bytes, hipStream_t s) {
+  const int N = ng->cur_N, Rp = ng->Rp, Dp = ng->Dp;
+  TDNNF_REQUIRE(wg_ws && wg_bytes >= wgrad_workspace_bytes(Rp, Rp, 1, N), "ng: workspace too small");
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  w.dY = H; w.lddy = Rp; w.X = H; w.ldx = Rp; w.Do = Rp; w.Di = Rp; w.K = 1; w.N = N; w.row_stride = 1; w.scale = 1.f;
+  w.G = ng->Ld; w.ldg = Rp; w.accumulate = 0;
+  TDNNF_HIP(wgrad(w, wg_ws, wg_bytes, s));  // L = H^T H
+  hipLaunchKernelGGL(ng_scalars_kernel, dim3(1), dim3(256), 0, s, part, rows_gemm_sumsq_blocks(N), ng->cur_ones ? (double)N : 0.0, ng->Ld, ng->WWT,
+                     Rp, ng->scal, ng->scale_f);
+  if (!ng->cur_upd) return TDNNF_OK;
   RowsGemmArgs k;
   memset(&k, 0, sizeof(k));
   k.A = ng->J; k.lda = Dp; k.B = ng->J; k.ldb = Dp; k.C = ng->Kd; k.ldc = Rp; k.M = Rp; k.N = Rp; k.init_mode = 2; k.nseg = 1;
@@ -452,6 +460,33 @@ int stats_core(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_by
   return TDNNF_OK;
 }
 
+// both halves on one stream; ws = [sumsq partials | wgrad workspace]
+int stats_core(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws_bytes, bool upd, hipStream_t s) {
+  TDNNF_REQUIRE(ws && ws_bytes >= stats_ws_bytes(ng->Rp, in.Di, in.ix.num_offsets, in.N), "ng: workspace too small");
+  double *part = (double *)ws;
+  const size_t part_bytes = ((size_t)rows_gemm_sumsq_blocks(in.N) * sizeof(double) + 63) & ~(size_t)63;
+  void *wg_ws = (char *)ws + part_bytes;
+  const size_t wg_bytes = ws_bytes - part_bytes;
+  int rc = stats_main(ng, in, H, part, wg_ws, wg_bytes, upd, s);
+  if (rc) return rc;
+  return stats_side(ng, H, part, wg_ws, wg_bytes, s);
+}
+
+// Init(): default state, then self-training on this minibatch (3 refreshes from the same data), all on stream s
+int init_from(tdnnf_ng *ng, const NgInput &in, int D, float *H, void *ws, size_t ws_bytes, hipStream_t s) {
+  int rc = init_default(ng, D, s);
+  if (rc) return rc;
+  if (ng->rank > 0) {
+    const int iters = in.N <= ng->rank ? 1 : 3;
+    for (int i = 0; i < iters; i++) {
+      if ((rc = stats_core(ng, in, H, ws, ws_bytes, true, s))) return rc;
+      if ((rc = finalize(ng, s))) return rc;
+    }
+  }
+  ng->t = 0;
+  return TDNNF_OK;
+}
+
 }  // namespace
 
 size_t ng_stats_workspace_bytes(int rank, int D, int K, int N) {
@@ -469,23 +504,40 @@ int ng_stats_step(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws
   const int K = in.ix.num_offsets, D = K * in.Di + (in.ones ? 1 : 0);
   TDNNF_REQUIRE(ng && H && in.N > 0 && K >= 1 && K <= kMaxSeg && in.Di > 0, "ng_stats_step: bad arguments");
   ProfClassOverride prof_as_ng(3);
-  if (ng->D == 0) {  // Init(): default state, then self-training on this minibatch (3 refreshes from the same data)
-    int rc = init_default(ng, D, s);
-    if (rc) return rc;
-    if (ng->rank > 0) {
-      const int iters = in.N <= ng->rank ? 1 : 3;
-      for (int i = 0; i < iters; i++) {
-        if ((rc = stats_core(ng, in, H, ws, ws_bytes, true, s))) return rc;
-        if ((rc = finalize(ng, s))) return rc;
-      }
-    }
-    ng->t = 0;
+  if (ng->D == 0) {
+    int rc0 = init_from(ng, in, D, H, ws, ws_bytes, s);
+    if (rc0) return rc0;
   }
   TDNNF_REQUIRE(ng->D == D, "ng: dimension changed from %d to %d", ng->D, D);
   if (ng->rank == 0) return TDNNF_OK;
   int rc = finalize(ng, s);  // a refresh started by the previous call on this object
   if (rc) return rc;
   rc = stats_core(ng, in, H, ws, ws_bytes, updating(ng), s);
+  ng->t += 1;
+  return rc;
+}
+
+int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *ws, size_t ws_bytes, hipStream_t s) {
+  const int K = in.ix.num_offsets, D = K * in.Di + (in.ones ? 1 : 0);
+  TDNNF_REQUIRE(ng && H && part && in.N > 0 && K >= 1 && K <= kMaxSeg && in.Di > 0, "ng_stats_main: bad arguments");
+  ProfClassOverride prof_as_ng(3);
+  if (ng->D == 0) {
+    int rc0 = init_from(ng, in, D, H, ws, ws_bytes, s);
+    if (rc0) return rc0;
+  }
+  TDNNF_REQUIRE(ng->D == D, "ng: dimension changed from %d to %d", ng->D, D);
+  ng->cur_N = 0;
+  if (ng->rank == 0) return TDNNF_OK;
+  int rc = finalize(ng, s);  // a refresh started by the previous call on this object
+  if (rc) return rc;
+  return stats_main(ng, in, H, part, ws, ws_bytes, updating(ng), s);
+}
+
+int ng_stats_side(tdnnf_ng *ng, const float *H, const double *part, void *ws, size_t ws_bytes, hipStream_t s) {
+  TDNNF_REQUIRE(ng && H && part, "ng_stats_side: bad arguments");
+  if (ng->rank == 0 || ng->cur_N == 0) return TDNNF_OK;
+  ProfClassOverride prof_as_ng(3);
+  int rc = stats_side(ng, H, part, ws, ws_bytes, s);
   ng->t += 1;
   return rc;
 }
