@@ -630,6 +630,7 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     if (a.N > 128) return hipErrorInvalidValue;
     ProfScope ps(0, flops, s);
     if (a.N <= 32) return launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    if (a.N <= 96) return launch_rows<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
     return launch_rows<2, 2, 2, 2, 32>(a, b_kc, vec, s);
   }
   // skinny outputs (the natural-gradient projections X W^T, rank <= 32): a 128x32 tile wastes no MFMA columns and
