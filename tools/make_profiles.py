@@ -25,7 +25,8 @@ def short(nm):
 def klass(nm):
     s = short(nm)
     # TAG 1 (last template argument) = launches of the natural-gradient statistics; the 128x32 tile is theirs alone
-    if (s.startswith("rows_gemm_kernel") or s.startswith("wgrad_kernel")) and (s.endswith(", 1>") or s.startswith("rows_gemm_kernel<4, 1, 1, 1")):
+    if (s.startswith("rows_gemm_kernel") or s.startswith("wgrad_kernel")) and (s.endswith(", 1>") or s.startswith("rows_gemm_kernel<4, 1, 1, 1")
+                                                                                or s.startswith("rows_gemm_kernel<4, 1, 1, 3")):
         return "ng_skinny_gemm_f32"
     if s.startswith("rows_gemm_kernel<2, 2, 2, 2"):
         return "rows_gemm_f32_128x128"
