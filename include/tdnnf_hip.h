@@ -365,6 +365,13 @@ int tdnnf_net_set_stats(tdnnf_net *, const double *stats_host, tdnnf_stream);
    both text and binary files are accepted.  Both calls synchronise the stream. */
 int tdnnf_net_write_model(const tdnnf_net *, const char *path, int binary, float learning_rate, tdnnf_stream);
 int tdnnf_net_read_model(tdnnf_net *, const char *path, tdnnf_stream);
+/* The trainer configuration for the graph a model file holds (no GPU needed): dimensions from the component blocks,
+   time strides / DARTS taps and flags from the Tdnn components, bypass scale and input dimensions from the config
+   lines, l2 / max-change / self-repair from the tokens, BatchNormTestComponent => cv_update, the bottleneck supernet's
+   blocks from its CopyN components.  What a model file does not record (chunk size, minibatch size, leaky-hmm,
+   max-param-change ...) is set to the recipe's values (run_tdnn_fbk_40_iv_sp_7q.sh:149-203).  Fails for graphs other
+   than the ones the trainer runs. */
+int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_sequences, tdnnf_net_config *out);
 /* debugging / parity: copy an internal activation by name ("tdnnf2.linear", "output", ...) into out */
 int tdnnf_net_get_activation(const tdnnf_net *, const char *name, tdnnf_mat *out, tdnnf_stream);
 int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, int *cols);

@@ -43,7 +43,6 @@ struct RowsGemmArgs {
   // scaled, spliced A operand, a by-product of staging it).  Needs N to fit one column tile (every A element is
   // then staged exactly once): rows_gemm() fails otherwise.  One double per 128-row block: rows_gemm_sumsq_blocks(M).
   double *sumsq;
-  int dbg;  // experiments only (TDNNF_GEMM_DEBUG): 1 = no global loads after the first tile, 2 = also no LDS refill / barrier
   int nseg;
   GemmSeg seg[kMaxSeg];
 };

@@ -322,14 +322,12 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       kc += BK;
       if (kc >= klen) next_seg();
       const bool more = seg < p.nseg;
-      if (more && p.dbg == 0) load_tile();  // in flight while the MFMAs run
+      if (more) load_tile();  // in flight while the MFMAs run
       compute(buf);
       if (!more) break;
-      if (p.dbg < 2) {
-        store_tile(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
-      }
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
     }
   }
 
@@ -610,11 +608,6 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
 hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   if (a_in.M <= 0 || a_in.N <= 0 || a_in.nseg <= 0) return hipSuccess;
   RowsGemmArgs a = a_in;
-  {
-    static int dbg = -1;
-    if (dbg < 0) dbg = getenv("TDNNF_GEMM_DEBUG") ? atoi(getenv("TDNNF_GEMM_DEBUG")) : 0;
-    a.dbg = dbg;
-  }
   a.c_vec = aligned16(a.C) && a.ldc % 4 == 0 && (a.init_mode != 1 || aligned16(a.bias)) && (!a.add || (aligned16(a.add) && a.ldadd % 4 == 0));
   // float4 path needs 16-byte aligned rows and segment starts; ragged tails fall back per float4
   bool vec = aligned16(a.A) && aligned16(a.B) && a.lda % 4 == 0 && a.ldb % 4 == 0;

@@ -806,6 +806,7 @@ struct Parsed {  // what one component block contributed
   double count = 0;
   std::vector<int> offsets;
   bool have_stats = false;
+  std::map<std::string, double> num;  // every scalar token of the block (bools as 0 / 1; pairs keep the first value)
 };
 
 // Reads the tokens of one component after its opening tag up to and including the closing tag.  `kinds` says how the
@@ -845,19 +846,24 @@ bool read_block(In &in, const std::string &type, Parsed *p) {
         break;
       case 'i':
         if (!in.i32(&i)) return false;
+        p->num[t] = i;
         break;
       case 'J':
         if (!in.i32(&i) || !in.i32(&i2)) return false;
+        p->num[t] = i;
         break;
       case 'f':
         if (!in.real(&f)) return false;
         if (t == "<Count>") p->count = f;
+        p->num[t] = f;
         break;
       case '2':
         if (!in.real(&f) || !in.real(&f2)) return false;
+        p->num[t] = f;
         break;
       case 'b':
         if (!in.boolean(&b)) return false;
+        p->num[t] = b ? 1.0 : 0.0;
         break;
       case 'I':
         if (!in.intvec(&p->offsets)) return false;
@@ -876,6 +882,62 @@ bool read_block(In &in, const std::string &type, Parsed *p) {
         break;
     }
   }
+}
+
+// Opens a model file, reads the config lines and every component block.
+struct ModelFile {
+  std::vector<std::string> config;
+  std::vector<std::pair<std::string, Parsed>> comps;
+  std::string err;
+};
+bool load_model_file(const char *path, ModelFile *mf) {
+  std::ifstream is(path, std::ios::in | std::ios::binary);
+  if (!is.good()) {
+    mf->err = std::string("cannot open ") + path;
+    return false;
+  }
+  bool binary = false;
+  if (is.peek() == '\0') {
+    is.get();
+    if (is.get() != 'B') {
+      mf->err = "bad binary header";
+      return false;
+    }
+    binary = true;
+  }
+  In in{is, binary, ""};
+  auto bad = [&]() {
+    mf->err = in.err;
+    return false;
+  };
+  if (!in.expect("<Nnet3>")) return bad();
+  std::string line;
+  std::getline(is, line);  // rest of the "<Nnet3>" line
+  while (std::getline(is, line)) {  // the config section ends with an empty line
+    if (line.empty() || line == "\r") break;
+    mf->config.push_back(line);
+  }
+  int num = 0;
+  if (!in.expect("<NumComponents>") || !in.i32(&num)) return bad();
+  if (num <= 0) {
+    mf->err = "bad <NumComponents>";
+    return false;
+  }
+  for (int k = 0; k < num; k++) {
+    std::string name, type;
+    if (!in.expect("<ComponentName>") || !in.token(&name) || !in.token(&type)) return bad();
+    if (type.size() <= 2 || type[0] != '<' || type.back() != '>') {
+      mf->err = "component " + name + ": bad type token " + type;
+      return false;
+    }
+    mf->comps.emplace_back(name, Parsed());
+    if (!read_block(in, type.substr(1, type.size() - 2), &mf->comps.back().second)) {
+      mf->err = "component " + name + ": " + in.err;
+      return false;
+    }
+  }
+  if (!in.expect("</Nnet3>")) return bad();
+  return true;
 }
 
 }  // namespace
@@ -916,15 +978,8 @@ int tdnnf_net_write_model(const tdnnf_net *n, const char *path, int binary, floa
 
 int tdnnf_net_read_model(tdnnf_net *n, const char *path, tdnnf_stream stream) {
   TDNNF_REQUIRE(n && n->params && path, "net_read_model: bad arguments (call net_set_buffers first)");
-  std::ifstream is(path, std::ios::in | std::ios::binary);
-  TDNNF_REQUIRE(is.good(), "net_read_model: cannot open %s", path);
-  bool binary = false;
-  if (is.peek() == '\0') {
-    is.get();
-    TDNNF_REQUIRE(is.get() == 'B', "net_read_model: %s: bad binary header", path);
-    binary = true;
-  }
-  In in{is, binary, ""};
+  ModelFile mf;
+  TDNNF_REQUIRE(load_model_file(path, &mf), "net_read_model: %s: %s", path, mf.err.c_str());
   HostNet h;
   stat_layout(n, &h);
   h.params.resize((size_t)n->num_params);
@@ -933,32 +988,15 @@ int tdnnf_net_read_model(tdnnf_net *n, const char *path, tdnnf_stream stream) {
   TDNNF_HIP(hipMemcpy(h.params.data(), n->params, sizeof(float) * h.params.size(), hipMemcpyDeviceToHost));
   int rc = tdnnf_net_get_stats(n, h.stats.data(), stream);
   if (rc) return rc;
-  // name -> component of the trainer
-  std::map<std::string, int> by_name;
+  std::map<std::string, int> by_name;  // name -> component of the trainer
   for (size_t i = 0; i < n->comps.size(); i++) by_name[n->comps[i].name] = (int)i;
   std::map<std::string, int> seen;
-  TDNNF_REQUIRE(in.expect("<Nnet3>"), "net_read_model: %s: %s", path, in.err.c_str());
-  std::string line;
-  std::getline(is, line);  // rest of the "<Nnet3>" line
-  int num_config_lines = 0;
-  while (std::getline(is, line)) {  // the config section ends with an empty line
-    if (line.empty() || line == "\r") break;
-    num_config_lines++;
-  }
-  int num = 0;
-  TDNNF_REQUIRE(in.expect("<NumComponents>") && in.i32(&num) && num > 0, "net_read_model: %s: %s", path, in.err.c_str());
-  for (int k = 0; k < num; k++) {
-    std::string name, type;
-    TDNNF_REQUIRE(in.expect("<ComponentName>") && in.token(&name) && in.token(&type), "net_read_model: %s: %s", path, in.err.c_str());
-    TDNNF_REQUIRE(type.size() > 2 && type[0] == '<' && type.back() == '>', "net_read_model: %s: component %s: bad type token %s", path,
-                  name.c_str(), type.c_str());
-    type = type.substr(1, type.size() - 2);
-    Parsed p;
-    TDNNF_REQUIRE(read_block(in, type, &p), "net_read_model: %s: component %s: %s", path, name.c_str(), in.err.c_str());
+  for (auto &np : mf.comps) {
+    const std::string &name = np.first;
+    const Parsed &p = np.second;
     seen[name]++;
     // ---- parameters
-    std::string pname = name;
-    auto it = by_name.find(pname);
+    auto it = by_name.find(name);
     if (it != by_name.end()) {
       const CompDesc &cd = n->comps[it->second];
       float *dst = h.params.data() + cd.begin;
@@ -1000,12 +1038,116 @@ int tdnnf_net_read_model(tdnnf_net *n, const char *path, tdnnf_stream stream) {
       }
     }
   }
-  TDNNF_REQUIRE(in.expect("</Nnet3>"), "net_read_model: %s: %s", path, in.err.c_str());
   for (size_t i = 0; i < n->comps.size(); i++)
     TDNNF_REQUIRE(seen.count(n->comps[i].name), "net_read_model: %s has no component named %s (%d config lines, %d components read)", path,
-                  n->comps[i].name.c_str(), num_config_lines, num);
+                  n->comps[i].name.c_str(), (int)mf.config.size(), (int)mf.comps.size());
   TDNNF_HIP(hipMemcpy(n->params, h.params.data(), sizeof(float) * h.params.size(), hipMemcpyHostToDevice));
   return tdnnf_net_set_stats(n, h.stats.data(), stream);
+}
+
+// The configuration of the trainer for the graph a model file holds (for the graphs of the
+// recipes): dimensions from the component blocks, time strides / DARTS taps from <TimeOffsets>, bypass scale and input
+// dimensions from the config lines, hyper-parameters a model file records (l2, max-change, self-repair) from the tokens.
+int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_sequences, tdnnf_net_config *cfg) {
+  TDNNF_REQUIRE(path && cfg && frames_per_chunk > 0 && num_sequences > 0, "net_config_from_model: bad arguments");
+  ModelFile mf;
+  TDNNF_REQUIRE(load_model_file(path, &mf), "net_config_from_model: %s: %s", path, mf.err.c_str());
+  std::map<std::string, const Parsed *> by;
+  for (auto &np : mf.comps) by[np.first] = &np.second;
+  auto need = [&](const std::string &nm) -> const Parsed * {
+    auto it = by.find(nm);
+    return it == by.end() ? nullptr : it->second;
+  };
+  auto num = [](const Parsed *p, const char *tok, double dflt) {
+    auto it = p->num.find(tok);
+    return it == p->num.end() ? dflt : it->second;
+  };
+  memset(cfg, 0, sizeof(*cfg));
+  // the recipe's training options, which no model file records (run_tdnn_fbk_40_iv_sp_7q.sh:149-203)
+  cfg->frames_per_chunk = frames_per_chunk;
+  cfg->num_sequences = num_sequences;
+  cfg->frame_subsampling = 3;
+  cfg->leaky_hmm = 0.1f;
+  cfg->chain_l2_regularize = 0.0f;
+  cfg->max_param_change = 2.0f;
+  cfg->batchnorm_stats_scale = 0.8f;
+  cfg->darts_temp_proportion = 1.0f;
+  cfg->bn_temp_proportion = 1.0f;
+  cfg->bypass_scale = 0.66f;
+  for (const std::string &l : mf.config) {
+    int d;
+    if (sscanf(l.c_str(), "input-node name=input dim=%d", &d) == 1) cfg->feat_dim = d;
+    if (sscanf(l.c_str(), "input-node name=ivector dim=%d", &d) == 1) cfg->ivector_dim = d;
+    const size_t p = l.find("input=Sum(Scale(");
+    if (l.find("component-node name=tdnnf2.noop ") == 0 && p != std::string::npos) cfg->bypass_scale = (float)atof(l.c_str() + p + 16);
+  }
+  const Parsed *t1 = need("tdnn1.affine"), *out = need("output.affine"), *pl = need("prefinal-l"), *oxent = need("output-xent.affine");
+  TDNNF_REQUIRE(t1 && out && pl && oxent && cfg->feat_dim > 0 && cfg->ivector_dim > 0,
+                "net_config_from_model: %s is not one of the supported TDNN-F graphs (tdnn1.affine / prefinal-l / output.affine / input nodes)", path);
+  TDNNF_REQUIRE(t1->cols == 3 * cfg->feat_dim + cfg->ivector_dim, "net_config_from_model: %s: tdnn1.affine input is %d wide, expected 3 x %d + %d", path,
+                t1->cols, cfg->feat_dim, cfg->ivector_dim);
+  cfg->hidden_dim = t1->rows;
+  cfg->num_pdfs = out->rows;
+  cfg->prefinal_small_dim = pl->rows;
+  cfg->l2_output = (float)num(out, "<L2Regularize>", 0.0);
+  cfg->max_change_output = (float)num(out, "<MaxChange>", 0.0);
+  const double xent_factor = num(oxent, "<LearningRateFactor>", 1.0);
+  // output-xent learning-rate-factor = 0.5 / xent_regularize (run_tdnn_fbk_40_iv_sp_7q.sh:151,184)
+  cfg->xent_regularize = xent_factor == 0.0 ? 0.1f : (float)(0.5 / xent_factor);
+  if (const Parsed *r = need("tdnn1.relu")) cfg->relu_self_repair_scale = (float)num(r, "<SelfRepairScale>", 0.0);
+  for (auto &np : mf.comps)
+    if (np.second.type == "BatchNormTestComponent") cfg->cv_update = 1;
+  int L = 0;
+  for (;; L++) {
+    const std::string p = layer_name(L);
+    const Parsed *lin = need(p + ".linear"), *aff = need(p + ".affine");
+    if (!lin || !aff) break;
+    TDNNF_REQUIRE(L < TDNNF_NET_MAX_LAYERS, "net_config_from_model: %s: too many tdnnf layers", path);
+    const int K = (int)lin->offsets.size();
+    TDNNF_REQUIRE(K >= 1 && (int)aff->offsets.size() == K && lin->cols == K * cfg->hidden_dim && aff->rows == cfg->hidden_dim && aff->cols == K * lin->rows,
+                  "net_config_from_model: %s: %s has inconsistent dimensions", path, p.c_str());
+    cfg->bottleneck_dim[L] = lin->rows;
+    if (lin->type == "TdnnDARTSV3Component") {
+      TDNNF_REQUIRE(cfg->darts_num_offsets == 0 || cfg->darts_num_offsets == K, "net_config_from_model: %s: layers with different numbers of taps", path);
+      cfg->darts_num_offsets = K;
+      cfg->darts_flags = (num(lin, "<use-gumbel>", 0) ? TDNNF_DARTS_USE_GUMBEL : 0) | (num(lin, "<free-select>", 0) ? TDNNF_DARTS_FREE_SELECT : 0) |
+                         (num(lin, "<uniform-sample>", 0) ? TDNNF_DARTS_UNIFORM_SAMPLE : 0) | (num(lin, "<use-entropy>", 0) ? TDNNF_DARTS_USE_ENTROPY : 0) |
+                         (num(lin, "<update-alpha>", 0) ? TDNNF_DARTS_UPDATE_ALPHA : 0);
+      cfg->darts_temp_proportion = (float)num(lin, "<Temp-Proportion>", 1.0);
+      cfg->time_stride[L] = 1;
+    } else {
+      TDNNF_REQUIRE(K <= 2, "net_config_from_model: %s: %s.linear has %d taps (plain tdnnf layers have 1 or 2)", path, p.c_str(), K);
+      cfg->time_stride[L] = K == 1 ? 0 : -lin->offsets[0];
+      TDNNF_REQUIRE(K == 1 || (lin->offsets[1] == 0 && aff->offsets[0] == 0 && aff->offsets[1] == -lin->offsets[0] && lin->offsets[0] < 0),
+                    "net_config_from_model: %s: %s time offsets are not {-s,0} / {0,s}", path, p.c_str());
+    }
+    if (L == 0) {
+      cfg->l2_hidden = (float)num(lin, "<L2Regularize>", 0.0);
+      cfg->max_change_hidden = (float)num(lin, "<MaxChange>", 0.0);
+    }
+    // bottleneck supernet: X.softmax / X.alpha + Xk.copyn blocks
+    const Parsed *sm = need(p + ".softmax");
+    if (sm && L == 0) {
+      int C = 0;
+      for (; C < 8; C++) {
+        const Parsed *cp = need(p + std::to_string(C) + ".copyn");
+        if (!cp) break;
+        cfg->bn_choice_dims[C] = (int)num(cp, "<OutputDim>", 0);
+      }
+      cfg->bn_num_choices = C;
+      if (sm->type == "OnehotFunctionComponent") cfg->bn_mode = 0;
+      else if (sm->type == "SoftmaxFlopsComponent") cfg->bn_mode = 1;
+      else if (sm->type == "GumbelSoftmaxFlopsComponent") cfg->bn_mode = 2;
+      else TDNNF_REQUIRE(false, "net_config_from_model: %s: %s.softmax is a %s", path, p.c_str(), sm->type.c_str());
+      cfg->bn_flops_scale = (float)num(sm, "<Scale>", 0.0);
+      cfg->bn_temp_proportion = (float)num(sm, "<TempProportion>", 1.0);
+    }
+  }
+  TDNNF_REQUIRE(L >= 1, "net_config_from_model: %s has no tdnnf2.linear / tdnnf2.affine", path);
+  cfg->num_layers = L;
+  // natural gradient: every updatable component of these graphs is a natural-gradient one
+  cfg->use_natural_gradient = 1;
+  return TDNNF_OK;
 }
 
 }  // extern "C"

@@ -78,6 +78,13 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
     return c
 
 
+def config_from_model(path, frames_per_chunk=150, num_sequences=64):
+    """NetConfig for the graph of an nnet3 raw model file (text or binary); see tdnnf_net_config_from_model."""
+    c = NetConfig()
+    hipabi.check(hipabi.load().tdnnf_net_config_from_model(str(path).encode(), int(frames_per_chunk), int(num_sequences), C.byref(c)))
+    return c
+
+
 class ChainNet:
     """One replica of the TDNN-F chain model on the current CUDA device."""
 

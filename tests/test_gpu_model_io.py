@@ -129,6 +129,50 @@ def test_reads_kaldi_formatted_text(pkg, tmp_path):
     b.close()
 
 
+@pytest.mark.parametrize("name,kw", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_config_from_model_rebuilds_the_net(pkg, tmp_path, name, kw):
+    """A net created only from the model file (tdnnf_net_config_from_model) computes what the original computes."""
+    cfg, a = trained_net(pkg, kw)
+    path = tmp_path / "m.raw"
+    a.write_model(path, binary=True)
+    cfg2 = pkg.trainer.config_from_model(path, frames_per_chunk=cfg.frames_per_chunk, num_sequences=cfg.num_sequences)
+    for f in ("feat_dim", "ivector_dim", "num_pdfs", "hidden_dim", "prefinal_small_dim", "num_layers", "darts_num_offsets", "darts_flags",
+              "bn_num_choices", "bn_mode", "cv_update"):
+        assert getattr(cfg2, f) == getattr(cfg, f), f
+    floats = ["bypass_scale", "l2_hidden", "l2_output", "max_change_hidden", "max_change_output", "xent_regularize", "relu_self_repair_scale"]
+    floats += ["darts_temp_proportion"] if cfg.darts_num_offsets else []
+    floats += ["bn_flops_scale"] if cfg.bn_mode else []
+    floats += ["bn_temp_proportion"] if cfg.bn_mode == 2 else []
+    for f in floats:
+        assert abs(getattr(cfg2, f) - getattr(cfg, f)) < 1e-6, f
+    L = cfg.num_layers
+    assert list(cfg2.bottleneck_dim[:L]) == list(cfg.bottleneck_dim[:L])
+    if not cfg.darts_num_offsets:
+        assert list(cfg2.time_stride[:L]) == list(cfg.time_stride[:L])
+    assert list(cfg2.bn_choice_dims[:cfg.bn_num_choices]) == list(cfg.bn_choice_dims[:cfg.bn_num_choices])
+    b = pkg.trainer.ChainNet(cfg2)
+    b.read_model(path)
+    feats, iv = pkg.trainer.synthetic_egs(a, seed=14)
+    den = pkg.synth.make_den_graph(20, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+    sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    draws = np.random.default_rng(8).uniform(0.01, 0.99, max(a.num_draws, 1)).astype(np.float32)
+    outs = []
+    for net in (a, b):
+        net.set_random_draws(draws)
+        net.grads.zero_()
+        r = host(net.forward_backward(dev(feats), dev(iv), dg, ds, step=5)).copy()
+        outs.append((r, host(net.activation("output")).copy(), host(net.grads).copy()))
+    if cfg.cv_update:  # BatchNormTest: the statistics come back through float mean / variance
+        assert rel_l2(outs[1][1], outs[0][1]) < 1e-4
+    else:
+        assert np.array_equal(outs[0][1], outs[1][1]) and outs[0][0][0] == outs[1][0][0]
+    if not cfg.use_natural_gradient:  # (the rebuilt net preconditions its gradients; the raw-gradient original does not)
+        assert rel_l2(outs[1][2], outs[0][2]) > 0
+    a.close()
+    b.close()
+
+
 def test_read_model_rejects_mismatches(pkg, tmp_path):
     cfg, a = trained_net(pkg, SMALL)
     path = tmp_path / "m.raw"
