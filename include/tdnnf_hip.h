@@ -349,6 +349,10 @@ int tdnnf_net_forward_backward(tdnnf_net *, const tdnnf_mat *feats, const tdnnf_
 /* delta = lr_c*(grad) - 2*l2_scale*lr_c*l2_c*params; max-change; params += delta; grads = 0; orthonormal
    constraint on the scheduled quarter of the constrained matrices; batchnorm stats *= batchnorm_stats_scale. */
 int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale, long long step, tdnnf_stream);
+/* The nnet edit "set-temperature-proportion name=* proportion=p" of the temperature schedule
+   (steps/libs/nnet3/train/temperature_schedule.py:51-60, applied by train.py:527-531 before every iteration): sets the
+   Temp-Proportion of every TdnnDARTSV3Component and GumbelSoftmax(Flops)Component of the net.  p > 0. */
+int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
 /* Model state outside the parameter vector, as doubles in network order (tdnn1, tdnnf2.., prefinal-chain, prefinal-xent):
    per BatchNorm [count, stats_sum[D], stats_sumsq[D]] (BatchNormComponent::StoreStats, nnet-normalize-component.cc:551-589)
    and per ReLU [count, value_sum[D], deriv_sum[D]] (NonlinearComponent::StoreStatsInternal, nnet-component-itf.cc:433);

@@ -42,6 +42,10 @@ inline bool vec4_ok(const MatView &m) {
 
 #define TDNNF_LAUNCH_CHECK(name) TDNNF_HIP(hipGetLastError())
 
+// CuMatrix::ApplyFloor semantics: `if (x < floor) x = floor`, so a NaN stays a NaN (fmaxf would swallow it and a
+// diverged minibatch would no longer be detected by the objective's finiteness check).
+__host__ __device__ inline float floor_keep_nan(float x, float f) { return x < f ? f : x; }
+
 inline int grid_for(long long work, int block, int cap = 2048) {
   long long g = (work + block - 1) / block;
   if (g > cap) g = cap;

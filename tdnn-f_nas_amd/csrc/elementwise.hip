@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float *parti
   const float mean = (float)(s / N), uvar = (float)(s2 / N);
   const float var_scale = 1.0f / (target_rms * target_rms);
   float v = var_scale * uvar - var_scale * mean * mean;
-  v = fmaxf(v, 0.f) + var_scale * epsilon;
+  v = floor_keep_nan(v, 0.f) + var_scale * epsilon;
   memo[d] = mean;
   memo[D + d] = uvar;
   memo[2 * D + d] = 1.0f / sqrtf(v);
@@ -210,7 +210,7 @@ __global__ void bn_derived_kernel(const double *stats, int D, float epsilon, flo
   float off = (float)(stats[1 + d] * (-1.0 / count));
   float sc = (float)(stats[1 + D + d] * (1.0 / count));
   sc += -1.0f * off * off;
-  sc = fmaxf(sc, 0.f) + epsilon;
+  sc = floor_keep_nan(sc, 0.f) + epsilon;
   sc = 1.0f / sqrtf(sc);
   sc *= target_rms;
   scale[d] = sc;
@@ -330,7 +330,7 @@ __global__ void softmax_rows_kernel(MatView in, const float *gumbel_u, float inv
   }
   float sum = 0.f;
   for (int c = 0; c < in.cols; c++) sum += expf(o[c] - mx);
-  for (int c = 0; c < in.cols; c++) o[c] = fmaxf(expf(o[c] - mx) / sum, 1.0e-20f);
+  for (int c = 0; c < in.cols; c++) o[c] = floor_keep_nan(expf(o[c] - mx) / sum, 1.0e-20f);
 }
 __global__ void softmax_flops_bwd_kernel(MatView p, MatView dp, float a, const float *flops, int dim, float inv_temp,
                                          MatView dx) {
@@ -472,7 +472,7 @@ __global__ void darts_coef_kernel(const float *log_alpha, int K, int flags, floa
     for (int i = 1; i < K; i++) mx = fmaxf(mx, c[i]);
     float s = 0.f;
     for (int i = 0; i < K; i++) s += expf(c[i] - mx);
-    for (int i = 0; i < K; i++) c[i] = fmaxf(expf(c[i] - mx) / s, 1.0e-20f);
+    for (int i = 0; i < K; i++) c[i] = floor_keep_nan(expf(c[i] - mx) / s, 1.0e-20f);
   } else {
     for (int i = 0; i < K; i++) c[i] = 1.0f / (1.0f + expf(-c[i]));
   }

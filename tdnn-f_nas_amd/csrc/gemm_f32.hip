@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
           const float4 o = *reinterpret_cast<const float4 *>(p.add + (long long)(m - p.add_lo) * p.ldadd + n);
           v.x += p.add_scale * o.x; v.y += p.add_scale * o.y; v.z += p.add_scale * o.z; v.w += p.add_scale * o.w;
         }
-        if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (p.relu) { v.x = floor_keep_nan(v.x, 0.f); v.y = floor_keep_nan(v.y, 0.f); v.z = floor_keep_nan(v.z, 0.f); v.w = floor_keep_nan(v.w, 0.f); }
         *reinterpret_cast<float4 *>(c) = v;
       } else {
         const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
             if (p.init_mode == 1) x += p.bias[n + e];
             else if (p.init_mode == 0) x += c[e];
             if (p.add && m >= p.add_lo && m < p.add_hi) x += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n + e];
-            if (p.relu) x = fmaxf(x, 0.f);
+            if (p.relu) x = floor_keep_nan(x, 0.f);
             c[e] = x;
           }
         }
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RowsGemmArgs p
     if (p.init_mode == 1) v += p.bias[n];
     else if (p.init_mode == 0) v += *c;
     if (p.add && m >= p.add_lo && m < p.add_hi) v += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n];
-    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.relu) v = floor_keep_nan(v, 0.f);
     *c = v;
   }
 }

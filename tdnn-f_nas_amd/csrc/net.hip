@@ -463,7 +463,7 @@ __global__ void bn_test_memo_kernel(const double *stats, int D, float epsilon, f
   float sc = (float)(stats[1 + D + d] * (1.0 / count));
   sc += -1.0f * off * off;
   memo[D + d] = sc;
-  sc = fmaxf(sc, 0.f) + epsilon;
+  sc = floor_keep_nan(sc, 0.f) + epsilon;
   sc = target_rms / sqrtf(sc);
   memo[d] = -off;
   memo[2 * D + d] = sc;
@@ -815,6 +815,13 @@ int tdnnf_net_set_stats(tdnnf_net *n, const double *host_in, tdnnf_stream stream
     TDNNF_HIP(hipMemcpy(x.first, host_in, sizeof(double) * (1 + 2 * x.second), hipMemcpyHostToDevice));
     host_in += 1 + 2 * x.second;
   }
+  return TDNNF_OK;
+}
+
+int tdnnf_net_set_temperature_proportion(tdnnf_net *n, float proportion) {
+  TDNNF_REQUIRE(n && proportion > 0.f, "net_set_temperature_proportion: proportion must be > 0");
+  n->cfg.darts_temp_proportion = proportion;
+  n->cfg.bn_temp_proportion = proportion;
   return TDNNF_OK;
 }
 

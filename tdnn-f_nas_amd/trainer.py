@@ -184,6 +184,10 @@ class ChainNet:
     def read_model(self, path):
         hipabi.check(self.lib.tdnnf_net_read_model(self.h, str(path).encode(), hipabi.stream()))
 
+    def set_temperature_proportion(self, proportion):
+        """nnet edit "set-temperature-proportion name=* proportion=p" (temperature_schedule.py:57-60)."""
+        hipabi.check(self.lib.tdnnf_net_set_temperature_proportion(self.h, float(proportion)))
+
     def set_params(self, flat):
         import torch
         self.params.copy_(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)))
@@ -253,3 +257,30 @@ def synthetic_egs(net, seed=0):
     feats = rng.standard_normal((net.num_t_in * B, net.cfg.feat_dim)).astype(np.float32)
     iv = rng.standard_normal((B, net.cfg.ivector_dim)).astype(np.float32)
     return feats, iv
+
+
+def temperature_proportion(data_fraction):
+    """get_temperature_edit_string, steps/libs/nnet3/train/temperature_schedule.py:51: the Gumbel temperature proportion
+    falls linearly from 1 to 0.03 with the fraction of the data processed."""
+    return (1.0 - data_fraction) * (1.0 - 0.03) + 0.03
+
+
+def temperature(temperature_init, temperature_final, data_fraction):
+    """get_temperature_edit_string_adapt, temperature_schedule.py:20: geometric interpolation."""
+    return temperature_init * (float(temperature_final) / temperature_init) ** data_fraction
+
+
+def training_schedule(num_iters, num_archives_to_process, num_jobs_initial=1, num_jobs_final=1, use_temperature_schedule=False,
+                      initial_effective_lrate=2.5e-4, final_effective_lrate=2.5e-5):
+    """The per-iteration settings train.py derives before launching its jobs (steps/nnet3/chain/train.py:473-531):
+    number of jobs (linear ramp, train.py:477-479 / common.py), learning rate (common.py:606-618), and -- with
+    --temperature_schedule -- the temperature proportion of the data fraction processed so far.  Yields dicts."""
+    processed = 0
+    for it in range(num_iters):
+        jobs = int(0.5 + num_jobs_initial + (num_jobs_final - num_jobs_initial) * float(it) / num_iters)
+        frac = float(processed) / num_archives_to_process
+        yield dict(iteration=it, num_jobs=jobs, data_fraction=frac,
+                   learning_rate=learning_rate(it, jobs, num_iters, processed, num_archives_to_process, initial_effective_lrate,
+                                               final_effective_lrate),
+                   temperature_proportion=temperature_proportion(frac) if use_temperature_schedule else None)
+        processed += jobs

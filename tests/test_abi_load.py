@@ -4,6 +4,8 @@ import ctypes as C
 import os
 import subprocess
 
+import pytest
+
 
 def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.hipabi.load()
@@ -42,3 +44,18 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in text.lower(), os.path.join(dirpath, f)
+
+
+def test_training_schedule_restates_train_py(pkg):
+    """steps/nnet3/chain/train.py:473-531 + common.py:606-618 + temperature_schedule.py:51 for a 2 -> 4 job ramp."""
+    tr = pkg.trainer
+    sched = list(tr.training_schedule(num_iters=6, num_archives_to_process=18, num_jobs_initial=2, num_jobs_final=4, use_temperature_schedule=True))
+    assert [s["num_jobs"] for s in sched] == [2, 2, 3, 3, 3, 4]
+    processed = [0, 2, 4, 7, 10, 13]
+    for s, p in zip(sched, processed):
+        assert abs(s["data_fraction"] - p / 18.0) < 1e-12
+        assert abs(s["temperature_proportion"] - ((1 - p / 18.0) * 0.97 + 0.03)) < 1e-12
+    import math
+    assert abs(sched[2]["learning_rate"] - 3 * 2.5e-4 * math.exp(4 * math.log(0.1) / 18)) < 1e-12
+    assert abs(sched[-1]["learning_rate"] - 4 * 2.5e-5) < 1e-15  # the last iteration runs at the final rate
+    assert abs(tr.temperature(1.0, 0.1, 0.5) - 10 ** -0.5) < 1e-12 and tr.temperature_proportion(1.0) == pytest.approx(0.03)

@@ -230,6 +230,58 @@ def test_net_update_constrains_tall_matrices_through_their_transpose(pkg):
     net.close()
 
 
+def test_net_drops_a_minibatch_whose_objective_failed(pkg):
+    """Non-finite network output: the chain objective reports failure (objf = -10 x weight, derivatives zeroed, as
+    chain::ComputeChainObjfAndDeriv does) and the minibatch contributes nothing to the accumulated gradient."""
+    cfg = pkg.trainer.make_config(relu_self_repair_scale=0.0, **CASES[0][1])
+    net = pkg.trainer.ChainNet(cfg)
+    net.set_params(net.init_params_numpy(seed=1, output_stddev=0.3))
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=2)
+    den = pkg.synth.make_den_graph(12, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+    sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    r = host(net.forward_backward(dev(feats), dev(iv), dg, ds, step=0)).copy()
+    good = net.grads.clone()
+    assert r[5] == 1.0 and good.abs().sum() > 0
+    bad = feats.copy()
+    bad[3, 2] = np.inf
+    r = host(net.forward_backward(dev(bad), dev(iv), dg, ds, step=1)).copy()
+    assert r[5] == 0.0 and r[0] == -10.0 * r[2]
+    assert torch.equal(net.grads, good)  # nothing was added
+    net.close()
+
+
+def test_net_temperature_proportion_edit(pkg):
+    """set-temperature-proportion (temperature_schedule.py:57-60) changes the Gumbel-softmax coefficients of the next step."""
+    cfg = pkg.trainer.make_config(**dict(_D, darts_num_offsets=4, darts_flags=1, darts_temp_proportion=1.0))
+    net = pkg.trainer.ChainNet(cfg)
+    params = net.init_params_numpy(seed=3, output_stddev=0.3)
+    rng = np.random.default_rng(17)
+    for c in net.components:
+        n = c["rows"] * c["cols"]
+        params[c["begin"] + n:c["begin"] + n + c["num_alpha"]] = rng.standard_normal(c["num_alpha"]).astype(np.float32)
+    net.set_params(params)
+    ref = OracleNet(pkg, cfg, net.components)
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=4)
+    den = pkg.synth.make_den_graph(40, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+    sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    draws = np.random.default_rng(5).uniform(0.01, 0.99, net.num_draws).astype(np.float32)
+    net.set_random_draws(draws)
+    outs = []
+    for prop in (1.0, pkg.trainer.temperature_proportion(0.9)):
+        net.set_temperature_proportion(prop)
+        cfg.darts_temp_proportion = prop
+        net.grads.zero_()
+        r = host(net.forward_backward(dev(feats), dev(iv), dg, ds, step=0)).copy()
+        res_ref, g_ref, acts = ref.forward_backward(params, feats, iv, den, sup, step=0, draws=draws)
+        assert abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"])
+        assert rel_l2(host(net.grads), g_ref) < 1e-3
+        outs.append(r[0])
+    assert outs[0] != outs[1]
+    net.close()
+
+
 def test_net_rejects_bad_shapes(pkg):
     cfg = pkg.trainer.make_config(**CASES[0][1])
     net = pkg.trainer.ChainNet(cfg)
