@@ -321,6 +321,11 @@ typedef struct {
      accumulated or rescaled), learning-rate factor 0 on every component (no model derivative is computed for them)
      except 1e-4 on the TdnnDARTSV3Components and 1 on the X.alpha vectors of the bottleneck supernet. */
   int cv_update;
+  /* Arithmetic of the trainer's GEMMs.  0: exact f32 MFMA (v_mfma_f32_32x32x2_f32), the reference's BaseFloat.
+     1: split-bf16: every f32 operand is a_hi + a_lo in bf16 and a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi on
+     v_mfma_f32_32x32x16_bf16 with f32 accumulation (products to ~2^-16 relative; BASELINE configs[4] names
+     "fp32 objf / bf16 MFMA GEMM").  The objective, BatchNorm, the optimizer step and all reductions stay f32 / f64. */
+  int gemm_precision;
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 

@@ -139,6 +139,14 @@ int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_d
     a.lda = out_deriv->stride;
     a.B = W;
     a.ldb = ldw;
+    // split-bf16 default arithmetic with a transposed copy of W registered (the trainer): B becomes k-contiguous,
+    // B[n = i][k = o] = WT[(tap Di + i) Do + o]
+    const float *WT = ldw == K * Di ? transposed_weights(W) : nullptr;
+    if (WT) {
+      a.B = WT;
+      a.ldb = Do;
+      for (int sg = 0; sg < nseg; sg++) a.seg[sg].b_off = (long long)seg_tap[sg] * Di * Do;
+    }
     a.C = in_deriv->data + (long long)cls * in_deriv->stride;
     a.ldc = (long long)in_deriv->stride * rho;
     a.M = u_max;
@@ -160,7 +168,7 @@ int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_d
     if (!eff_coef || contiguous) {
       a.coef = eff_coef ? eff_coef + seg_tap[0] : nullptr;
       a.nseg = nseg;
-      TDNNF_HIP(rows_gemm(a, false, (hipStream_t)stream));
+      TDNNF_HIP(rows_gemm(a, WT != nullptr, (hipStream_t)stream));
     } else {
       for (int s = 0; s < nseg; s++) {
         RowsGemmArgs b = a;
@@ -168,7 +176,7 @@ int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_d
         b.nseg = 1;
         b.coef = eff_coef + seg_tap[s];
         b.M = a.seg[s].m_hi;
-        TDNNF_HIP(rows_gemm(b, false, (hipStream_t)stream));
+        TDNNF_HIP(rows_gemm(b, WT != nullptr, (hipStream_t)stream));
       }
     }
   }
@@ -256,6 +264,11 @@ int tdnnf_affine_backprop(const tdnnf_mat *out_deriv, const float *W, int ldw, i
   a.lda = out_deriv->stride;
   a.B = W;
   a.ldb = ldw;
+  const float *WT = ldw == Di ? transposed_weights(W) : nullptr;  // (see tdnn_backprop_data_impl)
+  if (WT) {
+    a.B = WT;
+    a.ldb = out_deriv->cols;
+  }
   a.C = in_deriv->data;
   a.ldc = in_deriv->stride;
   a.M = out_deriv->rows;
@@ -265,7 +278,7 @@ int tdnnf_affine_backprop(const tdnnf_mat *out_deriv, const float *W, int ldw, i
   a.seg[0].klen = out_deriv->cols;
   a.seg[0].m_lo = 0;
   a.seg[0].m_hi = out_deriv->rows;
-  TDNNF_HIP(rows_gemm(a, false, (hipStream_t)stream));
+  TDNNF_HIP(rows_gemm(a, WT != nullptr, (hipStream_t)stream));
   return TDNNF_OK;
 }
 

@@ -43,6 +43,9 @@ struct RowsGemmArgs {
   // scaled, spliced A operand, a by-product of staging it).  Needs N to fit one column tile (every A element is
   // then staged exactly once): rows_gemm() fails otherwise.  One double per 128-row block: rows_gemm_sumsq_blocks(M).
   double *sumsq;
+  // 0: exact f32 MFMA (v_mfma_f32_32x32x2_f32).  1: split-bf16 (three v_mfma_f32_32x32x16_bf16 per 16 k, products accurate
+  // to ~2^-16 relative, f32 accumulation); needs a k-contiguous B and 16-byte alignment, otherwise the f32 kernel runs.
+  int prec;
   int nseg;
   GemmSeg seg[kMaxSeg];
 };
@@ -72,6 +75,24 @@ struct SplitKScratchOverride {
   ~SplitKScratchOverride();
 };
 
+// Default arithmetic of the GEMMs launched while one of these is alive (RowsGemmArgs::prec / WgradArgs::prec == 0 means
+// "the default"): 0 exact f32 MFMA, 1 split-bf16, 2 exact f32 even inside a split-bf16 scope (the natural-gradient
+// statistics: their eigen-decomposition amplifies operand errors).  The chain trainer wraps its forward / backward pass in one.
+struct GemmPrecisionScope {
+  int prev;
+  explicit GemmPrecisionScope(int prec);
+  ~GemmPrecisionScope();
+};
+// Transposed copies of weight matrices for the split-bf16 backward-data GEMMs (their B operand must be k-contiguous):
+// while alive, a weight pointer W inside [w_base, w_base + n) has its transpose (cols x rows, dense) at wt_base + (W - w_base).
+struct TransposedWeightsScope {
+  const float *prev_w, *prev_wt;
+  long long prev_n;
+  TransposedWeightsScope(const float *w_base, const float *wt_base, long long n);
+  ~TransposedWeightsScope();
+};
+const float *transposed_weights(const float *W);  // null when there is none (or split-bf16 is not the default)
+
 inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128; }
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).
@@ -96,6 +117,7 @@ struct WgradArgs {
   // active[0] = count n, active[1..n] = tap ids (device memory); max_active bounds n on the host.
   const int *active;
   int max_active;
+  int prec;  // 0: exact f32 MFMA, 1: split-bf16 (as RowsGemmArgs::prec)
 };
 size_t wgrad_workspace_bytes(int Do, int Di, int K, int N);  // valid for any max_active <= K
 hipError_t wgrad(const WgradArgs &args, void *workspace, size_t workspace_bytes, hipStream_t stream);

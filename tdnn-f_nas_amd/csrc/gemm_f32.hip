@@ -50,6 +50,25 @@ SplitKScratchOverride::SplitKScratchOverride(float *buf, size_t bytes) : prev_bu
   g_scratch_override = buf;
   g_scratch_override_bytes = bytes;
 }
+static int g_gemm_prec = 0;
+GemmPrecisionScope::GemmPrecisionScope(int prec) : prev(g_gemm_prec) { g_gemm_prec = prec; }
+GemmPrecisionScope::~GemmPrecisionScope() { g_gemm_prec = prev; }
+static const float *g_tw_w = nullptr, *g_tw_wt = nullptr;
+static long long g_tw_n = 0;
+TransposedWeightsScope::TransposedWeightsScope(const float *w_base, const float *wt_base, long long n) : prev_w(g_tw_w), prev_wt(g_tw_wt), prev_n(g_tw_n) {
+  g_tw_w = w_base;
+  g_tw_wt = wt_base;
+  g_tw_n = n;
+}
+TransposedWeightsScope::~TransposedWeightsScope() {
+  g_tw_w = prev_w;
+  g_tw_wt = prev_wt;
+  g_tw_n = prev_n;
+}
+const float *transposed_weights(const float *W) {
+  if (g_gemm_prec != 1 || !g_tw_w || !g_tw_wt || W < g_tw_w || W >= g_tw_w + g_tw_n) return nullptr;
+  return g_tw_wt + (W - g_tw_w);
+}
 SplitKScratchOverride::~SplitKScratchOverride() {
   g_scratch_override = prev_buf;
   g_scratch_override_bytes = prev_bytes;
@@ -409,6 +428,353 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
   }
 }
 
+// ------------------------------------------------------------------------ rows_gemm, split-bf16 arithmetic
+// The same GEMM (arguments, K-segment iterator, epilogue) computed as a = a_hi + a_lo, b = b_hi + b_lo in bf16 with
+//   a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi            (three v_mfma_f32_32x32x16_bf16 per 16 k, f32 accumulate):
+// 16 mantissa bits per operand, products accurate to ~2^-16 relative, at 3/16 of the f32 MFMA's cycles per flop.
+// The f32 operands are split when the staged tile goes to LDS (two bf16 planes per operand, 80-byte rows: conflict-free
+// 16-byte fragment reads); lane (r, h) of a fragment holds k = 8h..8h+7 of row r (MI355X guide, bf16 operand maps).
+// B must be k-contiguous (B_KC) and everything 16-byte aligned; rows_gemm() falls back to the f32 kernel otherwise.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_bf16(const float4 v, bf16x4 &hi, bf16x4 &lo) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const __bf16 h = (__bf16)x[i];
+    hi[i] = h;
+    lo[i] = (__bf16)(x[i] - (float)h);
+  }
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int TAG = 0>
+__global__ __launch_bounds__(256) void rows_gemm_x3_kernel(const RowsGemmArgs p, int ntm, int ntn) {
+  constexpr int VEC = 4;
+  constexpr bool B_KC = true;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int LDH = BK + 8;                 // bf16 per LDS row (80 bytes)
+  constexpr int A_TILE = 2 * BM * LDH / 2;    // floats per A buffer (hi + lo planes)
+  constexpr int B_TILE = 2 * BN * LDH / 2;
+  constexpr int A_F4 = (BM * BK / 4 + 255) / 256;
+  constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
+  constexpr int KF4 = BK / 4;  // float4 per k-row of a k-contiguous tile
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float *As = smem;               // [2][A_TILE]
+  float *Bs = smem + 2 * A_TILE;  // [2][B_TILE]
+
+  // XCD-aware tile order: blocks b and b+8 share an XCD (round-robin dispatch), so give each
+  // XCD a contiguous run of logical tile ids; within it tile_n varies fastest so the blocks
+  // that re-read the same A rows (and the taps' neighbouring rows) hit the same L2.
+  const int nblk = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  int sp = 0;
+  if (p.ksplit > 1) {  // split-K launch: consecutive block ids share a tile
+    sp = blockIdx.x % p.ksplit;
+    bid = blockIdx.x / p.ksplit;
+  }
+  const long long k_begin = (long long)sp * p.kchunk, k_end = p.ksplit > 1 ? k_begin + p.kchunk : (1LL << 60);
+  const int tile_m = bid / ntn, tile_n = bid % ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  // ---- K iterator over (segment, chunk), skipping zero-coefficient segments
+  // (a split-K block only visits the part of each segment inside its [k_begin, k_end) slice)
+  int seg = -1, kc = 0, klen = 0;
+  long long seg_kstart = 0, seg_knext = 0;
+  float cf = 1.f;
+  auto next_seg = [&]() {
+    for (++seg; seg < p.nseg; ++seg) {
+      seg_kstart = seg_knext;
+      seg_knext += p.seg[seg].klen;
+      cf = p.coef ? p.coef[seg] : 1.f;
+      const long long lo = k_begin > seg_kstart ? k_begin - seg_kstart : 0;
+      const long long hi = k_end < seg_knext ? k_end - seg_kstart : p.seg[seg].klen;
+      if (cf != 0.f && hi > lo) {
+        kc = (int)lo;
+        klen = (int)hi;
+        return;
+      }
+    }
+    kc = 0;
+    klen = 0;
+  };
+  next_seg();
+
+  float4 ra[A_F4], rb[B_F4];
+  // The tap coefficient (and the sum of squares of p.sumsq) is applied when a staged tile goes to LDS, not when it is
+  // loaded: anything that touches ra/rb right after the loads would wait for them in front of the MFMAs they are
+  // supposed to overlap with.
+  float cf_tile = 1.f;  // coefficient of the segment the tile in ra/rb was loaded from
+  float ssq = 0.f;      // p.sumsq: running sum of (coef * a)^2 over everything this thread stages
+  auto add_ssq = [&]() {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) q += ra[j].x * ra[j].x + ra[j].y * ra[j].y + ra[j].z * ra[j].z + ra[j].w * ra[j].w;
+    ssq += cf_tile * cf_tile * q;
+  };
+  // Per-segment, per-thread source pointers for the fast path (full K-step inside the segment, float4 loads):
+  // rows/columns that are out of range read 16 zero bytes instead of branching.
+  const float *aptr[A_F4], *bptr[B_F4];
+  int astep[A_F4], bstep[B_F4];
+  int ptr_seg = -1;
+  auto setup_ptrs = [&]() {
+    const GemmSeg sg = p.seg[seg];
+    const float *zero = reinterpret_cast<const float *>(&g_zero4);
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j, row = idx / KF4, m = m0 + row;
+      const bool rv = (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) && m < p.M && m >= sg.m_lo && m < sg.m_hi;
+      aptr[j] = rv ? p.A + sg.a_off + (long long)m * p.lda + (idx % KF4) * 4 : zero;
+      astep[j] = rv ? 1 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; j++) {
+      const int idx = t + 256 * j;
+      bool rv;
+      if (B_KC) {
+        const int n = n0 + idx / KF4;
+        rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n < p.N;
+        bptr[j] = rv ? p.B + sg.b_off + (long long)n * p.ldb + (idx % KF4) * 4 : zero;
+        bstep[j] = rv ? 1 : 0;
+      } else {
+        const int kr = idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+        rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n + 3 < p.N;
+        bptr[j] = rv ? p.B + sg.b_off + (long long)kr * p.ldb + n : zero;
+        bstep[j] = rv ? (int)p.ldb : 0;
+      }
+    }
+    ptr_seg = seg;
+  };
+  // !B_KC: a ragged last column group (n + 3 >= N) needs the general path for the whole launch
+  const bool fast_ok = VEC == 4 && (B_KC || p.N % 4 == 0);
+  auto load_tile = [&]() {  // global -> registers for chunk (seg, kc)
+    if (fast_ok && kc + BK <= klen) {
+      if (ptr_seg != seg) setup_ptrs();
+#pragma unroll
+      for (int j = 0; j < A_F4; j++) ra[j] = *reinterpret_cast<const float4 *>(aptr[j] + (long long)kc * astep[j]);
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) rb[j] = *reinterpret_cast<const float4 *>(bptr[j] + (long long)kc * bstep[j]);
+      cf_tile = cf;
+      return;
+    }
+    const GemmSeg sg = p.seg[seg];
+    const float *Ab = p.A + sg.a_off;
+    const float *Bb = p.B + sg.b_off;
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j;
+      const int row = idx / KF4, k = kc + (idx % KF4) * 4;
+      const int m = m0 + row;
+      const bool rv = (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) && m < p.M && m >= sg.m_lo && m < sg.m_hi;
+      const float *ptr = Ab + (long long)m * p.lda + k;
+      ra[j] = ld4(ptr, rv && k < klen, rv && k + 1 < klen, rv && k + 2 < klen, rv && k + 3 < klen, VEC == 4);
+    }
+    if (B_KC) {
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) {
+        const int idx = t + 256 * j;
+        const int row = idx / KF4, k = kc + (idx % KF4) * 4;
+        const int n = n0 + row;
+        const bool rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && n < p.N;
+        const float *ptr = Bb + (long long)n * p.ldb + k;
+        rb[j] = ld4(ptr, rv && k < klen, rv && k + 1 < klen, rv && k + 2 < klen, rv && k + 3 < klen, VEC == 4);
+      }
+    } else {
+      constexpr int NF4 = BN / 4;
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) {
+        const int idx = t + 256 * j;
+        const int kr = idx / NF4, n = n0 + (idx % NF4) * 4;
+        const bool rv = (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) && kc + kr < klen;
+        const float *ptr = Bb + (long long)(kc + kr) * p.ldb + n;
+        rb[j] = ld4(ptr, rv && n < p.N, rv && n + 1 < p.N, rv && n + 2 < p.N, rv && n + 3 < p.N, VEC == 4);
+      }
+    }
+    cf_tile = cf;
+  };
+  auto store_tile = [&](int buf) {  // registers -> LDS
+    float *as = As + buf * A_TILE, *bs = Bs + buf * B_TILE;
+    if (p.sumsq) add_ssq();
+    if (p.coef) {
+#pragma unroll
+      for (int j = 0; j < B_F4; j++) {
+        rb[j].x *= cf_tile; rb[j].y *= cf_tile; rb[j].z *= cf_tile; rb[j].w *= cf_tile;
+      }
+    }
+    __bf16 *ah = reinterpret_cast<__bf16 *>(as), *al = ah + BM * LDH, *bh = reinterpret_cast<__bf16 *>(bs), *bl = bh + BN * LDH;
+#pragma unroll
+    for (int j = 0; j < A_F4; j++) {
+      const int idx = t + 256 * j;
+      if (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) {
+        bf16x4 hi, lo;
+        split_bf16(ra[j], hi, lo);
+        const int o = (idx / KF4) * LDH + (idx % KF4) * 4;
+        *reinterpret_cast<bf16x4 *>(ah + o) = hi;
+        *reinterpret_cast<bf16x4 *>(al + o) = lo;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4; j++) {
+      const int idx = t + 256 * j;
+      if (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) {
+        bf16x4 hi, lo;
+        split_bf16(rb[j], hi, lo);
+        const int o = (idx / KF4) * LDH + (idx % KF4) * 4;
+        *reinterpret_cast<bf16x4 *>(bh + o) = hi;
+        *reinterpret_cast<bf16x4 *>(bl + o) = lo;
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const __bf16 *ah = reinterpret_cast<const __bf16 *>(As + buf * A_TILE) + (wm * TM * 32 + li) * LDH + lh * 8, *al = ah + BM * LDH;
+    const __bf16 *bh = reinterpret_cast<const __bf16 *>(Bs + buf * B_TILE) + (wn * TN * 32 + li) * LDH + lh * 8, *bl = bh + BN * LDH;
+#pragma unroll
+    for (int c = 0; c < BK / 16; c++) {
+      bf16x8 a_hi[TM], a_lo[TM], b_hi[TN], b_lo[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        a_hi[i] = *reinterpret_cast<const bf16x8 *>(ah + i * 32 * LDH + c * 16);
+        a_lo[i] = *reinterpret_cast<const bf16x8 *>(al + i * 32 * LDH + c * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TN; i++) {
+        b_hi[i] = *reinterpret_cast<const bf16x8 *>(bh + i * 32 * LDH + c * 16);
+        b_lo[i] = *reinterpret_cast<const bf16x8 *>(bl + i * 32 * LDH + c * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {  // the two cross terms first, the leading term last
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  if (seg < p.nseg) {
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+      kc += BK;
+      if (kc >= klen) next_seg();
+      const bool more = seg < p.nseg;
+      if (more) load_tile();  // in flight while the MFMAs run
+      compute(buf);
+      if (!more) break;
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+
+  // ---- epilogue.  C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // The accumulators go through LDS (reusing the staging buffers) so that C is read/written as whole
+  // 16-byte-per-lane row segments instead of 64 four-byte accesses per lane.
+  constexpr int LDCS = BN + 4;
+  constexpr int SMEM_FLOATS = 2 * (A_TILE + B_TILE);
+  constexpr int HALF = (BM * LDCS <= SMEM_FLOATS) ? BM : ((BM / 2) * LDCS <= SMEM_FLOATS ? BM / 2 : BM / 4);
+  static_assert(HALF * LDCS <= SMEM_FLOATS, "epilogue tile does not fit the staging LDS");
+  static_assert(HALF % (TM * 32) == 0, "a wave's rows must not straddle epilogue passes");
+  float *Cs = smem;
+  const bool cvec = p.c_vec != 0;
+  __syncthreads();
+  if (p.sumsq) {  // block total through LDS (the staging buffers are free now)
+    double v = ssq;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    double *red = reinterpret_cast<double *>(smem);
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (t == 0) p.sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int pass = 0; pass < BM / HALF; pass++) {
+    if ((wm * TM * 32) / HALF == pass) {
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh - pass * HALF;
+            Cs[row * LDCS + (wn * TN + j) * 32 + li] = acc[i][j][r];
+          }
+    }
+    __syncthreads();
+    for (int idx = t; idx < HALF * (BN / 4); idx += 256) {
+      const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+      const int m = m0 + pass * HALF + row, n = n0 + c4;
+      if (m >= p.M || n >= p.N) continue;
+      float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDCS + c4);
+      if (p.ksplit > 1) {  // raw partial tile; the reduce kernel applies the epilogue
+        const int ldp = (p.N + 3) & ~3;
+        *reinterpret_cast<float4 *>(p.partial + ((long long)sp * p.M + m) * ldp + n) = v;
+        continue;
+      }
+      float *c = p.C + (long long)m * p.ldc + n;
+      if (cvec && n + 3 < p.N) {
+        if (p.init_mode == 1) {
+          const float4 b = *reinterpret_cast<const float4 *>(p.bias + n);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        } else if (p.init_mode == 0) {
+          const float4 o = *reinterpret_cast<const float4 *>(c);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        if (p.add && m >= p.add_lo && m < p.add_hi) {
+          const float4 o = *reinterpret_cast<const float4 *>(p.add + (long long)(m - p.add_lo) * p.ldadd + n);
+          v.x += p.add_scale * o.x; v.y += p.add_scale * o.y; v.z += p.add_scale * o.z; v.w += p.add_scale * o.w;
+        }
+        if (p.relu) { v.x = floor_keep_nan(v.x, 0.f); v.y = floor_keep_nan(v.y, 0.f); v.z = floor_keep_nan(v.z, 0.f); v.w = floor_keep_nan(v.w, 0.f); }
+        *reinterpret_cast<float4 *>(c) = v;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          if (n + e < p.N) {
+            float x = vv[e];
+            if (p.init_mode == 1) x += p.bias[n + e];
+            else if (p.init_mode == 0) x += c[e];
+            if (p.add && m >= p.add_lo && m < p.add_hi) x += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n + e];
+            if (p.relu) x = floor_keep_nan(x, 0.f);
+            c[e] = x;
+          }
+        }
+      }
+    }
+    if (pass + 1 < BM / HALF) __syncthreads();
+  }
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int TAG>
+void launch_rows_x3_tagged(dim3 grid, const RowsGemmArgs &a, int ntm, int ntn, hipStream_t s) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = sizeof(__bf16) * 2 * 2 * (size_t)(BM + BN) * (BK + 8);  // double buffer x (hi, lo) planes
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute((const void *)rows_gemm_x3_kernel<WM, WN, TM, TN, BK, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((rows_gemm_x3_kernel<WM, WN, TM, TN, BK, TAG>), grid, dim3(256), lds, s, a, ntm, ntn);
+}
+
 template <int WM, int WN, int TM, int TN, int BK, int TAG>
 void rows_attr() {  // > 64 KiB of dynamic LDS must be opted into, once per instantiation
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -441,6 +807,11 @@ void launch_rows_kernel_tagged(dim3 grid, const RowsGemmArgs &a, int ntm, int nt
 // every rows_gemm_kernel launch goes through here
 template <int WM, int WN, int TM, int TN, int BK>
 void launch_rows_kernel(dim3 grid, const RowsGemmArgs &a, int ntm, int ntn, bool b_kc, bool vec, hipStream_t s) {
+  if (a.prec == 1 && b_kc && vec) {  // split-bf16 arithmetic
+    if (g_prof_override == 3) launch_rows_x3_tagged<WM, WN, TM, TN, BK, 1>(grid, a, ntm, ntn, s);
+    else launch_rows_x3_tagged<WM, WN, TM, TN, BK, 0>(grid, a, ntm, ntn, s);
+    return;
+  }
   if (g_prof_override == 3) launch_rows_kernel_tagged<WM, WN, TM, TN, BK, 1>(grid, a, ntm, ntn, b_kc, vec, s);
   else launch_rows_kernel_tagged<WM, WN, TM, TN, BK, 0>(grid, a, ntm, ntn, b_kc, vec, s);
 }
@@ -619,6 +990,14 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     const int lo = a.seg[i].m_lo > 0 ? a.seg[i].m_lo : 0, hi = a.seg[i].m_hi < a.M ? a.seg[i].m_hi : a.M;
     if (hi > lo) flops += 2.0 * (hi - lo) * a.N * a.seg[i].klen;
   }
+  if (a.prec == 0) a.prec = g_gemm_prec;
+  if (a.prec == 2) a.prec = 0;  // 2 = exact f32 regardless of the default
+  {
+    static int force = -1;  // experiments: TDNNF_GEMM_PREC=1 runs every eligible GEMM of the process in split-bf16
+    if (force < 0) force = getenv("TDNNF_GEMM_PREC") ? atoi(getenv("TDNNF_GEMM_PREC")) : 0;
+    if (force) a.prec = force;
+  }
+  if (!(b_kc && vec)) a.prec = 0;  // the split-bf16 kernels need a k-contiguous B and 16-byte alignment
   if (a.sumsq) {  // one column tile, no split-K tail: block b owns rows [128 b, 128 b + 128)
     if (a.N > 128) return hipErrorInvalidValue;
     ProfScope ps(0, flops, s);
@@ -638,7 +1017,7 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     // three blocks per CU cover each other's prologue / epilogue (+6..13 % measured); long reductions keep BK 32
     long long kt = 0;
     for (int i = 0; i < a.nseg; i++) kt += a.seg[i].klen;
-    if (kt <= 512) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
+    if (kt <= 512 && a.prec == 0) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
   }
   return launch_rows_balanced<2, 2, 2, 2, 32>(a, b_kc, vec, 0, flops, s);
 }
@@ -819,6 +1198,196 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, 
     }
 }
 
+// The weight gradient in split-bf16 arithmetic (see rows_gemm_x3_kernel).  Both operands are reduced over rows, so a
+// fragment needs 8 consecutive ROWS of one column: every thread loads one column of 8 rows (dword loads, consecutive
+// lanes on consecutive columns: coalesced), splits it and writes one 16-byte [column][k] piece per plane.
+template <int WM, int WN, int TM, int TN, int TAG = 0>
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs p, int ntm, int ntn_tap, int rows_per_split, float *partial) {
+  constexpr int BK = 32, LDH = BK + 8;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_IT = (BM * BK / 8 + 255) / 256, B_IT = (BN * BK / 8 + 255) / 256;  // (column, 8-row group) items per thread
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16 *As = reinterpret_cast<__bf16 *>(smem);       // [2 buffers][hi, lo][BM][LDH]
+  __bf16 *Bs = As + 2 * 2 * BM * LDH;                  // [2 buffers][hi, lo][BN][LDH]
+
+  int bid = blockIdx.x;
+  const int tile_m = bid % ntm;
+  int tap = (bid / ntm) / ntn_tap;
+  const int tile_n = (bid / ntm) % ntn_tap;
+  if (p.active) {
+    if (tap >= p.active[0]) return;
+    tap = p.active[1 + tap];
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int split = blockIdx.y;
+  const int r_begin = split * rows_per_split;
+  const int r_end = min(p.N, r_begin + rows_per_split);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; a++)
+#pragma unroll
+    for (int b = 0; b < TN; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const float cf = p.coef ? p.coef[tap] : 1.f;
+  const float *Xb = p.X + (long long)p.row_offsets[tap] * p.ldx;
+  const long long xrow = (long long)p.row_stride * p.ldx;
+
+  float ra[A_IT][8], rb[B_IT][8];
+  // per-item source: column pointer at row 0 of the item's 8-row group; an out-of-range column reads zeros (step 0)
+  const float *aptr[A_IT], *bptr[B_IT];
+  long long astep[A_IT], bstep[B_IT];
+  int akg[A_IT], bkg[B_IT];
+  {
+    const float *zero = reinterpret_cast<const float *>(&g_zero4);
+#pragma unroll
+    for (int j = 0; j < A_IT; j++) {
+      const int item = t + 256 * j, col = item % BM, kg = item / BM;
+      const bool v = (BM * BK / 8 % 256 == 0 || item < BM * BK / 8) && m0 + col < p.Do;
+      akg[j] = kg;
+      aptr[j] = v ? p.dY + (long long)(kg * 8) * p.lddy + m0 + col : zero;
+      astep[j] = v ? p.lddy : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; j++) {
+      const int item = t + 256 * j, col = item % BN, kg = item / BN;
+      const bool v = (BN * BK / 8 % 256 == 0 || item < BN * BK / 8) && n0 + col < p.Di;
+      bkg[j] = kg;
+      bptr[j] = v ? Xb + (long long)(kg * 8) * xrow + n0 + col : zero;
+      bstep[j] = v ? xrow : 0;
+    }
+  }
+  auto load_tile = [&](int r0) {
+    if (r0 + BK <= r_end) {  // whole K-step inside the split: unconditional loads (a branch-free steady state)
+#pragma unroll
+      for (int j = 0; j < A_IT; j++) {
+        const float *q = aptr[j] + (long long)r0 * astep[j];
+#pragma unroll
+        for (int i = 0; i < 8; i++) ra[j][i] = q[(long long)i * astep[j]];
+      }
+#pragma unroll
+      for (int j = 0; j < B_IT; j++) {
+        const float *q = bptr[j] + (long long)r0 * bstep[j];
+#pragma unroll
+        for (int i = 0; i < 8; i++) rb[j][i] = q[(long long)i * bstep[j]];
+      }
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < A_IT; j++) {
+      const float *q = aptr[j] + (long long)r0 * astep[j];
+#pragma unroll
+      for (int i = 0; i < 8; i++) ra[j][i] = r0 + akg[j] * 8 + i < r_end ? q[(long long)i * astep[j]] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; j++) {
+      const float *q = bptr[j] + (long long)r0 * bstep[j];
+#pragma unroll
+      for (int i = 0; i < 8; i++) rb[j][i] = r0 + bkg[j] * 8 + i < r_end ? q[(long long)i * bstep[j]] : 0.f;
+    }
+  };
+  auto split8 = [](const float *x, bf16x8 &hi, bf16x8 &lo) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const __bf16 h = (__bf16)x[i];
+      hi[i] = h;
+      lo[i] = (__bf16)(x[i] - (float)h);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    __bf16 *ah = As + buf * 2 * BM * LDH, *al = ah + BM * LDH, *bh = Bs + buf * 2 * BN * LDH, *bl = bh + BN * LDH;
+#pragma unroll
+    for (int j = 0; j < A_IT; j++) {
+      const int item = t + 256 * j;
+      if (BM * BK / 8 % 256 == 0 || item < BM * BK / 8) {
+        bf16x8 hi, lo;
+        split8(ra[j], hi, lo);
+        const int o = (item % BM) * LDH + (item / BM) * 8;
+        *reinterpret_cast<bf16x8 *>(ah + o) = hi;
+        *reinterpret_cast<bf16x8 *>(al + o) = lo;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; j++) {
+      const int item = t + 256 * j;
+      if (BN * BK / 8 % 256 == 0 || item < BN * BK / 8) {
+        bf16x8 hi, lo;
+        split8(rb[j], hi, lo);
+        const int o = (item % BN) * LDH + (item / BN) * 8;
+        *reinterpret_cast<bf16x8 *>(bh + o) = hi;
+        *reinterpret_cast<bf16x8 *>(bl + o) = lo;
+      }
+    }
+  };
+  auto compute = [&](int buf) {
+    const __bf16 *ah = As + buf * 2 * BM * LDH + (wm * TM * 32 + li) * LDH + lh * 8, *al = ah + BM * LDH;
+    const __bf16 *bh = Bs + buf * 2 * BN * LDH + (wn * TN * 32 + li) * LDH + lh * 8, *bl = bh + BN * LDH;
+#pragma unroll
+    for (int c = 0; c < BK / 16; c++) {
+      bf16x8 a_hi[TM], a_lo[TM], b_hi[TN], b_lo[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) {
+        a_hi[i] = *reinterpret_cast<const bf16x8 *>(ah + i * 32 * LDH + c * 16);
+        a_lo[i] = *reinterpret_cast<const bf16x8 *>(al + i * 32 * LDH + c * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TN; i++) {
+        b_hi[i] = *reinterpret_cast<const bf16x8 *>(bh + i * 32 * LDH + c * 16);
+        b_lo[i] = *reinterpret_cast<const bf16x8 *>(bl + i * 32 * LDH + c * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  float *P = partial + (long long)split * p.Do * (p.K * p.Di);
+  if (cf == 0.f) return;
+  if (r_begin >= r_end) {
+    for (int e = t; e < BM * BN; e += 256) {
+      const int m = m0 + e / BN, n = n0 + e % BN;
+      if (m < p.Do && n < p.Di) P[(long long)m * (p.K * p.Di) + tap * p.Di + n] = 0.f;
+    }
+    return;
+  }
+  load_tile(r_begin);
+  store_tile(0);
+  __syncthreads();
+  {
+    int buf = 0;
+    for (int r0 = r_begin;; r0 += BK) {
+      const bool more = r0 + BK < r_end;
+      if (more) load_tile(r0 + BK);
+      compute(buf);
+      if (!more) break;
+      store_tile(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      const int n = n0 + (wn * TN + j) * 32 + li;
+      if (n >= p.Di) continue;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m < p.Do) P[(long long)m * (p.K * p.Di) + tap * p.Di + n] = acc[i][j][r];
+      }
+    }
+}
+
 // G[o][c] (+)= scale * coef[tap(c)] * sum_split partial[split][o][c]
 __global__ void wgrad_reduce_kernel(const float *partial, int splits, int Do, int KDi, int Di, const float *coef,
                                     float scale, float *G, long long ldg, int accumulate) {
@@ -888,8 +1457,11 @@ struct WgradTile {
   int BM, BN, variant;  // variant 0: 128x128, 1: 160x128 (Do == 160-ish), 2: 128x160 (Di == 160-ish), 3: 32x128 (Do <= 32)
 };
 inline int waste_of(int n, int t) { return ((n + t - 1) / t) * t - n; }
-WgradTile wgrad_tile(int Do, int Di) {
-  if (Do <= 32) return {32, 128, 3};  // J = H^T X of a rank <= 32 preconditioner: HBM-bound on X, no wasted MFMA rows
+WgradTile wgrad_tile(int Do, int Di, bool x3 = false) {
+  if (Do <= 32) return {32, 128, 3};
+  // split-bf16 arithmetic is not MFMA bound: the 160-wide tiles (92 KiB of LDS in bf16 planes, one block per CU) lose to
+  // plain 128x128 tiles with a few wasted columns
+  if (x3) return {128, 128, 0};  // J = H^T X of a rank <= 32 preconditioner: HBM-bound on X, no wasted MFMA rows
   if (waste_of(Do, 160) * 128 < waste_of(Do, 128) * 160 && waste_of(Do, 160) < waste_of(Do, 128)) return {160, 128, 1};
   if (waste_of(Di, 160) < waste_of(Di, 128)) return {128, 160, 2};
   return {128, 128, 0};
@@ -919,10 +1491,10 @@ int wgrad_slots(int variant) {
 
 // Split the row (reduction) range so that tiles * splits fills whole rounds of resident blocks: every block
 // runs equally long, so a grid of q*slots + r blocks costs q+1 rounds; we want r == 0 (just under a multiple).
-WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0) {
-  if (ktaps > 0) { WgradPlan p2 = wgrad_plan(Do, Di, ktaps, N, slots); p2.slab_floats = (size_t)p2.splits * Do * K * Di; return p2; }
+WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0, bool x3 = false) {
+  if (ktaps > 0) { WgradPlan p2 = wgrad_plan(Do, Di, ktaps, N, slots, 0, x3); p2.slab_floats = (size_t)p2.splits * Do * K * Di; return p2; }
   WgradPlan pl;
-  const WgradTile wt = wgrad_tile(Do, Di);
+  const WgradTile wt = wgrad_tile(Do, Di, x3);
   const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
   const int max_splits = std::max(1, (N + 255) / 256);  // at least 256 rows per split
   int splits = 1;
@@ -948,8 +1520,9 @@ WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0) {
 size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
   // sized for the largest split count any device can ask for (4 rounds of 8 blocks on 304 CUs), so the
   // answer does not depend on the GPU being present
-  const WgradTile wt = wgrad_tile(Do, Di);
-  const int tiles = ((Do + wt.BM - 1) / wt.BM) * 1 * ((Di + wt.BN - 1) / wt.BN);  // worst case: one active tap
+  const WgradTile wt0 = wgrad_tile(Do, Di, false), wt1 = wgrad_tile(Do, Di, true);
+  const int tiles = std::min(((Do + wt0.BM - 1) / wt0.BM) * ((Di + wt0.BN - 1) / wt0.BN),
+                             ((Do + wt1.BM - 1) / wt1.BM) * ((Di + wt1.BN - 1) / wt1.BN));  // worst case: one active tap, either arithmetic
   // wgrad_plan picks one round when tiles <= slots/4 (splits = slots/tiles) and at most 4 rounds otherwise (< 16 splits);
   // slots <= 1024 on any gfx950 part
   size_t max_splits = std::max<size_t>(1, std::min<size_t>((N + 255) / 256, std::max<size_t>(1024 / tiles + 1, 16)));
@@ -959,9 +1532,11 @@ size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
 hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hipStream_t s) {
   if (a.N <= 0 || a.Do <= 0 || a.Di <= 0) return hipSuccess;
   if (workspace_bytes < wgrad_workspace_bytes(a.Do, a.Di, a.K, a.N)) return hipErrorInvalidValue;
-  const WgradTile wt = wgrad_tile(a.Do, a.Di);
+  static const int force_prec = getenv("TDNNF_GEMM_PREC") ? atoi(getenv("TDNNF_GEMM_PREC")) : 0;
+  const bool use_x3 = a.prec == 1 || (a.prec == 0 && (g_gemm_prec == 1 || force_prec == 1));
+  const WgradTile wt = wgrad_tile(a.Do, a.Di, use_x3);
   const int ktaps = a.active && a.max_active > 0 && a.max_active < a.K ? a.max_active : a.K;
-  WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant), ktaps == a.K ? 0 : ktaps);
+  WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant), ktaps == a.K ? 0 : ktaps, use_x3);
   if (sizeof(float) * pl.slab_floats > workspace_bytes) return hipErrorInvalidValue;
   float *partial = reinterpret_cast<float *>(workspace);
   float *cs_partial = partial + pl.slab_floats;
@@ -983,14 +1558,28 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
     if (vec) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 4, TAG>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial); \
     else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 1, TAG>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);     \
   }
-#define WG_LAUNCH(WM, WN, TM, TN)                      \
-  if (g_prof_override == 3) WG_LAUNCH_T(WM, WN, TM, TN, 1) \
+#define WG_LAUNCH_X3(WM, WN, TM, TN, TAG)                                                                                      \
+  {                                                                                                                             \
+    constexpr size_t lds3 = sizeof(__bf16) * 2 * 2 * (size_t)(WM * TM * 32 + WN * TN * 32) * 40;                                \
+    static bool attr_done3 = false;                                                                                             \
+    if (!attr_done3) {                                                                                                          \
+      hipFuncSetAttribute((const void *)wgrad_x3_kernel<WM, WN, TM, TN, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+      attr_done3 = true;                                                                                                        \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((wgrad_x3_kernel<WM, WN, TM, TN, TAG>), grid, block, lds3, s, a, ntm, ntn, pl.rows_per_split, partial);  \
+  }
+#define WG_LAUNCH(WM, WN, TM, TN)                                  \
+  if (use_x3) {                                                    \
+    if (g_prof_override == 3) WG_LAUNCH_X3(WM, WN, TM, TN, 1)      \
+    else WG_LAUNCH_X3(WM, WN, TM, TN, 0)                           \
+  } else if (g_prof_override == 3) WG_LAUNCH_T(WM, WN, TM, TN, 1)  \
   else WG_LAUNCH_T(WM, WN, TM, TN, 0)
     if (wt.variant == 1) { WG_LAUNCH(1, 4, 5, 1) }
     else if (wt.variant == 2) { WG_LAUNCH(4, 1, 1, 5) }
     else if (wt.variant == 3) { WG_LAUNCH(1, 4, 1, 1) }
     else { WG_LAUNCH(2, 2, 2, 2) }
 #undef WG_LAUNCH_T
+#undef WG_LAUNCH_X3
 #undef WG_LAUNCH
   }
   hipError_t e = hipGetLastError();

@@ -63,6 +63,7 @@ struct tdnnf_net {
   std::vector<tdnnf::CompDesc> comps;
   long long num_params;
   float *params, *grads;
+  float *paramsT;      // gemm_precision 1: per component, the transpose of its weight matrix at the same offset (backward-data GEMMs)
   int B, T, Tout;
   // graph
   tdnnf::Grid g_lda, g_feat;

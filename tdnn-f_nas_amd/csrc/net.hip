@@ -175,6 +175,21 @@ __global__ void commit_grads_kernel(float *grads, const float *gtmp, long long n
   if (results[5] == 0.0) return;
   for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) grads[i] += gtmp[i];
 }
+// paramsT[begin_c + col * rows + row] = params[begin_c + row * cols + col] for every component c (blockIdx.y)
+struct TransTable {
+  long long begin[128];
+  int rows[128], cols[128];
+};
+__global__ __launch_bounds__(256) void transpose_weights_kernel(const float *params, float *paramsT, TransTable tb) {
+  const int c = blockIdx.y, rows = tb.rows[c], cols = tb.cols[c];
+  const float *W = params + tb.begin[c];
+  float *WT = paramsT + tb.begin[c];
+  const long long total = (long long)rows * cols;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int col = (int)(e / rows), row = (int)(e % rows);  // consecutive threads: consecutive rows of one column -> coalesced writes
+    WT[e] = W[(long long)row * cols + col];
+  }
+}
 // out (cols x rows) = in (rows x cols)^T, both dense
 __global__ void transpose_kernel(const float *in, int rows, int cols, float *out) {
   const long long total = (long long)rows * cols;
@@ -364,6 +379,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
+  n->paramsT = n->cfg.gemm_precision == 1 ? A.take<float>((size_t)n->num_params + 16) : nullptr;
   n->ngBias = nullptr;
   n->s3_scratch = nullptr;
   n->s3_scratch_bytes = 0;
@@ -541,6 +557,7 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     for (int l = 0; l < c.num_layers; l++)
       TDNNF_REQUIRE(c.bottleneck_dim[l] == sum, "net_create: bottleneck_dim[%d] = %d but the choice blocks sum to %d", l, c.bottleneck_dim[l], sum);
   }
+  TDNNF_REQUIRE(c.gemm_precision == 0 || c.gemm_precision == 1, "net_create: gemm_precision must be 0 (f32) or 1 (split-bf16)");
   TDNNF_REQUIRE(c.darts_num_offsets == 0 || !(c.darts_flags & TDNNF_DARTS_USE_GUMBEL) || c.darts_temp_proportion > 0,
                 "net_create: gumbel mode needs temp-proportion > 0");
   TDNNF_REQUIRE(c.frame_subsampling >= 1 && c.frames_per_chunk > 0 && c.frames_per_chunk % c.frame_subsampling == 0 && c.num_sequences > 0,
@@ -914,6 +931,19 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
+  GemmPrecisionScope gemm_arith(c.gemm_precision);
+  TransposedWeightsScope gemm_wt(n->params, n->paramsT, n->paramsT ? n->num_params : 0);
+  if (n->paramsT) {  // split-bf16 backward-data GEMMs read W^T (k-contiguous B operand)
+    TransTable tb;
+    memset(&tb, 0, sizeof(tb));
+    const int nc = (int)n->comps.size();
+    for (int i = 0; i < nc; i++) {
+      tb.begin[i] = n->comps[i].begin;
+      tb.rows[i] = n->comps[i].rows;
+      tb.cols[i] = n->comps[i].cols;
+    }
+    hipLaunchKernelGGL(transpose_weights_kernel, dim3(256, nc), dim3(256), 0, s, n->params, n->paramsT, tb);
+  }
   TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout), "net_forward_backward: denominator graph changed size");
   // the reference's RandInt()/RandUniform() coin flips, made reproducible: k-th decision of this minibatch
   unsigned long long coin_k = 0;

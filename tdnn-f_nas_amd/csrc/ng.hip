@@ -504,6 +504,7 @@ int ng_stats_step(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws
   const int K = in.ix.num_offsets, D = K * in.Di + (in.ones ? 1 : 0);
   TDNNF_REQUIRE(ng && H && in.N > 0 && K >= 1 && K <= kMaxSeg && in.Di > 0, "ng_stats_step: bad arguments");
   ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
   if (ng->D == 0) {
     int rc0 = init_from(ng, in, D, H, ws, ws_bytes, s);
     if (rc0) return rc0;
@@ -521,6 +522,7 @@ int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void 
   const int K = in.ix.num_offsets, D = K * in.Di + (in.ones ? 1 : 0);
   TDNNF_REQUIRE(ng && H && part && in.N > 0 && K >= 1 && K <= kMaxSeg && in.Di > 0, "ng_stats_main: bad arguments");
   ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
   if (ng->D == 0) {
     int rc0 = init_from(ng, in, D, H, ws, ws_bytes, s);
     if (rc0) return rc0;
@@ -537,6 +539,7 @@ int ng_stats_side(tdnnf_ng *ng, const float *H, const double *part, void *ws, si
   TDNNF_REQUIRE(ng && H && part, "ng_stats_side: bad arguments");
   if (ng->rank == 0 || ng->cur_N == 0) return TDNNF_OK;
   ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
   int rc = stats_side(ng, H, part, ws, ws_bytes, s);
   ng->t += 1;
   return rc;
@@ -550,6 +553,7 @@ size_t ng_project_tmp_floats(const tdnnf_ng *in, const tdnnf_ng *out, int Do, in
 int ng_project(tdnnf_ng *in, tdnnf_ng *out, float *T, int Do, int Dx, int ldT, float *tmp, hipStream_t s) {
   TDNNF_REQUIRE(T && tmp && ldT % 4 == 0 && ldT >= Dx, "ng_project: bad arguments");
   ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
   if (in && in->rank > 0) {
     TDNNF_REQUIRE(in->D == Dx && in->Dp == ldT, "ng_project: input-side dimension mismatch");
     const int Rp = in->Rp;
@@ -629,6 +633,7 @@ int tdnnf_ng_precondition(tdnnf_ng *ng, tdnnf_mat *X, float *scale_host, tdnnf_s
   TDNNF_REQUIRE(ng && mat_ok(X) && X->rows > 0 && X->cols > 0, "ng_precondition: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
   if (X->cols == 1) {  // preconditioning one column is pointless (UPSTREAM)
     if (scale_host) *scale_host = 1.0f;
     return TDNNF_OK;
