@@ -123,9 +123,10 @@ def main():
                          "supernet of run_TDNN_DARTSV3_fbk_stride_pretrain.sh in pretrain (uniform-sample) mode; bn-supernet = "
                          "configs[4], the bottleneck-dimension supernet (8 candidate dims up to 240) in Onehot pretrain mode")
     ap.add_argument("--darts-offsets", type=int, default=7)
-    ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3"],
+    ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3", "bf16x6"],
                     help="GEMM arithmetic: f32 = exact v_mfma_f32_32x32x2_f32 (default, the reference's BaseFloat); bf16x3 = split-bf16 "
-                         "(three bf16 MFMAs per product, f32 accumulate)")
+                         "(three bf16 MFMAs per product, f32 accumulate; 16 operand bits); bf16x6 = three planes, six MFMAs "
+                         "(24 operand bits, f32-equivalent)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement reported under \"alt\" (N = 1, --gemm f32 only)")
     ap.add_argument("--natural-gradient", type=int, default=1, choices=[0, 1],
                     help="1 (default, what the reference's recipes train with) = OnlineNaturalGradient preconditioning of every "
@@ -163,7 +164,7 @@ def main():
     elif args.workload == "bn-supernet":
         extra = dict(bn_choice_dims=pkg.trainer.BN_CHOICE_DIMS, bn_mode=pkg.trainer.BN_ONEHOT)
     cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch,
-                                  use_natural_gradient=args.natural_gradient, gemm_precision=1 if args.gemm == "bf16x3" else 0, **extra)
+                                  use_natural_gradient=args.natural_gradient, gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.gemm], **extra)
     net = pkg.trainer.ChainNet(cfg)
     # identical initial model on every rank (seed), different egs per rank (data parallel over sequences)
     net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
@@ -229,7 +230,8 @@ def main():
             "metric": "LF-MMI training frames/sec per node (SWBD 7q TDNN-F)",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.gemm == "f32" else "bf16x3 (split-bf16 MFMA, f32 accumulate)", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, 2 planes / 3 products, f32 accumulate)",
+                                          "bf16x6": "bf16x6 (split-bf16 MFMA, 3 planes / 6 products, f32 accumulate; f32-equivalent)"}[args.gemm], "data": "synthetic",
             "config": {"workload": workload_text(args),
                        "frames_per_chunk": args.chunk, "sequences_per_gpu": cfg.num_sequences, "global_batch": world * cfg.num_sequences,
                        "den_graph": {"states": args.den_states, "arcs": int(len(den["src"]))},

@@ -324,7 +324,9 @@ typedef struct {
   /* Arithmetic of the trainer's GEMMs.  0: exact f32 MFMA (v_mfma_f32_32x32x2_f32), the reference's BaseFloat.
      1: split-bf16: every f32 operand is a_hi + a_lo in bf16 and a b ~ a_hi b_hi + a_hi b_lo + a_lo b_hi on
      v_mfma_f32_32x32x16_bf16 with f32 accumulation (products to ~2^-16 relative; BASELINE configs[4] names
-     "fp32 objf / bf16 MFMA GEMM").  The objective, BatchNorm, the optimizer step and all reductions stay f32 / f64. */
+     "fp32 objf / bf16 MFMA GEMM").  The objective, BatchNorm, the optimizer step and all reductions stay f32 / f64.
+     2: the same with three bf16 planes per operand and the six products a_i b_j, i + j <= 2 (24 mantissa bits per
+     operand, products to ~2^-24 relative: f32-equivalent results from the bf16 matrix cores). */
   int gemm_precision;
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;

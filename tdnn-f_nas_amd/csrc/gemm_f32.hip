@@ -66,7 +66,7 @@ TransposedWeightsScope::~TransposedWeightsScope() {
   g_tw_n = prev_n;
 }
 const float *transposed_weights(const float *W) {
-  if (g_gemm_prec != 1 || !g_tw_w || !g_tw_wt || W < g_tw_w || W >= g_tw_w + g_tw_n) return nullptr;
+  if ((g_gemm_prec != 1 && g_gemm_prec != 3) || !g_tw_w || !g_tw_wt || W < g_tw_w || W >= g_tw_w + g_tw_n) return nullptr;
   return g_tw_wt + (W - g_tw_w);
 }
 SplitKScratchOverride::~SplitKScratchOverride() {
@@ -435,27 +435,48 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
 // The f32 operands are split when the staged tile goes to LDS (two bf16 planes per operand, 80-byte rows: conflict-free
 // 16-byte fragment reads); lane (r, h) of a fragment holds k = 8h..8h+7 of row r (MI355X guide, bf16 operand maps).
 // B must be k-contiguous (B_KC) and everything 16-byte aligned; rows_gemm() falls back to the f32 kernel otherwise.
+// compile-time loop: f(IntC<0>{}), f(IntC<1>{}), ... -- register arrays indexed by the counter stay in registers without
+// depending on the loop unroller
+template <int V>
+struct IntC {
+  static constexpr int value = V;
+};
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+  (f(IntC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void split_bf16(const float4 v, bf16x4 &hi, bf16x4 &lo) {
+// x = pl[0] + pl[1] (+ pl[2]) + O(2^-8NP |x|): each plane is the bf16 rounding of what the planes above it left.
+template <int NP>
+__device__ __forceinline__ void split_bf16(const float4 v, bf16x4 (&pl)[NP]) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const __bf16 h = (__bf16)x[i];
-    hi[i] = h;
-    lo[i] = (__bf16)(x[i] - (float)h);
+    float r = x[i];
+#pragma unroll
+    for (int q = 0; q < NP; q++) {
+      const __bf16 h = (__bf16)r;
+      pl[q][i] = h;
+      r -= (float)h;
+    }
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int TAG = 0>
-__global__ __launch_bounds__(256) void rows_gemm_x3_kernel(const RowsGemmArgs p, int ntm, int ntn) {
+template <int WM, int WN, int TM, int TN, int BK, int NP, int D, int TAG = 0>
+__global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(const RowsGemmArgs p, int ntm, int ntn) {
   constexpr int VEC = 4;
   constexpr bool B_KC = true;
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int LDH = BK + 8;                 // bf16 per LDS row (80 bytes)
-  constexpr int A_TILE = 2 * BM * LDH / 2;    // floats per A buffer (hi + lo planes)
-  constexpr int B_TILE = 2 * BN * LDH / 2;
+  constexpr int LDH = BK + 8;                 // bf16 per LDS row (80 bytes at BK = 32)
+  constexpr int A_TILE = NP * BM * LDH / 2;   // floats per A buffer (NP planes)
+  constexpr int B_TILE = NP * BN * LDH / 2;
   constexpr int A_F4 = (BM * BK / 4 + 255) / 256;
   constexpr int B_F4 = (BN * BK / 4 + 255) / 256;
   constexpr int KF4 = BK / 4;  // float4 per k-row of a k-contiguous tile
@@ -515,17 +536,19 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(const RowsGemmArgs p,
   };
   next_seg();
 
-  float4 ra[A_F4], rb[B_F4];
+  // D staged K-steps in registers: one being split into LDS, D - 1 in flight behind it.  A bf16 K-step is 4..5x shorter
+  // than the f32 kernel's, far shorter than a global load's latency, so one step of prefetch leaves the MFMAs waiting.
+  float4 ra[D][A_F4], rb[D][B_F4];
   // The tap coefficient (and the sum of squares of p.sumsq) is applied when a staged tile goes to LDS, not when it is
   // loaded: anything that touches ra/rb right after the loads would wait for them in front of the MFMAs they are
   // supposed to overlap with.
-  float cf_tile = 1.f;  // coefficient of the segment the tile in ra/rb was loaded from
+  float cf_tile[D];     // coefficient of the segment the tile in ra/rb[slot] was loaded from
   float ssq = 0.f;      // p.sumsq: running sum of (coef * a)^2 over everything this thread stages
-  auto add_ssq = [&]() {
+  auto add_ssq = [&](const float4 (&xa)[A_F4], float c) {
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < A_F4; j++) q += ra[j].x * ra[j].x + ra[j].y * ra[j].y + ra[j].z * ra[j].z + ra[j].w * ra[j].w;
-    ssq += cf_tile * cf_tile * q;
+    for (int j = 0; j < A_F4; j++) q += xa[j].x * xa[j].x + xa[j].y * xa[j].y + xa[j].z * xa[j].z + xa[j].w * xa[j].w;
+    ssq += c * c * q;
   };
   // Per-segment, per-thread source pointers for the fast path (full K-step inside the segment, float4 loads):
   // rows/columns that are out of range read 16 zero bytes instead of branching.
@@ -562,7 +585,7 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(const RowsGemmArgs p,
   };
   // !B_KC: a ragged last column group (n + 3 >= N) needs the general path for the whole launch
   const bool fast_ok = VEC == 4 && (B_KC || p.N % 4 == 0);
-  auto load_tile = [&]() {  // global -> registers for chunk (seg, kc)
+  auto load_tile = [&](float4 (&ra)[A_F4], float4 (&rb)[B_F4], float &cf_tile) {  // global -> registers for chunk (seg, kc)
     if (fast_ok && kc + BK <= klen) {
       if (ptr_seg != seg) setup_ptrs();
 #pragma unroll
@@ -607,79 +630,82 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(const RowsGemmArgs p,
     }
     cf_tile = cf;
   };
-  auto store_tile = [&](int buf) {  // registers -> LDS
+  auto store_tile = [&](float4 (&ra)[A_F4], float4 (&rb)[B_F4], const float cf_tile, int buf) {  // registers -> LDS
     float *as = As + buf * A_TILE, *bs = Bs + buf * B_TILE;
-    if (p.sumsq) add_ssq();
+    if (p.sumsq) add_ssq(ra, cf_tile);
     if (p.coef) {
 #pragma unroll
       for (int j = 0; j < B_F4; j++) {
         rb[j].x *= cf_tile; rb[j].y *= cf_tile; rb[j].z *= cf_tile; rb[j].w *= cf_tile;
       }
     }
-    __bf16 *ah = reinterpret_cast<__bf16 *>(as), *al = ah + BM * LDH, *bh = reinterpret_cast<__bf16 *>(bs), *bl = bh + BN * LDH;
+    __bf16 *ah = reinterpret_cast<__bf16 *>(as), *bh = reinterpret_cast<__bf16 *>(bs);
 #pragma unroll
     for (int j = 0; j < A_F4; j++) {
       const int idx = t + 256 * j;
       if (BM * BK / 4 % 256 == 0 || idx < BM * BK / 4) {
-        bf16x4 hi, lo;
-        split_bf16(ra[j], hi, lo);
+        bf16x4 pl[NP];
+        split_bf16<NP>(ra[j], pl);
         const int o = (idx / KF4) * LDH + (idx % KF4) * 4;
-        *reinterpret_cast<bf16x4 *>(ah + o) = hi;
-        *reinterpret_cast<bf16x4 *>(al + o) = lo;
+#pragma unroll
+        for (int q = 0; q < NP; q++) *reinterpret_cast<bf16x4 *>(ah + q * BM * LDH + o) = pl[q];
       }
     }
 #pragma unroll
     for (int j = 0; j < B_F4; j++) {
       const int idx = t + 256 * j;
       if (BN * BK / 4 % 256 == 0 || idx < BN * BK / 4) {
-        bf16x4 hi, lo;
-        split_bf16(rb[j], hi, lo);
+        bf16x4 pl[NP];
+        split_bf16<NP>(rb[j], pl);
         const int o = (idx / KF4) * LDH + (idx % KF4) * 4;
-        *reinterpret_cast<bf16x4 *>(bh + o) = hi;
-        *reinterpret_cast<bf16x4 *>(bl + o) = lo;
+#pragma unroll
+        for (int q = 0; q < NP; q++) *reinterpret_cast<bf16x4 *>(bh + q * BN * LDH + o) = pl[q];
       }
     }
   };
   auto compute = [&](int buf) {
-    const __bf16 *ah = reinterpret_cast<const __bf16 *>(As + buf * A_TILE) + (wm * TM * 32 + li) * LDH + lh * 8, *al = ah + BM * LDH;
-    const __bf16 *bh = reinterpret_cast<const __bf16 *>(Bs + buf * B_TILE) + (wn * TN * 32 + li) * LDH + lh * 8, *bl = bh + BN * LDH;
+    const __bf16 *ah = reinterpret_cast<const __bf16 *>(As + buf * A_TILE) + (wm * TM * 32 + li) * LDH + lh * 8;
+    const __bf16 *bh = reinterpret_cast<const __bf16 *>(Bs + buf * B_TILE) + (wn * TN * 32 + li) * LDH + lh * 8;
 #pragma unroll
     for (int c = 0; c < BK / 16; c++) {
-      bf16x8 a_hi[TM], a_lo[TM], b_hi[TN], b_lo[TN];
+      bf16x8 a[NP][TM], b[NP][TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) {
-        a_hi[i] = *reinterpret_cast<const bf16x8 *>(ah + i * 32 * LDH + c * 16);
-        a_lo[i] = *reinterpret_cast<const bf16x8 *>(al + i * 32 * LDH + c * 16);
-      }
+      for (int q = 0; q < NP; q++) {
 #pragma unroll
-      for (int i = 0; i < TN; i++) {
-        b_hi[i] = *reinterpret_cast<const bf16x8 *>(bh + i * 32 * LDH + c * 16);
-        b_lo[i] = *reinterpret_cast<const bf16x8 *>(bl + i * 32 * LDH + c * 16);
+        for (int i = 0; i < TM; i++) a[q][i] = *reinterpret_cast<const bf16x8 *>(ah + q * BM * LDH + i * 32 * LDH + c * 16);
+#pragma unroll
+        for (int i = 0; i < TN; i++) b[q][i] = *reinterpret_cast<const bf16x8 *>(bh + q * BN * LDH + i * 32 * LDH + c * 16);
       }
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) {  // the two cross terms first, the leading term last
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; j++) {
+          // every plane product a_q b_r with q + r < NP, smallest terms first and the leading term last
+#pragma unroll
+          for (int d = NP - 1; d >= 0; d--)
+#pragma unroll
+            for (int q = 0; q <= d; q++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[d - q][j], acc[i][j], 0, 0, 0);
         }
     }
   };
 
+  // One staged K-step beyond the one in LDS.  Measured on MI355X: a deeper register ring (2-4 steps, counted vmcnt waits
+  // in a straight-line steady state) costs 60+ registers -> one block per CU or scratch, and ran 10-20 % slower than this
+  // loop with two blocks per CU covering each other's load latency.
   if (seg < p.nseg) {
-    load_tile();
-    store_tile(0);
+    load_tile(ra[0], rb[0], cf_tile[0]);
+    store_tile(ra[0], rb[0], cf_tile[0], 0);
     __syncthreads();
     int buf = 0;
     while (true) {
       kc += BK;
       if (kc >= klen) next_seg();
       const bool more = seg < p.nseg;
-      if (more) load_tile();  // in flight while the MFMAs run
+      if (more) load_tile(ra[0], rb[0], cf_tile[0]);  // in flight while the MFMAs run
       compute(buf);
       if (!more) break;
-      store_tile(buf ^ 1);
+      store_tile(ra[0], rb[0], cf_tile[0], buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
@@ -763,16 +789,18 @@ __global__ __launch_bounds__(256) void rows_gemm_x3_kernel(const RowsGemmArgs p,
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int TAG>
+template <int WM, int WN, int TM, int TN, int BK, int NP, int TAG>
 void launch_rows_x3_tagged(dim3 grid, const RowsGemmArgs &a, int ntm, int ntn, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t lds = sizeof(__bf16) * 2 * 2 * (size_t)(BM + BN) * (BK + 8);  // double buffer x (hi, lo) planes
+  constexpr int D = 1;  // staged K-steps beyond the one in LDS.  Measured: D = 2 needs > 256 registers (one block per CU, or
+                        // scratch) and runs 20 % slower than D = 1 with two blocks per CU covering each other's load latency
+  constexpr size_t lds = sizeof(__bf16) * 2 * NP * (size_t)(BM + BN) * (BK + 8);  // double buffer x NP planes
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute((const void *)rows_gemm_x3_kernel<WM, WN, TM, TN, BK, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute((const void *)rows_gemm_x3_kernel<WM, WN, TM, TN, BK, NP, D, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((rows_gemm_x3_kernel<WM, WN, TM, TN, BK, TAG>), grid, dim3(256), lds, s, a, ntm, ntn);
+  hipLaunchKernelGGL((rows_gemm_x3_kernel<WM, WN, TM, TN, BK, NP, D, TAG>), grid, dim3(256), lds, s, a, ntm, ntn);
 }
 
 template <int WM, int WN, int TM, int TN, int BK, int TAG>
@@ -807,10 +835,17 @@ void launch_rows_kernel_tagged(dim3 grid, const RowsGemmArgs &a, int ntm, int nt
 // every rows_gemm_kernel launch goes through here
 template <int WM, int WN, int TM, int TN, int BK>
 void launch_rows_kernel(dim3 grid, const RowsGemmArgs &a, int ntm, int ntn, bool b_kc, bool vec, hipStream_t s) {
-  if (a.prec == 1 && b_kc && vec) {  // split-bf16 arithmetic
-    if (g_prof_override == 3) launch_rows_x3_tagged<WM, WN, TM, TN, BK, 1>(grid, a, ntm, ntn, s);
-    else launch_rows_x3_tagged<WM, WN, TM, TN, BK, 0>(grid, a, ntm, ntn, s);
+  if (a.prec == 1 && b_kc && vec) {  // split-bf16 arithmetic, two planes (three products)
+    if (g_prof_override == 3) launch_rows_x3_tagged<WM, WN, TM, TN, BK, 2, 1>(grid, a, ntm, ntn, s);
+    else launch_rows_x3_tagged<WM, WN, TM, TN, BK, 2, 0>(grid, a, ntm, ntn, s);
     return;
+  }
+  if (a.prec == 3 && b_kc && vec) {  // three planes (six products): f32-equivalent
+    if constexpr (BK == 16) {
+      if (g_prof_override == 3) launch_rows_x3_tagged<WM, WN, TM, TN, BK, 3, 1>(grid, a, ntm, ntn, s);
+      else launch_rows_x3_tagged<WM, WN, TM, TN, BK, 3, 0>(grid, a, ntm, ntn, s);
+      return;
+    }
   }
   if (g_prof_override == 3) launch_rows_kernel_tagged<WM, WN, TM, TN, BK, 1>(grid, a, ntm, ntn, b_kc, vec, s);
   else launch_rows_kernel_tagged<WM, WN, TM, TN, BK, 0>(grid, a, ntm, ntn, b_kc, vec, s);
@@ -848,23 +883,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RowsGemmArgs p
 }
 
 template <int WM, int WN, int TM, int TN, int BK>
-int rows_slots(bool b_kc) {  // resident blocks on the chip for this tile variant
+int rows_slots(bool b_kc, int prec) {  // resident blocks on the chip for this tile variant
   // Blocks per CU are MEASURED (tools/residency_probe.py: time of a plain launch steps up when one more tile needs one
   // more round), not queried: hipOccupancyMaxActiveBlocksPerMultiprocessor answers 3 for the 128x160 tile (168
   // registers, 46 KiB LDS) where the steps sit at 513 and 1025 tiles, i.e. 2 per CU (MI355X_MICROARCH.md warns that the
   // query can over-report).  128x128 BK 32: 2 (73.7 KiB LDS); 128x128 BK 16: 3 (41 KiB, 154 registers; steps at 513,
   // 769, 1025); 128x160: 2.
+  // Split-bf16 variants are LDS-bound: 2 planes 128x128 BK 32 80 KiB (2), 128x160 BK 16 54 KiB (2); 3 planes 128x128
+  // BK 16 72 KiB (2), 128x160 BK 16 81 KiB (1).
   (void)b_kc;
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0, cus = 256;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    cus = 256;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    const int per_cu = (WM * TM == 4 && WN * TN == 4 && BK == 16) ? 3 : 2;
-    slots = per_cu * cus;
     (void)hipGetLastError();
   }
-  return slots;
+  int per_cu = (WM * TM == 4 && WN * TN == 4 && BK == 16 && prec == 0) ? 3 : 2;
+  if (prec == 3 && WN * TN == 5) per_cu = 1;
+  return per_cu * cus;
 }
 
 // scratch for split-K partial tiles: allocated once, on first use (64 MiB covers slots x BM x BN floats)
@@ -896,7 +934,7 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
     ProfScope ps(cls, flops, s);
     return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
   }
-  const int tiles = ntm * ntn, slots = rows_slots<WM, WN, TM, TN, BK>(b_kc);
+  const int tiles = ntm * ntn, slots = rows_slots<WM, WN, TM, TN, BK>(b_kc, (b_kc && vec) ? a.prec : 0);
   const int q = tiles / slots, r = tiles % slots;
   long long ktot = 0;
   bool k4 = true;
@@ -1017,7 +1055,7 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     // three blocks per CU cover each other's prologue / epilogue (+6..13 % measured); long reductions keep BK 32
     long long kt = 0;
     for (int i = 0; i < a.nseg; i++) kt += a.seg[i].klen;
-    if (kt <= 512 && a.prec == 0) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
+    if ((kt <= 512 && a.prec == 0) || a.prec == 3) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
   }
   return launch_rows_balanced<2, 2, 2, 2, 32>(a, b_kc, vec, 0, flops, s);
 }
@@ -1201,14 +1239,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, 
 // The weight gradient in split-bf16 arithmetic (see rows_gemm_x3_kernel).  Both operands are reduced over rows, so a
 // fragment needs 8 consecutive ROWS of one column: every thread loads one column of 8 rows (dword loads, consecutive
 // lanes on consecutive columns: coalesced), splits it and writes one 16-byte [column][k] piece per plane.
-template <int WM, int WN, int TM, int TN, int TAG = 0>
-__global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs p, int ntm, int ntn_tap, int rows_per_split, float *partial) {
-  constexpr int BK = 32, LDH = BK + 8;
+template <int WM, int WN, int TM, int TN, int NP, int D, int TAG = 0>
+__global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradArgs p, int ntm, int ntn_tap, int rows_per_split, float *partial) {
+  constexpr int BK = NP == 2 ? 32 : 16, LDH = BK + 8;  // three planes: half the K-step, the same LDS budget
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_IT = (BM * BK / 8 + 255) / 256, B_IT = (BN * BK / 8 + 255) / 256;  // (column, 8-row group) items per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16 *As = reinterpret_cast<__bf16 *>(smem);       // [2 buffers][hi, lo][BM][LDH]
-  __bf16 *Bs = As + 2 * 2 * BM * LDH;                  // [2 buffers][hi, lo][BN][LDH]
+  __bf16 *As = reinterpret_cast<__bf16 *>(smem);       // [2 buffers][NP planes][BM][LDH]
+  __bf16 *Bs = As + 2 * NP * BM * LDH;                 // [2 buffers][NP planes][BN][LDH]
 
   int bid = blockIdx.x;
   const int tile_m = bid % ntm;
@@ -1237,7 +1275,7 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs p, int nt
   const float *Xb = p.X + (long long)p.row_offsets[tap] * p.ldx;
   const long long xrow = (long long)p.row_stride * p.ldx;
 
-  float ra[A_IT][8], rb[B_IT][8];
+  float ra[D][A_IT][8], rb[D][B_IT][8];  // D staged K-steps (see rows_gemm_x3_kernel)
   // per-item source: column pointer at row 0 of the item's 8-row group; an out-of-range column reads zeros (step 0)
   const float *aptr[A_IT], *bptr[B_IT];
   long long astep[A_IT], bstep[B_IT];
@@ -1261,22 +1299,22 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs p, int nt
       bstep[j] = v ? xrow : 0;
     }
   }
-  auto load_tile = [&](int r0) {
-    if (r0 + BK <= r_end) {  // whole K-step inside the split: unconditional loads (a branch-free steady state)
+  // whole K-step inside the split: unconditional loads (a branch-free steady state, see rows_gemm_x3_kernel)
+  auto load_fast = [&](float (&ra)[A_IT][8], float (&rb)[B_IT][8], int r0) {
 #pragma unroll
-      for (int j = 0; j < A_IT; j++) {
-        const float *q = aptr[j] + (long long)r0 * astep[j];
+    for (int j = 0; j < A_IT; j++) {
+      const float *q = aptr[j] + (long long)r0 * astep[j];
 #pragma unroll
-        for (int i = 0; i < 8; i++) ra[j][i] = q[(long long)i * astep[j]];
-      }
-#pragma unroll
-      for (int j = 0; j < B_IT; j++) {
-        const float *q = bptr[j] + (long long)r0 * bstep[j];
-#pragma unroll
-        for (int i = 0; i < 8; i++) rb[j][i] = q[(long long)i * bstep[j]];
-      }
-      return;
+      for (int i = 0; i < 8; i++) ra[j][i] = q[(long long)i * astep[j]];
     }
+#pragma unroll
+    for (int j = 0; j < B_IT; j++) {
+      const float *q = bptr[j] + (long long)r0 * bstep[j];
+#pragma unroll
+      for (int i = 0; i < 8; i++) rb[j][i] = q[(long long)i * bstep[j]];
+    }
+  };
+  auto load_ragged = [&](float (&ra)[A_IT][8], float (&rb)[B_IT][8], int r0) {  // the split's last, partial K-step
 #pragma unroll
     for (int j = 0; j < A_IT; j++) {
       const float *q = aptr[j] + (long long)r0 * astep[j];
@@ -1290,62 +1328,65 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs p, int nt
       for (int i = 0; i < 8; i++) rb[j][i] = r0 + bkg[j] * 8 + i < r_end ? q[(long long)i * bstep[j]] : 0.f;
     }
   };
-  auto split8 = [](const float *x, bf16x8 &hi, bf16x8 &lo) {
+  auto split8 = [](const float *x, bf16x8 (&pl)[NP]) {
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      const __bf16 h = (__bf16)x[i];
-      hi[i] = h;
-      lo[i] = (__bf16)(x[i] - (float)h);
+      float r = x[i];
+#pragma unroll
+      for (int q = 0; q < NP; q++) {
+        const __bf16 h = (__bf16)r;
+        pl[q][i] = h;
+        r -= (float)h;
+      }
     }
   };
-  auto store_tile = [&](int buf) {
-    __bf16 *ah = As + buf * 2 * BM * LDH, *al = ah + BM * LDH, *bh = Bs + buf * 2 * BN * LDH, *bl = bh + BN * LDH;
+  auto store_tile = [&](const float (&ra)[A_IT][8], const float (&rb)[B_IT][8], int buf) {
+    __bf16 *ah = As + buf * NP * BM * LDH, *bh = Bs + buf * NP * BN * LDH;
 #pragma unroll
     for (int j = 0; j < A_IT; j++) {
       const int item = t + 256 * j;
       if (BM * BK / 8 % 256 == 0 || item < BM * BK / 8) {
-        bf16x8 hi, lo;
-        split8(ra[j], hi, lo);
+        bf16x8 pl[NP];
+        split8(ra[j], pl);
         const int o = (item % BM) * LDH + (item / BM) * 8;
-        *reinterpret_cast<bf16x8 *>(ah + o) = hi;
-        *reinterpret_cast<bf16x8 *>(al + o) = lo;
+#pragma unroll
+        for (int q = 0; q < NP; q++) *reinterpret_cast<bf16x8 *>(ah + q * BM * LDH + o) = pl[q];
       }
     }
 #pragma unroll
     for (int j = 0; j < B_IT; j++) {
       const int item = t + 256 * j;
       if (BN * BK / 8 % 256 == 0 || item < BN * BK / 8) {
-        bf16x8 hi, lo;
-        split8(rb[j], hi, lo);
+        bf16x8 pl[NP];
+        split8(rb[j], pl);
         const int o = (item % BN) * LDH + (item / BN) * 8;
-        *reinterpret_cast<bf16x8 *>(bh + o) = hi;
-        *reinterpret_cast<bf16x8 *>(bl + o) = lo;
+#pragma unroll
+        for (int q = 0; q < NP; q++) *reinterpret_cast<bf16x8 *>(bh + q * BN * LDH + o) = pl[q];
       }
     }
   };
   auto compute = [&](int buf) {
-    const __bf16 *ah = As + buf * 2 * BM * LDH + (wm * TM * 32 + li) * LDH + lh * 8, *al = ah + BM * LDH;
-    const __bf16 *bh = Bs + buf * 2 * BN * LDH + (wn * TN * 32 + li) * LDH + lh * 8, *bl = bh + BN * LDH;
+    const __bf16 *ah = As + buf * NP * BM * LDH + (wm * TM * 32 + li) * LDH + lh * 8;
+    const __bf16 *bh = Bs + buf * NP * BN * LDH + (wn * TN * 32 + li) * LDH + lh * 8;
 #pragma unroll
     for (int c = 0; c < BK / 16; c++) {
-      bf16x8 a_hi[TM], a_lo[TM], b_hi[TN], b_lo[TN];
+      bf16x8 a[NP][TM], b[NP][TN];
 #pragma unroll
-      for (int i = 0; i < TM; i++) {
-        a_hi[i] = *reinterpret_cast<const bf16x8 *>(ah + i * 32 * LDH + c * 16);
-        a_lo[i] = *reinterpret_cast<const bf16x8 *>(al + i * 32 * LDH + c * 16);
-      }
+      for (int q = 0; q < NP; q++) {
 #pragma unroll
-      for (int i = 0; i < TN; i++) {
-        b_hi[i] = *reinterpret_cast<const bf16x8 *>(bh + i * 32 * LDH + c * 16);
-        b_lo[i] = *reinterpret_cast<const bf16x8 *>(bl + i * 32 * LDH + c * 16);
+        for (int i = 0; i < TM; i++) a[q][i] = *reinterpret_cast<const bf16x8 *>(ah + q * BM * LDH + i * 32 * LDH + c * 16);
+#pragma unroll
+        for (int i = 0; i < TN; i++) b[q][i] = *reinterpret_cast<const bf16x8 *>(bh + q * BN * LDH + i * 32 * LDH + c * 16);
       }
 #pragma unroll
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_lo[i], b_hi[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_lo[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_hi[i], b_hi[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int d = NP - 1; d >= 0; d--)
+#pragma unroll
+            for (int q = 0; q <= d; q++)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[d - q][j], acc[i][j], 0, 0, 0);
         }
     }
   };
@@ -1359,19 +1400,74 @@ __global__ __launch_bounds__(256) void wgrad_x3_kernel(const WgradArgs p, int nt
     }
     return;
   }
-  load_tile(r_begin);
-  store_tile(0);
-  __syncthreads();
   {
+    bool have[D];
+    int rnext = r_begin;  // first row of the next K-step to stage
     int buf = 0;
-    for (int r0 = r_begin;; r0 += BK) {
-      const bool more = r0 + BK < r_end;
-      if (more) load_tile(r0 + BK);
-      compute(buf);
-      if (!more) break;
-      store_tile(buf ^ 1);
+    static_for<D>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      have[u] = rnext + BK <= r_end;
+      if (have[u]) {
+        load_fast(ra[u], rb[u], rnext);
+        rnext += BK;
+      }
+    });
+    if (have[0]) {
+      store_tile(ra[0], rb[0], 0);
       __syncthreads();
-      buf ^= 1;
+      if (have[D - 1]) {
+        // steady state: LDS buffer `buf` holds the step staged in slot u, slots u+1 .. u+D-1 the next D - 1 steps
+        bool run = true;
+        while (run) {
+          static_for<D>([&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            if (!run) return;
+            if (rnext + BK > r_end) {  // no full step left to stage: drain
+              static_for<D - 1>([&](auto jc) {
+                constexpr int nx = (u + 1 + decltype(jc)::value) % D;
+                compute(buf);
+                store_tile(ra[nx], rb[nx], buf ^ 1);
+                __syncthreads();
+                buf ^= 1;
+              });
+              compute(buf);
+              run = false;
+              return;
+            }
+            load_fast(ra[u], rb[u], rnext);
+            rnext += BK;
+            compute(buf);
+            constexpr int nx = (u + 1) % D;
+            store_tile(ra[nx], rb[nx], buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+          });
+        }
+      } else {  // fewer than D full steps
+        bool run = true;
+        static_for<D>([&](auto uc) {
+          constexpr int u = decltype(uc)::value;
+          if (!run) return;
+          compute(buf);
+          if constexpr (u + 1 >= D) {
+            run = false;
+          } else {
+            if (!have[u + 1]) {
+              run = false;
+              return;
+            }
+            store_tile(ra[u + 1], rb[u + 1], buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+          }
+        });
+      }
+    }
+    if (rnext < r_end) {  // ragged end; buffer buf ^ 1 is free (last read before the last barrier)
+      load_ragged(ra[0], rb[0], rnext);
+      store_tile(ra[0], rb[0], buf ^ 1);
+      __syncthreads();
+      compute(buf ^ 1);
     }
   }
 #pragma unroll
@@ -1533,7 +1629,13 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   if (a.N <= 0 || a.Do <= 0 || a.Di <= 0) return hipSuccess;
   if (workspace_bytes < wgrad_workspace_bytes(a.Do, a.Di, a.K, a.N)) return hipErrorInvalidValue;
   static const int force_prec = getenv("TDNNF_GEMM_PREC") ? atoi(getenv("TDNNF_GEMM_PREC")) : 0;
-  const bool use_x3 = a.prec == 1 || (a.prec == 0 && (g_gemm_prec == 1 || force_prec == 1));
+  int planes = 0;  // 0: f32 MFMA; 2 / 3: split-bf16 with that many planes per operand
+  {
+    int prec = a.prec;
+    if (prec == 0) prec = force_prec ? force_prec : g_gemm_prec;
+    planes = prec == 1 ? 2 : prec == 3 ? 3 : 0;
+  }
+  const bool use_x3 = planes != 0;
   const WgradTile wt = wgrad_tile(a.Do, a.Di, use_x3);
   const int ktaps = a.active && a.max_active > 0 && a.max_active < a.K ? a.max_active : a.K;
   WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant), ktaps == a.K ? 0 : ktaps, use_x3);
@@ -1558,27 +1660,35 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
     if (vec) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 4, TAG>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial); \
     else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 1, TAG>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);     \
   }
-#define WG_LAUNCH_X3(WM, WN, TM, TN, TAG)                                                                                      \
+#define WG_LAUNCH_X3(WM, WN, TM, TN, NP, TAG)                                                                                  \
   {                                                                                                                             \
-    constexpr size_t lds3 = sizeof(__bf16) * 2 * 2 * (size_t)(WM * TM * 32 + WN * TN * 32) * 40;                                \
+    constexpr size_t lds3 = sizeof(__bf16) * 2 * NP * (size_t)(WM * TM * 32 + WN * TN * 32) * (NP == 2 ? 40 : 24);              \
     static bool attr_done3 = false;                                                                                             \
     if (!attr_done3) {                                                                                                          \
-      hipFuncSetAttribute((const void *)wgrad_x3_kernel<WM, WN, TM, TN, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
+      hipFuncSetAttribute((const void *)wgrad_x3_kernel<WM, WN, TM, TN, NP, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3); \
       attr_done3 = true;                                                                                                        \
     }                                                                                                                           \
-    hipLaunchKernelGGL((wgrad_x3_kernel<WM, WN, TM, TN, TAG>), grid, block, lds3, s, a, ntm, ntn, pl.rows_per_split, partial);  \
+    hipLaunchKernelGGL((wgrad_x3_kernel<WM, WN, TM, TN, NP, 1, TAG>), grid, block, lds3, s, a, ntm, ntn, pl.rows_per_split, partial);  \
   }
 #define WG_LAUNCH(WM, WN, TM, TN)                                  \
-  if (use_x3) {                                                    \
-    if (g_prof_override == 3) WG_LAUNCH_X3(WM, WN, TM, TN, 1)      \
-    else WG_LAUNCH_X3(WM, WN, TM, TN, 0)                           \
+  if (planes == 2) {                                               \
+    if (g_prof_override == 3) WG_LAUNCH_X3(WM, WN, TM, TN, 2, 1)   \
+    else WG_LAUNCH_X3(WM, WN, TM, TN, 2, 0)                        \
+  } else if (planes == 3) {                                        \
+    if (g_prof_override == 3) WG_LAUNCH_X3(WM, WN, TM, TN, 3, 1)   \
+    else WG_LAUNCH_X3(WM, WN, TM, TN, 3, 0)                        \
   } else if (g_prof_override == 3) WG_LAUNCH_T(WM, WN, TM, TN, 1)  \
   else WG_LAUNCH_T(WM, WN, TM, TN, 0)
-    if (wt.variant == 1) { WG_LAUNCH(1, 4, 5, 1) }
-    else if (wt.variant == 2) { WG_LAUNCH(4, 1, 1, 5) }
+#define WG_LAUNCH_F32(WM, WN, TM, TN)                              \
+  if (g_prof_override == 3) WG_LAUNCH_T(WM, WN, TM, TN, 1)         \
+  else WG_LAUNCH_T(WM, WN, TM, TN, 0)
+    // (wgrad_tile() gives the split-bf16 arithmetic the 128x128 and 32x128 tiles only: the 160-wide ones need 92 KiB of LDS)
+    if (wt.variant == 1) { WG_LAUNCH_F32(1, 4, 5, 1) }
+    else if (wt.variant == 2) { WG_LAUNCH_F32(4, 1, 1, 5) }
     else if (wt.variant == 3) { WG_LAUNCH(1, 4, 1, 1) }
     else { WG_LAUNCH(2, 2, 2, 2) }
 #undef WG_LAUNCH_T
+#undef WG_LAUNCH_F32
 #undef WG_LAUNCH_X3
 #undef WG_LAUNCH
   }

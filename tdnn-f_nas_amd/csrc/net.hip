@@ -379,7 +379,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
-  n->paramsT = n->cfg.gemm_precision == 1 ? A.take<float>((size_t)n->num_params + 16) : nullptr;
+  n->paramsT = n->cfg.gemm_precision != 0 ? A.take<float>((size_t)n->num_params + 16) : nullptr;
   n->ngBias = nullptr;
   n->s3_scratch = nullptr;
   n->s3_scratch_bytes = 0;
@@ -557,7 +557,7 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     for (int l = 0; l < c.num_layers; l++)
       TDNNF_REQUIRE(c.bottleneck_dim[l] == sum, "net_create: bottleneck_dim[%d] = %d but the choice blocks sum to %d", l, c.bottleneck_dim[l], sum);
   }
-  TDNNF_REQUIRE(c.gemm_precision == 0 || c.gemm_precision == 1, "net_create: gemm_precision must be 0 (f32) or 1 (split-bf16)");
+  TDNNF_REQUIRE(c.gemm_precision >= 0 && c.gemm_precision <= 2, "net_create: gemm_precision must be 0 (f32), 1 (split-bf16, 3 products) or 2 (split-bf16, 6 products)");
   TDNNF_REQUIRE(c.darts_num_offsets == 0 || !(c.darts_flags & TDNNF_DARTS_USE_GUMBEL) || c.darts_temp_proportion > 0,
                 "net_create: gumbel mode needs temp-proportion > 0");
   TDNNF_REQUIRE(c.frame_subsampling >= 1 && c.frames_per_chunk > 0 && c.frames_per_chunk % c.frame_subsampling == 0 && c.num_sequences > 0,
@@ -931,7 +931,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
-  GemmPrecisionScope gemm_arith(c.gemm_precision);
+  GemmPrecisionScope gemm_arith(c.gemm_precision == 2 ? 3 : c.gemm_precision);  // scope values: 1 two planes, 3 three planes
   TransposedWeightsScope gemm_wt(n->params, n->paramsT, n->paramsT ? n->num_params : 0);
   if (n->paramsT) {  // split-bf16 backward-data GEMMs read W^T (k-contiguous B operand)
     TransTable tb;

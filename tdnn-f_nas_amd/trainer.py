@@ -39,7 +39,7 @@ STRIDES_MANUAL_OFFSET6 = [1, 1, 1, 0] + [6] * 10   # run_tdnn_7q_fbk_40_manual.s
 # candidate bottleneck dims 25, 50, 80, 100, 120, 160, 200, 240
 BN_CHOICE_DIMS = [25, 25, 30, 20, 20, 40, 40, 40]
 BN_ONEHOT, BN_SOFTMAX_FLOPS, BN_GUMBEL_SOFTMAX_FLOPS = 0, 1, 2
-GEMM_F32, GEMM_BF16X3 = 0, 1
+GEMM_F32, GEMM_BF16X3, GEMM_BF16X6 = 0, 1, 2
 
 
 def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck=160, feat_dim=40, ivector_dim=100,
@@ -76,7 +76,7 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
         c.bn_flops_scale = float(kw.get("bn_flops_scale", 0.0))
         c.bn_temp_proportion = float(kw.get("bn_temp_proportion", 1.0))
     c.cv_update = int(kw.get("cv_update", 0))
-    c.gemm_precision = int(kw.get("gemm_precision", 0))  # 0 exact f32 MFMA, 1 split-bf16 (GEMM_F32 / GEMM_BF16X3)
+    c.gemm_precision = int(kw.get("gemm_precision", 0))  # GEMM_F32 exact f32 MFMA, GEMM_BF16X3 / GEMM_BF16X6 split-bf16
     return c
 
 
