@@ -328,6 +328,13 @@ typedef struct {
      2: the same with three bf16 planes per operand and the six products a_i b_j, i + j <= 2 (24 mantissa bits per
      operand, products to ~2^-24 relative: f32-equivalent results from the bf16 matrix cores). */
   int gemm_precision;
+  /* Derived child networks (local/chain_NAS/scripts/generate_top_list.py:97-141, generate_optimal_stride.py): when
+     use_layer_offsets != 0, layer l's X.linear has time-offsets {-offset_left[l], 0} and its X.affine {0, offset_right[l]}
+     (a single tap where the offset is 0) instead of the symmetric time_stride[l]; any values in 0..64.  Ignored by the
+     offset supernet (darts_num_offsets >= 2). */
+  int use_layer_offsets;
+  int offset_left[TDNNF_NET_MAX_LAYERS];
+  int offset_right[TDNNF_NET_MAX_LAYERS];
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 

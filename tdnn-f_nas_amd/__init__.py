@@ -8,3 +8,4 @@ host mirror of the nnet3 components and the chain trainer step)."""
 from . import synth  # noqa: F401
 from . import hipabi  # noqa: F401
 from . import trainer  # noqa: F401
+from . import derive  # noqa: F401

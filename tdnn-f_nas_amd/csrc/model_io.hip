@@ -1098,16 +1098,18 @@ int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_
   for (auto &np : mf.comps)
     if (np.second.type == "BatchNormTestComponent") cfg->cv_update = 1;
   int L = 0;
+  int left[TDNNF_NET_MAX_LAYERS] = {0}, right[TDNNF_NET_MAX_LAYERS] = {0};
   for (;; L++) {
     const std::string p = layer_name(L);
     const Parsed *lin = need(p + ".linear"), *aff = need(p + ".affine");
     if (!lin || !aff) break;
     TDNNF_REQUIRE(L < TDNNF_NET_MAX_LAYERS, "net_config_from_model: %s: too many tdnnf layers", path);
-    const int K = (int)lin->offsets.size();
-    TDNNF_REQUIRE(K >= 1 && (int)aff->offsets.size() == K && lin->cols == K * cfg->hidden_dim && aff->rows == cfg->hidden_dim && aff->cols == K * lin->rows,
+    const int K = (int)lin->offsets.size(), Ka = (int)aff->offsets.size();
+    TDNNF_REQUIRE(K >= 1 && Ka >= 1 && lin->cols == K * cfg->hidden_dim && aff->rows == cfg->hidden_dim && aff->cols == Ka * lin->rows,
                   "net_config_from_model: %s: %s has inconsistent dimensions", path, p.c_str());
     cfg->bottleneck_dim[L] = lin->rows;
     if (lin->type == "TdnnDARTSV3Component") {
+      TDNNF_REQUIRE(Ka == K, "net_config_from_model: %s: %s.linear / .affine have different numbers of taps", path, p.c_str());
       TDNNF_REQUIRE(cfg->darts_num_offsets == 0 || cfg->darts_num_offsets == K, "net_config_from_model: %s: layers with different numbers of taps", path);
       cfg->darts_num_offsets = K;
       cfg->darts_flags = (num(lin, "<use-gumbel>", 0) ? TDNNF_DARTS_USE_GUMBEL : 0) | (num(lin, "<free-select>", 0) ? TDNNF_DARTS_FREE_SELECT : 0) |
@@ -1116,10 +1118,17 @@ int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_
       cfg->darts_temp_proportion = (float)num(lin, "<Temp-Proportion>", 1.0);
       cfg->time_stride[L] = 1;
     } else {
-      TDNNF_REQUIRE(K <= 2, "net_config_from_model: %s: %s.linear has %d taps (plain tdnnf layers have 1 or 2)", path, p.c_str(), K);
-      cfg->time_stride[L] = K == 1 ? 0 : -lin->offsets[0];
-      TDNNF_REQUIRE(K == 1 || (lin->offsets[1] == 0 && aff->offsets[0] == 0 && aff->offsets[1] == -lin->offsets[0] && lin->offsets[0] < 0),
-                    "net_config_from_model: %s: %s time offsets are not {-s,0} / {0,s}", path, p.c_str());
+      // plain layer: X.linear {-a, 0} or {0}, X.affine {0, b} or {0}; a == b is the recipes' time-stride, anything else a
+      // derived child (generate_top_list.py:97-141)
+      TDNNF_REQUIRE(K <= 2 && Ka <= 2, "net_config_from_model: %s: %s has %d / %d taps (plain tdnnf layers have 1 or 2)", path, p.c_str(), K, Ka);
+      TDNNF_REQUIRE((K == 1 ? lin->offsets[0] == 0 : (lin->offsets[0] < 0 && lin->offsets[1] == 0)) &&
+                        (Ka == 1 ? aff->offsets[0] == 0 : (aff->offsets[0] == 0 && aff->offsets[1] > 0)),
+                    "net_config_from_model: %s: %s time offsets are not {-a,0} / {0,b}", path, p.c_str());
+      const int a = K == 1 ? 0 : -lin->offsets[0], b = Ka == 1 ? 0 : aff->offsets[1];
+      left[L] = a;
+      right[L] = b;
+      cfg->time_stride[L] = a > b ? a : b;
+      if (a != b) cfg->use_layer_offsets = 1;
     }
     if (L == 0) {
       cfg->l2_hidden = (float)num(lin, "<L2Regularize>", 0.0);
@@ -1145,6 +1154,11 @@ int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_
   }
   TDNNF_REQUIRE(L >= 1, "net_config_from_model: %s has no tdnnf2.linear / tdnnf2.affine", path);
   cfg->num_layers = L;
+  if (cfg->use_layer_offsets)
+    for (int l = 0; l < L; l++) {
+      cfg->offset_left[l] = left[l];
+      cfg->offset_right[l] = right[l];
+    }
   // natural gradient: every updatable component of these graphs is a natural-gradient one
   cfg->use_natural_gradient = 1;
   return TDNNF_OK;

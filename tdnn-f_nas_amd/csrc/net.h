@@ -42,6 +42,7 @@ struct Tdnn {  // one TdnnComponent instance inside the net
 
 struct TdnnfLayer {
   int stride, bn;
+  int left, right;  // X.linear taps {-left, 0}, X.affine taps {0, right} (= stride unless the config gives layer offsets)
   Tdnn lin, aff;
   Grid gin, gout, glin;
   bool perm;  // affine input needs the rho row order

@@ -577,8 +577,11 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
   for (int l = c.num_layers - 1; l >= 0; l--) {
     TdnnfLayer &L = n->layers[l];
     L.stride = c.time_stride[l];
+    L.left = c.use_layer_offsets ? c.offset_left[l] : L.stride;
+    L.right = c.use_layer_offsets ? c.offset_right[l] : L.stride;
     L.bn = c.bottleneck_dim[l];
-    TDNNF_REQUIRE(L.bn > 0 && L.bn <= 512 && L.stride >= 0, "net_create: layer %d: bottleneck-dim must be in 1..512, time-stride >= 0", l);
+    TDNNF_REQUIRE(L.bn > 0 && L.bn <= 512 && L.left >= 0 && L.right >= 0 && L.left <= 64 && L.right <= 64,
+                  "net_create: layer %d: bottleneck-dim must be in 1..512, time-stride / layer offsets in 0..64", l);
     L.gout = g;
     L.perm = false;
     Grid lin = g, in = g;
@@ -594,17 +597,29 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
         L.perm = true;
       }
       in = Grid{lin.t0 - (Kd - 1), 1, lin.n + Kd - 1};
-    } else if (L.stride > 0) {
-      const int s = L.stride;
-      if (s % g.step == 0) {
-        lin = Grid{g.t0, g.step, g.n + s / g.step};
+    } else if (L.left > 0 || L.right > 0) {
+      // X.linear taps {-a, 0}, X.affine taps {0, b} (time-stride s: a = b = s; a derived child: any a, b >= 0).  The
+      // linear runs on the coarsest regular grid that holds every frame the affine needs and whose own taps stay on the
+      // input grid: step gcd(output step, a, b).  When that is finer than the output grid the affine has row_stride
+      // rho > 1 and the grid is padded to a multiple of rho (nnet-tdnn-component.cc:841-843).
+      const int a = L.left, b = L.right;
+      auto gcd = [](int x, int y) {
+        while (y) {
+          const int t = x % y;
+          x = y;
+          y = t;
+        }
+        return x;
+      };
+      const int ls = gcd(gcd(g.step, a), b);
+      if (ls == g.step) {
+        lin = Grid{g.t0, g.step, g.n + b / g.step};
       } else {
-        TDNNF_REQUIRE(g.step % s == 0 && s < g.step, "net_create: layer %d: time-stride %d does not fit output step %d", l, s, g.step);
-        lin = Grid{g.t0, s, (g.step / s) * g.n};  // padded to a multiple of rho (nnet-tdnn-component.cc:841-843)
+        const int rho = g.step / ls, cnt = ((g.n - 1) * g.step + b) / ls + 1;
+        lin = Grid{g.t0, ls, ((cnt + rho - 1) / rho) * rho};
         L.perm = true;
       }
-      TDNNF_REQUIRE(s % lin.step == 0, "net_create: layer %d: unsupported stride combination", l);
-      in = Grid{lin.t0 - s, lin.step, lin.n + s / lin.step};
+      in = Grid{lin.t0 - a, ls, lin.n + a / ls};
     }
     L.glin = lin;
     L.gin = in;
@@ -623,20 +638,18 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     TdnnfLayer &L = n->layers[l];
     const int Kd = c.darts_num_offsets;
     const bool darts = Kd >= 2;
-    const int K = darts ? Kd : (L.stride > 0 ? 2 : 1);
+    const int K = darts ? Kd : 0;  // taps of a searched component
     std::vector<int> lin_off, aff_off;
     if (darts) {
       for (int i = 0; i < K; i++) {
         lin_off.push_back(-(K - 1) + i);
         aff_off.push_back(i);
       }
-    } else if (K == 2) {
-      lin_off = {-L.stride, 0};
-      aff_off = {0, L.stride};
-    } else {
-      lin_off = {0};
-      aff_off = {0};
+    } else {  // a zero offset leaves a single tap ("time-offsets=0", composite_layers.py:145-150, generate_top_list.py:109-118)
+      lin_off = L.left > 0 ? std::vector<int>{-L.left, 0} : std::vector<int>{0};
+      aff_off = L.right > 0 ? std::vector<int>{0, L.right} : std::vector<int>{0};
     }
+    const int Kl = (int)lin_off.size(), Ka = (int)aff_off.size();
     char nm[64];
     L.c_arch = -1;
     L.arch_draw0 = 0;
@@ -652,9 +665,9 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     snprintf(nm, sizeof(nm), "tdnnf%d.linear", l + 2);
     // DARTS: bias forced on (scripts/generate_config.py:25-26), K logits in front of it, and the orthonormal
     // constraint is inert because ConstrainOrthonormal does not match TdnnDARTSV3Component (nnet-utils.cc:1047-1061)
-    const int cl = add_comp(n, nm, L.bn, K * Hd, darts ? 1 : 0, 1.f, c.l2_hidden, c.max_change_hidden, darts ? 0.f : -1.0f, darts ? K : 0);
+    const int cl = add_comp(n, nm, L.bn, Kl * Hd, darts ? 1 : 0, 1.f, c.l2_hidden, c.max_change_hidden, darts ? 0.f : -1.0f, darts ? K : 0);
     snprintf(nm, sizeof(nm), "tdnnf%d.affine", l + 2);
-    const int ca = add_comp(n, nm, Hd, K * L.bn, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f, darts ? K : 0);
+    const int ca = add_comp(n, nm, Hd, Ka * L.bn, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f, darts ? K : 0);
     make_tdnn(&L.lin, cl, Hd, L.bn, lin_off, L.gin, L.glin, B);
     make_tdnn(&L.aff, ca, L.bn, Hd, aff_off, L.glin, L.gout, B);
     if (darts) {

@@ -27,7 +27,8 @@ class NetConfig(C.Structure):
                 ("darts_num_offsets", C.c_int), ("darts_flags", C.c_int), ("darts_temp_proportion", C.c_float),
                 ("use_natural_gradient", C.c_int),
                 ("bn_num_choices", C.c_int), ("bn_choice_dims", C.c_int * 8), ("bn_mode", C.c_int),
-                ("bn_flops_scale", C.c_float), ("bn_temp_proportion", C.c_float), ("cv_update", C.c_int), ("gemm_precision", C.c_int)]
+                ("bn_flops_scale", C.c_float), ("bn_temp_proportion", C.c_float), ("cv_update", C.c_int), ("gemm_precision", C.c_int),
+                ("use_layer_offsets", C.c_int), ("offset_left", C.c_int * MAX_LAYERS), ("offset_right", C.c_int * MAX_LAYERS)]
 
 DARTS_USE_GUMBEL, DARTS_FREE_SELECT, DARTS_UNIFORM_SAMPLE, DARTS_USE_ENTROPY, DARTS_UPDATE_ALPHA = 1, 2, 4, 8, 16
 
@@ -44,6 +45,10 @@ GEMM_F32, GEMM_BF16X3, GEMM_BF16X6 = 0, 1, 2
 
 def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck=160, feat_dim=40, ivector_dim=100,
                 num_pdfs=6034, hidden_dim=1536, small_dim=256, **kw):
+    # layer_offsets = [(a, b)] per layer: a derived child (derive.child_config_kwargs): X.linear taps {-a, 0}, X.affine {0, b}
+    layer_offsets = kw.get("layer_offsets")
+    if layer_offsets is not None and strides is None:
+        strides = [max(a, b) for a, b in layer_offsets]
     strides = list(STRIDES_7Q if strides is None else strides)
     bns = bottleneck if isinstance(bottleneck, (list, tuple)) else [bottleneck] * len(strides)
     c = NetConfig()
@@ -75,6 +80,11 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
         c.bn_mode = int(kw.get("bn_mode", BN_ONEHOT))
         c.bn_flops_scale = float(kw.get("bn_flops_scale", 0.0))
         c.bn_temp_proportion = float(kw.get("bn_temp_proportion", 1.0))
+    if layer_offsets is not None:
+        assert len(layer_offsets) == len(strides)
+        c.use_layer_offsets = 1
+        for i, (a, b) in enumerate(layer_offsets):
+            c.offset_left[i], c.offset_right[i] = int(a), int(b)
     c.cv_update = int(kw.get("cv_update", 0))
     c.gemm_precision = int(kw.get("gemm_precision", 0))  # GEMM_F32 exact f32 MFMA, GEMM_BF16X3 / GEMM_BF16X6 split-bf16
     return c

@@ -3,6 +3,7 @@ component restatements (oracle/*.c) -- test infrastructure.  It re-derives every
 and row indexes on its own (tdnn-f_nas_amd/synth.tdnn_indexes restates PrecomputeIndexes), so it also
 cross-checks the C++ trainer's bookkeeping.  Graph: run_tdnn_fbk_40_iv_sp_7q.sh:160-186."""
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -30,6 +31,10 @@ class OracleNet:
         self.sub = cfg.frame_subsampling
         self.Tout = self.T // self.sub
         strides = [cfg.time_stride[i] for i in range(cfg.num_layers)]
+        if getattr(cfg, "use_layer_offsets", 0):  # derived child: X.linear {-a, 0}, X.affine {0, b}
+            strides = [(cfg.offset_left[i], cfg.offset_right[i]) for i in range(cfg.num_layers)]
+        else:
+            strides = [(v, v) for v in strides]
         self.bn = [cfg.bottleneck_dim[i] for i in range(cfg.num_layers)]
         # grids (t0, step, n), derived backwards from the output grid (0, sub, Tout)
         g = (0, self.sub, self.Tout)
@@ -47,14 +52,21 @@ class OracleNet:
                     lin = (out[0], 1, -(-cnt // rho) * rho)
                 inn = (lin[0] - (K - 1), 1, lin[2] + K - 1)
                 s = None
-            elif s == 0:
+            elif s == (0, 0):
                 lin = inn = out
             else:
-                if s % out[1] == 0:
-                    lin = (out[0], out[1], out[2] + s // out[1])
+                # the linear's grid: the coarsest regular one holding every frame the affine asks for, on which the
+                # linear's own taps stay regular too -> step gcd(out step, a, b); finer than the output grid = rho > 1,
+                # padded to a multiple of rho (nnet-tdnn-component.cc:841-843)
+                a, b = s
+                ls = math.gcd(math.gcd(out[1], a), b)
+                if ls == out[1]:
+                    lin = (out[0], out[1], out[2] + b // out[1])
                 else:
-                    lin = (out[0], s, (out[1] // s) * out[2])  # padded, needs the rho row order
-                inn = (lin[0] - s, lin[1], lin[2] + s // lin[1])
+                    rho = out[1] // ls
+                    cnt = ((out[2] - 1) * out[1] + b) // ls + 1
+                    lin = (out[0], ls, -(-cnt // rho) * rho)  # needs the rho row order
+                inn = (lin[0] - a, ls, lin[2] + a // ls)
             self.layers.append(dict(stride=s, out=out, lin=lin, inn=inn))
             g = inn
         self.layers.reverse()
@@ -331,7 +343,8 @@ class OracleNet:
                 ca, ea = self._darts_coef(self.alpha(p, nm + ".affine"), draws[d0 + K + 1:d0 + 2 * K + 2], 0)
                 dl, da = dict(coef=cl, eff=el, share=K - 1), dict(coef=ca, eff=ea, share=0)
             else:
-                lin_off, aff_off = ([-s, 0], [0, s]) if s > 0 else ([0], [0])
+                lin_off = [-s[0], 0] if s[0] > 0 else [0]
+                aff_off = [0, s[1]] if s[1] > 0 else [0]
             lin = self._tdnn_fwd(prev, Wlin, None, lin_off, Ly["inn"], Ly["lin"], eff=dl["eff"] if dl else None)
             rho = Ly["out"][1] // Ly["lin"][1]
             arch = None

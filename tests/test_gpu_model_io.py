@@ -17,6 +17,8 @@ VARIANTS = [
     ("darts-k3", dict(SMALL, darts_num_offsets=3, darts_flags=1 | 16, darts_temp_proportion=0.8)),
     ("bn-supernet-onehot", dict(SMALL, bn_choice_dims=[4, 4, 8], bn_mode=0)),
     ("bn-supernet-gumbel-cv", dict(SMALL, bn_choice_dims=[4, 4, 8], bn_mode=2, bn_flops_scale=0.25, bn_temp_proportion=0.9, cv_update=1)),
+    # a derived child: per-layer X.linear {-a, 0} / X.affine {0, b} and per-layer bottleneck dims
+    ("child", dict(SMALL, strides=None, layer_offsets=[(2, 1), (0, 3), (5, 0), (1, 2)], bottleneck=[16, 8, 24, 16])),
 ]
 
 
@@ -149,6 +151,9 @@ def test_config_from_model_rebuilds_the_net(pkg, tmp_path, name, kw):
     assert list(cfg2.bottleneck_dim[:L]) == list(cfg.bottleneck_dim[:L])
     if not cfg.darts_num_offsets:
         assert list(cfg2.time_stride[:L]) == list(cfg.time_stride[:L])
+    assert cfg2.use_layer_offsets == cfg.use_layer_offsets
+    if cfg.use_layer_offsets:
+        assert list(cfg2.offset_left[:L]) == list(cfg.offset_left[:L]) and list(cfg2.offset_right[:L]) == list(cfg.offset_right[:L])
     assert list(cfg2.bn_choice_dims[:cfg.bn_num_choices]) == list(cfg.bn_choice_dims[:cfg.bn_num_choices])
     b = pkg.trainer.ChainNet(cfg2)
     b.read_model(path)

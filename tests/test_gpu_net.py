@@ -58,6 +58,14 @@ CASES += [
     ("7q-shape-small-NG-bf16x3", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=24, feat_dim=40,
                                       ivector_dim=100, num_pdfs=150, hidden_dim=96, small_dim=48, use_natural_gradient=1, gemm_precision=1), 60),
 ]
+# derived children (derive.child_config_kwargs; generate_top_list.py:97-141): X.linear {-a, 0}, X.affine {0, b} per layer,
+# single taps where the offset is 0, per-layer bottleneck dims; the last layer's (2, 1) / (4, 5) need the rho = 3 row order
+_C = dict(frames_per_chunk=24, num_sequences=3, feat_dim=40, ivector_dim=100, num_pdfs=120, hidden_dim=128, small_dim=32)
+CASES += [
+    ("child-offsets", dict(_C, layer_offsets=[(1, 2), (0, 1), (2, 0), (3, 0), (2, 1)], bottleneck=32), 40),
+    ("child-offsets-dims-NG", dict(_C, frames_per_chunk=48, num_sequences=6, layer_offsets=[(6, 0), (0, 0), (3, 6), (4, 5)],
+                                   bottleneck=[24, 48, 16, 80], use_natural_gradient=1), 40),
+]
 # gemm_precision 2: three bf16 planes per operand, six products -- 24 operand bits, held to the SAME tolerances as exact f32
 CASES += [
     ("7q-shape-small-bf16x6", dict(CASES[1][1], gemm_precision=2), 60),

@@ -46,3 +46,17 @@ def test_config_from_model_errors(pkg, tmp_path):
     p.write_text(re.sub(r"<ComponentName> tdnnf2\.affine ", "<ComponentName> tdnnfX.affine ", text))
     with pytest.raises(pkg.hipabi.HipAbiError, match="no tdnnf2"):
         pkg.trainer.config_from_model(p)
+
+
+def test_config_from_child_model(pkg, tmp_path):
+    # a derived child (generate_top_list.py:97-141): asymmetric time offsets come back as layer offsets
+    text = open(FIX).read()
+    assert pkg.trainer.config_from_model(FIX).use_layer_offsets == 0
+    p = tmp_path / "child.txt"
+    p.write_text(text.replace("<TimeOffsets> [ -1 0 ]", "<TimeOffsets> [ -2 0 ]").replace("<TimeOffsets> [ 0 3 ]", "<TimeOffsets> [ 0 5 ]"))
+    c = pkg.trainer.config_from_model(p, 12, 2)
+    assert c.use_layer_offsets == 1 and list(c.offset_left[:3]) == [2, 0, 3] and list(c.offset_right[:3]) == [1, 0, 5]
+    assert list(c.time_stride[:3]) == [2, 0, 5]
+    p.write_text(text.replace("<TimeOffsets> [ -1 0 ]", "<TimeOffsets> [ 0 1 ]"))
+    with pytest.raises(pkg.hipabi.HipAbiError, match="time offsets"):
+        pkg.trainer.config_from_model(p)
