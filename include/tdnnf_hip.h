@@ -390,6 +390,13 @@ int tdnnf_net_read_model(tdnnf_net *, const char *path, tdnnf_stream);
    max-param-change ...) is set to the recipe's values (run_tdnn_fbk_40_iv_sp_7q.sh:149-203).  Fails for graphs other
    than the ones the trainer runs. */
 int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_sequences, tdnnf_net_config *out);
+/* The graph of a configuration as nnet3 config lines (input-node / component-node / dim-range-node / output-node: the
+   part of a final.config that Nnet::Write keeps in a model file), newline-terminated, as tdnnf_net_write_model writes them.
+   Mirrors the node lines of steps/libs/nnet3/xconfig/composite_layers.py:135-215,1283-1331 and of
+   local/chain_NAS/scripts/generate_bottleneckCB8share_onehottrain_config.py:10-120, add_flopsconstraint.py:18-30.
+   No GPU needed.  *needed (optional) receives the size including the terminating 0; out may be null with capacity 0 to
+   query it. */
+int tdnnf_net_config_text(const tdnnf_net_config *cfg, char *out, size_t capacity, size_t *needed);
 /* debugging / parity: copy an internal activation by name ("tdnnf2.linear", "output", ...) into out */
 int tdnnf_net_get_activation(const tdnnf_net *, const char *name, tdnnf_mat *out, tdnnf_stream);
 int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, int *cols);

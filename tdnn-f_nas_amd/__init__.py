@@ -9,3 +9,4 @@ from . import synth  # noqa: F401
 from . import hipabi  # noqa: F401
 from . import trainer  # noqa: F401
 from . import derive  # noqa: F401
+from . import configs  # noqa: F401

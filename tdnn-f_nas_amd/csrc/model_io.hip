@@ -333,8 +333,7 @@ void stat_layout(const tdnnf_net *n, HostNet *h) {  // the order of tdnnf_net_ge
 std::string layer_name(int l) { return "tdnnf" + std::to_string(l + 2); }
 
 // ------------------------------------------------------------------------------------------------- config lines
-std::vector<std::string> config_lines(const tdnnf_net *n) {
-  const tdnnf_net_config &c = n->cfg;
+std::vector<std::string> config_lines(const tdnnf_net_config &c) {
   std::vector<std::string> L;
   char buf[512];
   auto add = [&](const char *fmt, ...) {
@@ -353,8 +352,8 @@ std::vector<std::string> config_lines(const tdnnf_net *n) {
   cn("tdnn1.batchnorm", "tdnn1.relu");
   cn("tdnn1.dropout", "tdnn1.batchnorm");
   std::string prev = "tdnn1.dropout";
-  for (size_t l = 0; l < n->layers.size(); l++) {
-    const std::string p = layer_name((int)l);
+  for (int l = 0; l < c.num_layers; l++) {
+    const std::string p = layer_name(l);
     std::string aff_in = p + ".linear";
     if (c.bn_num_choices > 0) {  // generate_bottleneckCB8share_onehottrain_config.py:10-85 / add_flopsconstraint.py:18-30
       const int C = c.bn_num_choices;
@@ -964,7 +963,7 @@ int tdnnf_net_write_model(const tdnnf_net *n, const char *path, int binary, floa
   Ctx x{n, &h, &o, learning_rate};
   o.token("<Nnet3>");
   os << "\n";
-  for (const std::string &line : config_lines(n)) os << line << "\n";
+  for (const std::string &line : config_lines(n->cfg)) os << line << "\n";
   os << "\n";
   o.token("<NumComponents>");
   o.i32(write_components(x, true));
@@ -973,6 +972,21 @@ int tdnnf_net_write_model(const tdnnf_net *n, const char *path, int binary, floa
   o.token("</Nnet3>");
   os.flush();
   TDNNF_REQUIRE(os.good(), "net_write_model: write to %s failed", path);
+  return TDNNF_OK;
+}
+
+int tdnnf_net_config_text(const tdnnf_net_config *cfg, char *out, size_t capacity, size_t *needed) {
+  TDNNF_REQUIRE(cfg && cfg->num_layers >= 1 && cfg->num_layers <= TDNNF_NET_MAX_LAYERS && (out || capacity == 0),
+                "net_config_text: bad arguments");
+  std::string text;
+  for (const std::string &line : config_lines(*cfg)) text += line + "\n";
+  if (needed) *needed = text.size() + 1;
+  if (out && capacity > 0) {
+    const size_t n = std::min(capacity - 1, text.size());
+    memcpy(out, text.data(), n);
+    out[n] = 0;
+  }
+  TDNNF_REQUIRE(!out || capacity >= text.size() + 1, "net_config_text: buffer of %zu bytes, %zu needed", capacity, text.size() + 1);
   return TDNNF_OK;
 }
 

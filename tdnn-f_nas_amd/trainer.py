@@ -97,6 +97,16 @@ def config_from_model(path, frames_per_chunk=150, num_sequences=64):
     return c
 
 
+def config_text(config):
+    """The graph of a NetConfig as nnet3 config node lines (tdnnf_net_config_text; no GPU needed)."""
+    lib = hipabi.load()
+    need = C.c_size_t()
+    hipabi.check(lib.tdnnf_net_config_text(C.byref(config), None, 0, C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    hipabi.check(lib.tdnnf_net_config_text(C.byref(config), buf, need.value, None))
+    return buf.value.decode().rstrip("\n")
+
+
 class ChainNet:
     """One replica of the TDNN-F chain model on the current CUDA device."""
 
