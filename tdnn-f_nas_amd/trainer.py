@@ -289,7 +289,20 @@ def temperature_proportion(data_fraction):
 
 def temperature(temperature_init, temperature_final, data_fraction):
     """get_temperature_edit_string_adapt, temperature_schedule.py:20: geometric interpolation."""
-    return temperature_init * (float(temperature_final) / temperature_init) ** data_fraction
+    return temperature_init * (temperature_final / temperature_init) ** data_fraction
+
+
+def temperature_edit_string(data_fraction):
+    """The nnet3-copy command train.py prepends to the model of an iteration under --temperature_schedule
+    (get_temperature_edit_string, temperature_schedule.py:34-67); ChainNet.set_temperature_proportion is its effect."""
+    return "nnet3-copy --edits='set-temperature-proportion name=* proportion={0}' - - |".format(temperature_proportion(data_fraction))
+
+
+def temperature_adapt_edit_string(temperature_init, temperature_final, data_fraction):
+    """get_temperature_edit_string_adapt, temperature_schedule.py:15-32 (None when either end is None)."""
+    if temperature_init is None or temperature_final is None:
+        return None
+    return "nnet3-copy --edits='set-temperature temperature={0}' - - |".format(temperature(temperature_init, temperature_final, data_fraction))
 
 
 def training_schedule(num_iters, num_archives_to_process, num_jobs_initial=1, num_jobs_final=1, use_temperature_schedule=False,

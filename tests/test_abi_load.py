@@ -59,3 +59,17 @@ def test_training_schedule_restates_train_py(pkg):
     assert abs(sched[2]["learning_rate"] - 3 * 2.5e-4 * math.exp(4 * math.log(0.1) / 18)) < 1e-12
     assert abs(sched[-1]["learning_rate"] - 4 * 2.5e-5) < 1e-15  # the last iteration runs at the final rate
     assert abs(tr.temperature(1.0, 0.1, 0.5) - 10 ** -0.5) < 1e-12 and tr.temperature_proportion(1.0) == pytest.approx(0.03)
+
+
+def test_temperature_schedule_against_the_reference_module(pkg):
+    # tests/golden/r01_schedule_golden.json: return values of the reference's temperature_schedule.py, imported in the
+    # build container (tests/golden/make_schedule_golden.py)
+    import json
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "r01_schedule_golden.json")))
+    t = pkg.trainer
+    for c in G["proportion"]:
+        assert t.temperature_edit_string(c["data_fraction"]) == c["edit"]
+        assert "proportion=%s'" % t.temperature_proportion(c["data_fraction"]) in c["edit"]
+    for c in G["adapt"]:
+        assert t.temperature_adapt_edit_string(c["init"], c["final"], c["data_fraction"]) == c["edit"]
+    assert G["adapt_none"] is None and t.temperature_adapt_edit_string(None, 0.5, 0.3) is None
