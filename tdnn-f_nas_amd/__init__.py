@@ -10,3 +10,4 @@ from . import hipabi  # noqa: F401
 from . import trainer  # noqa: F401
 from . import derive  # noqa: F401
 from . import configs  # noqa: F401
+from . import outer_loop  # noqa: F401

@@ -73,3 +73,29 @@ def test_temperature_schedule_against_the_reference_module(pkg):
     for c in G["adapt"]:
         assert t.temperature_adapt_edit_string(c["init"], c["final"], c["data_fraction"]) == c["edit"]
     assert G["adapt_none"] is None and t.temperature_adapt_edit_string(None, 0.5, 0.3) is None
+
+
+def test_outer_loop_plan(pkg):
+    """train.py:405-531 bookkeeping (host only): iteration count, job ramp, learning rates, archives, combination set."""
+    o = pkg.outer_loop
+    to_process, iters = o.num_iterations(num_epochs=4, num_archives=10, frame_subsampling_factor=3, num_jobs_initial=2, num_jobs_final=6)
+    assert (to_process, iters) == (120, 30)  # 4 * 10 * 3 archives at an average of 4 jobs
+    plan = o.iteration_plan(4, 10, 3, 2, 6, 2.5e-4, 2.5e-5, temperature_schedule=True)
+    assert len(plan) == 30 and plan[0]["num_jobs"] == 2 and plan[-1]["num_jobs"] == 6
+    assert [p["num_jobs"] for p in plan] == sorted(p["num_jobs"] for p in plan)
+    assert abs(sum(p["num_jobs"] for p in plan) - to_process) <= 6
+    assert plan[0]["learning_rate"] == pytest.approx(2 * 2.5e-4) and plan[-1]["learning_rate"] == pytest.approx(6 * 2.5e-5)
+    eff = [p["learning_rate"] / p["num_jobs"] for p in plan]
+    assert all(a > b for a, b in zip(eff, eff[1:]))  # the effective rate decays monotonically
+    assert plan[0]["temperature_proportion"] == 1.0 and 0.03 < plan[-1]["temperature_proportion"] < 0.1
+    assert plan[0]["archives"] == [0, 1] and plan[1]["archives"] == [2, 3] and all(0 <= a < 30 for p in plan for a in p["archives"])
+    with pytest.raises(ValueError):
+        o.num_iterations(1, 2, 3, 1, 7)
+    with pytest.raises(ValueError):
+        o.shrinkage_value(1e-3, proportional_shrink=600.0)
+    assert o.shrinkage_value(1e-3, 150.0) == pytest.approx(0.85)
+    # common.py:562-603 worked by hand: half an epoch at the final rate is 3 iterations (<= max 20) -> the last
+    # min(20, iters // 2) models; 51 iterations (> 20) -> every 2nd of the last 51, plus the last
+    assert o.model_combine_iters(30, 4, 30, 20, 6) == set(range(16, 31))
+    assert o.model_combine_iters(400, 4, 600, 20, 6) == set(range(350, 401, 2))
+    assert o.model_combine_iters(10, 1, 4, 20, 1) == {6, 7, 8, 9, 10}

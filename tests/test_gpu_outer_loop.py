@@ -1,0 +1,68 @@
+"""-m gpu: the outer loop (tdnn-f_nas_amd/outer_loop.py) on a tiny net: one model file per iteration,
+the jobs of an iteration averaged, final combination, reproducible."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(frames_per_chunk=24, num_sequences=4, strides=[1, 0, 3], bottleneck=16, feat_dim=40, ivector_dim=100, num_pdfs=40, hidden_dim=64, small_dim=32,
+          use_natural_gradient=1)
+
+
+def _setup(pkg):
+    cfg = pkg.trainer.make_config(**KW)
+
+    def factory():
+        net = pkg.trainer.ChainNet(cfg)
+        net.set_params(net.init_params_numpy(seed=1, output_stddev=0.1))
+        return net
+
+    probe = factory()
+    den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+    cache = {}
+
+    def egs(archive, m):  # a fixed set of "archives": the same few minibatches come back every epoch
+        key = (archive % 2, m)
+        if key not in cache:
+            feats, iv = pkg.trainer.synthetic_egs(probe, seed=100 + 10 * key[0] + m)
+            sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=200 + 10 * key[0] + m)
+            cache[key] = (dev(feats), dev(iv), pkg.hipabi.Supervision(sup))
+        f, i, s = cache[key]
+        return f, i, den, s
+
+    return cfg, factory, egs, probe
+
+
+def test_outer_loop_runs_the_schedule(pkg, tmp_path):
+    cfg, factory, egs, probe = _setup(pkg)
+    o = pkg.outer_loop
+    args = dict(num_epochs=3, num_archives=2, minibatches_per_archive=3, frame_subsampling_factor=3, num_jobs_initial=1, num_jobs_final=2,
+                initial_effective_lrate=2e-3, final_effective_lrate=2e-4, max_models_combine=4)
+    plan, combine, to_process = o.run(factory, egs, str(tmp_path / "a"), **args)
+    assert to_process == 18 and len(plan) == 12 and combine == [9, 10, 11, 12]
+    assert all(os.path.exists(tmp_path / "a" / ("%d.mdl" % i)) for i in range(13)) and os.path.exists(tmp_path / "a" / "final.mdl")
+    objf = [p["objf_per_frame"] for p in plan]
+    assert all(np.isfinite(objf)) and np.mean(objf[-3:]) > np.mean(objf[:3])  # it learns the repeated archives
+    # final.mdl is the average of the combined models, statistics included
+    models = []
+    for i in combine:
+        probe.read_model(tmp_path / "a" / ("%d.mdl" % i))
+        models.append((probe.params.detach().cpu().numpy().copy(), probe.get_stats().copy()))
+    p, s = o.average_models(models)
+    probe.read_model(tmp_path / "a" / "final.mdl")
+    np.testing.assert_allclose(probe.params.detach().cpu().numpy(), p, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(probe.get_stats(), s, rtol=1e-5)
+    # an iteration with two jobs wrote the mean of two different models: neither job's model alone
+    two = next(p for p in plan if p["num_jobs"] == 2)
+    assert two["archives"][0] != two["archives"][1]
+    # reproducible: the same call again gives the same final model
+    o.run(factory, egs, str(tmp_path / "b"), **args)
+    q = factory()
+    q.read_model(tmp_path / "b" / "final.mdl")
+    assert np.array_equal(q.params.detach().cpu().numpy(), probe.params.detach().cpu().numpy())
+    q.close()
+    probe.close()
