@@ -132,7 +132,9 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
             acc_s += net.get_stats()
         step += minibatches_per_archive
         if world > 1:
-            buf = torch.from_numpy(np.concatenate([acc_p, acc_s, [objf, weight]])).cuda()
+            buf = torch.from_numpy(np.concatenate([acc_p, acc_s, [objf, weight]]))
+            if dist.get_backend() != "gloo":  # RCCL reduces device buffers; gloo (rehearsals on one GPU) host ones
+                buf = buf.cuda()
             dist.all_reduce(buf)
             buf = buf.cpu().numpy()
             acc_p, acc_s, objf, weight = buf[:acc_p.size], buf[acc_p.size:acc_p.size + acc_s.size], buf[-2], buf[-1]

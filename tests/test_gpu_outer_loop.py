@@ -66,3 +66,39 @@ def test_outer_loop_runs_the_schedule(pkg, tmp_path):
     assert np.array_equal(q.params.detach().cpu().numpy(), probe.params.detach().cpu().numpy())
     q.close()
     probe.close()
+
+
+def _rank_main(rank, world, port, work_dir):
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    cfg, factory, egs, probe = _setup(pkg)
+    probe.close()
+    pkg.outer_loop.run(factory, egs, work_dir, **ARGS2)
+    dist.destroy_process_group()
+
+
+ARGS2 = dict(num_epochs=2, num_archives=2, minibatches_per_archive=2, frame_subsampling_factor=3, num_jobs_initial=2, num_jobs_final=2,
+             initial_effective_lrate=2e-3, final_effective_lrate=2e-4, max_models_combine=4)
+
+
+def test_outer_loop_two_ranks_match_one(pkg, tmp_path):
+    """Two processes (both on this GPU, gloo) share the two jobs of every iteration: the averaged models are the ones a
+    single process computes by running the jobs one after the other."""
+    import socket
+    import torch.multiprocessing as mp
+    cfg, factory, egs, probe = _setup(pkg)
+    pkg.outer_loop.run(factory, egs, str(tmp_path / "one"), **ARGS2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path / "two")), nprocs=2, join=True)
+    probe.read_model(tmp_path / "one" / "final.mdl")
+    a, sa = probe.params.detach().cpu().numpy().copy(), probe.get_stats().copy()
+    probe.read_model(tmp_path / "two" / "final.mdl")
+    b, sb = probe.params.detach().cpu().numpy(), probe.get_stats()
+    np.testing.assert_allclose(b, a, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(sb, sa, rtol=1e-5)
+    probe.close()
