@@ -43,6 +43,7 @@ struct RowsGemmArgs {
   // scaled, spliced A operand, a by-product of staging it).  Needs N to fit one column tile (every A element is
   // then staged exactly once): rows_gemm() fails otherwise.  One double per 128-row block: rows_gemm_sumsq_blocks(M).
   double *sumsq;
+  int sumsq_cap;  // set by rows_gemm(): rows_gemm_sumsq_blocks(M)
   // 0: exact f32 MFMA (v_mfma_f32_32x32x2_f32).  1: split-bf16 (three v_mfma_f32_32x32x16_bf16 per 16 k, products accurate
   // to ~2^-16 relative, f32 accumulation); needs a k-contiguous B and 16-byte alignment, otherwise the f32 kernel runs.
   int prec;
@@ -93,7 +94,10 @@ struct TransposedWeightsScope {
 };
 const float *transposed_weights(const float *W);  // null when there is none (or split-bf16 is not the default)
 
-inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128; }
+// capacity of the p.sumsq array for M rows: one entry per 128-row block, or per (block, K-slice) when rows_gemm() splits K
+// over idle CUs for a launch of few blocks (then blocks x slices <= the chip's resident blocks <= 1024); the kernel zeroes
+// the entries it does not write, consumers sum all of them
+inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128 > 1024 ? (M + 127) / 128 : 1024; }
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).
 hipError_t rows_gemm(const RowsGemmArgs &args, bool b_kcontig, hipStream_t stream);

@@ -368,6 +368,8 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
     if (lane == 0) red[wave] = v;
     __syncthreads();
     if (t == 0) p.sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0)  // entries no block owns (the array is sized for a split-K launch)
+      for (int i = gridDim.x + t; i < p.sumsq_cap; i += 256) p.sumsq[i] = 0.0;
     __syncthreads();
   }
 #pragma unroll
@@ -729,6 +731,8 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(const RowsGemmArgs
     if (lane == 0) red[wave] = v;
     __syncthreads();
     if (t == 0) p.sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0)  // entries no block owns (the array is sized for a split-K launch)
+      for (int i = gridDim.x + t; i < p.sumsq_cap; i += 256) p.sumsq[i] = 0.0;
     __syncthreads();
   }
 #pragma unroll
@@ -1012,6 +1016,42 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
 }
 
+// A launch with p.sumsq: one column tile, block b owns rows [BM b, BM b + BM).  Few row blocks and a long reduction (the
+// natural-gradient H = X W^T of a small minibatch: 30 blocks for 256 CUs, each crawling through K at load latency): split K
+// over the idle CUs; every (block, slice) then writes the sum of squares of its own slice.
+template <int WM, int WN, int TM, int TN, int BK>
+hipError_t launch_rows_sumsq(const RowsGemmArgs &a, bool b_kc, bool vec, hipStream_t s) {
+  constexpr int BM = WM * TM * 32;
+  const int tiles = (a.M + BM - 1) / BM, slots = rows_slots<WM, WN, TM, TN, BK>(b_kc, 0);
+  long long ktot = 0;
+  bool k4 = true;
+  for (int i = 0; i < a.nseg; i++) {
+    ktot += a.seg[i].klen;
+    k4 = k4 && (a.seg[i].klen % 4 == 0 || a.nseg == 1);
+  }
+  float *scratch = nullptr;
+  size_t scratch_bytes = 0;
+  static const bool nobal = getenv("TDNNF_GEMM_NOBAL") != nullptr;
+  if (!nobal && tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
+    const long long kt = (ktot + BK - 1) / BK;
+    int S = slots / tiles;
+    if (S > kt / 4) S = (int)(kt / 4);
+    if (S > 16) S = 16;
+    const size_t need = sizeof(float) * (size_t)S * a.M * ((a.N + 3) & ~3);
+    if (S >= 2 && need <= scratch_bytes && tiles * S <= a.sumsq_cap) {
+      RowsGemmArgs at = a;
+      at.kchunk = (int)(((kt + S - 1) / S) * BK);
+      at.ksplit = (int)((ktot + at.kchunk - 1) / at.kchunk);
+      at.partial = scratch;
+      launch_rows_kernel<WM, WN, TM, TN, BK>(dim3(tiles * at.ksplit), at, tiles, 1, b_kc, vec, s);
+      const long long total = (long long)at.M * at.N;
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, at);
+      return hipGetLastError();
+    }
+  }
+  return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
+}
+
 }  // namespace
 
 hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
@@ -1038,10 +1078,11 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   if (!(b_kc && vec)) a.prec = 0;  // the split-bf16 kernels need a k-contiguous B and 16-byte alignment
   if (a.sumsq) {  // one column tile, no split-K tail: block b owns rows [128 b, 128 b + 128)
     if (a.N > 128) return hipErrorInvalidValue;
+    a.sumsq_cap = rows_gemm_sumsq_blocks(a.M);
     ProfScope ps(0, flops, s);
-    if (a.N <= 32) return launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
-    if (a.N <= 96) return launch_rows<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
-    return launch_rows<2, 2, 2, 2, 32>(a, b_kc, vec, s);
+    if (a.N <= 32) return launch_rows_sumsq<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    if (a.N <= 96) return launch_rows_sumsq<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
+    return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);
   }
   // skinny outputs (the natural-gradient projections X W^T, rank <= 32): a 128x32 tile wastes no MFMA columns and
   // keeps three blocks per CU resident to pull the A operand at HBM rate

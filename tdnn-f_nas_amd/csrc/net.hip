@@ -422,8 +422,8 @@ void layout_arena(tdnnf_net *n, Arena &A) {
       S.H_out = A.take<float>(maxN * 80 + 64);
       S.T = A.take<float>(mt + 16);
       S.Tmp = A.take<float>(mtmp + 64);
-      S.part_in = A.take<double>(maxN / 128 + 8);
-      S.part_out = A.take<double>(maxN / 128 + 8);
+      S.part_in = A.take<double>((size_t)rows_gemm_sumsq_blocks(maxN) + 8);
+      S.part_out = A.take<double>((size_t)rows_gemm_sumsq_blocks(maxN) + 8);
       S.ws = A.take<char>(n->ngset_ws_bytes);
     }
     n->s3_scratch_bytes = 16u << 20;
