@@ -65,7 +65,16 @@ CASES += [
     ("child-offsets", dict(_C, layer_offsets=[(1, 2), (0, 1), (2, 0), (3, 0), (2, 1)], bottleneck=32), 40),
     ("child-offsets-dims-NG", dict(_C, frames_per_chunk=48, num_sequences=6, layer_offsets=[(6, 0), (0, 0), (3, 6), (4, 5)],
                                    bottleneck=[24, 48, 16, 80], use_natural_gradient=1), 40),
+    # the joint search: bottleneck supernet over a derived child's offsets
+    # (generate_optimal_context_offset_bottleneckCB8share_onehottrain_config.py)
+    ("child-offsets-bn-supernet", dict(_C, layer_offsets=[(1, 2), (0, 1), (3, 0), (2, 3)], bn_choice_dims=[8, 8, 16, 32], bn_mode=0), 40),
 ]
+# random children: offsets drawn from the K = 7 search space (-6..0 / 0..6), as generate_top_list.py would hand them over
+for _seed in (2, 3, 4):
+    _r = np.random.default_rng(_seed)
+    _lo = [(int(_r.integers(0, 7)), int(_r.integers(0, 7))) for _ in range(5)]
+    CASES.append(("child-random-%d-" % _seed + "_".join("%d.%d" % ab for ab in _lo),
+                  dict(_C, frames_per_chunk=30, layer_offsets=_lo, bottleneck=[int(v) for v in _r.choice([16, 24, 40], 5)]), 40))
 # gemm_precision 2: three bf16 planes per operand, six products -- 24 operand bits, held to the SAME tolerances as exact f32
 CASES += [
     ("7q-shape-small-bf16x6", dict(CASES[1][1], gemm_precision=2), 60),
@@ -113,6 +122,10 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
             # (our own intermediate check; split-bf16 products carry ~2^-16 relative error, which the occupancy
             #  differences of output.deriv amplify; the BASELINE bars below are the same for both arithmetics)
             assert e < (1e-3 if x3 else 1e-4), (key, e)
+        # a ReLU input within rounding of 0 can come out 0 on one side and 1e-8 on the other: that flips one derivative and moves
+        # the gradient by ~1 % on nets this small -- a tie, not a difference in arithmetic; such a case needs another seed
+        ties = [i for i in range(cfg.num_layers)
+                if ((host(net.activation(f"tdnnf{i + 2}.relu")) > 0) != (acts[f"tdnnf{i + 2}.relu"] > 0)).any()]
         assert r[5] == 1.0 and r[2] == res_ref["weight"]
         assert abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"]), (r[0], res_ref["objf"])
         assert abs(r[6] - res_ref["xent_objf"]) < 1e-4 * abs(res_ref["xent_objf"])
@@ -123,7 +136,7 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
         gtol = 5e-3 if cfg.use_natural_gradient else (2e-3 if x3 else 1e-3)
         if cfg.use_natural_gradient and x3:
             gtol = 3e-2  # the preconditioners' eigen-decomposition (initialised from this very minibatch) amplifies the 1e-5 input differences
-        assert rel_l2(g, g_ref) < gtol, rel_l2(g, g_ref)
+        assert rel_l2(g, g_ref) < gtol, (rel_l2(g, g_ref), "ReLU ties in layers %s: choose other inputs for this case" % ties if ties else "")
         for c in net.components[1:]:
             sl = slice(c["begin"], c["begin"] + c["rows"] * c["cols"] + c["num_alpha"] + (c["rows"] if c["has_bias"] else 0))
             # per component (our own, stricter than the BASELINE bar above).  Split-bf16: the small gradients of the xent branch
