@@ -338,6 +338,42 @@ typedef struct {
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 
+/* ========================================================================== egs
+ * Chain examples ("cegs" archives of NnetChainExample) in and out, and their merge into the buffers
+ * tdnnf_net_forward_backward / tdnnf_supervision_create take.  Host code, no GPU needed.  The formats are upstream
+ * Kaldi / OpenFst (nnet3/nnet-chain-example.cc, nnet-example.cc, chain/chain-supervision.cc, matrix/compressed-matrix.cc,
+ * OpenFst compact-fst.h), restated; the reference only passes flags for them (run_TDNN_DARTSV3_fbk_stride_pretrain.sh:192-199,
+ * steps/nnet3/chain/train.py:373-406).  Binary archives only. */
+typedef struct tdnnf_egs_reader tdnnf_egs_reader;
+typedef struct tdnnf_egs_writer tdnnf_egs_writer;
+typedef struct tdnnf_eg tdnnf_eg;
+int tdnnf_egs_reader_open(const char *path, tdnnf_egs_reader **out);
+void tdnnf_egs_reader_close(tdnnf_egs_reader *);
+/* *out = the next example, or NULL at the end of the archive (still TDNNF_OK) */
+int tdnnf_egs_reader_next(tdnnf_egs_reader *, tdnnf_eg **out);
+void tdnnf_eg_destroy(tdnnf_eg *);
+const char *tdnnf_eg_key(const tdnnf_eg *);
+/* input "input" / "ivector": dimensions and the time of its first row; copy of the (decompressed) rows x cols values */
+int tdnnf_eg_input_info(const tdnnf_eg *, const char *name, int *rows, int *cols, int *first_t);
+int tdnnf_eg_input_copy(const tdnnf_eg *, const char *name, float *out);
+int tdnnf_eg_supervision_info(const tdnnf_eg *, float *weight, int *num_sequences, int *frames_per_seq, int *label_dim, int *num_states,
+                              int *num_arcs, int *first_t, int *t_step);
+/* nnet3-chain-merge-egs for n single-sequence examples (+ nnet3-chain-copy-egs --frame-shift): features t-major
+   (row = (t - first_t) * n + b, t = first_t .. first_t + num_t - 1 as tdnnf_net_input_frames reports), ivectors n x dim
+   (NULL if unused), and the arrays of tdnnf_supervision_create (sizes from tdnnf_egs_merge_sizes; labels are pdf-id + 1,
+   weights costs: arc_pdf = label - 1, log-probs = -cost). */
+int tdnnf_egs_merge_sizes(const tdnnf_eg *const *egs, int n, int *num_states, int *num_arcs, int *frames_per_seq, int *feat_dim, int *ivector_dim);
+int tdnnf_egs_merge(const tdnnf_eg *const *egs, int n, int first_t, int num_t, int frame_shift, float *feats, float *ivectors, int *seq_state_begin,
+                    int *seq_arc_begin, int *state_time, float *final_logprob, int *arc_src, int *arc_dst, int *arc_pdf, float *arc_logprob,
+                    float *weight_out);
+int tdnnf_egs_writer_open(const char *path, tdnnf_egs_writer **out);
+int tdnnf_egs_writer_close(tdnnf_egs_writer *);
+/* one single-sequence example; the supervision as ONE sequence's arrays of tdnnf_supervision_create (state 0 = start);
+   compress != 0 writes the features as a 16-bit CompressedMatrix ("CM2"), as nnet3-chain-get-egs does by default */
+int tdnnf_egs_writer_write(tdnnf_egs_writer *, const char *key, const float *feats, int rows, int feat_dim, int first_t, const float *ivector,
+                           int ivector_dim, int compress, float weight, int frames, int t_step, int label_dim, int num_states, int num_arcs,
+                           const float *final_logprob, const int *arc_src, const int *arc_dst, const int *arc_pdf, const float *arc_logprob);
+
 int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out);
 void tdnnf_net_destroy(tdnnf_net *);
 long long tdnnf_net_num_params(const tdnnf_net *);

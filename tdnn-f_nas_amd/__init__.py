@@ -11,3 +11,4 @@ from . import trainer  # noqa: F401
 from . import derive  # noqa: F401
 from . import configs  # noqa: F401
 from . import outer_loop  # noqa: F401
+from . import egs  # noqa: F401
