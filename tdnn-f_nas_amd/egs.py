@@ -136,25 +136,68 @@ class Writer:
         self.close()
 
 
-def minibatches(path, net, frame_shift=0, discard_partial=True):
+def minibatches(path, net, frame_shift=0, discard_partial=True, prefetch=0):
     """Reads an archive and yields (feats, ivectors, hipabi.Supervision) device objects for ChainNet.forward_backward, merging
     net.cfg.num_sequences examples at a time in archive order (nnet3-chain-merge-egs --minibatch-size; the archive is expected to
-    be shuffled already, as nnet3-chain-shuffle-egs leaves it)."""
+    be shuffled already, as nnet3-chain-shuffle-egs leaves it).  prefetch > 0: reading, decompression and the merge run on a
+    worker thread that many minibatches ahead (the C calls release the GIL), the copy to the device stays on the caller."""
     import torch
     B = net.cfg.num_sequences
-    group = []
+    first_t, num_t, with_iv = net.first_t, net.num_t_in, net.cfg.ivector_dim > 0
+    chunk, sub = net.cfg.frames_per_chunk, net.cfg.frame_subsampling
 
-    def emit(g):
-        f, iv, sup = merge(g, net.first_t, net.num_t_in, frame_shift, with_ivectors=net.cfg.ivector_dim > 0)
-        for e in g:
-            e.close()
-        assert sup["T"] * net.cfg.frame_subsampling == net.cfg.frames_per_chunk, "examples of another chunk width than the net"
+    def host_batches():
+        group = []
+        for eg in Reader(path):
+            group.append(eg)
+            if len(group) == B:
+                f, iv, sup = merge(group, first_t, num_t, frame_shift, with_ivectors=with_iv)
+                for e in group:
+                    e.close()
+                group = []
+                if sup["T"] * sub != chunk:
+                    raise ValueError("examples of %d output frames, the net was built for %d" % (sup["T"], chunk // sub))
+                yield f, iv, sup
+        if group and not discard_partial:
+            raise ValueError("the last %d examples do not fill a minibatch of %d" % (len(group), B))
+
+    def to_device(f, iv, sup):
         return torch.from_numpy(f).cuda(), torch.from_numpy(iv).cuda() if iv is not None else None, hipabi.Supervision(sup)
 
-    for eg in Reader(path):
-        group.append(eg)
-        if len(group) == B:
-            yield emit(group)
-            group = []
-    if group and not discard_partial:
-        raise ValueError("the last %d examples do not fill a minibatch of %d" % (len(group), B))
+    if prefetch <= 0:
+        for item in host_batches():
+            yield to_device(*item)
+        return
+    import queue
+    import threading
+    q = queue.Queue(maxsize=prefetch)
+    stop = threading.Event()
+
+    def worker():
+        try:
+            for item in host_batches():
+                while not stop.is_set():
+                    try:
+                        q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        pass
+                if stop.is_set():
+                    return
+            q.put(None)
+        except BaseException as e:  # handed to the consumer
+            q.put(e)
+
+    th = threading.Thread(target=worker, daemon=True)
+    th.start()
+    try:
+        while True:
+            item = q.get()
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            yield to_device(*item)
+    finally:
+        stop.set()
+        th.join(timeout=5)

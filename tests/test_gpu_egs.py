@@ -37,6 +37,10 @@ def test_training_step_from_an_archive(pkg, tmp_path):
         net.grads.zero_()
         r2 = host(net.forward_backward(dev(feats), dev(iv), den, pkg.hipabi.Supervision(sup), step=3))
         assert r1[5] == 1.0 and np.array_equal(r1, r2) and np.array_equal(g1, host(net.grads))
+    ahead = list(E.minibatches(path, net, prefetch=2))  # the same minibatches through the worker thread
+    assert len(ahead) == 2 and all(np.array_equal(host(a[0]), host(g[0])) for a, g in zip(ahead, got))
+    with pytest.raises(pkg.hipabi.HipAbiError, match="the net needs"):
+        list(E.minibatches(path, net, frame_shift=3, prefetch=1))  # errors of the worker reach the caller
     # a frame shift moves the window; shifting by more than the spare context is refused
     shifted = list(E.minibatches(path, net, frame_shift=1))
     assert not np.array_equal(host(shifted[0][0]), batches[0][0])
