@@ -118,7 +118,8 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
             net.read_model(path(i))
             if it["temperature_proportion"] is not None:
                 net.set_temperature_proportion(it["temperature_proportion"])
-            g = torch.Generator(device="cpu").manual_seed(srand + 1000 * i + j)
+            g = torch.Generator(device="cuda")
+            g.manual_seed(srand + 1000 * i + j)
             for m in range(minibatches_per_archive):
                 feats, iv, den, sup = egs_for_archive(it["archives"][j], m)
                 if net.num_draws:

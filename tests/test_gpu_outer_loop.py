@@ -102,3 +102,29 @@ def test_outer_loop_two_ranks_match_one(pkg, tmp_path):
     np.testing.assert_allclose(b, a, rtol=0, atol=1e-6)
     np.testing.assert_allclose(sb, sa, rtol=1e-5)
     probe.close()
+
+
+def test_outer_loop_on_the_offset_supernet_with_temperature_schedule(pkg, tmp_path):
+    """The search stage: Gumbel coefficients need random draws every minibatch and the temperature proportion of the iteration."""
+    T = pkg.trainer
+    cfg = T.make_config(**dict(KW, use_natural_gradient=0, darts_num_offsets=3, darts_flags=T.DARTS_USE_GUMBEL | T.DARTS_UPDATE_ALPHA))
+
+    def factory():
+        net = T.ChainNet(cfg)
+        net.set_params(net.init_params_numpy(seed=1, output_stddev=0.1))
+        return net
+
+    probe = factory()
+    den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+    feats, iv = T.synthetic_egs(probe, seed=3)
+    sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=4))
+    fd, ivd = dev(feats), dev(iv)
+    plan, combine, _ = pkg.outer_loop.run(factory, lambda a, m: (fd, ivd, den, sup), str(tmp_path / "s"), num_epochs=1, num_archives=2, minibatches_per_archive=2,
+                                          num_jobs_initial=1, num_jobs_final=1, temperature_schedule=True, initial_effective_lrate=1e-3, final_effective_lrate=1e-4)
+    assert len(plan) == 6 and plan[0]["temperature_proportion"] == 1.0 and plan[-1]["temperature_proportion"] < 0.3
+    assert all(np.isfinite(p["objf_per_frame"]) for p in plan)
+    a0 = pkg.derive.logits_from_net(probe)
+    probe.read_model(tmp_path / "s" / "final.mdl")
+    a1 = pkg.derive.logits_from_net(probe)
+    assert a0.shape == (6, 3) and np.abs(a1 - a0).max() > 0  # the architecture logits moved
+    probe.close()
