@@ -102,7 +102,8 @@ def workload_text(args):
     if args.workload == "darts-offset":
         return (f"BASELINE configs[3]: DARTS offset supernet, {args.darts_offsets} taps per TdnnDARTSV3 component, pretrain mode "
                 "(uniform tap sample per layer and minibatch), otherwise as configs[1]; " + tail)
-    return ("BASELINE configs[4]: bottleneck-dimension supernet (candidate dims 25..240 in 8 blocks, Onehot sample per layer and "
+    dims = "25..240 in 8 blocks, the recipe's set" if args.bn_choices == "reference" else "80, 160, 240, 320 in 4 blocks"
+    return (f"BASELINE configs[4]: bottleneck-dimension supernet (candidate dims {dims}, Onehot sample per layer and "
             "minibatch), otherwise as configs[1]; " + tail)
 
 
@@ -123,6 +124,9 @@ def main():
                          "supernet of run_TDNN_DARTSV3_fbk_stride_pretrain.sh in pretrain (uniform-sample) mode; bn-supernet = "
                          "configs[4], the bottleneck-dimension supernet (8 candidate dims up to 240) in Onehot pretrain mode")
     ap.add_argument("--darts-offsets", type=int, default=7)
+    ap.add_argument("--bn-choices", default="reference", choices=["reference", "baseline"],
+                    help="bottleneck supernet candidates: reference = 25,50,80,100,120,160,200,240 (the recipe's 8); baseline = 80,160,240,320 "
+                         "(BASELINE configs[4])")
     ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3", "bf16x6"],
                     help="GEMM arithmetic: f32 = exact v_mfma_f32_32x32x2_f32 (default, the reference's BaseFloat); bf16x3 = split-bf16 "
                          "(three bf16 MFMAs per product, f32 accumulate; 16 operand bits); bf16x6 = three planes, six MFMAs "
@@ -162,7 +166,7 @@ def main():
     if args.workload == "darts-offset":
         extra = dict(darts_num_offsets=args.darts_offsets)
     elif args.workload == "bn-supernet":
-        extra = dict(bn_choice_dims=pkg.trainer.BN_CHOICE_DIMS, bn_mode=pkg.trainer.BN_ONEHOT)
+        extra = dict(bn_choice_dims=pkg.trainer.BN_CHOICE_DIMS if args.bn_choices == "reference" else [80, 80, 80, 80], bn_mode=pkg.trainer.BN_ONEHOT)
     cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch,
                                   use_natural_gradient=args.natural_gradient, gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.gemm], **extra)
     net = pkg.trainer.ChainNet(cfg)
