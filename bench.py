@@ -132,6 +132,9 @@ def main():
                          "(three bf16 MFMAs per product, f32 accumulate; 16 operand bits); bf16x6 = three planes, six MFMAs "
                          "(24 operand bits, f32-equivalent)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra split-bf16 measurement reported under \"alt\" (N = 1, --gemm f32 only)")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="GeneralDropout proportion during the timed steps (the recipes' schedule 0,0@0.20,0.5@0.50,0 is at 0 for the first fifth "
+                         "of training and peaks at 0.5); 0 = identity")
     ap.add_argument("--natural-gradient", type=int, default=1, choices=[0, 1],
                     help="1 (default, what the reference's recipes train with) = OnlineNaturalGradient preconditioning of every "
                          "updatable component's gradient; 0 = raw-gradient SGD step")
@@ -168,8 +171,11 @@ def main():
     elif args.workload == "bn-supernet":
         extra = dict(bn_choice_dims=pkg.trainer.BN_CHOICE_DIMS if args.bn_choices == "reference" else [80, 80, 80, 80], bn_mode=pkg.trainer.BN_ONEHOT)
     cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch,
-                                  use_natural_gradient=args.natural_gradient, gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.gemm], **extra)
+                                  use_natural_gradient=args.natural_gradient, gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.gemm],
+                                  use_dropout=int(args.dropout > 0), **extra)
     net = pkg.trainer.ChainNet(cfg)
+    if args.dropout > 0:
+        net.set_dropout_proportion(args.dropout)
     # identical initial model on every rank (seed), different egs per rank (data parallel over sequences)
     net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
     feats, iv = pkg.trainer.synthetic_egs(net, seed=100 + rank)

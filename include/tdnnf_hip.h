@@ -335,6 +335,13 @@ typedef struct {
   int use_layer_offsets;
   int offset_left[TDNNF_NET_MAX_LAYERS];
   int offset_right[TDNNF_NET_MAX_LAYERS];
+  /* GeneralDropoutComponent of tdnn1 and of every tdnnf layer (UPSTREAM; emitted with "continuous=true" and no
+     time-period by composite_layers.py:186-199: one mask row per sequence, shared over time, scale uniform on
+     [1 - 2p, 1 + 2p]).  The recipes train with --trainer.dropout-schedule '0,0@0.20,0.5@0.50,0'
+     (run_tdnn_fbk_40_iv_sp_7q.sh:48,216).  use_dropout != 0 reserves the masks and (num_layers + 1) * num_sequences *
+     hidden_dim further random draws per step (after the others); the proportion p of the moment is set with
+     tdnnf_net_set_dropout_proportion (0 = identity, the initial value).  Off in cv-update mode (test mode). */
+  int use_dropout;
 } tdnnf_net_config;
 typedef struct tdnnf_net tdnnf_net;
 
@@ -402,6 +409,8 @@ int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale
 /* The nnet edit "set-temperature-proportion name=* proportion=p" of the temperature schedule
    (steps/libs/nnet3/train/temperature_schedule.py:51-60, applied by train.py:527-531 before every iteration): sets the
    Temp-Proportion of every TdnnDARTSV3Component and GumbelSoftmax(Flops)Component of the net.  p > 0. */
+/* "nnet3-copy --edits='set-dropout-proportion name=* proportion=p'" of train.py's dropout schedule */
+int tdnnf_net_set_dropout_proportion(tdnnf_net *, float proportion);
 int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
 /* Model state outside the parameter vector, as doubles in network order (tdnn1, tdnnf2.., prefinal-chain, prefinal-xent):
    per BatchNorm [count, stats_sum[D], stats_sumsq[D]] (BatchNormComponent::StoreStats, nnet-normalize-component.cc:551-589)

@@ -6,13 +6,16 @@ namespace tdnnf {
 
 // out = (x - memo.mean) * memo.scale + bypass * prev  (prev.data may be null); memo = 5 x D BatchNorm memo.
 // x / prev / out may be "super row" views (cols > D): runs of D-column rows, each `period` elements apart.
-hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s);
+// mask (may be null): B x D GeneralDropoutComponent mask between the BatchNorm and the bypass sum; row r of a plain view belongs to
+// sequence r % B.
+hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s,
+                           const float *mask = nullptr, int B = 1);
 
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols);
 // BatchNorm backward + ReLU backward (+ self-repair, ReLU statistics, bias-gradient column sums) in two passes.
 // bn_test_mode: the BatchNorm is a BatchNormTestComponent (memo rows 0 and 2 hold the stored mean / scale): dX = dZ * scale.
 hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
-                       void *ws, size_t ws_bytes, hipStream_t s);
+                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask = nullptr, int B = 1);  // mask: dz is multiplied by it first
 
 }  // namespace tdnnf

@@ -34,7 +34,7 @@ __device__ __forceinline__ void st(float *p, const float (&v)[4], bool vec) {
 // (cols = k * D): the column parameters repeat with period D.
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const float *mean, const float *scale, int D, int period,
-                                                              MatView prev, float bypass, MatView out) {
+                                                              MatView prev, float bypass, MatView out, const float *mask, int B) {
   const int cv = x.cols / VEC;
   const long long total = (long long)x.rows * cv;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
@@ -43,8 +43,10 @@ __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const f
     float xv[4], pv[4] = {0, 0, 0, 0}, o[4];
     ld(x.data + (long long)r * x.stride + c, xv, VEC == 4);
     if (prev.data) ld(prev.data + (long long)r * prev.stride + c, pv, VEC == 4);
+    // GeneralDropoutComponent between the BatchNorm and the bypass sum: one mask row per sequence, shared over time
+    const float *mk = mask ? mask + (long long)(x.cols > D ? c / period : r % B) * D + cd : nullptr;
 #pragma unroll
-    for (int j = 0; j < VEC; j++) o[j] = (xv[j] - mean[cd + j]) * scale[cd + j] + bypass * pv[j];
+    for (int j = 0; j < VEC; j++) o[j] = (xv[j] - mean[cd + j]) * scale[cd + j] * (mk ? mk[j] : 1.f) + bypass * pv[j];
     st(out.data + (long long)r * out.stride + c, o, VEC == 4);
   }
 }
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const f
 // partial layout: [quantity][chunk][col].
 template <int VEC, bool RELU_STATS>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatView dz, const float *mean, const float *scale,
-                                                                 int rows_per_chunk, int chunks, float *partial) {
+                                                                 int rows_per_chunk, int chunks, float *partial, const float *mask, int B) {
   __shared__ float red[4][4][64 * 4 + 4];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + tc) * VEC;
@@ -70,6 +72,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
       float xv[4], dv[4];
       ld(x.data + (long long)r * x.stride + col, xv, VEC == 4);
       ld(dz.data + (long long)r * dz.stride + col, dv, VEC == 4);
+      if (mask) {  // derivative through the dropout mask first (row r belongs to sequence r % B)
+        const float *mk = mask + (long long)(r % B) * x.cols + col;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) dv[j] *= mk[j];
+      }
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         const float z = (xv[j] - mu[j]) * sc[j];
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_finalize_kernel(const float *
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatView dz, const float *memo, int D,
                                                                 const double *repair_stats, float self_repair_scale,
-                                                                int rows_per_chunk, int chunks, MatView d_aff, float *partial) {
+                                                                int rows_per_chunk, int chunks, MatView d_aff, float *partial, const float *mask, int B) {
   __shared__ float red[4][64 * 4 + 4];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + tc) * VEC;
@@ -158,6 +165,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
       float xv[4], dv[4], o[4];
       ld(x.data + (long long)r * x.stride + col, xv, VEC == 4);
       ld(dz.data + (long long)r * dz.stride + col, dv, VEC == 4);
+      if (mask) {
+        const float *mk = mask + (long long)(r % B) * x.cols + col;
+#pragma unroll
+        for (int j = 0; j < VEC; j++) dv[j] *= mk[j];
+      }
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         const float z = (xv[j] - mu[j]) * sc[j];
@@ -195,13 +207,13 @@ __global__ __launch_bounds__(256) void colsum_add_kernel(const float *partial, i
 
 }  // namespace
 
-hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s) {
+hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s, const float *mask, int B) {
   if (x.rows == 0) return hipSuccess;
   // period: a super row (cols > D) is a run of rows of D values, each padded to `period` (the plain rows' stride)
   const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0;
   const long long work = (long long)x.rows * (vec ? x.cols / 4 : x.cols);
-  if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out);
-  else hipLaunchKernelGGL((bn_apply_bypass_kernel<1>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out);
+  if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
+  else hipLaunchKernelGGL((bn_apply_bypass_kernel<1>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
   return hipGetLastError();
 }
 
@@ -214,7 +226,7 @@ size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
 // valid).  Writes d_aff (may alias dz) and adds lr_scale * colsum(d_aff) into bias_acc (may be null).
 hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
-                       void *ws, size_t ws_bytes, hipStream_t s) {
+                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask, int B) {
   if (x.rows == 0) return hipSuccess;
   if (ws_bytes < bn_relu_bwd_workspace_bytes(x.rows, x.cols)) return hipErrorInvalidValue;
   const int D = x.cols;
@@ -227,17 +239,17 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
   // Order as in the reference: StoreStats runs with the forward pass, RepairGradients in Backprop sees the
   // statistics including this minibatch (when it was stored).
   if (store_relu_stats) {
-    if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, true>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
-    else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, true>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
+    if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, true>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
+    else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, true>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
   } else {
-    if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
-    else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial);
+    if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
+    else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
   }
   hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(256), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
                      store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0);
   const double *rep = self_repair ? relu_stats : nullptr;
-  if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);
-  else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial);
+  if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
+  else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
   if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 63) / 64), dim3(256), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
   return hipGetLastError();
 }

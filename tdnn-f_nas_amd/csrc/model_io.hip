@@ -611,7 +611,7 @@ void write_nonlinear(Ctx &x, const char *type, int D, const std::string &stat_na
   o.token(std::string("</") + type + ">");
 }
 
-void write_dropout(Ctx &x, int D) {  // GeneralDropoutComponent (UPSTREAM): dropout-proportion 0, continuous
+void write_dropout(Ctx &x, int D) {  // GeneralDropoutComponent (UPSTREAM): continuous, the proportion of the moment
   Out &o = *x.o;
   o.token("<GeneralDropoutComponent>");
   o.token("<Dim>");
@@ -621,7 +621,7 @@ void write_dropout(Ctx &x, int D) {  // GeneralDropoutComponent (UPSTREAM): drop
   o.token("<TimePeriod>");
   o.i32(0);
   o.token("<DropoutProportion>");
-  o.f32(0.0f);
+  o.f32(x.n->dropout_proportion);
   o.token("<Continuous>");
   o.token("</GeneralDropoutComponent>");
 }

@@ -378,6 +378,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     if (L.lin.darts) tg = std::max(tg, (size_t)L.bn * L.lin.K * Hd);
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
+  n->dropout_masks = (c.use_dropout && !c.cv_update) ? A.take<float>((size_t)(c.num_layers + 1) * B * Hd) : nullptr;
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
   n->paramsT = n->cfg.gemm_precision != 0 ? A.take<float>((size_t)n->num_params + 16) : nullptr;
   n->ngBias = nullptr;
@@ -467,6 +468,12 @@ tdnnf_mat sub_grid_view(float *data, const Grid &g, const Grid &sub, int B, int 
   if (ratio == 1) return tdnnf_mat{data + (size_t)tau0 * B * stride, sub.n * B, cols, stride};
   // every ratio-th block of B rows: n "super rows" of B*stride elements
   return tdnnf_mat{data + (size_t)tau0 * B * stride, sub.n, B * stride - (stride - cols), ratio * B * stride};
+}
+
+// GeneralDropoutComponent::GetMemo (UPSTREAM), continuous form: mask = 1 - 2p + 4p U, U uniform on (0, 1)
+__global__ void dropout_mask_kernel(const float *u, float p, long long n, float *mask) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    mask[i] = 1.0f - 2.0f * p + 4.0f * p * u[i];
 }
 
 // BatchNormTestComponent (cv-update): memo rows 0 (mean) and 2 (scale) from the stored statistics, ComputeDerived
@@ -679,6 +686,9 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
       n->num_draws += 2 * (K + 1);
     }
   }
+  n->dropout_draw0 = n->num_draws;
+  n->dropout_proportion = 0.f;
+  if (c.use_dropout && !c.cv_update) n->num_draws += (c.num_layers + 1) * B * Hd;  // one B x Hd mask per GeneralDropoutComponent
   n->c_prefinal_l = add_comp(n, "prefinal-l", S, Hd, 0, 1.f, c.l2_hidden, c.max_change_hidden, -1.0f);
   const char *hn[2] = {"chain", "xent"};
   for (int h = 0; h < 2; h++) {
@@ -848,6 +858,13 @@ int tdnnf_net_set_stats(tdnnf_net *n, const double *host_in, tdnnf_stream stream
   return TDNNF_OK;
 }
 
+int tdnnf_net_set_dropout_proportion(tdnnf_net *n, float proportion) {
+  TDNNF_REQUIRE(n && proportion >= 0.f && proportion <= 0.5f, "net_set_dropout_proportion: proportion must be in [0, 0.5] (continuous masks: scale in [1 - 2p, 1 + 2p])");
+  TDNNF_REQUIRE(proportion == 0.f || n->dropout_masks, "net_set_dropout_proportion: the net was created without use_dropout (or in cv-update mode)");
+  n->dropout_proportion = proportion;
+  return TDNNF_OK;
+}
+
 int tdnnf_net_set_temperature_proportion(tdnnf_net *n, float proportion) {
   TDNNF_REQUIRE(n && proportion > 0.f, "net_set_temperature_proportion: proportion must be > 0");
   n->cfg.darts_temp_proportion = proportion;
@@ -973,12 +990,22 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   ix1.num_offsets = 1;
   tdnnf_mat t1r = M(n->t1_relu, N0, Hd), t1b = M(n->t1_bn, N0, Hd);
   const MatView none{nullptr, 0, 0, 0};
+  // dropout masks of this minibatch (mask m: tdnn1 = 0, tdnnf layer l = l + 1); null = identity
+  const bool drop = n->dropout_masks && n->dropout_proportion > 0.f;
+  if (drop) {
+    TDNNF_REQUIRE(n->draws, "net_forward_backward: dropout needs net_set_random_draws before every step");
+    const long long nm = (long long)(c.num_layers + 1) * B * Hd;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(nm, 256)), dim3(256), 0, s, n->draws + n->dropout_draw0, n->dropout_proportion, nm, n->dropout_masks);
+  }
+  auto mask_of = [&](int m) -> const float * { return drop ? n->dropout_masks + (size_t)m * B * Hd : nullptr; };
   // tdnn1: affine (+bias, ReLU in the GEMM epilogue) -> BatchNorm
   CK(tdnn_propagate_impl(&ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, 1, 1, &t1r, s));
   CK(bn_stats(n, n->t1_relu, N0, Hd, n->t1_bn_memo, n->t1_bn_stats, s));
-  TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, ldpad(Hd), none, 0.f, view(&t1b), s));
+  TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, ldpad(Hd), none, 0.f, view(&t1b), s, mask_of(0), B));
   float *prev = n->t1_bn;
+  int layer_no = 0;
   for (auto &L : n->layers) {
+    layer_no++;
     tdnnf_mat in = M(prev, N_of(L.gin, B), Hd);
     tdnnf_mat lin = M(L.lin_out, L.lin.rows_out, L.bn);
     const float *lin_eff = nullptr, *aff_eff = nullptr;
@@ -1013,14 +1040,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
     CK(tdnn_propagate_impl(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, 1, 1, &relu, s));
     CK(bn_stats(n, L.relu_out, L.aff.rows_out, Hd, L.bn_memo, L.bn_stats, s));
-    // noop = Sum(Scale(bypass, input), batchnorm(relu))  in one pass (dropout-proportion 0 -> GeneralDropout is a copy)
+    // noop = Sum(Scale(bypass, input), dropout(batchnorm(relu)))  in one pass
     tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
     tdnnf_mat x = relu, out = M(L.noop_out, L.aff.rows_out, Hd);
     if (byp.rows != out.rows) {  // strided bypass rows: view everything as (n, B*stride) super rows
       x = tdnnf_mat{L.relu_out, L.gout.n, byp.cols, B * ldpad(Hd)};
       out = tdnnf_mat{L.noop_out, L.gout.n, byp.cols, B * ldpad(Hd)};
     }
-    TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, ldpad(Hd), view(&byp), c.bypass_scale, view(&out), s));
+    TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, ldpad(Hd), view(&byp), c.bypass_scale, view(&out), s, mask_of(layer_no), B));
     prev = L.noop_out;
   }
   const int No = n->Tout * B;
@@ -1058,12 +1085,12 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // BatchNorm backward + ReLU backward (+ StoreStats / self-repair coin flips as in the reference:
   // RectifiedLinearComponent::StoreStats nnet-simple-component.cc:1084, RepairGradients :1017) in two fused
   // passes; also yields the bias gradient of the affine layer in front of the ReLU.
-  auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc) -> int {
+  auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc, const float *mask = nullptr) -> int {
     const bool store = coin() || step == 0;
     const bool repair = c.relu_self_repair_scale > 0.f && coin();
     tdnnf_mat x = M(relu_out, rows, Hd), d = M(d_io, rows, Hd);
     TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, cv, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
-                          n->ws, n->ws_bytes, s));
+                          n->ws, n->ws_bytes, s, mask, B));
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
@@ -1172,7 +1199,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
       tdnnf_mat x = M(L.relu_out, no, Hd);
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
-                            view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s));
+                            view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B));
     }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : (L.c_arch >= 0 ? M(L.lin_masked, nl, L.bn) : lin);
@@ -1239,7 +1266,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     std::swap(d_cur, d_next);
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
-    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp)));
+    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), mask_of(0)));
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }

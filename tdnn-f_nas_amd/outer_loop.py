@@ -54,7 +54,7 @@ def shrinkage_value(learning_rate, proportional_shrink=0.0):
 
 
 def iteration_plan(num_epochs, num_archives, frame_subsampling_factor=3, num_jobs_initial=1, num_jobs_final=1, initial_effective_lrate=2.5e-4,
-                   final_effective_lrate=2.5e-5, proportional_shrink=0.0, temperature_schedule=False):
+                   final_effective_lrate=2.5e-5, proportional_shrink=0.0, temperature_schedule=False, dropout_schedule=None):
     """One dict per iteration with everything train.py:473-531 derives before it launches the jobs."""
     to_process, num_iters = num_iterations(num_epochs, num_archives, frame_subsampling_factor, num_jobs_initial, num_jobs_final)
     plan = []
@@ -66,6 +66,8 @@ def iteration_plan(num_epochs, num_archives, frame_subsampling_factor=3, num_job
         num_archives_expanded = num_archives * frame_subsampling_factor
         plan.append(dict(iteration=it, num_jobs=jobs, learning_rate=lr, shrink=shrinkage_value(lr, proportional_shrink), data_fraction=frac,
                          temperature_proportion=T.temperature_proportion(frac) if temperature_schedule else None,
+                         # train.py:519-527: get_dropout_edit_string(dropout_schedule, data fraction, iter)
+                         dropout_proportion=T.dropout_proportion(dropout_schedule, frac) if dropout_schedule else None,
                          # job j (1-based) of this iteration reads archive (processed + j - 1) % expanded + 1, i.e. archive k of the
                          # egs dir at frame shift (k_expanded // num_archives) -- the upstream convention, stated
                          archives=[(processed + j) % num_archives_expanded for j in range(jobs)]))
@@ -83,7 +85,7 @@ def average_models(models):
 
 def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, minibatches_per_archive, frame_subsampling_factor=3, num_jobs_initial=1,
         num_jobs_final=1, initial_effective_lrate=2.5e-4, final_effective_lrate=2.5e-5, proportional_shrink=0.0, temperature_schedule=False,
-        do_final_combination=True, max_models_combine=20, srand=0, binary=True, log=None):
+        do_final_combination=True, max_models_combine=20, srand=0, binary=True, log=None, dropout_schedule=None):
     """Runs the whole schedule.  net_factory() -> a ChainNet with initial parameters set (called once per job: a fresh process in
     the reference, so fresh natural-gradient state; BatchNorm / ReLU statistics and parameters come from <iter>.mdl).
     egs_for_archive(archive_index, minibatch_index) -> (feats, ivectors, den_graph, supervision) device objects for
@@ -94,7 +96,7 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
     os.makedirs(work_dir, exist_ok=True)
     plan = iteration_plan(num_epochs, num_archives, frame_subsampling_factor, num_jobs_initial, num_jobs_final, initial_effective_lrate,
-                          final_effective_lrate, proportional_shrink, temperature_schedule)
+                          final_effective_lrate, proportional_shrink, temperature_schedule, dropout_schedule)
     num_iters = len(plan)
     to_process = int(num_epochs * num_archives * frame_subsampling_factor)
     combine = model_combine_iters(num_iters, num_epochs, num_archives * frame_subsampling_factor, max_models_combine, num_jobs_final) \
@@ -118,6 +120,8 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
             net.read_model(path(i))
             if it["temperature_proportion"] is not None:
                 net.set_temperature_proportion(it["temperature_proportion"])
+            if it["dropout_proportion"] is not None:
+                net.set_dropout_proportion(it["dropout_proportion"])
             g = torch.Generator(device="cuda")
             g.manual_seed(srand + 1000 * i + j)
             for m in range(minibatches_per_archive):

@@ -28,7 +28,8 @@ class NetConfig(C.Structure):
                 ("use_natural_gradient", C.c_int),
                 ("bn_num_choices", C.c_int), ("bn_choice_dims", C.c_int * 8), ("bn_mode", C.c_int),
                 ("bn_flops_scale", C.c_float), ("bn_temp_proportion", C.c_float), ("cv_update", C.c_int), ("gemm_precision", C.c_int),
-                ("use_layer_offsets", C.c_int), ("offset_left", C.c_int * MAX_LAYERS), ("offset_right", C.c_int * MAX_LAYERS)]
+                ("use_layer_offsets", C.c_int), ("offset_left", C.c_int * MAX_LAYERS), ("offset_right", C.c_int * MAX_LAYERS),
+                ("use_dropout", C.c_int)]
 
 DARTS_USE_GUMBEL, DARTS_FREE_SELECT, DARTS_UNIFORM_SAMPLE, DARTS_USE_ENTROPY, DARTS_UPDATE_ALPHA = 1, 2, 4, 8, 16
 
@@ -85,6 +86,7 @@ def make_config(frames_per_chunk=150, num_sequences=64, strides=None, bottleneck
         c.use_layer_offsets = 1
         for i, (a, b) in enumerate(layer_offsets):
             c.offset_left[i], c.offset_right[i] = int(a), int(b)
+    c.use_dropout = int(kw.get("use_dropout", 0))  # reserve the GeneralDropout masks / draws; ChainNet.set_dropout_proportion
     c.cv_update = int(kw.get("cv_update", 0))
     c.gemm_precision = int(kw.get("gemm_precision", 0))  # GEMM_F32 exact f32 MFMA, GEMM_BF16X3 / GEMM_BF16X6 split-bf16
     return c
@@ -206,6 +208,10 @@ class ChainNet:
     def read_model(self, path):
         hipabi.check(self.lib.tdnnf_net_read_model(self.h, str(path).encode(), hipabi.stream()))
 
+    def set_dropout_proportion(self, proportion):
+        """nnet3-copy --edits='set-dropout-proportion name=* proportion=p' (train.py's --trainer.dropout-schedule)."""
+        hipabi.check(self.lib.tdnnf_net_set_dropout_proportion(self.h, float(proportion)))
+
     def set_temperature_proportion(self, proportion):
         """nnet edit "set-temperature-proportion name=* proportion=p" (temperature_schedule.py:57-60)."""
         hipabi.check(self.lib.tdnnf_net_set_temperature_proportion(self.h, float(proportion)))
@@ -290,6 +296,43 @@ def temperature_proportion(data_fraction):
 def temperature(temperature_init, temperature_final, data_fraction):
     """get_temperature_edit_string_adapt, temperature_schedule.py:20: geometric interpolation."""
     return temperature_init * (temperature_final / temperature_init) ** data_fraction
+
+
+def dropout_proportion(schedule, data_fraction):
+    """Value at data_fraction of a --trainer.dropout-schedule function such as '0,0@0.20,0.5@0.50,0'
+    (run_tdnn_fbk_40_iv_sp_7q.sh:48; semantics in the option's help text, steps/libs/nnet3/train/common.py:883-905; the parser
+    itself, dropout_schedule.py, is upstream): comma-separated values, optionally value@x; the first and last sit at x = 0 and
+    x = 1, unspecified x are spread evenly between their specified neighbours, linear in between.  One function for every
+    component (the recipes give no per-pattern rules)."""
+    if schedule is None:
+        return 0.0
+    pts = []
+    for tok in str(schedule).split(","):
+        v, _, x = tok.strip().partition("@")
+        pts.append([float(v), float(x) if x else None])
+    if len(pts) == 1:
+        return pts[0][0]
+    if pts[0][1] is None:
+        pts[0][1] = 0.0
+    if pts[-1][1] is None:
+        pts[-1][1] = 1.0
+    i = 0
+    while i < len(pts):  # fill runs of unspecified x between known ones
+        if pts[i][1] is None:
+            j = i
+            while pts[j][1] is None:
+                j += 1
+            x0, x1, n = pts[i - 1][1], pts[j][1], j - i + 1
+            for k in range(i, j):
+                pts[k][1] = x0 + (x1 - x0) * (k - i + 1) / n
+            i = j
+        i += 1
+    assert all(a[1] <= b[1] for a, b in zip(pts, pts[1:])) and pts[0][1] == 0.0 and pts[-1][1] == 1.0, "x values must rise from 0 to 1"
+    f = min(max(float(data_fraction), 0.0), 1.0)
+    for (v0, x0), (v1, x1) in zip(pts, pts[1:]):
+        if f <= x1:
+            return v0 if x1 == x0 else v0 + (v1 - v0) * (f - x0) / (x1 - x0)
+    return pts[-1][0]
 
 
 def temperature_edit_string(data_fraction):

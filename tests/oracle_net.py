@@ -75,6 +75,7 @@ class OracleNet:
         self.bn_stats = {}
         self.relu_stats = {}
         self.cv = bool(getattr(cfg, "cv_update", 0))
+        self.dropout_p = 0.0  # set_dropout_proportion; GeneralDropoutComponent of tdnn1 and of every tdnnf layer
         self.bnC = int(getattr(cfg, "bn_num_choices", 0))
         self.bn_dims = [cfg.bn_choice_dims[k] for k in range(self.bnC)]
         self.use_ng = bool(getattr(cfg, "use_natural_gradient", 0))
@@ -86,6 +87,26 @@ class OracleNet:
                 spliced = c["cols"] + (1 if c["has_bias"] else 0)
                 self.ng[c["name"]] = (self.L.oracle_ng_create(min(20, (spliced + 1) // 2), 4, 2000.0, 4.0),
                                       self.L.oracle_ng_create(min(80, (c["rows"] + 1) // 2), 4, 2000.0, 4.0))
+
+    def set_dropout_proportion(self, p):
+        self.dropout_p = float(p)
+
+    def _dropout_masks(self, draws):
+        """GeneralDropoutComponent (UPSTREAM), continuous=true, time-period 0: one mask row per sequence, shared over time,
+        1 - 2p + 4p U; the trainer's draws for them follow all the others.  Returns [mask_tdnn1, mask_layer0, ...] of B x Hd, or
+        None when dropout is off (proportion 0, cv-update / test mode, or a net created without use_dropout)."""
+        if not getattr(self.cfg, "use_dropout", 0) or self.cv or self.dropout_p <= 0.0:
+            return None
+        L, Hd = self.cfg.num_layers, self.cfg.hidden_dim
+        base = (2 * (self.Kd + 1) * L if self.Kd >= 2 else 0)
+        if self.bnC:
+            base += (1 if self.cfg.bn_mode == 0 else (self.bnC if self.cfg.bn_mode == 2 else 0)) * L
+        u = np.asarray(draws[base:base + (L + 1) * self.B * Hd], F).reshape(L + 1, self.B, Hd)
+        p = F(self.dropout_p)
+        return (F(1.0) - F(2.0) * p + F(4.0) * p * u).astype(F)
+
+    def _mask_rows(self, mask, rows):
+        return np.tile(mask, (rows // self.B, 1))  # row r belongs to sequence r % B
 
     def _ng_grad(self, name, xs, dy, Wg, bg):
         """UpdateNaturalGradient :592-624: xs = spliced input [c_i X_i ...] (N x K*Di), dy = out_deriv."""
@@ -327,6 +348,10 @@ class OracleNet:
         Lb.oracle_affine_propagate(ora.omat(lda), ora.fptr(W1), W1.shape[1], ora.fptr(b1), W1.shape[0], ora.omat(t1))
         t1_relu = np.maximum(t1, 0)
         t1_bn, t1_memo = self._bn_fwd("tdnn1", t1_relu)
+        masks = self._dropout_masks(draws) if draws is not None else None
+        t1_bn_pre = t1_bn
+        if masks is not None:
+            t1_bn = (t1_bn * self._mask_rows(masks[0], N0)).astype(F)
         acts["tdnn1.batchnorm"] = t1_bn
         prev, store = t1_bn, []
         for i, Ly in enumerate(self.layers):
@@ -356,10 +381,13 @@ class OracleNet:
             aff = self._tdnn_fwd(aff_in, Waff, baff, aff_off, Ly["lin"], Ly["out"], eff=da["eff"] if da else None)
             relu = np.maximum(aff, 0)
             bn, memo = self._bn_fwd(nm, relu)
+            bn_pre = bn
+            if masks is not None:
+                bn = (bn * self._mask_rows(masks[i + 1], bn.shape[0])).astype(F)
             rows = self._rows_on(Ly["inn"], Ly["out"])
             out = (F(cfg.bypass_scale) * prev[rows] + bn).astype(F)
             acts[nm + ".linear"], acts[nm + ".relu"], acts[nm + ".batchnorm"], acts[nm + ".noop"] = lin, relu, bn, out
-            store.append(dict(inp=prev, lin=lin, aff_in=aff_in, relu=relu, bn=bn, memo=memo, rows=rows, rho=rho,
+            store.append(dict(inp=prev, lin=lin, aff_in=aff_in, relu=relu, bn=bn_pre, memo=memo, rows=rows, rho=rho,
                               lin_off=lin_off, aff_off=aff_off, Wlin=Wlin, Waff=Waff, dl=dl, da=da, arch=arch))
             prev = out
         No = self.Tout * B
@@ -469,7 +497,8 @@ class OracleNet:
         for i in reversed(range(len(self.layers))):
             Ly, st = self.layers[i], store[i]
             nm = f"tdnnf{i + 2}"
-            d_relu = self._bn_bwd(st["bn"], d_cur, st["memo"])
+            d_bn = d_cur if masks is None else (d_cur * self._mask_rows(masks[i + 1], d_cur.shape[0])).astype(F)
+            d_relu = self._bn_bwd(st["bn"], d_bn, st["memo"])
             d_aff = relu_bwd(nm, st["relu"], d_relu)
             Wg, bgv = np.ascontiguousarray(Gw(nm + ".affine")), Gb(nm + ".affine")
             bg = np.ascontiguousarray(bgv)
@@ -494,7 +523,8 @@ class OracleNet:
                 Gb(nm + ".linear")[:] = blin
             d_in[st["rows"]] += F(cfg.bypass_scale) * d_cur
             d_cur = d_in
-        d_relu = self._bn_bwd(t1_bn, d_cur, t1_memo)
+        d_bn = d_cur if masks is None else (d_cur * self._mask_rows(masks[0], N0)).astype(F)
+        d_relu = self._bn_bwd(t1_bn_pre, d_bn, t1_memo)
         d_aff = relu_bwd("tdnn1", t1_relu, d_relu)
         affine_bwd(lda, d_aff, W1, "tdnn1.affine", want_dx=False)
         res = dict(objf=objf.value, l2_term=l2t.value, weight=w.value, ok=ok, xent_objf=xent_objf)

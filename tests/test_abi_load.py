@@ -80,7 +80,13 @@ def test_outer_loop_plan(pkg):
     o = pkg.outer_loop
     to_process, iters = o.num_iterations(num_epochs=4, num_archives=10, frame_subsampling_factor=3, num_jobs_initial=2, num_jobs_final=6)
     assert (to_process, iters) == (120, 30)  # 4 * 10 * 3 archives at an average of 4 jobs
-    plan = o.iteration_plan(4, 10, 3, 2, 6, 2.5e-4, 2.5e-5, temperature_schedule=True)
+    plan = o.iteration_plan(4, 10, 3, 2, 6, 2.5e-4, 2.5e-5, temperature_schedule=True, dropout_schedule='0,0@0.20,0.5@0.50,0')
+    dp = [p["dropout_proportion"] for p in plan]
+    assert dp[0] == 0.0 and max(dp) > 0.45 and dp[-1] < 0.1 and all(v == 0.0 for p, v in zip(plan, dp) if p["data_fraction"] <= 0.2)
+    t = pkg.trainer  # the option's own examples (common.py:883-905)
+    assert t.dropout_proportion('0,0.2,0', 0.5) == pytest.approx(0.2) and t.dropout_proportion('0,0.2,0', 0.25) == pytest.approx(0.1)
+    assert t.dropout_proportion('0,0.2@0.25,0', 0.25) == pytest.approx(0.2) and t.dropout_proportion('0,0.2@0.25,0', 0.625) == pytest.approx(0.1)
+    assert t.dropout_proportion('0,0@0.20,0.5@0.50,0', 0.35) == pytest.approx(0.25) and t.dropout_proportion(None, 0.3) == 0.0
     assert len(plan) == 30 and plan[0]["num_jobs"] == 2 and plan[-1]["num_jobs"] == 6
     assert [p["num_jobs"] for p in plan] == sorted(p["num_jobs"] for p in plan)
     assert abs(sum(p["num_jobs"] for p in plan) - to_process) <= 6

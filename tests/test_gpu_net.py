@@ -75,6 +75,13 @@ for _seed in (2, 3, 4):
     _lo = [(int(_r.integers(0, 7)), int(_r.integers(0, 7))) for _ in range(5)]
     CASES.append(("child-random-%d-" % _seed + "_".join("%d.%d" % ab for ab in _lo),
                   dict(_C, frames_per_chunk=30, layer_offsets=_lo, bottleneck=[int(v) for v in _r.choice([16, 24, 40], 5)]), 40))
+# GeneralDropoutComponent active (the recipes' --trainer.dropout-schedule reaches 0.5): masks from the draws, one row per
+# sequence; the last layer's strided bypass exercises the super-row form of the fused kernel
+CASES += [
+    ("7q-shape-small-dropout", dict(CASES[1][1], use_dropout=1, dropout_proportion=0.3), 60),
+    ("darts-k7-uniform-dropout-NG", dict(_D, frames_per_chunk=48, num_sequences=6, darts_num_offsets=7, darts_flags=4, use_dropout=1, dropout_proportion=0.5,
+                                         use_natural_gradient=1), 40),
+]
 # gemm_precision 2: three bf16 planes per operand, six products -- 24 operand bits, held to the SAME tolerances as exact f32
 CASES += [
     ("7q-shape-small-bf16x6", dict(CASES[1][1], gemm_precision=2), 60),
@@ -88,6 +95,8 @@ CASES += [
 
 @pytest.mark.parametrize("name,kw,H", CASES, ids=[c[0] for c in CASES])
 def test_net_step_matches_oracle(pkg, name, kw, H):
+    kw = dict(kw)
+    dropout_p = kw.pop("dropout_proportion", 0.0)
     cfg = pkg.trainer.make_config(**kw)
     x3 = cfg.gemm_precision == 1  # 16-bit operands; gemm_precision 2 is f32-equivalent and gets the f32 tolerances
     net = pkg.trainer.ChainNet(cfg)
@@ -105,6 +114,9 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
     net.set_params(params)
     ref = OracleNet(pkg, cfg, net.components)
     assert ref.num_t_in == net.num_t_in
+    if dropout_p:
+        net.set_dropout_proportion(dropout_p)
+        ref.set_dropout_proportion(dropout_p)
     feats, iv = pkg.trainer.synthetic_egs(net, seed=4)
     den = pkg.synth.make_den_graph(H, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
     sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)

@@ -107,7 +107,7 @@ def test_outer_loop_two_ranks_match_one(pkg, tmp_path):
 def test_outer_loop_on_the_offset_supernet_with_temperature_schedule(pkg, tmp_path):
     """The search stage: Gumbel coefficients need random draws every minibatch and the temperature proportion of the iteration."""
     T = pkg.trainer
-    cfg = T.make_config(**dict(KW, use_natural_gradient=0, darts_num_offsets=3, darts_flags=T.DARTS_USE_GUMBEL | T.DARTS_UPDATE_ALPHA))
+    cfg = T.make_config(**dict(KW, use_natural_gradient=0, darts_num_offsets=3, darts_flags=T.DARTS_USE_GUMBEL | T.DARTS_UPDATE_ALPHA, use_dropout=1))
 
     def factory():
         net = T.ChainNet(cfg)
@@ -120,9 +120,10 @@ def test_outer_loop_on_the_offset_supernet_with_temperature_schedule(pkg, tmp_pa
     sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=4))
     fd, ivd = dev(feats), dev(iv)
     plan, combine, _ = pkg.outer_loop.run(factory, lambda a, m: (fd, ivd, den, sup), str(tmp_path / "s"), num_epochs=1, num_archives=2, minibatches_per_archive=2,
-                                          num_jobs_initial=1, num_jobs_final=1, temperature_schedule=True, initial_effective_lrate=1e-3, final_effective_lrate=1e-4)
+                                          num_jobs_initial=1, num_jobs_final=1, temperature_schedule=True, initial_effective_lrate=1e-3, final_effective_lrate=1e-4,
+                                          dropout_schedule='0,0@0.20,0.5@0.50,0')
     assert len(plan) == 6 and plan[0]["temperature_proportion"] == 1.0 and plan[-1]["temperature_proportion"] < 0.3
-    assert all(np.isfinite(p["objf_per_frame"]) for p in plan)
+    assert all(np.isfinite(p["objf_per_frame"]) for p in plan) and max(p["dropout_proportion"] for p in plan) == 0.5
     a0 = pkg.derive.logits_from_net(probe)
     probe.read_model(tmp_path / "s" / "final.mdl")
     a1 = pkg.derive.logits_from_net(probe)

@@ -263,3 +263,43 @@ def test_child_forward_by_time_lookup(pkg, lo):
         rho = go[1] // gl[1]
         assert gl[0] == go[0] and 0 <= (gl[0] + (gl[2] - 1) * gl[1]) - last_needed < max(rho, 1) * gl[1]
         assert gi[0] == gl[0] - a and gi[0] + (gi[2] - 1) * gi[1] == gl[0] + (gl[2] - 1) * gl[1]
+
+
+def test_oracle_dropout_gradients_by_finite_differences(pkg):
+    """GeneralDropoutComponent masks (continuous, one row per sequence) between BatchNorm and the bypass sum: with the masks
+    fixed the net stays differentiable; also: proportion 0 is the identity, the masks have mean ~1 and live in [1 - 2p, 1 + 2p]."""
+    cfg, comps, params, net, feats, iv, den, sup = tiny_setup(pkg, strides=(1, 0, 3), T=18, relu_self_repair_scale=0.0, use_dropout=1)
+    nd = (cfg.num_layers + 1) * cfg.num_sequences * cfg.hidden_dim
+    draws = np.random.default_rng(9).uniform(0, 1, nd).astype(np.float32)
+    r0, g0, a0 = net.forward_backward(params, feats, iv, den, sup, draws=draws)
+    net.set_dropout_proportion(0.0)
+    r1, g1, _ = net.forward_backward(params, feats, iv, den, sup)
+    assert r0["objf"] == r1["objf"] and np.array_equal(g0, g1)  # proportion 0: nothing changes
+    net.set_dropout_proportion(0.3)
+    masks = net._dropout_masks(draws)
+    assert masks.shape == (cfg.num_layers + 1, cfg.num_sequences, cfg.hidden_dim) and masks.min() >= 0.4 - 1e-6 and masks.max() <= 1.6 + 1e-6
+    assert abs(masks.mean() - 1.0) < 0.05
+    res, grads, acts = net.forward_backward(params, feats, iv, den, sup, draws=draws)
+    assert res["objf"] != r0["objf"]
+    post = acts["xent.post"]
+
+    def total(p):
+        r, _, _ = net.forward_backward(p, feats, iv, den, sup, fixed_xent_post=post, forward_only=True, draws=draws)
+        return r["objf"] + r["l2_term"] + cfg.xent_regularize * r["xent_objf"]
+
+    rng = np.random.default_rng(5)
+    bad = total_checked = 0
+    for c in comps[1:]:
+        n = c["rows"] * c["cols"] + (c["rows"] if c["has_bias"] else 0)
+        for idx in rng.choice(n, size=3, replace=False):
+            i = c["begin"] + int(idx)
+            ok = False
+            for eps in (4e-3, 1e-3):
+                pp, pm = params.copy(), params.copy()
+                pp[i] += eps
+                pm[i] -= eps
+                fd = (total(pp) - total(pm)) / (2 * eps)
+                ok = ok or abs(fd - grads[i]) <= 2e-2 * max(abs(fd), abs(grads[i])) + 3e-3
+            total_checked += 1
+            bad += not ok
+    assert bad <= max(1, total_checked // 10), (bad, total_checked)
