@@ -382,6 +382,12 @@ int tdnnf_egs_writer_write(tdnnf_egs_writer *, const char *key, const float *fea
                            const float *final_logprob, const int *arc_src, const int *arc_dst, const int *arc_pdf, const float *arc_logprob);
 
 int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out);
+/* A second net for ANOTHER MINIBATCH SHAPE of the same model (cfg differing from the primary's only in frames_per_chunk /
+   num_sequences): the recipes cut examples of several chunk widths (--egs.chunk-width 150,110,100) and merge each width
+   into its own minibatches.  It shares the primary's natural-gradient preconditioners and model statistics (BatchNorm /
+   ReLU); give it the primary's parameter and gradient buffers with tdnnf_net_set_buffers.  Use the nets one after the
+   other on one stream; destroy the primary last. */
+int tdnnf_net_create_shared(const tdnnf_net_config *cfg, const tdnnf_net *primary, tdnnf_net **out);
 void tdnnf_net_destroy(tdnnf_net *);
 long long tdnnf_net_num_params(const tdnnf_net *);
 int tdnnf_net_num_components(const tdnnf_net *);

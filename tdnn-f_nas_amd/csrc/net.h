@@ -113,6 +113,7 @@ struct tdnnf_net {
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den;
   int num_draws;
+  bool owns_ng = true;    // false: created by tdnnf_net_create_shared, the preconditioners belong to the primary net
   int dropout_draw0;      // first of the (num_layers + 1) * B * hidden_dim dropout draws (cfg.use_dropout)
   float *dropout_masks;   // (num_layers + 1) x B x hidden_dim: tdnn1, then the tdnnf layers
   float dropout_proportion;

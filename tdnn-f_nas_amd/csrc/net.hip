@@ -543,7 +543,16 @@ int tdnnf_reorder_rows(const tdnnf_mat *in, int B, int rho, int to_rho, tdnnf_ma
   return TDNNF_OK;
 }
 
-int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
+static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, tdnnf_net **out);
+
+int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) { return net_create_impl(cfg, nullptr, out); }
+
+int tdnnf_net_create_shared(const tdnnf_net_config *cfg, const tdnnf_net *primary, tdnnf_net **out) {
+  TDNNF_REQUIRE(primary, "net_create_shared: null primary net");
+  return net_create_impl(cfg, primary, out);
+}
+
+static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, tdnnf_net **out) {
   TDNNF_REQUIRE(cfg && out, "net_create: null argument");
   const tdnnf_net_config &c = *cfg;
   TDNNF_REQUIRE(c.feat_dim > 0 && c.ivector_dim > 0 && c.num_pdfs > 0 && c.hidden_dim > 0 && c.prefinal_small_dim > 0,
@@ -710,7 +719,20 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
     // update-alpha's x10000), the freshly added X.alpha vectors keep factor 1.
     for (auto &cd : n->comps) cd.lr_factor = cd.plain ? 1.0f : (cd.num_alpha > 0 ? 1.0e-4f : 0.0f);
   }
-  if (c.use_natural_gradient) {
+  n->owns_ng = share == nullptr;
+  if (share) {  // another minibatch shape of the same model: same components, the primary's preconditioners
+    bool same = share->comps.size() == n->comps.size() && share->num_params == n->num_params &&
+                (share->cfg.use_natural_gradient != 0) == (c.use_natural_gradient != 0) && share->cfg.cv_update == c.cv_update;
+    for (size_t i = 0; same && i < n->comps.size(); i++)
+      same = share->comps[i].name == n->comps[i].name && share->comps[i].rows == n->comps[i].rows && share->comps[i].cols == n->comps[i].cols &&
+             share->comps[i].begin == n->comps[i].begin;
+    if (!same) {
+      delete n;
+      TDNNF_REQUIRE(false, "net_create_shared: the configuration describes another model than the primary net's");
+    }
+    n->ng_in = share->ng_in;
+    n->ng_out = share->ng_out;
+  } else if (c.use_natural_gradient) {
     // one input-side and one output-side preconditioner per updatable component; configuration of
     // TdnnDARTSV3Component::InitFromConfig (nnet-tdnn-component.cc:183-210), the same defaults as
     // NaturalGradientAffineComponent / LinearComponent
@@ -751,6 +773,19 @@ int tdnnf_net_create(const tdnnf_net_config *cfg, tdnnf_net **out) {
   Arena real;
   real.base = n->arena;
   layout_arena(n, real);
+  if (share) {  // the model's BatchNorm / ReLU statistics live in the primary net
+    n->t1_bn_stats = share->t1_bn_stats;
+    n->t1_relu_stats = share->t1_relu_stats;
+    for (size_t l = 0; l < n->layers.size(); l++) {
+      n->layers[l].bn_stats = share->layers[l].bn_stats;
+      n->layers[l].relu_stats = share->layers[l].relu_stats;
+    }
+    for (int h = 0; h < 2; h++) {
+      n->head[h].bn1_stats = share->head[h].bn1_stats;
+      n->head[h].bn2_stats = share->head[h].bn2_stats;
+      n->head[h].relu_stats = share->head[h].relu_stats;
+    }
+  }
   // named activations for parity tests
   auto name = [&](const std::string &s, float *p, int rows, int cols) { n->named.push_back({s, M(p, rows, cols)}); };
   name("lda", n->lda_out, N_of(n->g_lda, B), lda_dim);
@@ -776,8 +811,10 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (!n) return;
   if (n->s3) hipStreamSynchronize(n->s3);  // its kernels use the preconditioners' buffers
   if (n->s2) hipStreamSynchronize(n->s2);
-  for (auto *g : n->ng_in) tdnnf_ng_destroy(g);
-  for (auto *g : n->ng_out) tdnnf_ng_destroy(g);
+  if (n->owns_ng) {
+    for (auto *g : n->ng_in) tdnnf_ng_destroy(g);
+    for (auto *g : n->ng_out) tdnnf_ng_destroy(g);
+  }
   hipFree(n->arena);
   hipFree(n->chain_ws);
   if (n->s2) hipStreamDestroy(n->s2);

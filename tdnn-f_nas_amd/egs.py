@@ -201,3 +201,25 @@ def minibatches(path, net, frame_shift=0, discard_partial=True, prefetch=0):
     finally:
         stop.set()
         th.join(timeout=5)
+
+
+def minibatches_by_width(path, nets, frame_shift=0):
+    """An archive with examples of several chunk widths (--egs.chunk-width 150,110,100) and one ChainNet per width
+    (ChainNet(cfg, share=primary)): examples are binned by their number of output frames and a minibatch is emitted for a
+    width as soon as its bin holds that net's num_sequences examples (nnet3-chain-merge-egs).  Yields (net, feats, ivectors,
+    hipabi.Supervision); what is left in the bins at the end of the archive is dropped."""
+    import torch
+    by_frames = {n.cfg.frames_per_chunk // n.cfg.frame_subsampling: n for n in nets}
+    bins = {k: [] for k in by_frames}
+    for eg in Reader(path):
+        T = eg.supervision_info()["frames_per_seq"]
+        if T not in by_frames:
+            raise ValueError("example %s has %d output frames, nets were given for %s" % (eg.key, T, sorted(by_frames)))
+        net, group = by_frames[T], bins[T]
+        group.append(eg)
+        if len(group) == net.cfg.num_sequences:
+            f, iv, sup = merge(group, net.first_t, net.num_t_in, frame_shift, with_ivectors=net.cfg.ivector_dim > 0)
+            for e in group:
+                e.close()
+            bins[T] = []
+            yield net, torch.from_numpy(f).cuda(), torch.from_numpy(iv).cuda() if iv is not None else None, hipabi.Supervision(sup)

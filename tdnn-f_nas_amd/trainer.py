@@ -112,15 +112,21 @@ def config_text(config):
 class ChainNet:
     """One replica of the TDNN-F chain model on the current CUDA device."""
 
-    def __init__(self, config):
+    def __init__(self, config, share=None):
+        """share: a ChainNet of the same model built for another minibatch shape (chunk width / number of sequences): this one
+        then uses its parameters, gradients, natural-gradient state and model statistics (tdnnf_net_create_shared)."""
         import torch
         self.lib = hipabi.load()
         self.cfg = config
         self.h = C.c_void_p()
-        hipabi.check(self.lib.tdnnf_net_create(C.byref(config), C.byref(self.h)))
+        self.share = share  # keeps the primary alive
+        if share is None:
+            hipabi.check(self.lib.tdnnf_net_create(C.byref(config), C.byref(self.h)))
+        else:
+            hipabi.check(self.lib.tdnnf_net_create_shared(C.byref(config), share.h, C.byref(self.h)))
         self.num_params = int(self.lib.tdnnf_net_num_params(self.h))
-        self.params = torch.zeros(self.num_params, dtype=torch.float32, device="cuda")
-        self.grads = torch.zeros(self.num_params, dtype=torch.float32, device="cuda")
+        self.params = torch.zeros(self.num_params, dtype=torch.float32, device="cuda") if share is None else share.params
+        self.grads = torch.zeros(self.num_params, dtype=torch.float32, device="cuda") if share is None else share.grads
         hipabi.check(self.lib.tdnnf_net_set_buffers(self.h, hipabi.ptr(self.params), hipabi.ptr(self.grads)))
         self.components = []
         for i in range(self.lib.tdnnf_net_num_components(self.h)):

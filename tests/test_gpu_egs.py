@@ -47,3 +47,26 @@ def test_training_step_from_an_archive(pkg, tmp_path):
     with pytest.raises(pkg.hipabi.HipAbiError, match="the net needs"):
         list(E.minibatches(path, net, frame_shift=3))
     net.close()
+
+
+def test_archive_with_several_chunk_widths(pkg, tmp_path):
+    E, T = pkg.egs, pkg.trainer
+    base = dict(num_sequences=2, strides=[1, 0, 3], bottleneck=16, feat_dim=40, ivector_dim=100, num_pdfs=60, hidden_dim=64, small_dim=32)
+    a = T.ChainNet(T.make_config(frames_per_chunk=24, **base))
+    b = T.ChainNet(T.make_config(frames_per_chunk=18, **base), share=a)
+    a.set_params(a.init_params_numpy(seed=1, output_stddev=0.3))
+    den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, 60, mean_out_degree=4.0, seed=5))
+    path = tmp_path / "mixed.ark"
+    order = [a, b, b, a, b, a, a, b, b]  # widths interleaved as after nnet3-chain-shuffle-egs; the last example fills no minibatch
+    with E.Writer(path) as w:
+        for i, net in enumerate(order):
+            feats, iv = T.synthetic_egs(net, seed=40 + i)
+            sup = pkg.synth.make_supervision(net.cfg.num_sequences, net.cfg.frames_per_chunk // 3, 60, seed=50 + i)
+            w.write("e%d" % i, feats[0::2], net.first_t, E.sequence_of(sup, 0), 60, ivector=iv[0], compress=True)
+    got = list(E.minibatches_by_width(path, [a, b]))
+    assert [g[0] is a for g in got] == [False, True, True, False]  # b fills first (examples 1, 2), then a (0, 3), a (5, 6), b (4, 7)
+    for net, f, iv, sup in got:
+        r = host(net.forward_backward(f, iv, den, sup, step=0))
+        assert r[5] == 1.0 and np.isfinite(r[0]) and f.shape[0] == net.num_t_in * 2
+    b.close()
+    a.close()

@@ -354,3 +354,45 @@ def test_net_rejects_bad_shapes(pkg):
     with pytest.raises(pkg.hipabi.HipAbiError, match="feats must be"):
         net.forward_backward(dev(feats[:-2]), dev(iv), dg, ds)
     net.close()
+
+
+def test_nets_for_several_chunk_widths_share_the_model(pkg):
+    """--egs.chunk-width 150,110,100: one net per width on the same parameters, natural-gradient preconditioners and model
+    statistics (tdnnf_net_create_shared).  Minibatches of the three widths in turn, against the oracle wired the same way."""
+    base = dict(num_sequences=4, strides=[1, 0, 3], bottleneck=16, feat_dim=40, ivector_dim=100, num_pdfs=60, hidden_dim=64, small_dim=32,
+                use_natural_gradient=1)
+    widths = [30, 24, 18]
+    cfgs = [pkg.trainer.make_config(frames_per_chunk=w, **base) for w in widths]
+    nets = [pkg.trainer.ChainNet(cfgs[0])]
+    nets += [pkg.trainer.ChainNet(c, share=nets[0]) for c in cfgs[1:]]
+    assert nets[1].params.data_ptr() == nets[0].params.data_ptr() and nets[2].grads.data_ptr() == nets[0].grads.data_ptr()
+    params = nets[0].init_params_numpy(seed=3, output_stddev=0.3)
+    nets[0].set_params(params)
+    refs = [OracleNet(pkg, c, nets[0].components) for c in cfgs]
+    for r in refs[1:]:  # one model: the oracle's per-component state is shared the same way
+        r.ng, r.bn_stats, r.relu_stats = refs[0].ng, refs[0].bn_stats, refs[0].relu_stats
+    den = pkg.synth.make_den_graph(40, cfgs[0].num_pdfs, mean_out_degree=4.0, seed=5)
+    dg = pkg.hipabi.DenGraph(den)
+    for step, k in enumerate([0, 1, 2, 1, 0]):
+        net, ref, cfg = nets[k], refs[k], cfgs[k]
+        feats, iv = pkg.trainer.synthetic_egs(net, seed=10 + step)
+        sup = pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=20 + step)
+        res_ref, g_ref, _ = ref.forward_backward(params, feats, iv, den, sup, step=step)
+        net.grads.zero_()
+        r = host(net.forward_backward(dev(feats), dev(iv), dg, pkg.hipabi.Supervision(sup), step=step))
+        assert r[5] == 1.0 and abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"])
+        assert rel_l2(host(net.grads), g_ref) < 5e-3, (step, k, rel_l2(host(net.grads), g_ref))
+        p_ref = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
+        net.update(1e-3, step=step)
+        assert rel_l2(host(net.params) - params, p_ref - params) < 1e-2
+        params = p_ref
+        net.set_params(params)
+        # the statistics a model file would carry are the same whichever net is asked
+        np.testing.assert_allclose(nets[0].get_stats(), nets[2].get_stats(), rtol=0, atol=0)
+        np.testing.assert_allclose(nets[0].get_stats(), ref.get_stats(), rtol=1e-4, atol=1e-4)
+    # not a model of another shape
+    other = pkg.trainer.make_config(frames_per_chunk=24, **dict(base, hidden_dim=96))
+    with pytest.raises(pkg.hipabi.HipAbiError, match="another model"):
+        pkg.trainer.ChainNet(other, share=nets[0])
+    for n in reversed(nets):
+        n.close()
