@@ -75,6 +75,15 @@ def iteration_plan(num_epochs, num_archives, frame_subsampling_factor=3, num_job
     return plan
 
 
+def archive_and_frame_shift(expanded_index, num_archives, frame_subsampling_factor=3):
+    """(1-based archive of the egs dir, frame shift) for the k-th processed archive, k = expanded_index (the numbers in
+    iteration_plan()['archives']): chain_lib.train_new_models (upstream) reads archive k % num_archives + 1 with the inputs
+    shifted by (archive + k // num_archives) % frame_subsampling_factor frames, so that every archive is seen at every shift
+    over the epochs.  Pass the shift to egs.minibatches(..., frame_shift=...)."""
+    archive = expanded_index % num_archives + 1
+    return archive, (archive + expanded_index // num_archives) % frame_subsampling_factor
+
+
 def average_models(models):
     """nnet3-average: the mean of parameters and of the stored statistics (BatchNorm count / sums, ReLU averages are linear
     in Component::Add / Scale).  models = [(params, stats)] numpy arrays."""

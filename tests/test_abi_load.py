@@ -95,6 +95,9 @@ def test_outer_loop_plan(pkg):
     assert all(a > b for a, b in zip(eff, eff[1:]))  # the effective rate decays monotonically
     assert plan[0]["temperature_proportion"] == 1.0 and 0.03 < plan[-1]["temperature_proportion"] < 0.1
     assert plan[0]["archives"] == [0, 1] and plan[1]["archives"] == [2, 3] and all(0 <= a < 30 for p in plan for a in p["archives"])
+    seen = {o.archive_and_frame_shift(k, 10, 3) for k in range(30)}
+    assert seen == {(a, sh) for a in range(1, 11) for sh in range(3)}  # one epoch of expanded archives = every archive at every shift
+    assert o.archive_and_frame_shift(0, 10) == (1, 1) and o.archive_and_frame_shift(10, 10) == (1, 2)
     with pytest.raises(ValueError):
         o.num_iterations(1, 2, 3, 1, 7)
     with pytest.raises(ValueError):
