@@ -284,6 +284,44 @@ def learning_rate(iteration, num_jobs, num_iters, num_archives_processed, num_ar
     return float(num_jobs * eff)
 
 
+def read_kaldi_matrix(path):
+    """A Kaldi matrix file as float32 (text "[ a b\n c d ]" or binary "\0B" + "FM "/"DM " + rows + cols + data): the
+    lda.mat of configs/ that the fixed-affine-layer reads (run_tdnn_fbk_40_iv_sp_7q.sh:167).  Formats upstream, restated."""
+    import struct
+    raw = open(path, "rb").read()
+    if raw[:2] == b"\0B":
+        tok, rest = raw[2:].split(b" ", 1)
+        if tok not in (b"FM", b"DM"):
+            raise ValueError("%s: unsupported matrix type %r" % (path, tok))
+        if rest[0] != 4 or rest[5] != 4:
+            raise ValueError("%s: bad matrix header" % path)
+        rows, cols = struct.unpack("<i", rest[1:5])[0], struct.unpack("<i", rest[6:10])[0]
+        dt = np.dtype("<f4") if tok == b"FM" else np.dtype("<f8")
+        data = np.frombuffer(rest[10:10 + rows * cols * dt.itemsize], dtype=dt)
+        if data.size != rows * cols:
+            raise ValueError("%s: truncated matrix" % path)
+        return data.reshape(rows, cols).astype(np.float32)
+    text = raw.decode().strip()
+    if not (text.startswith("[") and text.endswith("]")):
+        raise ValueError("%s: not a Kaldi text matrix" % path)
+    rows = [r.split() for r in text[1:-1].strip().split("\n") if r.strip()]
+    if len({len(r) for r in rows}) != 1:
+        raise ValueError("%s: ragged text matrix" % path)
+    return np.asarray(rows, dtype=np.float32)
+
+
+def set_lda(params, components, lda_matrix):
+    """Puts a D x (D + 1) lda.mat ([linear | offset], as FixedAffineComponent::Init splits it) into a flat parameter vector."""
+    c = next(c for c in components if c["name"] == "lda")
+    m = np.asarray(lda_matrix, np.float32)
+    if m.shape != (c["rows"], c["cols"] + 1):
+        raise ValueError("lda matrix is %s, the net's lda layer wants %d x %d" % (m.shape, c["rows"], c["cols"] + 1))
+    n = c["rows"] * c["cols"]
+    params[c["begin"]:c["begin"] + n] = m[:, :-1].reshape(-1)
+    params[c["begin"] + n:c["begin"] + n + c["rows"]] = m[:, -1]
+    return params
+
+
 def synthetic_egs(net, seed=0):
     """fbank ~ N(0,1) [num_t_in*B, feat_dim] t-major and ivector ~ N(0,1) [B, ivector_dim]."""
     rng = np.random.default_rng(seed)

@@ -108,3 +108,23 @@ def test_outer_loop_plan(pkg):
     assert o.model_combine_iters(30, 4, 30, 20, 6) == set(range(16, 31))
     assert o.model_combine_iters(400, 4, 600, 20, 6) == set(range(350, 401, 2))
     assert o.model_combine_iters(10, 1, 4, 20, 1) == {6, 7, 8, 9, 10}
+
+
+def test_lda_matrix_files(pkg, tmp_path):
+    import struct
+    import numpy as np
+    t = pkg.trainer
+    m = np.random.default_rng(0).standard_normal((5, 6)).astype(np.float32)
+    (tmp_path / "b.mat").write_bytes(b"\0BFM " + b"\x04" + struct.pack("<i", 5) + b"\x04" + struct.pack("<i", 6) + m.tobytes())
+    (tmp_path / "d.mat").write_bytes(b"\0BDM " + b"\x04" + struct.pack("<i", 5) + b"\x04" + struct.pack("<i", 6) + m.astype(np.float64).tobytes())
+    (tmp_path / "t.mat").write_text(" [\n  " + "\n  ".join(" ".join("%.9g" % v for v in r) for r in m) + " ]\n")
+    for name in ("b.mat", "d.mat", "t.mat"):
+        assert np.array_equal(t.read_kaldi_matrix(tmp_path / name), m), name
+    comps = [dict(name="lda", begin=8, rows=5, cols=5, has_bias=1)]
+    p = t.set_lda(np.zeros(64, np.float32), comps, m)
+    assert np.array_equal(p[8:33].reshape(5, 5), m[:, :5]) and np.array_equal(p[33:38], m[:, 5]) and not p[38:].any() and not p[:8].any()
+    with pytest.raises(ValueError):
+        t.set_lda(np.zeros(64, np.float32), comps, m[:, :5])
+    (tmp_path / "x.mat").write_bytes(b"\0BFM " + b"\x04" + struct.pack("<i", 5) + b"\x04" + struct.pack("<i", 6) + m.tobytes()[:40])
+    with pytest.raises(ValueError):
+        t.read_kaldi_matrix(tmp_path / "x.mat")
