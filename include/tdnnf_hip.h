@@ -211,6 +211,11 @@ int tdnnf_supervision_create(int num_sequences, int frames_per_sequence, const i
                              float weight, tdnnf_supervision **out);
 void tdnnf_supervision_destroy(tdnnf_supervision *);
 
+/* The denominator recursion has two forms: one persistent workgroup per sequence with the state vectors in LDS (graphs up
+   to ~10 000 states), and one launch per frame over all sequences on sequence-minor arrays (larger graphs).  0 = chosen by
+   graph size (default), 1 / 2 force one (tests, experiments).  Affects the workspace size: set it before
+   tdnnf_chain_workspace_bytes / tdnnf_net_create. */
+int tdnnf_chain_set_denominator_mode(int mode);
 size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *, int num_sequences, int frames_per_sequence);
 /* results_dev (device doubles): [0] objf, [1] l2_term, [2] weight, [3] num logprob (weighted),
    [4] den logprob (weighted), [5] ok flag (1.0 / 0.0), [6] xent objf when xent_output given.

@@ -224,6 +224,197 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------- denominator, wide form
+// The persistent kernels above give a sequence one workgroup and keep its state vectors in LDS: right while they fit (up to
+// ~10 000 states), a crawl beyond (30 000 states / 360 000 arcs: every arc is a 4-byte gather from L2, 580 ms per
+// minibatch).  The wide form runs the recursion one frame per launch over ALL sequences with the SEQUENCE as the fastest
+// index of every array (alpha[t][state][seq], x[t][pdf][seq] -- Kaldi's own layout, for the same reason): a wave walks one
+// state's arcs, its lanes are 64 sequences, so every arc costs two coalesced 256-byte reads.  The leaky-HMM terms are
+// applied where the stored alpha / beta_dash are read (alpha_dash = alpha + leaky A init; beta = beta_dash + leaky
+// sum_j init_j beta_dash_j), so a frame is two launches forward (recursion, normaliser) and three backward.
+constexpr int kWideRows = 16;  // rows (states / pdfs) per 256-thread block: 4 per wave
+
+// xT[t][p][s] = exp(clamp(y[t*B + s][p])): per frame a B x P -> P x B transpose through LDS
+__global__ __launch_bounds__(256) void den_wide_prep_kernel(MatView y, int B, int P, float *xT) {
+  __shared__ float tile[64][65];
+  const int t = blockIdx.z, p0 = blockIdx.x * 64, s0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int sq = s0 + i, p = p0 + tx;
+    tile[i][tx] = (sq < B && p < P) ? exp_limited(y.data[(size_t)(t * B + sq) * y.stride + p]) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int p = p0 + i, sq = s0 + tx;
+    if (p < P && sq < B) xT[((size_t)t * P + p) * B + sq] = tile[tx][i];
+  }
+}
+// deriv[t*B + s][p] = dT[t][p][s]
+__global__ __launch_bounds__(256) void den_wide_unprep_kernel(const float *dT, int B, int P, MatView deriv) {
+  __shared__ float tile[64][65];
+  const int t = blockIdx.z, p0 = blockIdx.x * 64, s0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int p = p0 + i, sq = s0 + tx;
+    tile[i][tx] = (p < P && sq < B) ? dT[((size_t)t * P + p) * B + sq] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int sq = s0 + i, p = p0 + tx;
+    if (sq < B && p < P) deriv.data[(size_t)(t * B + sq) * deriv.stride + p] = tile[tx][i];
+  }
+}
+
+__global__ __launch_bounds__(256) void den_wide_init_kernel(DenDev g, int B, float *alphaT, float *asum) {
+  const long long e = blockIdx.x * 256LL + threadIdx.x;
+  if (e < (long long)g.H * B) alphaT[e] = g.init[e / B];  // alpha(0, h) before the leaky term
+  if (e < B) asum[e] = g.init_sum;
+}
+
+// block-level sum over the 4 waves of per-lane values -> part[blockIdx.x][s]
+__device__ __forceinline__ void wide_store_partial(float v, float (*red)[64], float *part, int B, int sq) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  red[wave][lane] = v;
+  __syncthreads();
+  if (wave == 0 && sq < B) part[(size_t)blockIdx.x * B + sq] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// alpha(t, h, s) = 1/A(t-1, s) sum_arcs alpha_dash(t-1, src, s) p x(t-1, pdf, s); partials of sum_h alpha(t, h, s)
+__global__ __launch_bounds__(256) void den_wide_fwd_kernel(DenDev g, int B, int t, float leaky, const float *xT, float *alphaT, const float *asum, int Hs,
+                                                           float *part) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *prev = alphaT + (size_t)(t - 1) * Hs * B;
+  float *cur = alphaT + (size_t)t * Hs * B;
+  const float *x = xT + (size_t)(t - 1) * g.P * B;
+  for (int s0 = 0; s0 < B; s0 += 64) {
+    const int sq = s0 + lane;
+    const bool on = sq < B;
+    const float Aprev = on ? asum[(size_t)(t - 1) * B + sq] : 1.f;
+    const float inv = 1.0f / Aprev, lk = leaky * Aprev;
+    float total = 0.f;
+    for (int r = 0; r < kWideRows / 4; r++) {
+      const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
+      if (slot >= g.by_dst.nslices * 64) break;
+      const unsigned h = g.by_dst.row[slot];
+      if (h == 0xffffffffu) continue;
+      const int sl = slot >> 6, b0 = g.by_dst.base[sl], w = (g.by_dst.base[sl + 1] - b0) >> 6;
+      const uint2 *ap = g.by_dst.arc + b0 + (slot & 63);
+      float acc = 0.f;
+      if (on) {
+#pragma unroll 4
+        for (int j = 0; j < w; j++) {
+          const uint2 a = ap[j * 64];
+          const unsigned src = a.x & 0xffffu, pdf = a.x >> 16;
+          acc += (prev[(size_t)src * B + sq] + lk * g.init[src]) * __uint_as_float(a.y) * x[(size_t)pdf * B + sq];
+        }
+        acc *= inv;
+        cur[(size_t)h * B + sq] = acc;
+      }
+      total += acc;
+    }
+    wide_store_partial(total, red, part, B, sq);
+  }
+}
+
+// out[s] = sum over the nblk partial rows (fixed order: deterministic); 1024 threads = 16 waves stride the rows
+__global__ __launch_bounds__(1024) void den_wide_sum_kernel(const float *part, int nblk, int B, float *out) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sq = blockIdx.x * 64 + lane;
+  float v = 0.f;
+  if (sq < B)
+    for (int i = wave; i < nblk; i += 16) v += part[(size_t)i * B + sq];
+  red[wave][lane] = v;
+  __syncthreads();
+  if (wave == 0 && sq < B) {
+    float tot = 0.f;
+    for (int q = 0; q < 16; q++) tot += red[q][lane];
+    out[sq] = tot;
+  }
+}
+
+// tot(s) = sum_h alpha_dash(T, h, s) = A(T, s) (1 + leaky init_sum); log-prob; beta_dash(T, ., s) = 1 / tot and its init-weighted sum
+__global__ __launch_bounds__(256) void den_wide_total_kernel(DenDev g, int B, int T, float leaky, const float *asum, float *tot, double *logprob,
+                                                             float *bnextT, float *lsum) {
+  const int sq = blockIdx.x * 256 + threadIdx.x;
+  if (sq >= B) return;
+  const float tt = asum[(size_t)T * B + sq] * (1.0f + leaky * g.init_sum);
+  double lc = 0.0;
+  for (int t = 0; t < T; t++) lc += (double)logf(asum[(size_t)t * B + sq]);
+  logprob[sq] = (double)logf(tt) + lc;
+  tot[sq] = tt;
+  lsum[sq] = g.init_sum / tt;
+  (void)bnextT;
+}
+__global__ __launch_bounds__(256) void den_wide_beta_init_kernel(DenDev g, int B, const float *tot, float *bnextT) {
+  const long long e = blockIdx.x * 256LL + threadIdx.x;
+  if (e < (long long)g.H * B) bnextT[e] = 1.0f / tot[e % B];  // BetaDashLastFrame
+}
+
+// beta_dash(t, h, s) = 1/A(t, s) sum_arcs p x(t, pdf, s) beta(t+1, dst, s); partials of sum_h init_h beta_dash(t, h, s)
+__global__ __launch_bounds__(256) void den_wide_beta_kernel(DenDev g, int B, int t, float leaky, const float *xT, const float *asum, const float *bnextT,
+                                                            const float *lsum_next, float *bcurT, float *part) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *x = xT + (size_t)t * g.P * B;
+  for (int s0 = 0; s0 < B; s0 += 64) {
+    const int sq = s0 + lane;
+    const bool on = sq < B;
+    const float inv = on ? 1.0f / asum[(size_t)t * B + sq] : 0.f, lk = on ? leaky * lsum_next[sq] : 0.f;
+    float total = 0.f;
+    for (int r = 0; r < kWideRows / 4; r++) {
+      const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
+      if (slot >= g.by_src.nslices * 64) break;
+      const unsigned h = g.by_src.row[slot];
+      if (h == 0xffffffffu) continue;
+      const int sl = slot >> 6, b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
+      const uint2 *ap = g.by_src.arc + b0 + (slot & 63);
+      float acc = 0.f;
+      if (on) {
+#pragma unroll 4
+        for (int j = 0; j < w; j++) {
+          const uint2 a = ap[j * 64];
+          const unsigned dst = a.x & 0xffffu, pdf = a.x >> 16;
+          acc += __uint_as_float(a.y) * x[(size_t)pdf * B + sq] * (bnextT[(size_t)dst * B + sq] + lk);
+        }
+        acc *= inv;
+        bcurT[(size_t)h * B + sq] = acc;
+      }
+      total += g.init[h] * acc;
+    }
+    wide_store_partial(total, red, part, B, sq);
+  }
+}
+
+// x(t, p, s) <- deriv_weight gamma_den(t, p, s) = deriv_weight x(t, p, s) sum_arcs p alpha_dash(t, src, s)/A(t, s) beta(t+1, dst, s)  (in place)
+__global__ __launch_bounds__(256) void den_wide_gamma_kernel(DenDev g, int B, int t, float leaky, float *xT, const float *alphaT, const float *asum, int Hs,
+                                                             const float *bnextT, const float *lsum_next, float deriv_weight) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *alpha = alphaT + (size_t)t * Hs * B;
+  float *x = xT + (size_t)t * g.P * B;
+  for (int s0 = 0; s0 < B; s0 += 64) {
+    const int sq = s0 + lane;
+    if (sq >= B) continue;
+    const float A = asum[(size_t)t * B + sq], inv = 1.0f / A, lka = leaky * A, lkb = leaky * lsum_next[sq];
+    for (int r = 0; r < kWideRows / 4; r++) {
+      const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
+      if (slot >= g.by_pdf.nslices * 64) break;
+      const unsigned p = g.by_pdf.row[slot];
+      if (p == 0xffffffffu) continue;
+      const int sl = slot >> 6, b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
+      const uint2 *ap = g.by_pdf.arc + b0 + (slot & 63);
+      float acc = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < w; j++) {
+        const uint2 a = ap[j * 64];
+        const unsigned src = a.x & 0xffffu, dst = a.x >> 16;
+        acc += __uint_as_float(a.y) * ((alpha[(size_t)src * B + sq] + lka * g.init[src]) * inv) * (bnextT[(size_t)dst * B + sq] + lkb);
+      }
+      x[(size_t)p * B + sq] *= deriv_weight * acc;
+    }
+  }
+}
+
 __device__ __forceinline__ float log_add(float a, float b) {
   if (a == -INFINITY) return b;
   if (b == -INFINITY) return a;
@@ -410,9 +601,12 @@ int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, floa
 struct ChainPlan {
   int Hs;
   bool lds_state;
+  bool wide;          // den_wide_*: one launch per frame over all sequences, sequence-minor arrays
+  int wide_blocks;    // partial rows of the widest launch
   size_t alpha_floats, asum_floats, gstate_floats, la_floats;
   size_t lds_fwd, lds_bwd;
 };
+int g_den_mode = 0;  // tdnnf_chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide
 ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup) {
   ChainPlan p;
   p.Hs = (g->H + 3) & ~3;
@@ -424,9 +618,13 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
     p.lds_fwd = sizeof(float) * P4;
     p.lds_bwd = sizeof(float) * P4;
   }
+  p.wide = g_den_mode == 2 || (g_den_mode == 0 && !p.lds_state);
+  const int rows = std::max(std::max(g->by_dst.nslices, g->by_src.nslices), g->by_pdf.nslices) * 64;
+  p.wide_blocks = (rows + kWideRows - 1) / kWideRows;
   p.alpha_floats = (size_t)B * (T + 1) * p.Hs;
-  p.asum_floats = (size_t)B * (T + 1);
-  p.gstate_floats = p.lds_state ? 0 : (size_t)B * 3 * p.Hs;
+  p.asum_floats = (size_t)B * (T + 4);  // wide: A(0..T), tot, and two rows of init-weighted beta sums
+  // wide: beta_dash double buffer, partial rows, and x = exp(clamp(y)) / the derivative, sequence-minor (T x P x B)
+  p.gstate_floats = p.wide ? (size_t)B * (2 * p.Hs + p.wide_blocks) + (size_t)T * g->P * B : (p.lds_state ? 0 : (size_t)B * 3 * p.Hs);
   p.la_floats = 2 * (size_t)num_states_sup;
   return p;
 }
@@ -581,6 +779,12 @@ void tdnnf_supervision_destroy(tdnnf_supervision *sp) {
 
 // workspace layout: [doubles: den_lp[B], num_lp[B], xent[B], l2sum[1]] [alpha] [asum] [gstate] [la, lb]
 // (the numerator scratch is sized for up to 4*(T+1) states per sequence; larger graphs are rejected)
+int tdnnf_chain_set_denominator_mode(int mode) {
+  TDNNF_REQUIRE(mode >= 0 && mode <= 2, "chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide");
+  g_den_mode = mode;
+  return TDNNF_OK;
+}
+
 size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *g, int B, int T) {
   if (!g || B <= 0 || T <= 0) return 0;
   ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
@@ -625,6 +829,33 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
   ChainBufs b = chain_bufs(g, B, T, ws);
   DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
   MatView yv = view(y), dv = view(deriv);
+  if (b.p.wide) {
+    const int Hs = b.p.Hs, P = g->P;
+    const int nb_dst = (g->by_dst.nslices * 64 + kWideRows - 1) / kWideRows, nb_src = (g->by_src.nslices * 64 + kWideRows - 1) / kWideRows,
+              nb_pdf = (g->by_pdf.nslices * 64 + kWideRows - 1) / kWideRows;
+    float *alphaT = b.alpha, *asum = b.asum, *tot = asum + (size_t)(T + 1) * B, *lsA = tot + B, *lsB = lsA + B;
+    float *bufa = b.gstate, *bufb = bufa + (size_t)B * Hs, *part = bufb + (size_t)B * Hs, *xT = part + (size_t)B * b.p.wide_blocks;
+    const dim3 blk(256), tr((P + 63) / 64, (B + 63) / 64, T), nseq((B + 63) / 64);
+    hipLaunchKernelGGL(den_wide_prep_kernel, tr, blk, 0, s, yv, B, P, xT);
+    hipLaunchKernelGGL(den_wide_init_kernel, dim3(grid_for((long long)g->H * B, 256)), blk, 0, s, gd, B, alphaT, asum);
+    for (int t = 1; t <= T; t++) {
+      hipLaunchKernelGGL(den_wide_fwd_kernel, dim3(nb_dst), blk, 0, s, gd, B, t, leaky, xT, alphaT, asum, Hs, part);
+      hipLaunchKernelGGL(den_wide_sum_kernel, nseq, dim3(1024), 0, s, part, nb_dst, B, asum + (size_t)t * B);
+    }
+    hipLaunchKernelGGL(den_wide_total_kernel, dim3((B + 255) / 256), blk, 0, s, gd, B, T, leaky, asum, tot, b.den_lp, bufa, lsA);
+    hipLaunchKernelGGL(den_wide_beta_init_kernel, dim3(grid_for((long long)g->H * B, 256)), blk, 0, s, gd, B, tot, bufa);
+    float *bnext = bufa, *bcur = bufb, *ls_next = lsA, *ls_cur = lsB;
+    for (int t = T - 1; t >= 0; t--) {
+      hipLaunchKernelGGL(den_wide_beta_kernel, dim3(nb_src), blk, 0, s, gd, B, t, leaky, xT, asum, bnext, ls_next, bcur, part);
+      hipLaunchKernelGGL(den_wide_gamma_kernel, dim3(nb_pdf), blk, 0, s, gd, B, t, leaky, xT, alphaT, asum, Hs, bnext, ls_next, -sp->weight);
+      hipLaunchKernelGGL(den_wide_sum_kernel, nseq, dim3(1024), 0, s, part, nb_src, B, ls_cur);
+      std::swap(bnext, bcur);
+      std::swap(ls_next, ls_cur);
+    }
+    hipLaunchKernelGGL(den_wide_unprep_kernel, tr, blk, 0, s, xT, B, P, dv);
+    TDNNF_LAUNCH_CHECK();
+    return TDNNF_OK;
+  }
   if (b.p.lds_state) {
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_bwd));

@@ -441,6 +441,104 @@ __global__ __launch_bounds__(256) void log_softmax_fwd_kernel(MatView in, MatVie
     for (int c = threadIdx.x; c < in.cols; c += 256) o[c] = x[c] - lse;
   }
 }
+// One pass per row with the row held in registers (up to 256 * 4 * NV columns, 16-byte aligned rows): the 6034-wide output
+// rows are read once and written once instead of three reads through L2.
+template <int NV>
+__global__ __launch_bounds__(256) void log_softmax_fwd_regs_kernel(MatView in, MatView out) {
+  __shared__ float red[2][4];
+  const int t = threadIdx.x, nc4 = (in.cols + 3) / 4;
+  for (int r = blockIdx.x; r < in.rows; r += gridDim.x) {
+    const float *x = in.data + (long long)r * in.stride;
+    float *o = out.data + (long long)r * out.stride;
+    float4 v[NV];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int c4 = t + 256 * k, c = c4 * 4;
+      v[k] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (c4 < nc4) {
+        if (c + 3 < in.cols) v[k] = *reinterpret_cast<const float4 *>(x + c);
+        else {
+          v[k].x = x[c];
+          if (c + 1 < in.cols) v[k].y = x[c + 1];
+          if (c + 2 < in.cols) v[k].z = x[c + 2];
+        }
+      }
+      mx = fmaxf(mx, fmaxf(fmaxf(v[k].x, v[k].y), fmaxf(v[k].z, v[k].w)));
+    }
+    mx = wave_max(mx);
+    if ((t & 63) == 0) red[0][t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) s += expf(v[k].x - mx) + expf(v[k].y - mx) + expf(v[k].z - mx) + expf(v[k].w - mx);  // exp(-inf) = 0 for the padding
+    s = wave_sum(s);
+    if ((t & 63) == 0) red[1][t >> 6] = s;
+    __syncthreads();
+    const float lse = mx + logf((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int c4 = t + 256 * k, c = c4 * 4;
+      if (c4 >= nc4) continue;
+      if (c + 3 < in.cols) *reinterpret_cast<float4 *>(o + c) = make_float4(v[k].x - lse, v[k].y - lse, v[k].z - lse, v[k].w - lse);
+      else {
+        o[c] = v[k].x - lse;
+        if (c + 1 < in.cols) o[c + 1] = v[k].y - lse;
+        if (c + 2 < in.cols) o[c + 2] = v[k].z - lse;
+      }
+    }
+    __syncthreads();  // red[] is reused by the next row
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void log_softmax_bwd_regs_kernel(MatView y, MatView dy, MatView dx) {
+  __shared__ float red[4];
+  const int t = threadIdx.x, nc4 = (y.cols + 3) / 4;
+  for (int r = blockIdx.x; r < y.rows; r += gridDim.x) {
+    const float *yv = y.data + (long long)r * y.stride, *e = dy.data + (long long)r * dy.stride;
+    float *d = dx.data + (long long)r * dx.stride;
+    float4 ev[NV], pv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int c4 = t + 256 * k, c = c4 * 4;
+      ev[k] = pv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 < nc4) {
+        if (c + 3 < y.cols) {
+          ev[k] = *reinterpret_cast<const float4 *>(e + c);
+          const float4 q = *reinterpret_cast<const float4 *>(yv + c);
+          pv[k] = make_float4(expf(q.x), expf(q.y), expf(q.z), expf(q.w));
+        } else {
+          ev[k].x = e[c];
+          pv[k].x = expf(yv[c]);
+          if (c + 1 < y.cols) { ev[k].y = e[c + 1]; pv[k].y = expf(yv[c + 1]); }
+          if (c + 2 < y.cols) { ev[k].z = e[c + 2]; pv[k].z = expf(yv[c + 2]); }
+        }
+      }
+      s += (ev[k].x + ev[k].y) + (ev[k].z + ev[k].w);
+    }
+    s = wave_sum(s);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    s = (red[0] + red[1]) + (red[2] + red[3]);
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int c4 = t + 256 * k, c = c4 * 4;
+      if (c4 >= nc4) continue;
+      const float4 o = make_float4(ev[k].x - pv[k].x * s, ev[k].y - pv[k].y * s, ev[k].z - pv[k].z * s, ev[k].w - pv[k].w * s);
+      if (c + 3 < y.cols) *reinterpret_cast<float4 *>(d + c) = o;
+      else {
+        d[c] = o.x;
+        if (c + 1 < y.cols) d[c + 1] = o.y;
+        if (c + 2 < y.cols) d[c + 2] = o.z;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256) void log_softmax_bwd_kernel(MatView y, MatView dy, MatView dx) {
   __shared__ float red[4];
   for (int r = blockIdx.x; r < y.rows; r += gridDim.x) {
@@ -781,7 +879,11 @@ int tdnnf_relu_store_stats(const tdnnf_mat *out_value, double *stats, void *ws, 
 int tdnnf_log_softmax_propagate(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_stream stream) {
   TDNNF_REQUIRE(mat_ok(in) && mat_ok(out) && same_dim(in, out) && in->cols > 0, "log_softmax_propagate: bad matrices");
   if (in->rows == 0) return TDNNF_OK;
-  hipLaunchKernelGGL(log_softmax_fwd_kernel, dim3(in->rows < 8192 ? in->rows : 8192), dim3(256), 0, (hipStream_t)stream, view(in), view(out));
+  const dim3 grid(in->rows < 8192 ? in->rows : 8192);
+  const bool al = in->stride % 4 == 0 && out->stride % 4 == 0 && ((uintptr_t)in->data & 15) == 0 && ((uintptr_t)out->data & 15) == 0;
+  if (al && in->cols <= 256 * 4 * 2) hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out));
+  else if (al && in->cols <= 256 * 4 * 8) hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out));
+  else hipLaunchKernelGGL(log_softmax_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out));
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }
@@ -789,7 +891,12 @@ int tdnnf_log_softmax_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_
   TDNNF_REQUIRE(mat_ok(out_value) && mat_ok(out_deriv) && mat_ok(in_deriv) && same_dim(out_value, out_deriv) && same_dim(out_value, in_deriv),
                 "log_softmax_backprop: bad matrices");
   if (out_value->rows == 0) return TDNNF_OK;
-  hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(out_value->rows < 8192 ? out_value->rows : 8192), dim3(256), 0, (hipStream_t)stream, view(out_value), view(out_deriv), view(in_deriv));
+  const dim3 grid(out_value->rows < 8192 ? out_value->rows : 8192);
+  const bool al = out_value->stride % 4 == 0 && out_deriv->stride % 4 == 0 && in_deriv->stride % 4 == 0 && ((uintptr_t)out_value->data & 15) == 0 &&
+                  ((uintptr_t)out_deriv->data & 15) == 0 && ((uintptr_t)in_deriv->data & 15) == 0;
+  if (al && out_value->cols <= 256 * 4 * 2) hipLaunchKernelGGL((log_softmax_bwd_regs_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, view(out_value), view(out_deriv), view(in_deriv));
+  else if (al && out_value->cols <= 256 * 4 * 8) hipLaunchKernelGGL((log_softmax_bwd_regs_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, view(out_value), view(out_deriv), view(in_deriv));
+  else hipLaunchKernelGGL(log_softmax_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, view(out_value), view(out_deriv), view(in_deriv));
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }

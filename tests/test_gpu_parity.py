@@ -364,8 +364,19 @@ def test_affine(hip, ora):
 CHAIN_CASES = [(50, 40, 3, 8, 0.1, 0.0), (300, 200, 6, 30, 0.1, 5e-5), (2000, 600, 4, 25, 0.1, 0.0), (64, 6034, 2, 10, 0.0, 0.0)]
 
 
-@pytest.mark.parametrize("H,P,B,T,leaky,l2", CHAIN_CASES)
-def test_chain_objf_and_deriv(hip, ora, pkg, H, P, B, T, leaky, l2):
+# both forms of the denominator recursion: one persistent workgroup per sequence (state vectors in LDS), one launch per frame
+# over all sequences on sequence-minor arrays (the form large graphs get); B = 70 and 130 put sequences in a second chunk of lanes
+@pytest.mark.parametrize("mode", [1, 2], ids=["persistent", "wide"])
+@pytest.mark.parametrize("H,P,B,T,leaky,l2", CHAIN_CASES + [(500, 300, 70, 6, 0.1, 0.0), (120, 90, 130, 4, 0.05, 1e-5)])
+def test_chain_objf_and_deriv(hip, ora, pkg, H, P, B, T, leaky, l2, mode):
+    pkg.hipabi.check(pkg.hipabi.load().tdnnf_chain_set_denominator_mode(mode))
+    try:
+        _chain_case(hip, ora, pkg, H, P, B, T, leaky, l2)
+    finally:
+        pkg.hipabi.load().tdnnf_chain_set_denominator_mode(0)
+
+
+def _chain_case(hip, ora, pkg, H, P, B, T, leaky, l2):
     L = ora.lib()
     g = pkg.synth.make_den_graph(H, P, mean_out_degree=6.0, seed=H)
     sup = pkg.synth.make_supervision(B, T, P, seed=T, weight=1.0)
@@ -401,7 +412,16 @@ def test_chain_objf_and_deriv(hip, ora, pkg, H, P, B, T, leaky, l2):
     assert torch.equal(dd2, dd) and host(res)[0] == r[0]
 
 
-def test_chain_failure_path(hip, ora, pkg):
+@pytest.mark.parametrize("mode", [1, 2], ids=["persistent", "wide"])
+def test_chain_failure_path(hip, ora, pkg, mode):
+    pkg.hipabi.check(pkg.hipabi.load().tdnnf_chain_set_denominator_mode(mode))
+    try:
+        _chain_failure(hip, ora, pkg)
+    finally:
+        pkg.hipabi.load().tdnnf_chain_set_denominator_mode(0)
+
+
+def _chain_failure(hip, ora, pkg):
     g = pkg.synth.make_den_graph(30, 20, seed=1)
     sup = pkg.synth.make_supervision(2, 5, 20, seed=1)
     y = np.zeros((10, 20), F)
