@@ -72,3 +72,8 @@ run("outprobe K6144", [0], 500, B, 256, 6144)
 run("outprobe K6034 N4096->", [0], 500, B, 4096, 6034)
 run("probe160 longK 1round", [-1, 0], 512, B, 1536, 160)
 run("probe128 longK", [-1, 0], 512, B, 1536, 1536)
+# shapes of the natural-gradient statistics H = X W^T (rank 80 on the output side, 20 on the input side); "fwd" lines only
+run("ngshape out affine R80", [0], 1563, B, 1536, 80)
+run("ngshape in linear R20", [-1, 0], 1564, B, 1536, 20)
+run("ngshape in affine R20", [0, 1], 1563, B, 160, 20)
+run("ngshape out linear R80", [0], 1564, B, 160, 80)
