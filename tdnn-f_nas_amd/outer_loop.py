@@ -8,9 +8,11 @@ Kaldi, not shipped with the reference; restated here from the command lines trai
  * every job of an iteration starts from <iter>.mdl, trains on its own archive with the iteration's learning rate
    (nnet3-chain-train; a fresh process, so the natural-gradient state starts from scratch), writes <iter+1>.<job>.raw;
  * the jobs' models are averaged (nnet3-average) into <iter+1>.mdl, scaled by the shrinkage value;
- * final.mdl = combination of the models of `model_combine_iters` -- here their plain average (nnet3-combine's default
-   since Kaldi 5.4 when no held-out objective is evaluated: "--combine-sum-to-one-penalty" era weights are gone); stated,
-   not pinned.
+ * final.mdl = combination of the models of `model_combine_iters`: with combine egs given, nnet3-chain-combine's search
+   (combine_models below: running average over the models, latest first, the average with the best objective on the
+   combine egs wins, its BatchNorm statistics are recomputed); without, their plain average.  Restated from the upstream
+   binary's published behaviour, not pinned.
+ * diagnostics: compute_prob = nnet3-chain-compute-prob (BatchNorm in test mode, no dropout, no update).
 On several GPUs the jobs of an iteration are spread over the ranks (one process per GPU, torch.distributed over RCCL) and
 the average is one all-reduce of parameters and statistics -- the same arithmetic, no gradient exchange.
 """
@@ -92,14 +94,91 @@ def average_models(models):
     return p, s
 
 
+def evaluation_config(config, batchnorm_test_mode):
+    """The configuration of a net that only evaluates the objective of the same model: no natural gradient state, and with
+    batchnorm_test_mode the BatchNorm components use the stored statistics (cv_update: BatchNormTest, every learning-rate
+    factor of the weights 0, so no parameter gradient is formed).  Same parameter and statistics layout as `config`."""
+    c = type(config).from_buffer_copy(bytes(config))
+    c.use_natural_gradient = 0
+    if batchnorm_test_mode:
+        c.cv_update = 1
+    return c
+
+
+def _objective(net, minibatches, seed=0):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    tot = np.zeros(7)
+    for m, (feats, iv, den, sup) in enumerate(minibatches):
+        if net.num_draws:
+            net.set_random_draws(generator=g)
+        tot += net.forward_backward(feats, iv, den, sup, step=m).cpu().numpy()[:7]
+    return tot
+
+
+def compute_prob(net, minibatches):
+    """nnet3-chain-compute-prob on a net built from evaluation_config(cfg, True) that holds the model: per-frame objective of
+    the chain output (objf + l2 term) and of the xent output, as the "Overall log-probability for 'output' / 'output-xent'"
+    log lines give them."""
+    if net.cfg.use_dropout:
+        net.set_dropout_proportion(0.0)  # dropout test mode
+    t = _objective(net, minibatches)
+    return dict(output=(t[0] + t[1]) / t[2], output_xent=t[6] / t[2], weight=t[2])
+
+
+def combine_models(net, models, num_models, minibatches, max_objective_evaluations=30, log=None):
+    """nnet3-chain-combine (UPSTREAM, restated from its usage text and log lines): models = an iterable of num_models (parameters,
+    statistics) pairs, latest first (train.py hands the files over in reversed order); a running average A_n = A_{n-1} (n-1)/n + M_n / n over parameters and statistics; the
+    objective (objf + l2 term) / weight of 'output' on the combine egs -- BatchNorm in TRAINING mode, dropout in test mode, the
+    binary's defaults -- is evaluated for n = 1 and then every `mod` models, mod = ceil(num_models / max_objective_evaluations);
+    the best average wins and its BatchNorm statistics are recomputed on the same egs.  net: built from
+    evaluation_config(cfg, False).  Leaves the winner in net (parameters + statistics); returns (number combined, objf before,
+    objf after)."""
+    minibatches = list(minibatches)
+    if net.cfg.use_dropout:
+        net.set_dropout_proportion(0.0)
+    mod = (num_models + max_objective_evaluations - 1) // max_objective_evaluations
+    avg_p = avg_s = best = None
+    for n, (p, s) in enumerate(models):
+        p, s = np.asarray(p, np.float64), np.asarray(s, np.float64)
+        if n == 0:
+            avg_p, avg_s = p, s
+        else:
+            avg_p = avg_p * (n / (n + 1.0)) + p / (n + 1.0)
+            avg_s = avg_s * (n / (n + 1.0)) + s / (n + 1.0)
+        if n == 0 or (n - 1) % mod == 0:
+            net.set_params(avg_p.astype(np.float32))
+            net.set_stats(avg_s)
+            t = _objective(net, minibatches)
+            objf = (t[0] + t[1]) / t[2]
+            if log:
+                log("Combining last %d models, objective function is %.6f" % (n + 1, objf))
+            if n == 0:
+                first = objf
+            if best is None or objf > best[0]:
+                best = (objf, n + 1, avg_p.copy(), avg_s.copy())
+    objf, count, p, s = best
+    net.set_params(p.astype(np.float32))
+    # RecomputeStats: zeroed statistics, one training-mode pass over the egs accumulates them again
+    net.set_stats(np.zeros_like(s))
+    _objective(net, minibatches)
+    if log:
+        log("Combining %d nnets, objective function changed from %.6f to %.6f" % (count, first, objf))
+    return count, first, objf
+
+
 def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, minibatches_per_archive, frame_subsampling_factor=3, num_jobs_initial=1,
         num_jobs_final=1, initial_effective_lrate=2.5e-4, final_effective_lrate=2.5e-5, proportional_shrink=0.0, temperature_schedule=False,
-        do_final_combination=True, max_models_combine=20, srand=0, binary=True, log=None, dropout_schedule=None):
+        do_final_combination=True, max_models_combine=20, srand=0, binary=True, log=None, dropout_schedule=None, combine_egs=None,
+        diagnostic_egs=None):
     """Runs the whole schedule.  net_factory() -> a ChainNet with initial parameters set (called once per job: a fresh process in
     the reference, so fresh natural-gradient state; BatchNorm / ReLU statistics and parameters come from <iter>.mdl).
     egs_for_archive(archive_index, minibatch_index) -> (feats, ivectors, den_graph, supervision) device objects for
     ChainNet.forward_backward.  Writes <work_dir>/<iter>.mdl for every iteration and final.mdl; returns the plan with the
-    per-iteration mean objective added.  Ranks of an initialised torch.distributed group share the jobs of an iteration."""
+    per-iteration mean objective added.  combine_egs: minibatches [(feats, ivectors, den_graph, supervision)] for the final
+    combination (combine_models; without them the plain average); diagnostic_egs: {"valid": minibatches, "train": ...}
+    evaluated on every iteration's model by compute_prob (train.py's compute_train_cv_probabilities), results in the plan.  Ranks of an initialised torch.distributed group share the jobs of an iteration."""
     import torch
     import torch.distributed as dist
     world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
@@ -115,10 +194,19 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
     if rank == 0:
         net.write_model(path(0), binary=binary)
     step = 0
+    prob_net = T.ChainNet(evaluation_config(net.cfg, True)) if diagnostic_egs and rank == 0 else None
     for it in plan:
         i, jobs, lr = it["iteration"], it["num_jobs"], it["learning_rate"]
         if world > 1:
             dist.barrier()
+        if prob_net is not None:  # on <iter>.mdl, as train.py does before it launches the iteration's jobs
+            net.read_model(path(i))
+            prob_net.params.copy_(net.params)
+            prob_net.set_stats(net.get_stats())
+            it["compute_prob"] = {k: compute_prob(prob_net, v) for k, v in diagnostic_egs.items()}
+            if log:
+                log("iter %d  " % i + "  ".join("%s objf/frame %.5f (xent %.5f)" % (k, v["output"], v["output_xent"])
+                                                  for k, v in it["compute_prob"].items()))
         acc_p = np.zeros(net.num_params, np.float64)
         acc_s = np.zeros(net.get_stats().size, np.float64)
         objf, weight = 0.0, 0.0
@@ -162,7 +250,19 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
     if world > 1:
         dist.barrier()
     if rank == 0:
-        if combine:
+        if combine and combine_egs:
+            comb = T.ChainNet(evaluation_config(net.cfg, False))
+
+            def models_latest_first():
+                for i in sorted(combine, reverse=True):
+                    net.read_model(path(i))
+                    yield net.params.detach().cpu().numpy().copy(), net.get_stats().copy()
+
+            combine_models(comb, models_latest_first(), len(combine), combine_egs, log=log)
+            net.params.copy_(comb.params)
+            net.set_stats(comb.get_stats())
+            comb.close()
+        elif combine:
             models = []
             for i in sorted(combine):
                 net.read_model(path(i))
@@ -173,5 +273,7 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
         else:
             net.read_model(path(num_iters))
         net.write_model(os.path.join(work_dir, "final.mdl"), binary=binary)
+    if prob_net is not None:
+        prob_net.close()
     net.close()
     return plan, (sorted(combine) if combine else None), to_process

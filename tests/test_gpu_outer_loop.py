@@ -129,3 +129,54 @@ def test_outer_loop_on_the_offset_supernet_with_temperature_schedule(pkg, tmp_pa
     a1 = pkg.derive.logits_from_net(probe)
     assert a0.shape == (6, 3) and np.abs(a1 - a0).max() > 0  # the architecture logits moved
     probe.close()
+
+
+def test_compute_prob_and_combination_by_objective(pkg, tmp_path):
+    """Diagnostics on every iteration's model (test-mode BatchNorm, no update) and the final combination chosen by the objective
+    on combine egs (running average, latest model first), BatchNorm statistics recomputed on those egs."""
+    cfg, factory, egs, probe = _setup(pkg)
+    o = pkg.outer_loop
+    held_out = [egs(0, 0), egs(1, 1)]
+    logs = []
+    args = dict(num_epochs=2, num_archives=2, minibatches_per_archive=3, frame_subsampling_factor=3, num_jobs_initial=1, num_jobs_final=1,
+                initial_effective_lrate=2e-3, final_effective_lrate=2e-4, max_models_combine=4)
+    plan, combine, _ = o.run(factory, egs, str(tmp_path / "c"), combine_egs=held_out, diagnostic_egs={"valid": held_out}, log=logs.append, **args)
+    # compute_prob leaves the model alone and is repeatable
+    ev = pkg.trainer.ChainNet(o.evaluation_config(cfg, True))
+    probe.read_model(tmp_path / "c" / "3.mdl")
+    ev.params.copy_(probe.params)
+    ev.set_stats(probe.get_stats())
+    before = ev.params.detach().cpu().numpy().copy()
+    a, b = o.compute_prob(ev, held_out), o.compute_prob(ev, held_out)
+    assert a == b and np.array_equal(ev.params.detach().cpu().numpy(), before)
+    assert abs(a["output"] - plan[3]["compute_prob"]["valid"]["output"]) < 1e-9 and a["weight"] == 2 * cfg.num_sequences * (cfg.frames_per_chunk // 3)
+    valid = [p["compute_prob"]["valid"]["output"] for p in plan]
+    assert all(np.isfinite(valid)) and valid[-1] > valid[0]  # the held-out minibatches are training data here
+    ev.close()
+    # the combination: redo it by hand from the model files
+    models = []
+    for i in sorted(combine, reverse=True):
+        probe.read_model(tmp_path / "c" / ("%d.mdl" % i))
+        models.append((probe.params.detach().cpu().numpy().astype(np.float64), np.asarray(probe.get_stats(), np.float64)))
+    comb = pkg.trainer.ChainNet(o.evaluation_config(cfg, False))
+    best = None
+    for n in range(1, len(models) + 1):
+        comb.set_params(np.mean([m[0] for m in models[:n]], axis=0).astype(np.float32))
+        comb.set_stats(np.mean([m[1] for m in models[:n]], axis=0))
+        t = np.zeros(3)
+        for m, (f, iv, den, sup) in enumerate(held_out):
+            t += comb.forward_backward(f, iv, den, sup, step=m).cpu().numpy()[:3]
+        objf = (t[0] + t[1]) / t[2]
+        if best is None or objf > best[0]:
+            best = (objf, n)
+    line = [x for x in logs if x.startswith("Combining %d nnets" % best[1])]
+    assert line, logs
+    comb.set_params(np.mean([m[0] for m in models[:best[1]]], axis=0).astype(np.float32))
+    comb.set_stats(np.zeros_like(models[0][1]))
+    for m, (f, iv, den, sup) in enumerate(held_out):
+        comb.forward_backward(f, iv, den, sup, step=m)
+    probe.read_model(tmp_path / "c" / "final.mdl")
+    np.testing.assert_allclose(probe.params.detach().cpu().numpy(), comb.params.detach().cpu().numpy(), rtol=0, atol=1e-7)
+    np.testing.assert_allclose(probe.get_stats(), comb.get_stats(), rtol=1e-5, atol=1e-7)
+    comb.close()
+    probe.close()
