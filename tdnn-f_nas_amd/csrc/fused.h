@@ -11,11 +11,23 @@ namespace tdnnf {
 hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s,
                            const float *mask = nullptr, int B = 1);
 
+// Natural-gradient statistic of the component that produced x, formed by the same sweep (ng.h, ng_external_begin):
+// H (rows x Rp) = d_aff W^T and the per-128-row-block sums of squares of d_aff (`part`, part_cap doubles, unused tail zeroed).
+struct NgFuse {
+  const float *W;  // Rp x ldw, k-contiguous
+  int Rp, ldw;
+  float *H;
+  double *part;
+  int part_cap;
+};
+bool bn_relu_bwd_ng_ok(MatView x, MatView dz, MatView d_aff, int Rp);  // shapes / alignment the fused sweep takes
+
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols);
 // BatchNorm backward + ReLU backward (+ self-repair, ReLU statistics, bias-gradient column sums) in two passes.
 // bn_test_mode: the BatchNorm is a BatchNormTestComponent (memo rows 0 and 2 hold the stored mean / scale): dX = dZ * scale.
 hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
-                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask = nullptr, int B = 1);  // mask: dz is multiplied by it first
+                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask = nullptr, int B = 1,  // mask: dz is multiplied by it first
+                       const NgFuse *ng = nullptr);
 
 }  // namespace tdnnf

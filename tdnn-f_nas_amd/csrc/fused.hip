@@ -11,6 +11,8 @@
 // Arithmetic is the components' (nnet-normalize-component.cc:421-452,505-542; nnet-simple-component.cc:
 // 958-1074), only the number of trips through HBM changes.  All column reductions are two-stage and
 // deterministic.
+#include <algorithm>
+
 #include "common.h"
 #include "fused.h"
 
@@ -194,6 +196,146 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
   }
 }
 
+// The apply pass above with the natural-gradient statistic of the output side riding on it: a block owns 128 whole rows,
+// walks them 32 columns at a time, writes d_aff and stages the same values in LDS as the A operand of
+// H[128 x Rp] += d_aff[128 x 32] W[Rp x 32]^T on the f32 matrix cores (v_mfma_f32_32x32x2_f32, wave w owns rows 32w..32w+31).
+// The sweep is HBM-bound (x, dz in, d_aff out), the 2 N D Rp flops of H hide behind it: separately the two passes cost
+// an elementwise pass plus a GEMM that re-reads d_aff.  partial[block][col] = column sums of d_aff, part[block] = sum of squares.
+template <int NT>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
+                                                                   float self_repair_scale, MatView d_aff, float *partial, const float *mask, int B,
+                                                                   NgFuse ng) {
+  constexpr int BM = 128, BK = 32, LD = BK + 4;
+  __shared__ __attribute__((aligned(16))) float As[BM * LD];
+  __shared__ __attribute__((aligned(16))) float Bs[NT * 32 * LD];
+  __shared__ float colred[4][BK];
+  __shared__ double red[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int c4 = t & 7, rr = t >> 3;  // this thread's float4 of a 32-column row segment, rows rr + 32 i
+  const int r0 = blockIdx.x * BM;
+  typedef float acc_t __attribute__((ext_vector_type(16)));
+  acc_t acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; j++)
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
+  float ssq = 0.f;
+  const float count = repair_stats ? (float)repair_stats[0] : 0.f;
+  // register stage of the NEXT 32-column tile: requested before the MFMAs of the current one, so the trips to HBM (x, dz) and
+  // L2 (W) run under them
+  float xv[4][4], dv[4][4];
+  float4 wv[NT];
+  auto request = [&](int k0) {
+    const int col = k0 + c4 * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = r0 + rr + 32 * i;
+      if (r < x.rows) {
+        ld(x.data + (long long)r * x.stride + col, xv[i], true);
+        ld(dz.data + (long long)r * dz.stride + col, dv[i], true);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {  // W tile: NT * 32 rows x 32 k, rows >= Rp are zero
+      const int idx = t + 256 * j, n = idx >> 3, kk = (idx & 7) * 4;
+      wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < ng.Rp) wv[j] = *reinterpret_cast<const float4 *>(ng.W + (long long)n * ng.ldw + k0 + kk);
+    }
+  };
+  request(0);
+  for (int k0 = 0; k0 < D; k0 += BK) {
+    const int col = k0 + c4 * 4;
+    const float4 mu = *reinterpret_cast<const float4 *>(memo + col), sc = *reinterpret_cast<const float4 *>(memo + 2 * D + col),
+                 vdm = *reinterpret_cast<const float4 *>(memo + 3 * D + col), tmp = *reinterpret_cast<const float4 *>(memo + 4 * D + col);
+    float rep[4] = {0.f, 0.f, 0.f, 0.f};
+    if (repair_stats && self_repair_scale != 0.f && count != 0.f) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float stv = (float)repair_stats[1 + D + col + j];
+        const float v = (stv - 0.05f * count > 0.f ? 1.f : 0.f) + (stv - 0.95f * count > 0.f ? 1.f : 0.f) - 1.f;
+        rep[j] = v * (-self_repair_scale / 0.5f);
+      }
+    }
+    const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, sc_[4] = {sc.x, sc.y, sc.z, sc.w}, vdm_[4] = {vdm.x, vdm.y, vdm.z, vdm.w},
+                tmp_[4] = {tmp.x, tmp.y, tmp.z, tmp.w};
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = r0 + rr + 32 * i;
+      float o[4] = {0.f, 0.f, 0.f, 0.f};
+      if (r < x.rows) {
+        if (mask) {
+          const float *mk = mask + (long long)(r % B) * x.cols + col;
+#pragma unroll
+          for (int j = 0; j < 4; j++) dv[i][j] *= mk[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float z = (xv[i][j] - mu_[j]) * sc_[j];
+          const float dr = (dv[i][j] + tmp_[j]) * sc_[j] + z * vdm_[j];
+          float v = (xv[i][j] > 0.f ? 1.f : 0.f) * dr;
+          if (rep[j] != 0.f) v += rep[j];
+          o[j] = v;
+          cs[j] += v;
+          ssq += v * v;
+        }
+        st(d_aff.data + (long long)r * d_aff.stride + col, o, true);
+      }
+      *reinterpret_cast<float4 *>(As + (rr + 32 * i) * LD + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+      const int idx = t + 256 * j, n = idx >> 3, kk = (idx & 7) * 4;
+      *reinterpret_cast<float4 *>(Bs + n * LD + kk) = wv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // column sums over the wave's 8 row groups (lanes 8 apart hold the same columns)
+      float v = cs[j];
+      v += __shfl_xor(v, 8, 64);
+      v += __shfl_xor(v, 16, 64);
+      v += __shfl_xor(v, 32, 64);
+      if (lane < 8) colred[wave][lane * 4 + j] = v;
+    }
+    if (k0 + BK < D) request(k0 + BK);
+    __syncthreads();
+    {
+      const float *as = As + (wave * 32 + li) * LD + lh * 4;
+      const float *bs = Bs + li * LD + lh * 4;
+#pragma unroll
+      for (int kg = 0; kg < BK / 8; kg++) {
+        const float4 a = *reinterpret_cast<const float4 *>(as + kg * 8);
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+          const float4 b = *reinterpret_cast<const float4 *>(bs + j * 32 * LD + kg * 8);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[j], 0, 0, 0);
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (t < BK) partial[(long long)blockIdx.x * D + k0 + t] = (colred[0][t] + colred[1][t]) + (colred[2][t] + colred[3][t]);
+    __syncthreads();  // the tile buffers are rewritten next
+  }
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int j = 0; j < NT; j++) {
+    const int n = j * 32 + li;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+      const int r = r0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+      if (n < ng.Rp && r < x.rows) ng.H[(long long)r * ng.Rp + n] = acc[j][e];
+    }
+  }
+  double v = ssq;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (t == 0) ng.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (blockIdx.x == 0)
+    for (int i = gridDim.x + t; i < ng.part_cap; i += 256) ng.part[i] = 0.0;
+}
+
 __global__ __launch_bounds__(256) void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
   __shared__ float red[4][64];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
@@ -217,18 +359,25 @@ hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatV
   return hipGetLastError();
 }
 
+bool bn_relu_bwd_ng_ok(MatView x, MatView dz, MatView d_aff, int Rp) {
+  return vec4_ok(x) && vec4_ok(dz) && vec4_ok(d_aff) && x.cols % 32 == 0 && Rp >= 1 && Rp <= 96 && x.rows >= 1;
+}
+
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
   ColReducePlan p = colreduce_plan(rows, cols);
-  return sizeof(float) * 5 * (size_t)p.chunks * cols + 64;
+  const size_t blocks128 = ((size_t)rows + 127) / 128;  // column-sum partials of the natural-gradient form: one row per 128-row block
+  return sizeof(float) * (4 * (size_t)p.chunks + std::max((size_t)p.chunks, blocks128)) * cols + 64;
 }
 
 // x: ReLU output (= BatchNorm input), dz: derivative w.r.t. the BatchNorm output, memo: forward memo (rows 0-2
 // valid).  Writes d_aff (may alias dz) and adds lr_scale * colsum(d_aff) into bias_acc (may be null).
 hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
-                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask, int B) {
+                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask, int B, const NgFuse *ng) {
   if (x.rows == 0) return hipSuccess;
   if (ws_bytes < bn_relu_bwd_workspace_bytes(x.rows, x.cols)) return hipErrorInvalidValue;
+  if (ng && (!bn_relu_bwd_ng_ok(x, dz, d_aff, ng->Rp) || (reinterpret_cast<uintptr_t>(memo) & 15) || (reinterpret_cast<uintptr_t>(ng->W) & 15) || ng->ldw % 4))
+    return hipErrorInvalidValue;
   const int D = x.cols;
   ColReducePlan pl = colreduce_plan(x.rows, D);
   const bool vec = vec4_ok(x) && vec4_ok(dz) && vec4_ok(d_aff);
@@ -248,6 +397,14 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
   hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(256), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
                      store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0);
   const double *rep = self_repair ? relu_stats : nullptr;
+  if (ng) {
+    const int blocks = (x.rows + 127) / 128;
+    if (ng->Rp <= 32) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<1>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
+    else if (ng->Rp <= 64) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<2>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
+    else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<3>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
+    if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 63) / 64), dim3(256), 0, s, bias_partial, blocks, D, bias_scale, bias_acc);
+    return hipGetLastError();
+  }
   if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
   else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
   if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 63) / 64), dim3(256), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);

@@ -1122,12 +1122,37 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // BatchNorm backward + ReLU backward (+ StoreStats / self-repair coin flips as in the reference:
   // RectifiedLinearComponent::StoreStats nnet-simple-component.cc:1084, RepairGradients :1017) in two fused
   // passes; also yields the bias gradient of the affine layer in front of the ReLU.
-  auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc, const float *mask = nullptr) -> int {
+  // With natural gradient the same sweep also forms the output-side statistic H = dY Wy^T of the affine component in front
+  // of the ReLU (fused.h NgFuse): into the buffer set the component's param_grad call, which must come next, will take.
+  int fused_comp = -1;
+  tdnnf_net::NgSet *fused_set = nullptr;
+  auto out_stats_fuse = [&](int comp, MatView xv, MatView dzv, MatView dv, NgFuse &f) -> int {  // 1: f is to be passed on
+    fused_comp = -1;
+    if (!c.use_natural_gradient || n->ng_out.empty() || !n->ng_out[comp] || n->comps[comp].lr_factor == 0.f) return 0;
+    if (const char *e = getenv("TDNNF_NG_FUSE")) {  // test switch: 0 = the statistic by its own GEMM
+      if (atoi(e) == 0) return 0;
+    }
+    auto &S = n->ngset[n->ng_next % 4];
+    if (S.used) TDNNF_HIP(hipStreamWaitEvent(s, S.done, 0));
+    const float *W = nullptr;
+    int Rp = 0, ldw = 0;
+    CK(ng_external_begin(n->ng_out[comp], dv.cols, &W, &Rp, &ldw, s));
+    if (!W || !bn_relu_bwd_ng_ok(xv, dzv, dv, Rp)) return 0;
+    f.W = W; f.Rp = Rp; f.ldw = ldw; f.H = S.H_out; f.part = S.part_out; f.part_cap = rows_gemm_sumsq_blocks(dv.rows);
+    fused_comp = comp;
+    fused_set = &S;
+    return 1;
+  };
+  auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc, int comp,
+                              const float *mask = nullptr) -> int {
     const bool store = coin() || step == 0;
     const bool repair = c.relu_self_repair_scale > 0.f && coin();
     tdnnf_mat x = M(relu_out, rows, Hd), d = M(d_io, rows, Hd);
+    NgFuse f;
+    const int fuse = out_stats_fuse(comp, view(&x), view(&d), view(&d), f);
+    if (fuse < 0) return TDNNF_EINVAL;
     TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, cv, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
-                          n->ws, n->ws_bytes, s, mask, B));
+                          n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr));
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
@@ -1176,7 +1201,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     NgInput yin;
     memset(&yin, 0, sizeof(yin));
     yin.x = view(dyv); yin.ix.row_stride = 1; yin.ix.num_offsets = 1; yin.Di = Do; yin.N = N;
-    CK(ng_stats_main(n->ng_out[comp], yin, S.H_out, S.part_out, n->ws, n->ws_bytes, s));
+    if (fused_comp == comp) {  // H_out and its partials came with the BatchNorm/ReLU backward sweep
+      TDNNF_REQUIRE(fused_set == &S, "net_forward_backward: the fused statistics went to another buffer set");
+      fused_comp = -1;
+      CK(ng_external_end(n->ng_out[comp], yin, S.H_out, n->ws, n->ws_bytes, s));
+    } else {
+      CK(ng_stats_main(n->ng_out[comp], yin, S.H_out, S.part_out, n->ws, n->ws_bytes, s));
+    }
     // ---- the R x R work, the projections of the raw gradient and the commit, on the side stream
     TDNNF_HIP(hipEventRecord(S.ready, s));
     TDNNF_HIP(hipStreamWaitEvent(n->s3, S.ready, 0));
@@ -1209,7 +1240,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     else CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
     CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
-    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine)));  // dA -> d affine out
+    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine));  // dA -> d affine out
     CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
@@ -1235,8 +1266,11 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const bool store = coin() || step == 0;
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
       tdnnf_mat x = M(L.relu_out, no, Hd);
+      NgFuse f;
+      const int fuse = out_stats_fuse(L.aff.comp, view(&x), view(&d_out), view(&d_aff), f);
+      if (fuse < 0) return TDNNF_EINVAL;
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
-                            view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B));
+                            view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr));
     }
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : (L.c_arch >= 0 ? M(L.lin_masked, nl, L.bn) : lin);
@@ -1303,7 +1337,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     std::swap(d_cur, d_next);
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
-    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), mask_of(0)));
+    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, mask_of(0)));
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }

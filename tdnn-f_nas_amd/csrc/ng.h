@@ -37,6 +37,13 @@ int ng_stats_step(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws
 // ng_stats_workspace_bytes(); ws of ng_stats_side wgrad_workspace_bytes(rank_padded, rank_padded, 1, N).
 int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *ws, size_t ws_bytes, hipStream_t s);
 int ng_stats_side(tdnnf_ng *ng, const float *H, const double *part, void *ws, size_t ws_bytes, hipStream_t s);
+// The first half with H formed by the caller's own kernel (fused.hip: the BatchNorm/ReLU backward pass produces dY and
+// H = dY W^T in one sweep): ng_external_begin completes a pending refresh and hands out W_t (rank_padded x ldw, rows
+// >= rank are zero); *W == nullptr means "use ng_stats_main" (first minibatch, W_0 is initialised from the data).  After
+// the producer is enqueued on s (H with leading dimension rank_padded, `part` as for ng_stats_main), ng_external_end does
+// the bookkeeping and, on refresh steps, J.
+int ng_external_begin(tdnnf_ng *ng, int D, const float **W, int *Rp, int *ldw, hipStream_t s);
+int ng_external_end(tdnnf_ng *ng, const NgInput &in, const float *H, void *ws, size_t ws_bytes, hipStream_t s);
 int ng_h_ld(const tdnnf_ng *ng);        // leading dimension (padded rank) of H, W W^T, ...
 int ng_dim(const tdnnf_ng *ng);         // D (0 before the first call)
 const float *ng_scale_dev(const tdnnf_ng *ng);  // device float: sqrt(tr(XX^T)/tr(X^X^^T)) of the last call

@@ -388,6 +388,27 @@ size_t stats_ws_bytes(int Rp, int Di, int K, int N) {
   return part + std::max(wgrad_workspace_bytes(Rp, Rp, 1, N), wgrad_workspace_bytes(Rp, Di, K, N));
 }
 
+// What follows H in the first half: the bookkeeping of the call in flight and, on a refresh, J = H^T X.
+int stats_after_h(tdnnf_ng *ng, const NgInput &in, const float *H, void *wg_ws, size_t wg_bytes, bool upd, hipStream_t s) {
+  const int N = in.N, K = in.ix.num_offsets, Di = in.Di, Rp = ng->Rp, Dp = ng->Dp, D = ng->D;
+  ng->cur_upd = upd;
+  ng->cur_N = N;
+  ng->cur_ones = in.ones;
+  if (!upd) return TDNNF_OK;
+  TDNNF_REQUIRE(wg_ws && wg_bytes >= wgrad_workspace_bytes(Rp, Di, K, N), "ng: workspace too small");
+  TDNNF_HIP(hipMemsetAsync(ng->J, 0, sizeof(float) * (size_t)Rp * Dp, s));
+  if (in.ones) TDNNF_HIP(hipMemsetAsync(ng->tmpR, 0, sizeof(float) * Rp, s));
+  WgradArgs j;
+  memset(&j, 0, sizeof(j));
+  j.dY = H; j.lddy = Rp; j.X = in.x.data; j.ldx = in.x.stride; j.Do = Rp; j.Di = Di; j.K = K; j.N = N; j.row_stride = in.ix.row_stride;
+  for (int i = 0; i < K; i++) j.row_offsets[i] = in.ix.row_offsets[i];
+  j.coef = in.eff; j.scale = 1.f; j.G = ng->J; j.ldg = Dp; j.accumulate = 1; j.bias_acc = in.ones ? ng->tmpR : nullptr;
+  j.active = in.active; j.max_active = in.max_active;
+  TDNNF_HIP(wgrad(j, wg_ws, wg_bytes, s));  // J = H^T X  (last column: column sums of H)
+  if (in.ones) hipLaunchKernelGGL(scatter_col_kernel, dim3((Rp + 63) / 64), dim3(64), 0, s, ng->tmpR, Rp, ng->J, Dp, D - 1);
+  return TDNNF_OK;
+}
+
 // First half of one PreconditionDirections call, everything N x D sized: H = X W_t^T (with ||X||^2 per block into
 // `part`) and, on a refresh, J = H^T X.  W_t is left untouched.
 int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg_ws, size_t wg_bytes, bool upd, hipStream_t s) {
@@ -408,22 +429,7 @@ int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg
     a.seg[i].m_hi = N;
   }
   TDNNF_HIP(rows_gemm(a, true, s));  // H = X W^T (+ ||X||_F^2 per block)
-  ng->cur_upd = upd;
-  ng->cur_N = N;
-  ng->cur_ones = in.ones;
-  if (!upd) return TDNNF_OK;
-  TDNNF_REQUIRE(wg_ws && wg_bytes >= wgrad_workspace_bytes(Rp, Di, K, N), "ng: workspace too small");
-  TDNNF_HIP(hipMemsetAsync(ng->J, 0, sizeof(float) * (size_t)Rp * Dp, s));
-  if (in.ones) TDNNF_HIP(hipMemsetAsync(ng->tmpR, 0, sizeof(float) * Rp, s));
-  WgradArgs j;
-  memset(&j, 0, sizeof(j));
-  j.dY = H; j.lddy = Rp; j.X = in.x.data; j.ldx = in.x.stride; j.Do = Rp; j.Di = Di; j.K = K; j.N = N; j.row_stride = in.ix.row_stride;
-  for (int i = 0; i < K; i++) j.row_offsets[i] = in.ix.row_offsets[i];
-  j.coef = in.eff; j.scale = 1.f; j.G = ng->J; j.ldg = Dp; j.accumulate = 1; j.bias_acc = in.ones ? ng->tmpR : nullptr;
-  j.active = in.active; j.max_active = in.max_active;
-  TDNNF_HIP(wgrad(j, wg_ws, wg_bytes, s));  // J = H^T X  (last column: column sums of H)
-  if (in.ones) hipLaunchKernelGGL(scatter_col_kernel, dim3((Rp + 63) / 64), dim3(64), 0, s, ng->tmpR, Rp, ng->J, Dp, D - 1);
-  return TDNNF_OK;
+  return stats_after_h(ng, in, H, wg_ws, wg_bytes, upd, s);
 }
 
 // Second half, R x R sized and latency bound: L = H^T H, traces and scale; on a refresh K = J J^T and the hand-off to the
@@ -533,6 +539,27 @@ int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void 
   int rc = finalize(ng, s);  // a refresh started by the previous call on this object
   if (rc) return rc;
   return stats_main(ng, in, H, part, ws, ws_bytes, updating(ng), s);
+}
+
+int ng_external_begin(tdnnf_ng *ng, int D, const float **W, int *Rp, int *ldw, hipStream_t s) {
+  TDNNF_REQUIRE(ng && W && Rp && ldw, "ng_external_begin: bad arguments");
+  *W = nullptr;
+  if (ng->D == 0 || ng->rank == 0) return TDNNF_OK;  // first minibatch (W_0 comes from the data) / nothing to precondition
+  TDNNF_REQUIRE(ng->D == D, "ng: dimension changed from %d to %d", ng->D, D);
+  ng->cur_N = 0;
+  int rc = finalize(ng, s);  // a refresh started by the previous call on this object
+  if (rc) return rc;
+  *W = ng->W;
+  *Rp = ng->Rp;
+  *ldw = ng->Dp;
+  return TDNNF_OK;
+}
+
+int ng_external_end(tdnnf_ng *ng, const NgInput &in, const float *H, void *ws, size_t ws_bytes, hipStream_t s) {
+  TDNNF_REQUIRE(ng && H && ng->D != 0 && ng->rank > 0 && in.N > 0, "ng_external_end: bad arguments");
+  ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
+  return stats_after_h(ng, in, H, ws, ws_bytes, updating(ng), s);
 }
 
 int ng_stats_side(tdnnf_ng *ng, const float *H, const double *part, void *ws, size_t ws_bytes, hipStream_t s) {

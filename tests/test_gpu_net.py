@@ -91,6 +91,11 @@ CASES += [
     ("7q-shape-small-NG-bf16x6", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=24, feat_dim=40,
                                       ivector_dim=100, num_pdfs=150, hidden_dim=96, small_dim=48, use_natural_gradient=1, gemm_precision=2), 60),
 ]
+# hidden_dim 160: output-side rank 80, the three-tile form of the fused BatchNorm/ReLU-backward + statistic sweep (step 1)
+CASES += [
+    ("7q-shape-small-NG-rank80", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 0, 3], bottleneck=24, feat_dim=40, ivector_dim=100,
+                                      num_pdfs=150, hidden_dim=160, small_dim=64, use_natural_gradient=1), 60),
+]
 
 
 @pytest.mark.parametrize("name,kw,H", CASES, ids=[c[0] for c in CASES])
@@ -266,6 +271,41 @@ def test_net_cv_update_after_pretrain_matches_oracle(pkg, name, pre_kw, cv_kw):
         params = p_ref
     assert np.array_equal(net2.get_stats()[:1 + 2 * cfg2.hidden_dim], st_gpu[:1 + 2 * cfg2.hidden_dim])  # BatchNormTest: stats untouched
     net2.close()
+
+
+@pytest.mark.parametrize("hidden", [64, 160], ids=["rank32", "rank80"])
+def test_fused_output_statistics_match_the_separate_pass(pkg, hidden, monkeypatch):
+    """With natural gradient the BatchNorm/ReLU backward sweep also forms H = dY Wy^T of the affine in front (fused.hip); with
+    TDNNF_NG_FUSE=0 the statistic comes from its own GEMM.  Same net, same minibatches: the gradients agree step after step
+    (refresh steps included: the first ten minibatches refresh every time)."""
+    T = pkg.trainer
+    kw = dict(frames_per_chunk=30, num_sequences=8, strides=[1, 1, 0, 3, 3], bottleneck=16, feat_dim=8, ivector_dim=4, hidden_dim=hidden, small_dim=32,
+              num_pdfs=50, use_natural_gradient=1, use_dropout=1)
+
+    def run(fuse):
+        monkeypatch.setenv("TDNNF_NG_FUSE", str(fuse))
+        cfg = T.make_config(**kw)
+        net = T.ChainNet(cfg)
+        net.set_params(net.init_params_numpy(seed=1, output_stddev=0.1))
+        net.set_dropout_proportion(0.2)
+        den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+        out = []
+        for i in range(5):
+            feats, iv = T.synthetic_egs(net, seed=100 + i)
+            sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=200 + i))
+            net.set_random_draws(np.random.default_rng(300 + i).uniform(1e-3, 1 - 1e-3, net.num_draws).astype(np.float32))
+            r = host(net.forward_backward(dev(feats), dev(iv), den, sup, step=i))
+            out.append((host(net.grads).copy(), r.copy()))
+            net.update(1e-3, step=i)
+        net.close()
+        return out
+
+    fused, separate = run(1), run(0)
+    assert np.array_equal(fused[0][0], separate[0][0])  # the first minibatch initialises the preconditioners: nothing to fuse yet
+    for (ga, ra), (gb, rb) in zip(fused, separate):
+        assert ra[5] == 1.0 and abs(ra[0] - rb[0]) <= 1e-5 * (abs(rb[3]) + abs(rb[4])), (ra, rb)  # objf = num - den log-probs
+        assert rel_l2(ga, gb) < 1e-4, rel_l2(ga, gb)
+    assert any(not np.array_equal(ga, gb) for (ga, _), (gb, _) in zip(fused[1:], separate[1:]))  # the switch did switch
 
 
 def test_net_update_constrains_tall_matrices_through_their_transpose(pkg):
