@@ -21,6 +21,7 @@ struct NgFuse {
   int part_cap;
 };
 bool bn_relu_bwd_ng_ok(MatView x, MatView dz, MatView d_aff, int Rp);  // shapes / alignment the fused sweep takes
+bool bn_relu_bwd_ng_pays(int rows);  // whether the launch fills its rounds of resident blocks well enough to beat the separate passes
 
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols);
 // BatchNorm backward + ReLU backward (+ self-repair, ReLU statistics, bias-gradient column sums) in two passes.

@@ -363,6 +363,20 @@ bool bn_relu_bwd_ng_ok(MatView x, MatView dz, MatView d_aff, int Rp) {
   return vec4_ok(x) && vec4_ok(dz) && vec4_ok(d_aff) && x.cols % 32 == 0 && Rp >= 1 && Rp <= 96 && x.rows >= 1;
 }
 
+// Two 128-row blocks are resident per CU (registers): a launch of a few blocks more than one round of them runs as two
+// (514 blocks on 256 CUs: 0.50 ms against 0.32 ms for 512), and then the separate passes are faster.
+bool bn_relu_bwd_ng_pays(int rows) {
+  static int slots = 0;
+  if (!slots) {
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    slots = 2 * cus;
+  }
+  const int blocks = (rows + 127) / 128, rounds = (blocks + slots - 1) / slots;
+  return blocks <= slots || 4 * blocks >= 3 * rounds * slots;  // one round, or the rounds at least 3/4 used
+}
+
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
   ColReducePlan p = colreduce_plan(rows, cols);
   const size_t blocks128 = ((size_t)rows + 127) / 128;  // column-sum partials of the natural-gradient form: one row per 128-row block

@@ -1129,15 +1129,17 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   auto out_stats_fuse = [&](int comp, MatView xv, MatView dzv, MatView dv, NgFuse &f) -> int {  // 1: f is to be passed on
     fused_comp = -1;
     if (!c.use_natural_gradient || n->ng_out.empty() || !n->ng_out[comp] || n->comps[comp].lr_factor == 0.f) return 0;
-    if (const char *e = getenv("TDNNF_NG_FUSE")) {  // test switch: 0 = the statistic by its own GEMM
+    bool fuse_always = false;
+    if (const char *e = getenv("TDNNF_NG_FUSE")) {  // test switch: 0 = the statistic by its own GEMM, 2 = fused whatever the row count
       if (atoi(e) == 0) return 0;
+      fuse_always = atoi(e) == 2;
     }
     auto &S = n->ngset[n->ng_next % 4];
     if (S.used) TDNNF_HIP(hipStreamWaitEvent(s, S.done, 0));
     const float *W = nullptr;
     int Rp = 0, ldw = 0;
     CK(ng_external_begin(n->ng_out[comp], dv.cols, &W, &Rp, &ldw, s));
-    if (!W || !bn_relu_bwd_ng_ok(xv, dzv, dv, Rp)) return 0;
+    if (!W || !bn_relu_bwd_ng_ok(xv, dzv, dv, Rp) || !(fuse_always || bn_relu_bwd_ng_pays(dv.rows))) return 0;
     f.W = W; f.Rp = Rp; f.ldw = ldw; f.H = S.H_out; f.part = S.part_out; f.part_cap = rows_gemm_sumsq_blocks(dv.rows);
     fused_comp = comp;
     fused_set = &S;

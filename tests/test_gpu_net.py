@@ -300,7 +300,7 @@ def test_fused_output_statistics_match_the_separate_pass(pkg, hidden, monkeypatc
         net.close()
         return out
 
-    fused, separate = run(1), run(0)
+    fused, separate = run(2), run(0)
     assert np.array_equal(fused[0][0], separate[0][0])  # the first minibatch initialises the preconditioners: nothing to fuse yet
     for (ga, ra), (gb, rb) in zip(fused, separate):
         assert ra[5] == 1.0 and abs(ra[0] - rb[0]) <= 1e-5 * (abs(rb[3]) + abs(rb[4])), (ra, rb)  # objf = num - den log-probs
