@@ -21,8 +21,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(MatView a, MatView b, in
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(a.rows, r0 + rows_per_chunk);
   float s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
   if (col < a.cols) {
-    for (int r = r0 + tr; r < r1; r += 4) {
-      float va[4], vb[4];
+    auto fetch = [&](int r, float (&va)[4], float (&vb)[4]) {
       if (VEC == 4) {
         float4 x = *reinterpret_cast<const float4 *>(a.data + (long long)r * a.stride + col);
         va[0] = x.x; va[1] = x.y; va[2] = x.z; va[3] = x.w;
@@ -30,10 +29,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(MatView a, MatView b, in
           float4 y = *reinterpret_cast<const float4 *>(b.data + (long long)r * b.stride + col);
           vb[0] = y.x; vb[1] = y.y; vb[2] = y.z; vb[3] = y.w;
         }
+      } else if (VEC == 2) {
+        float2 x = *reinterpret_cast<const float2 *>(a.data + (long long)r * a.stride + col);
+        va[0] = x.x; va[1] = x.y;
+        if (KIND == 2) {
+          float2 y = *reinterpret_cast<const float2 *>(b.data + (long long)r * b.stride + col);
+          vb[0] = y.x; vb[1] = y.y;
+        }
       } else {
         va[0] = a.data[(long long)r * a.stride + col];
         if (KIND == 2) vb[0] = b.data[(long long)r * b.stride + col];
       }
+    };
+    auto add = [&](const float (&va)[4], const float (&vb)[4]) {
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
         if (KIND == 0) s0[j] += va[j];
@@ -41,6 +49,19 @@ __global__ __launch_bounds__(256) void colreduce_kernel(MatView a, MatView b, in
         if (KIND == 2) { s0[j] += va[j] * vb[j]; s1[j] += vb[j]; }
         if (KIND == 3) { s0[j] += va[j]; s1[j] += va[j] > 0.f ? 1.f : 0.f; }
       }
+    };
+    int r = r0 + tr;
+    for (; r + 12 < r1; r += 16) {  // four rows requested before the first is added: the pass is bound by requests in flight
+      float va[4][4], vb[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) fetch(r + 4 * u, va[u], vb[u]);
+#pragma unroll
+      for (int u = 0; u < 4; u++) add(va[u], vb[u]);
+    }
+    for (; r < r1; r += 4) {
+      float va[4], vb[4];
+      fetch(r, va, vb);
+      add(va, vb);
     }
   }
 #pragma unroll
@@ -82,10 +103,13 @@ size_t colreduce_bytes(int rows, int cols) {
 hipError_t colreduce_partial(int kind, MatView a, MatView b, float *partial, hipStream_t s) {
   ColReducePlan p = colreduce_plan(a.rows, a.cols);
   const bool vec = vec4_ok(a) && (kind != 2 || vec4_ok(b));
-  const int per = vec ? 256 : 64;
+  auto vec2_ok = [](const MatView &m) { return m.cols % 2 == 0 && m.stride % 2 == 0 && (reinterpret_cast<uintptr_t>(m.data) & 7) == 0; };
+  const bool vec2 = !vec && vec2_ok(a) && (kind != 2 || vec2_ok(b));  // e.g. the 6034-wide output layer
+  const int per = vec ? 256 : (vec2 ? 128 : 64);
   dim3 grid((a.cols + per - 1) / per, p.chunks), block(256);
 #define CR(K)                                                                                              \
   if (vec) hipLaunchKernelGGL((colreduce_kernel<K, 4>), grid, block, 0, s, a, b, p.rows_per_chunk, p.chunks, partial); \
+  else if (vec2) hipLaunchKernelGGL((colreduce_kernel<K, 2>), grid, block, 0, s, a, b, p.rows_per_chunk, p.chunks, partial); \
   else hipLaunchKernelGGL((colreduce_kernel<K, 1>), grid, block, 0, s, a, b, p.rows_per_chunk, p.chunks, partial);
   switch (kind) {
     case 0: CR(0) break;
