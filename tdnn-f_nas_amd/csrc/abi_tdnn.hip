@@ -52,7 +52,8 @@ int tdnnf_abi_version(void) { return 1; }
 namespace tdnnf {
 // Propagate with an optional fused ReLU in the GEMM epilogue (trainer-internal; the C-ABI entry has relu = 0)
 int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
-                        const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream) {
+                        const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream,
+                        float *colstats, int *colstats_rows) {
   TDNNF_REQUIRE(mat_ok(in) && mat_ok(out) && W, "tdnn_propagate: bad matrices");
   TDNNF_REQUIRE(Do > 0 && Di > 0 && in->cols == Di && out->cols == Do, "tdnn_propagate: dims: in.cols=%d Di=%d out.cols=%d Do=%d",
                 in ? in->cols : -1, Di, out ? out->cols : -1, Do);
@@ -73,6 +74,8 @@ int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const
   a.coef = eff_coef;
   a.init_mode = init_mode;
   a.relu = relu;
+  a.colstats = colstats;  // BatchNorm statistics of the output, when the launch can form them (gemm_f32.h)
+  a.colstats_rows = colstats_rows;
   a.nseg = ix->num_offsets;
   for (int i = 0; i < a.nseg; i++) {
     a.seg[i].a_off = (long long)ix->row_offsets[i] * in->stride;

@@ -71,6 +71,10 @@ ColReducePlan colreduce_plan(int rows, int cols);
 size_t colreduce_bytes(int rows, int cols);
 // partial[q][chunk][col] for q < nq; kind: 0 = (sum a), 1 = (sum a, sum a*a), 2 = (sum a*b, sum b), 3 = (sum a, sum a>0)
 hipError_t colreduce_partial(int kind, MatView a, MatView b, float *partial, hipStream_t s);
+// the same with the chunking given: partial[c * cols + col] and, second quantity, partial[(sq_row_offset + c) * cols + col], c < chunks
+hipError_t colreduce_partial_into(int kind, MatView a, MatView b, int chunks, int rows_per_chunk, int sq_row_offset, float *partial, hipStream_t s);
+// BatchNorm forward: memo rows 0-2 from column partial sums / sums of squares laid out as above with sq_row_offset == chunks
+hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s);
 hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s);
 hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s);  // ws: colreduce_bytes(rows, cols)
 
@@ -83,7 +87,8 @@ int chain_finish(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const td
 
 // trainer-internal variants of the TDNN entry points (abi_tdnn.hip)
 int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di,
-                        const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream);
+                        const float *bias, const float *eff_coef, int init_mode, int relu, tdnnf_mat *out, tdnnf_stream stream,
+                        float *colstats = nullptr, int *colstats_rows = nullptr);
 int tdnn_update_simple_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int Do, int Di,
                             const float *eff_coef, float lr, float *W_acc, int ldw, float *bias_acc, void *ws, size_t ws_bytes,
                             const int *active_dev, int max_active, tdnnf_stream stream);

@@ -102,15 +102,18 @@ size_t colreduce_bytes(int rows, int cols) {
 }
 hipError_t colreduce_partial(int kind, MatView a, MatView b, float *partial, hipStream_t s) {
   ColReducePlan p = colreduce_plan(a.rows, a.cols);
+  return colreduce_partial_into(kind, a, b, p.chunks, p.rows_per_chunk, p.chunks, partial, s);
+}
+hipError_t colreduce_partial_into(int kind, MatView a, MatView b, int chunks, int rows_per_chunk, int sq_row_offset, float *partial, hipStream_t s) {
   const bool vec = vec4_ok(a) && (kind != 2 || vec4_ok(b));
   auto vec2_ok = [](const MatView &m) { return m.cols % 2 == 0 && m.stride % 2 == 0 && (reinterpret_cast<uintptr_t>(m.data) & 7) == 0; };
   const bool vec2 = !vec && vec2_ok(a) && (kind != 2 || vec2_ok(b));  // e.g. the 6034-wide output layer
   const int per = vec ? 256 : (vec2 ? 128 : 64);
-  dim3 grid((a.cols + per - 1) / per, p.chunks), block(256);
+  dim3 grid((a.cols + per - 1) / per, chunks), block(256);
 #define CR(K)                                                                                              \
-  if (vec) hipLaunchKernelGGL((colreduce_kernel<K, 4>), grid, block, 0, s, a, b, p.rows_per_chunk, p.chunks, partial); \
-  else if (vec2) hipLaunchKernelGGL((colreduce_kernel<K, 2>), grid, block, 0, s, a, b, p.rows_per_chunk, p.chunks, partial); \
-  else hipLaunchKernelGGL((colreduce_kernel<K, 1>), grid, block, 0, s, a, b, p.rows_per_chunk, p.chunks, partial);
+  if (vec) hipLaunchKernelGGL((colreduce_kernel<K, 4>), grid, block, 0, s, a, b, rows_per_chunk, sq_row_offset, partial); \
+  else if (vec2) hipLaunchKernelGGL((colreduce_kernel<K, 2>), grid, block, 0, s, a, b, rows_per_chunk, sq_row_offset, partial); \
+  else hipLaunchKernelGGL((colreduce_kernel<K, 1>), grid, block, 0, s, a, b, rows_per_chunk, sq_row_offset, partial);
   switch (kind) {
     case 0: CR(0) break;
     case 1: CR(1) break;
@@ -669,6 +672,10 @@ hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *me
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols,
                      a.rows, epsilon, target_rms, memo);
+  return hipGetLastError();
+}
+hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s) {
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo);
   return hipGetLastError();
 }
 // acc[c] += scale * colsum(a)[c]   (two-stage, float4 loads)

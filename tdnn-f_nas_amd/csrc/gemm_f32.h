@@ -44,6 +44,14 @@ struct RowsGemmArgs {
   // then staged exactly once): rows_gemm() fails otherwise.  One double per 128-row block: rows_gemm_sumsq_blocks(M).
   double *sumsq;
   int sumsq_cap;  // set by rows_gemm(): rows_gemm_sumsq_blocks(M)
+  // optional: column sums and sums of squares of the STORED C values (after bias / addend / ReLU) -- the BatchNorm statistics
+  // of the layer output as a by-product of writing it.  One partial row per 128-row tile (and per chunk of the rows a split-K
+  // tail launch finishes): colstats[c * N + n] sums, colstats[(rows + c) * N + n] sums of squares, rows = *colstats_rows as
+  // set by rows_gemm() (0: this launch cannot do it -- not the exact-f32 128-wide tile -- and nothing was written).
+  // Capacity needed: 2 * N * rows_gemm_colstats_cap(M) floats.
+  float *colstats;
+  int *colstats_rows;  // host, out
+  int colstats_stride;  // set by rows_gemm(): the `rows` above
   // 0: exact f32 MFMA (v_mfma_f32_32x32x2_f32).  1: split-bf16 (three v_mfma_f32_32x32x16_bf16 per 16 k, products accurate
   // to ~2^-16 relative, f32 accumulation); needs a k-contiguous B and 16-byte alignment, otherwise the f32 kernel runs.
   int prec;
@@ -97,6 +105,7 @@ const float *transposed_weights(const float *W);  // null when there is none (or
 // capacity of the p.sumsq array for M rows: one entry per 128-row block, or per (block, K-slice) when rows_gemm() splits K
 // over idle CUs for a launch of few blocks (then blocks x slices <= the chip's resident blocks <= 1024); the kernel zeroes
 // the entries it does not write, consumers sum all of them
+inline int rows_gemm_colstats_cap(int M) { return (M + 127) / 128 + 64; }
 inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128 > 1024 ? (M + 127) / 128 : 1024; }
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).

@@ -372,6 +372,9 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       for (int i = gridDim.x + t; i < p.sumsq_cap; i += 256) p.sumsq[i] = 0.0;
     __syncthreads();
   }
+  constexpr bool kColStats = 256 % (BN / 4) == 0 && (HALF * (BN / 4)) % 256 == 0;  // a thread keeps one float4 column group
+  const bool colstats = kColStats && p.colstats && p.ksplit <= 1;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f}, cq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int pass = 0; pass < BM / HALF; pass++) {
     if ((wm * TM * 32) / HALF == pass) {
@@ -411,6 +414,10 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
         }
         if (p.relu) { v.x = floor_keep_nan(v.x, 0.f); v.y = floor_keep_nan(v.y, 0.f); v.z = floor_keep_nan(v.z, 0.f); v.w = floor_keep_nan(v.w, 0.f); }
         *reinterpret_cast<float4 *>(c) = v;
+        if (colstats) {
+          cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w;
+          cq[0] += v.x * v.x; cq[1] += v.y * v.y; cq[2] += v.z * v.z; cq[3] += v.w * v.w;
+        }
       } else {
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -422,11 +429,35 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
             if (p.add && m >= p.add_lo && m < p.add_hi) x += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n + e];
             if (p.relu) x = floor_keep_nan(x, 0.f);
             c[e] = x;
+            if (colstats) { cs[e] += x; cq[e] += x * x; }
           }
         }
       }
     }
     if (pass + 1 < BM / HALF) __syncthreads();
+  }
+  if (kColStats && colstats) {
+    // thread t owns columns 4 (t % (BN/4)) .. +3 of every row it stored: lanes 32 apart share them when BN = 128, then the
+    // four waves; one partial row per row tile
+    constexpr int G = BN / 4;
+    __syncthreads();
+    float *red = smem;  // [256 / G][BN][2]
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      red[((t / G) * BN + (t % G) * 4 + e) * 2] = cs[e];
+      red[((t / G) * BN + (t % G) * 4 + e) * 2 + 1] = cq[e];
+    }
+    __syncthreads();
+    if (t < BN && n0 + t < p.N) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int g = 0; g < 256 / G; g++) {
+        a0 += red[(g * BN + t) * 2];
+        a1 += red[(g * BN + t) * 2 + 1];
+      }
+      p.colstats[(long long)tile_m * p.N + n0 + t] = a0;
+      p.colstats[((long long)p.colstats_stride + tile_m) * p.N + n0 + t] = a1;
+    }
   }
 }
 
@@ -940,6 +971,7 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   }
   const int tiles = ntm * ntn, slots = rows_slots<WM, WN, TM, TN, BK>(b_kc, (b_kc && vec) ? a.prec : 0);
   const int q = tiles / slots, r = tiles % slots;
+  const bool stats = a.colstats != nullptr;  // (rows_gemm() leaves it set only for the exact-f32 128 x 128 tile)
   long long ktot = 0;
   bool k4 = true;
   for (int i = 0; i < a.nseg; i++) {
@@ -954,7 +986,7 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   // A handful of tiles with a long reduction (the R x D products of the natural-gradient state, P = M M^T of the
   // orthonormal constraint): one block per tile would crawl through K at load latency on a few CUs, so split K
   // over the idle ones.
-  if (tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
+  if (!stats && tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
     const long long kt = (ktot + BK - 1) / BK;
     int S = slots / tiles;
     if (S > kt / 4) S = (int)(kt / 4);
@@ -975,6 +1007,19 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
     const int m_main = main_mt * BM;
     RowsGemmArgs am = a;
     am.M = m_main;
+    // column statistics: the main launch writes one partial row per row tile, the tail rows follow as the chunks of a
+    // column-reduction pass over the finished C (split-K tail) or as the tail launch's own row tiles (plain tail)
+    const int tail_rows = a.M - m_main;
+    const long long kt_tail = (ktot + BK - 1) / BK;
+    const int tail_tiles0 = ((tail_rows + BM - 1) / BM) * ntn;
+    int S_tail = slots / tail_tiles0;
+    if (S_tail > kt_tail / 2) S_tail = (int)(kt_tail / 2);
+    const bool tail_split = S_tail >= 2 && sizeof(float) * (size_t)S_tail * tail_rows * ((a.N + 3) & ~3) <= scratch_bytes;
+    ColReducePlan tail_plan = colreduce_plan(tail_rows, a.N);
+    if (stats) {
+      am.colstats_stride = main_mt + (tail_split ? tail_plan.chunks : (tail_rows + BM - 1) / BM);
+      *a.colstats_rows = am.colstats_stride;
+    }
     {
       ProfScope ps(cls, flops * m_main / a.M, s);
       hipError_t e = launch_rows<WM, WN, TM, TN, BK>(am, b_kc, vec, s);
@@ -990,12 +1035,14 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
     }
     at.add_lo -= m_main;
     at.add_hi -= m_main;
-    const int tail_tiles = ((at.M + BM - 1) / BM) * ntn;
-    const long long kt = (ktot + BK - 1) / BK;
-    int S = slots / tail_tiles;
-    if (S > kt / 2) S = (int)(kt / 2);
-    const size_t need = sizeof(float) * (size_t)S * at.M * ((a.N + 3) & ~3);
-    if (S >= 2 && need <= scratch_bytes) {
+    if (stats) {  // partial rows main_mt .. of the same array (the sums of squares sit colstats_stride rows further in both views)
+      at.colstats = a.colstats + (long long)main_mt * a.N;
+      at.colstats_stride = am.colstats_stride;
+    }
+    const int tail_tiles = tail_tiles0;
+    const long long kt = kt_tail;
+    const int S = S_tail;
+    if (tail_split) {
       at.kchunk = (int)(((kt + S - 1) / S) * BK);
       at.ksplit = (int)((ktot + at.kchunk - 1) / at.kchunk);
       at.partial = scratch;
@@ -1006,6 +1053,11 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
         const long long total = (long long)at.M * at.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, at);
       }
+      if (stats) {
+        MatView ct{at.C, at.M, at.N, (int)at.ldc};
+        hipError_t e = colreduce_partial_into(1, ct, ct, tail_plan.chunks, tail_plan.rows_per_chunk, am.colstats_stride, at.colstats, s);
+        if (e != hipSuccess) return e;
+      }
       return hipGetLastError();
     }
     // tail too small to split: plain launch of the remaining rows
@@ -1013,6 +1065,12 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
     return launch_rows<WM, WN, TM, TN, BK>(at, b_kc, vec, s);
   }
   ProfScope ps(cls, flops, s);
+  if (stats) {
+    RowsGemmArgs as = a;
+    as.colstats_stride = ntm;
+    *a.colstats_rows = ntm;
+    return launch_rows<WM, WN, TM, TN, BK>(as, b_kc, vec, s);
+  }
   return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
 }
 
@@ -1076,6 +1134,8 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     if (force) a.prec = force;
   }
   if (!(b_kc && vec)) a.prec = 0;  // the split-bf16 kernels need a k-contiguous B and 16-byte alignment
+  if (a.colstats_rows) *a.colstats_rows = 0;
+  if (!a.colstats_rows || a.prec != 0 || a.sumsq || a.N <= 32 || waste160 < waste128 || a.ksplit > 1) a.colstats = nullptr;
   if (a.sumsq) {  // one column tile, no split-K tail: block b owns rows [128 b, 128 b + 128)
     if (a.N > 128) return hipErrorInvalidValue;
     a.sumsq_cap = rows_gemm_sumsq_blocks(a.M);

@@ -436,6 +436,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   auto upd = [&](size_t b) { ws = std::max(ws, b); };
   upd(wgrad_workspace_bytes(Hd, lda_dim, 1, N0));
   upd(colreduce_bytes(max_rows, Hd));
+  upd(sizeof(float) * 2 * (size_t)Hd * rows_gemm_colstats_cap(std::max(max_rows, std::max(N0, No))));  // BatchNorm partials out of the GEMM epilogue
   upd(bn_relu_bwd_workspace_bytes(max_rows, Hd));
   for (auto &L : n->layers) {
     upd(wgrad_workspace_bytes(L.lin.Do, L.lin.Di, L.lin.K, L.lin.rows_out));
@@ -508,6 +509,22 @@ int bn_fwd(tdnnf_net *n, float *in, float *out, int rows, int cols, float *memo,
   }
   CK(tdnnf_batchnorm_propagate(&a, 1.0e-3f, 1.0f, &o, memo, n->ws, n->ws_bytes, s));
   return tdnnf_batchnorm_store_stats(memo, cols, rows, stats, s);  // StoreStats runs on every minibatch
+}
+// Affine (+ bias) + ReLU into `out` and the BatchNorm statistics of that output; the GEMM's epilogue forms the column sums
+// while it stores the tile when it can (exact-f32 128-wide tile), otherwise a pass over `out` does.  The normalisation itself
+// is applied later by a fused pass.
+int affine_relu_bn_stats(tdnnf_net *n, const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const float *W, int ldw, int Do, int Di, const float *bias,
+                         const float *eff, tdnnf_mat *out, float *memo, double *stats, hipStream_t s) {
+  if (n->cfg.cv_update) {
+    CK(tdnn_propagate_impl(ix, in, W, ldw, Do, Di, bias, eff, 1, 1, out, s));
+    return bn_test_memo(memo, stats, Do, s);
+  }
+  int prows = 0;
+  const bool room = n->ws_bytes >= sizeof(float) * 2 * (size_t)Do * rows_gemm_colstats_cap(out->rows);
+  CK(tdnn_propagate_impl(ix, in, W, ldw, Do, Di, bias, eff, 1, 1, out, s, room ? (float *)n->ws : nullptr, room ? &prows : nullptr));
+  if (prows > 0) TDNNF_HIP(batchnorm_stats_from_partials((const float *)n->ws, prows, out->rows, Do, 1.0e-3f, 1.0f, memo, s));
+  else TDNNF_HIP(batchnorm_stats(view(out), 1.0e-3f, 1.0f, memo, n->ws, s));
+  return tdnnf_batchnorm_store_stats(memo, Do, out->rows, stats, s);
 }
 // statistics of BatchNorm(x) only; the normalisation itself is applied by a fused pass
 int bn_stats(tdnnf_net *n, float *x, int rows, int cols, float *memo, double *stats, hipStream_t s) {
@@ -789,6 +806,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   // named activations for parity tests
   auto name = [&](const std::string &s, float *p, int rows, int cols) { n->named.push_back({s, M(p, rows, cols)}); };
   name("lda", n->lda_out, N_of(n->g_lda, B), lda_dim);
+  name("tdnn1.relu", n->t1_relu, N_of(n->g_lda, B), Hd);
   name("tdnn1.batchnorm", n->t1_bn, N_of(n->g_lda, B), Hd);
   for (int l = 0; l < c.num_layers; l++) {
     TdnnfLayer &L = n->layers[l];
@@ -1036,8 +1054,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   auto mask_of = [&](int m) -> const float * { return drop ? n->dropout_masks + (size_t)m * B * Hd : nullptr; };
   // tdnn1: affine (+bias, ReLU in the GEMM epilogue) -> BatchNorm
-  CK(tdnn_propagate_impl(&ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, 1, 1, &t1r, s));
-  CK(bn_stats(n, n->t1_relu, N0, Hd, n->t1_bn_memo, n->t1_bn_stats, s));
+  CK(affine_relu_bn_stats(n, &ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, &t1r, n->t1_bn_memo, n->t1_bn_stats, s));
   TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, ldpad(Hd), none, 0.f, view(&t1b), s, mask_of(0), B));
   float *prev = n->t1_bn;
   int layer_no = 0;
@@ -1075,8 +1092,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_reorder_rows(&src, B, L.aff.ix.row_stride, 1, &aff_in, s));
     }
     tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
-    CK(tdnn_propagate_impl(&L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, 1, 1, &relu, s));
-    CK(bn_stats(n, L.relu_out, L.aff.rows_out, Hd, L.bn_memo, L.bn_stats, s));
+    CK(affine_relu_bn_stats(n, &L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, &relu, L.bn_memo, L.bn_stats, s));
     // noop = Sum(Scale(bypass, input), dropout(batchnorm(relu)))  in one pass
     tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
     tdnnf_mat x = relu, out = M(L.noop_out, L.aff.rows_out, Hd);
@@ -1095,8 +1111,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   for (int h = 0; h < 2; h++) {
     auto &H = n->head[h];
     tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), yh = M(H.y, No, P);
-    CK(tdnn_propagate_impl(&ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, 1, 1, &ar, s));
-    CK(bn_stats(n, H.aff_relu, No, Hd, H.bn1_memo, H.bn1_stats, s));
+    CK(affine_relu_bn_stats(n, &ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, &ar, H.bn1_memo, H.bn1_stats, s));
     TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, ldpad(Hd), none, 0.f, view(&b1), s));
     CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
     CK(bn_fwd(n, H.lin_out, H.bn2_out, No, S, H.bn2_memo, H.bn2_stats, s));

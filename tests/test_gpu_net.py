@@ -308,6 +308,28 @@ def test_fused_output_statistics_match_the_separate_pass(pkg, hidden, monkeypatc
     assert any(not np.array_equal(ga, gb) for (ga, _), (gb, _) in zip(fused[1:], separate[1:]))  # the switch did switch
 
 
+def test_batchnorm_statistics_out_of_the_gemm_epilogue_at_full_width(pkg):
+    """At 1536 columns the affine GEMM forms the BatchNorm statistics of its output while storing it (row tiles of the plain
+    launch + the chunks of a pass over the rows its split-K tail finishes: 10 000+ rows take both routes).  Checked through
+    the activations: tdnn1.batchnorm must be the normalisation of tdnn1.relu by that matrix's own float64 column statistics."""
+    T = pkg.trainer
+    cfg = T.make_config(frames_per_chunk=150, num_sequences=64, strides=[1, 3], bottleneck=32, feat_dim=40, ivector_dim=100, num_pdfs=90,
+                        hidden_dim=1536, small_dim=64)
+    net = T.ChainNet(cfg)
+    net.set_params(net.init_params_numpy(seed=2, output_stddev=0.1))
+    feats, iv = T.synthetic_egs(net, seed=3)
+    den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(40, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+    sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6))
+    r = host(net.forward_backward(dev(feats), dev(iv), den, sup, step=0))
+    assert r[5] == 1.0
+    x = host(net.activation("tdnn1.relu")).astype(np.float64)
+    assert x.shape[0] > 8192 + 128 and x.shape[1] == 1536  # more than one round of 128 x 128 tiles plus a tail
+    mean, var = x.mean(0), x.var(0)
+    want = (x - mean) / np.sqrt(var + 1e-3)
+    assert rel_l2(host(net.activation("tdnn1.batchnorm")), want) < 1e-5
+    net.close()
+
+
 def test_net_update_constrains_tall_matrices_through_their_transpose(pkg):
     """ConstrainOrthonormal on a matrix with more rows than columns works on the transpose (nnet-utils.cc:1068-1075):
     the stride-0 layer of the bottleneck supernet (240 x hidden) is such a matrix when hidden < 240."""
