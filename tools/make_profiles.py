@@ -37,7 +37,7 @@ def klass(nm):
     return s
 
 
-stats = glob.glob(f"gpurun_out/{stats_dir}/*/*_kernel_stats.csv")[0]
+stats = (glob.glob(f"gpurun_out/{stats_dir}/*/*_kernel_stats.csv") + glob.glob(f"gpurun_out/{stats_dir}/*_kernel_stats.csv"))[0]
 shutil.copy(stats, f"profiles/{tag}_bench_7q_T1500_B128_kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
 by = collections.defaultdict(lambda: [0, 0])
@@ -53,7 +53,7 @@ with open(f"profiles/{tag}_bench_7q_T1500_B128_kernel_classes.csv", "w") as f:
 
 
 def load(d):
-    f = glob.glob(f"gpurun_out/{d}/*/*_counter_collection.csv")
+    f = glob.glob(f"gpurun_out/{d}/*/*_counter_collection.csv") + glob.glob(f"gpurun_out/{d}/*_counter_collection.csv")
     return list(csv.DictReader(open(f[0]))) if f else []
 
 
