@@ -63,6 +63,48 @@ inline unsigned long long tdnnf_decision(unsigned long long step, unsigned long 
   return (z ^ (z >> 31)) >> 8;
 }
 
+// Second stage of the column reductions: a 1024-thread block owns 32 columns, its 32 lanes per column walk the partial rows
+// four requests deep, then lane 0 adds the lanes' sums in a fixed order (deterministic).  The partial rows are few MB at most,
+// the stage is pure latency: with 4 lanes x 24 blocks it took 45-300 us per call, ~5 ms per training step.
+constexpr int kFinCols = 32, kFinLanes = 32, kFinThreads = kFinCols * kFinLanes;
+inline unsigned finalize_grid(int D) { return (unsigned)((D + kFinCols - 1) / kFinCols); }
+#ifdef __HIPCC__
+// q[k] = sum over c < chunks of partial[((long long)k * qstride_rows + c) * D + d] for the calling thread's column d;
+// valid afterwards in the threads with (threadIdx.x >> 5) == 0.  red: NQ * kFinLanes * (kFinCols + 1) elements of Acc.
+template <int NQ, class Acc>
+__device__ __forceinline__ void finalize_sums(const float *partial, int chunks, long long qstride_rows, int D, int nq, Acc (&q)[NQ], Acc *red) {
+  const int tc = threadIdx.x & (kFinCols - 1), lane = threadIdx.x / kFinCols, d = blockIdx.x * kFinCols + tc;
+#pragma unroll
+  for (int k = 0; k < NQ; k++) q[k] = 0;
+  if (d < D) {
+    for (int k = 0; k < NQ; k++) {
+      if (k >= nq) break;
+      const float *p = partial + (long long)k * qstride_rows * D + d;
+      Acc s = 0;
+      int c = lane;
+      for (; c + 3 * kFinLanes < chunks; c += 4 * kFinLanes) {
+        const float v0 = p[(long long)c * D], v1 = p[(long long)(c + kFinLanes) * D], v2 = p[(long long)(c + 2 * kFinLanes) * D],
+                    v3 = p[(long long)(c + 3 * kFinLanes) * D];
+        s += v0; s += v1; s += v2; s += v3;
+      }
+      for (; c < chunks; c += kFinLanes) s += p[(long long)c * D];
+      q[k] = s;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NQ; k++) red[(k * kFinLanes + lane) * (kFinCols + 1) + tc] = q[k];
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < NQ; k++) {
+      Acc s = 0;
+      for (int l = 0; l < kFinLanes; l++) s += red[(k * kFinLanes + l) * (kFinCols + 1) + tc];
+      q[k] = s;
+    }
+  }
+}
+#endif
+
 // two-stage deterministic column reduction (colreduce.hip)
 struct ColReducePlan {
   int chunks, rows_per_chunk;

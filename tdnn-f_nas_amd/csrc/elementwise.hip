@@ -128,23 +128,14 @@ namespace {
 
 // ---------------------------------------------------------------------------- batchnorm
 // finalize forward stats: memo rows 0 mean, 1 uvar, 2 scale  (nnet-normalize-component.cc:433-445)
-__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float *partial, int chunks, int D, int N, float epsilon,
-                                                              float target_rms, float *memo) {
-  __shared__ double red[2][4][64];
-  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
-  double s = 0, s2 = 0;
-  if (d < D)
-    for (int c = tr; c < chunks; c += 4) {
-      s += partial[(long long)c * D + d];
-      s2 += partial[((long long)chunks + c) * D + d];
-    }
-  red[0][tr][tc] = s;
-  red[1][tr][tc] = s2;
-  __syncthreads();
-  if (tr != 0 || d >= D) return;
-  s = (red[0][0][tc] + red[0][1][tc]) + (red[0][2][tc] + red[0][3][tc]);
-  s2 = (red[1][0][tc] + red[1][1][tc]) + (red[1][2][tc] + red[1][3][tc]);
-  const float mean = (float)(s / N), uvar = (float)(s2 / N);
+__global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(const float *partial, int chunks, int D, int N, float epsilon,
+                                                                      float target_rms, float *memo) {
+  __shared__ double red[2 * kFinLanes * (kFinCols + 1)];
+  const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
+  double q[2];
+  finalize_sums<2, double>(partial, chunks, chunks, D, 2, q, red);
+  if (threadIdx.x >= kFinCols || d >= D) return;
+  const float mean = (float)(q[0] / N), uvar = (float)(q[1] / N);
   const float var_scale = 1.0f / (target_rms * target_rms);
   float v = var_scale * uvar - var_scale * mean * mean;
   v = floor_keep_nan(v, 0.f) + var_scale * epsilon;
@@ -153,17 +144,15 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float *parti
   memo[2 * D + d] = 1.0f / sqrtf(v);
 }
 // memo rows 3 var_deriv_mod, 4 temp (:520-526)
-__global__ void bn_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms, float *memo) {
-  const int d = blockIdx.x * blockDim.x + threadIdx.x;
-  if (d >= D) return;
-  double zz = 0, sd = 0;
-  for (int c = 0; c < chunks; c++) {
-    zz += partial[(long long)c * D + d];
-    sd += partial[((long long)chunks + c) * D + d];
-  }
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms, float *memo) {
+  __shared__ double red[2 * kFinLanes * (kFinCols + 1)];
+  const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
+  double q[2];
+  finalize_sums<2, double>(partial, chunks, chunks, D, 2, q, red);
+  if (threadIdx.x >= kFinCols || d >= D) return;
   const float coeff = -1.0f / (target_rms * target_rms * N);
-  memo[3 * D + d] = (float)(coeff * zz) * memo[2 * D + d];
-  memo[4 * D + d] = (float)(-sd / N);
+  memo[3 * D + d] = (float)(coeff * q[0]) * memo[2 * D + d];
+  memo[4 * D + d] = (float)(-q[1] / N);
 }
 
 // generic per-column affine maps.  MODE 0: out = (in + add[c]) * mul[c]      (bn train fwd, add=-mean)
@@ -329,15 +318,12 @@ __global__ void relu_repair_kernel(const double *stats, int D, float self_repair
 }
 
 // colsum finalize: acc[c] += scale * sum_chunks partial
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
-  __shared__ float red[4][64];
-  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
-  float s = 0.f;
-  if (d < D)
-    for (int c = tr; c < chunks; c += 4) s += partial[(long long)c * D + d];
-  red[tr][tc] = s;
-  __syncthreads();
-  if (tr == 0 && d < D) acc[d] += scale * ((red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]));
+__global__ __launch_bounds__(kFinThreads) void colsum_finalize_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
+  __shared__ float red[kFinLanes * (kFinCols + 1)];
+  const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
+  float q[1];
+  finalize_sums<1, float>(partial, chunks, chunks, D, 1, q, red);
+  if (threadIdx.x < kFinCols && d < D) acc[d] += scale * q[0];
 }
 
 // ----------------------------------------------------------------- softmax-style row ops (cols <= 64)
@@ -670,12 +656,12 @@ hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *me
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   hipError_t e = colreduce_partial(1, a, a, (float *)ws, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(a.cols)), dim3(kFinThreads), 0, s, (const float *)ws, pl.chunks, a.cols,
                      a.rows, epsilon, target_rms, memo);
   return hipGetLastError();
 }
 hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo);
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo);
   return hipGetLastError();
 }
 // acc[c] += scale * colsum(a)[c]   (two-stage, float4 loads)
@@ -683,7 +669,7 @@ hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t 
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   hipError_t e = colreduce_partial(0, a, a, (float *)ws, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, s, (const float *)ws, pl.chunks, a.cols, scale, acc);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(finalize_grid(a.cols)), dim3(kFinThreads), 0, s, (const float *)ws, pl.chunks, a.cols, scale, acc);
   return hipGetLastError();
 }
 }  // namespace tdnnf
@@ -704,7 +690,7 @@ int tdnnf_batchnorm_propagate(const tdnnf_mat *in, float epsilon, float target_r
   MatView a = view(in), o = view(out);
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   TDNNF_HIP(colreduce_partial(1, a, a, (float *)ws, s));
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, s, (const float *)ws, pl.chunks,
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(a.cols)), dim3(kFinThreads), 0, s, (const float *)ws, pl.chunks,
                      a.cols, a.rows, epsilon, target_rms, memo);
   const bool vec = vec4_ok(a) && vec4_ok(o) && (reinterpret_cast<uintptr_t>(memo) & 15) == 0;
   const long long work = (long long)a.rows * (vec ? a.cols / 4 : a.cols);
@@ -726,7 +712,7 @@ int tdnnf_batchnorm_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_de
   const int D = z.cols;
   ColReducePlan pl = colreduce_plan(z.rows, D);
   TDNNF_HIP(colreduce_partial(2, z, dz, (float *)ws, s));
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((D + 255) / 256), dim3(256), 0, s, (const float *)ws, pl.chunks, D,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, (const float *)ws, pl.chunks, D,
                      z.rows, target_rms, memo);
   const bool vec = vec4_ok(z) && vec4_ok(dz) && vec4_ok(dx);
   const long long work = (long long)z.rows * (vec ? D / 4 : D);
@@ -842,7 +828,7 @@ int tdnnf_constant_function_backprop(const tdnnf_mat *out_deriv, float lr, float
   MatView a = view(out_deriv);
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   TDNNF_HIP(colreduce_partial(0, a, a, (float *)ws, (hipStream_t)stream));
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((a.cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float *)ws, pl.chunks, a.cols, 5.0f * lr, output_acc);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(finalize_grid(a.cols)), dim3(kFinThreads), 0, (hipStream_t)stream, (const float *)ws, pl.chunks, a.cols, 5.0f * lr, output_acc);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }

@@ -110,20 +110,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
 
 // memo rows 3 (var_deriv_mod) and 4 (temp) from the partials (nnet-normalize-component.cc:520-526);
 // optionally the ReLU statistics [count, value_sum[D], deriv_sum[D]] (StoreStatsInternal).
-__global__ __launch_bounds__(256) void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms,
-                                                                   float *memo, double *relu_stats, int test_mode) {
-  __shared__ double red[4][4][64];
-  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
+__global__ __launch_bounds__(kFinThreads) void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms,
+                                                                           float *memo, double *relu_stats, int test_mode) {
+  __shared__ double red[4 * kFinLanes * (kFinCols + 1)];
+  const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
   if (relu_stats && blockIdx.x == 0 && threadIdx.x == 0) relu_stats[0] += (double)N;
-  double q[4] = {0, 0, 0, 0};
-  const int nq = relu_stats ? 4 : 2;
-  if (d < D)
-    for (int c = tr; c < chunks; c += 4)
-      for (int k = 0; k < nq; k++) q[k] += partial[((long long)k * chunks + c) * D + d];
-  for (int k = 0; k < 4; k++) red[k][tr][tc] = q[k];
-  __syncthreads();
-  if (tr != 0 || d >= D) return;
-  for (int k = 0; k < 4; k++) q[k] = (red[k][0][tc] + red[k][1][tc]) + (red[k][2][tc] + red[k][3][tc]);
+  double q[4];
+  finalize_sums<4, double>(partial, chunks, chunks, D, relu_stats ? 4 : 2, q, red);
+  if (threadIdx.x >= kFinCols || d >= D) return;
   const float coeff = -1.0f / (target_rms * target_rms * N);
   // test mode (BatchNormTestComponent::Backprop, nnet-normalize-component.cc:879-922): in_deriv = out_deriv * scale
   memo[3 * D + d] = test_mode ? 0.f : (float)(coeff * q[0]) * memo[2 * D + d];
@@ -336,15 +330,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, Ma
     for (int i = gridDim.x + t; i < ng.part_cap; i += 256) ng.part[i] = 0.0;
 }
 
-__global__ __launch_bounds__(256) void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
-  __shared__ float red[4][64];
-  const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6, d = blockIdx.x * 64 + tc;
-  float s = 0.f;
-  if (d < D)
-    for (int c = tr; c < chunks; c += 4) s += partial[(long long)c * D + d];
-  red[tr][tc] = s;
-  __syncthreads();
-  if (tr == 0 && d < D) acc[d] += scale * ((red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]));
+__global__ __launch_bounds__(kFinThreads) void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
+  __shared__ float red[kFinLanes * (kFinCols + 1)];
+  const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
+  float q[1];
+  finalize_sums<1, float>(partial, chunks, chunks, D, 1, q, red);
+  if (threadIdx.x < kFinCols && d < D) acc[d] += scale * q[0];
 }
 
 }  // namespace
@@ -408,7 +399,7 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
     else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
   }
-  hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3((D + 63) / 64), dim3(256), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
+  hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
                      store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0);
   const double *rep = self_repair ? relu_stats : nullptr;
   if (ng) {
@@ -416,12 +407,12 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     if (ng->Rp <= 32) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<1>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
     else if (ng->Rp <= 64) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<2>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
     else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<3>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
-    if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 63) / 64), dim3(256), 0, s, bias_partial, blocks, D, bias_scale, bias_acc);
+    if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, bias_partial, blocks, D, bias_scale, bias_acc);
     return hipGetLastError();
   }
   if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
   else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
-  if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3((D + 63) / 64), dim3(256), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
+  if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
   return hipGetLastError();
 }
 
