@@ -876,8 +876,10 @@ int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
   MatView yv = view(y);
   MatView xdv = xent_deriv ? view(xent_deriv) : MatView{nullptr, 0, 0, 0};
   MatView xov = xent_output ? view(xent_output) : MatView{nullptr, 0, 0, 0};
-  if (xent_deriv)
-    hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long long)xdv.rows * xdv.cols, 256)), dim3(256), 0, s, xdv);
+  if (xent_deriv) {
+    if (xdv.stride == xdv.cols) TDNNF_HIP(hipMemsetAsync(xdv.data, 0, sizeof(float) * (size_t)xdv.rows * xdv.cols, s));  // one contiguous fill
+    else hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long long)xdv.rows * xdv.cols, 256)), dim3(256), 0, s, xdv);
+  }
   hipLaunchKernelGGL(numerator_kernel, dim3(B), dim3(64), 0, s, sup_dev(sp), yv, xov, b.la, b.lb, b.num_lp, b.xent, MatView{nullptr, 0, 0, 0},
                      xdv, xent_regularize, 1);
   TDNNF_LAUNCH_CHECK();
