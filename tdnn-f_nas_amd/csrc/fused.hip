@@ -355,7 +355,8 @@ bool bn_relu_bwd_ng_ok(MatView x, MatView dz, MatView d_aff, int Rp) {
 }
 
 // Two 128-row blocks are resident per CU (registers): a launch of a few blocks more than one round of them runs as two
-// (514 blocks on 256 CUs: 0.50 ms against 0.32 ms for 512), and then the separate passes are faster.
+// (514 blocks on 256 CUs: 0.50 ms against 0.32 ms for 512), and a launch of few blocks (a 9 600-row minibatch: 75) leaves most
+// CUs idle while each block walks all its columns; in both cases the separate passes are faster.
 bool bn_relu_bwd_ng_pays(int rows) {
   static int slots = 0;
   if (!slots) {
@@ -365,7 +366,7 @@ bool bn_relu_bwd_ng_pays(int rows) {
     slots = 2 * cus;
   }
   const int blocks = (rows + 127) / 128, rounds = (blocks + slots - 1) / slots;
-  return blocks <= slots || 4 * blocks >= 3 * rounds * slots;  // one round, or the rounds at least 3/4 used
+  return 4 * blocks >= 3 * rounds * slots;  // the rounds at least 3/4 used: fewer blocks walk their 1536 columns on idle CUs' time
 }
 
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
