@@ -111,8 +111,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=12,
-                    help="untimed steps; 12 takes the natural-gradient state past its first 10 minibatches, which refresh every step")
+    ap.add_argument("--warmup", type=int, default=4, help="untimed steps (after the setup minibatches, see --ng-burn-in)")
+    ap.add_argument("--ng-burn-in", type=int, default=10,
+                    help="setup, with natural gradient on: minibatches run before the warmup so that the preconditioners are past their "
+                         "first 10 calls, which refresh on EVERY call (OnlineNaturalGradient's num_initial_updates); afterwards every 4th "
+                         "does, and that steady state -- refresh steps included -- is what is timed.  0: time a fresh process's first steps")
     ap.add_argument("--chunk", type=int, default=1500, help="frames per chunk (north_star: 1500-frame chunks)")
     ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU")
     ap.add_argument("--den-states", type=int, default=4000)
@@ -201,14 +204,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    burn = args.ng_burn_in if args.natural_gradient else 0
+    for i in range(burn + args.warmup):
         step(i)
     sync()
     pkg.hipabi.check(lib.tdnnf_profile_enable(1))
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(burn + args.warmup + i)
     sync()
     dt = time.perf_counter() - t0
     pkg.hipabi.check(lib.tdnnf_profile_enable(0))
@@ -246,7 +250,8 @@ def main():
                        "frames_per_chunk": args.chunk, "sequences_per_gpu": cfg.num_sequences, "global_batch": world * cfg.num_sequences,
                        "den_graph": {"states": args.den_states, "arcs": int(len(den["src"]))},
                        "natural_gradient": {"on": bool(args.natural_gradient), "rank_in": 20, "rank_out": 80, "update_period": 4,
-                                            "refresh_steps_in_timed_region": sum(1 for t in range(args.warmup, args.warmup + args.steps)
+                                            "setup_minibatches_before_warmup": burn,
+                                            "refresh_steps_in_timed_region": sum(1 for t in range(burn + args.warmup, burn + args.warmup + args.steps)
                                                                                  if t <= 10 or (t - 10) % 4 == 0) if args.natural_gradient else 0},
                        "parallelism": f"dp{world}", "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
@@ -264,12 +269,12 @@ def main():
                                            gemm_precision=1, **extra)
             net = pkg.trainer.ChainNet(cfg2)
             net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
-            for i in range(args.warmup):
+            for i in range(burn + args.warmup):
                 step(i)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(args.steps):
-                step(args.warmup + i)
+                step(burn + args.warmup + i)
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t1
             out["alt"] = {"gemm": "bf16x3 (split-bf16 MFMA, f32 accumulate; --gemm bf16x3)", "value": round(frames / dt2, 1), "unit": "frames/s",
