@@ -868,15 +868,16 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }
+float chain_supervision_weight(const tdnnf_supervision *sp) { return sp->weight; }
 // (2) numerator recursion; xent_deriv = xent_regularize * gamma_num, xent objective -> workspace.  Does not touch deriv.
 int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output,
-              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s) {
+              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised) {
   const int B = sp->B, T = sp->T;
   ChainBufs b = chain_bufs(g, B, T, ws);
   MatView yv = view(y);
   MatView xdv = xent_deriv ? view(xent_deriv) : MatView{nullptr, 0, 0, 0};
   MatView xov = xent_output ? view(xent_output) : MatView{nullptr, 0, 0, 0};
-  if (xent_deriv) {
+  if (xent_deriv && !xent_deriv_initialised) {  // (initialised: the posteriors are added onto what the caller put there)
     if (xdv.stride == xdv.cols) TDNNF_HIP(hipMemsetAsync(xdv.data, 0, sizeof(float) * (size_t)xdv.rows * xdv.cols, s));  // one contiguous fill
     else hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long long)xdv.rows * xdv.cols, 256)), dim3(256), 0, s, xdv);
   }

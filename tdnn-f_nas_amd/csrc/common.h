@@ -121,9 +121,11 @@ hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *me
 hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s);  // ws: colreduce_bytes(rows, cols)
 
 // the three separately launchable parts of the chain objective (chain.hip)
+bool log_softmax_propagate_with_aux(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_mat *aux, float aux_scale, hipStream_t s);  // elementwise.hip
+float chain_supervision_weight(const tdnnf_supervision *sp);
 int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws, hipStream_t s);
 int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output,
-              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s);
+              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised = false);
 int chain_finish(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float l2_regularize, double *results,
                  tdnnf_mat *deriv, tdnnf_mat *xent_deriv, void *ws, hipStream_t s);
 

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void log_softmax_fwd_kernel(MatView in, MatVie
 // One pass per row with the row held in registers (up to 256 * 4 * NV columns, 16-byte aligned rows): the 6034-wide output
 // rows are read once and written once instead of three reads through L2.
 template <int NV>
-__global__ __launch_bounds__(256) void log_softmax_fwd_regs_kernel(MatView in, MatView out) {
+__global__ __launch_bounds__(256) void log_softmax_fwd_regs_kernel(MatView in, MatView out, MatView aux, float aux_scale) {
   __shared__ float red[2][4];
   const int t = threadIdx.x, nc4 = (in.cols + 3) / 4;
   for (int r = blockIdx.x; r < in.rows; r += gridDim.x) {
@@ -499,6 +499,16 @@ __global__ __launch_bounds__(256) void log_softmax_fwd_regs_kernel(MatView in, M
         o[c] = v[k].x - lse;
         if (c + 1 < in.cols) o[c + 1] = v[k].y - lse;
         if (c + 2 < in.cols) o[c + 2] = v[k].z - lse;
+      }
+      if (aux.data) {  // aux = aux_scale * softmax(in): the dense part of the backward pass for a derivative with a known row sum
+        float *a = aux.data + (long long)r * aux.stride;
+        if (c + 3 < in.cols) *reinterpret_cast<float4 *>(a + c) = make_float4(aux_scale * expf(v[k].x - lse), aux_scale * expf(v[k].y - lse),
+                                                                                aux_scale * expf(v[k].z - lse), aux_scale * expf(v[k].w - lse));
+        else {
+          a[c] = aux_scale * expf(v[k].x - lse);
+          if (c + 1 < in.cols) a[c + 1] = aux_scale * expf(v[k].y - lse);
+          if (c + 2 < in.cols) a[c + 2] = aux_scale * expf(v[k].z - lse);
+        }
       }
     }
     __syncthreads();  // red[] is reused by the next row
@@ -898,12 +908,29 @@ int tdnnf_log_softmax_propagate(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_strea
   if (in->rows == 0) return TDNNF_OK;
   const dim3 grid(in->rows < 8192 ? in->rows : 8192);
   const bool al = in->stride % 4 == 0 && out->stride % 4 == 0 && ((uintptr_t)in->data & 15) == 0 && ((uintptr_t)out->data & 15) == 0;
-  if (al && in->cols <= 256 * 4 * 2) hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out));
-  else if (al && in->cols <= 256 * 4 * 8) hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out));
+  if (al && in->cols <= 256 * 4 * 2) hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out), MatView{nullptr, 0, 0, 0}, 0.f);
+  else if (al && in->cols <= 256 * 4 * 8) hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<8>), grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out), MatView{nullptr, 0, 0, 0}, 0.f);
   else hipLaunchKernelGGL(log_softmax_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, view(in), view(out));
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }
+}  // extern "C"
+namespace tdnnf {
+// LogSoftmax forward that also leaves aux = aux_scale * softmax(in).  For an output derivative dy whose rows all sum to the
+// same known c (xent_regularize * weight * numerator posteriors), the backward pass dy - softmax * rowsum(dy) is then
+// aux (aux_scale = -c) plus dy's few non-zeros added on top: no zero fill, no second dense pass.  false: shapes the
+// one-pass kernel does not take (nothing launched).
+bool log_softmax_propagate_with_aux(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_mat *aux, float aux_scale, hipStream_t s) {
+  const bool al = in->stride % 4 == 0 && out->stride % 4 == 0 && aux->stride % 4 == 0 && ((uintptr_t)in->data & 15) == 0 &&
+                  ((uintptr_t)out->data & 15) == 0 && ((uintptr_t)aux->data & 15) == 0;
+  if (!al || in->cols > 256 * 4 * 8 || in->rows == 0) return false;
+  const dim3 grid(in->rows < 8192 ? in->rows : 8192);
+  if (in->cols <= 256 * 4 * 2) hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<2>), grid, dim3(256), 0, s, view(in), view(out), view(aux), aux_scale);
+  else hipLaunchKernelGGL((log_softmax_fwd_regs_kernel<8>), grid, dim3(256), 0, s, view(in), view(out), view(aux), aux_scale);
+  return true;
+}
+}  // namespace tdnnf
+extern "C" {
 int tdnnf_log_softmax_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_deriv, tdnnf_mat *in_deriv, tdnnf_stream stream) {
   TDNNF_REQUIRE(mat_ok(out_value) && mat_ok(out_deriv) && mat_ok(in_deriv) && same_dim(out_value, out_deriv) && same_dim(out_value, in_deriv),
                 "log_softmax_backprop: bad matrices");

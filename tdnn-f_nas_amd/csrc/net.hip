@@ -1127,11 +1127,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   tdnnf_mat yx = M(n->head[1].y, No, P);
-  CK(tdnnf_log_softmax_propagate(&yx, &lsm, s));
-  // objective, part 2: numerator recursion -> xent_deriv = xent_regularize * posteriors, xent objective
-  CK(chain_num(den, sup, &y, &lsm, c.xent_regularize, &dx, n->chain_ws, s));
-  // log-softmax backward, in place into d_xent
-  CK(tdnnf_log_softmax_backprop(&lsm, &dx, &dx, s));
+  // xent head: LogSoftmax, numerator posteriors, LogSoftmax backward.  The derivative handed to LogSoftmax is xent_regularize *
+  // weight * (posteriors of a frame: they sum to 1), so its backward pass is -xent_regularize * weight * softmax -- written by the
+  // forward kernel while the row is in registers -- plus the posteriors the numerator kernel adds on top.
+  const bool dense_first = log_softmax_propagate_with_aux(&yx, &lsm, &dx, -c.xent_regularize * chain_supervision_weight(sup), s);
+  if (!dense_first) CK(tdnnf_log_softmax_propagate(&yx, &lsm, s));
+  // objective, part 2: numerator recursion -> xent_deriv (+)= xent_regularize * posteriors, xent objective
+  CK(chain_num(den, sup, &y, &lsm, c.xent_regularize, &dx, n->chain_ws, s, dense_first));
+  if (!dense_first) CK(tdnnf_log_softmax_backprop(&lsm, &dx, &dx, s));  // in place into d_xent
 
   // ================================================================= backward
   // BatchNorm backward + ReLU backward (+ StoreStats / self-repair coin flips as in the reference:
