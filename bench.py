@@ -13,12 +13,19 @@ backward with gradient accumulation (OnlineNaturalGradient-preconditioned, as th
 Prints ONE JSON line (rank 0).  metric = BASELINE.json's "LF-MMI training frames/sec per node".
 Workload (config.workload): BASELINE.json configs[1], the fixed 7q TDNN-F (14 tdnnf layers, bottleneck
 160, strides 1,1,1,0,3x10) on 40-dim fbank + 100-dim ivector egs, chunks of --chunk frames, --minibatch
-sequences per GPU (weak scaling: per-GPU work is fixed as N grows).
+sequences per GPU (--scaling weak, the default: per-GPU work is fixed as N grows) or per node (--scaling strong:
+every rank takes minibatch / N sequences of one global minibatch).
+
+At N = 1 the line also carries: "roofline" (live HIP-event timing of the dominant GEMM class + algorithmic bytes),
+"parity" (the HIP step against the CPU oracle on a bounded sample of the same workload, asserted), "cpu_baseline"
+(the oracle timed on this box's host cores), "alt" (split-bf16 GEMM arithmetic) and "also" (the reference's own egs
+shape and SWBD-scale denominator graphs as further line items).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,70 +34,106 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")  # tools/make_profiles.py: separate --pmc passes of this command
+
+# parity bars of BASELINE.json's north_star: objective 1e-4 relative, parameter-gradient L2 1e-3; with natural gradient the
+# preconditioners' eigen-decompositions feed rounding differences back (tests hold 5e-3 there)
+OBJF_TOL, GRAD_TOL, GRAD_TOL_NG = 1e-4, 1e-3, 5e-3
 
 
-def cpu_baseline(pkg, args):
-    """The CPU restatement of the same training step (oracle, float-accumulating OpenMP build) timed on this
-    box's host cores on a bounded sample: same net, chunk 150, a few sequences."""
-    from tests.oracle_net import OracleNet
-    B, T = args.cpu_sequences, 150
-    cfg = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B, use_natural_gradient=args.natural_gradient)
-    comps, begin = [], 0
-    # component table without touching the GPU: same layout rule as the trainer (16-byte aligned blocks)
-    lda_dim = 3 * cfg.feat_dim + cfg.ivector_dim
+def workload_kwargs(args):
+    if args.workload == "darts-offset":
+        return dict(darts_num_offsets=args.darts_offsets)
+    if args.workload == "bn-supernet":
+        import __graft_entry__ as ge
+        T = ge.load_package().trainer
+        return dict(bn_choice_dims=T.BN_CHOICE_DIMS if args.bn_choices == "reference" else [80, 80, 80, 80], bn_mode=T.BN_ONEHOT)
+    return {}
 
-    def add(name, rows, cols, hb, lrf=1.0, l2=0.01, mc=0.75, orth=0.0):
-        nonlocal begin
-        comps.append(dict(name=name, begin=begin, rows=rows, cols=cols, has_bias=hb, lr_factor=lrf, l2=l2, max_change=mc, orthonormal=orth))
-        begin = (begin + rows * cols + (rows if hb else 0) + 3) // 4 * 4
 
-    add("lda", lda_dim, lda_dim, 1, lrf=0.0, l2=0.0, mc=0.0)
-    add("tdnn1.affine", cfg.hidden_dim, lda_dim, 1)
-    for i in range(cfg.num_layers):
-        K = 2 if cfg.time_stride[i] > 0 else 1
-        add(f"tdnnf{i + 2}.linear", cfg.bottleneck_dim[i], K * cfg.hidden_dim, 0, orth=-1.0)
-        add(f"tdnnf{i + 2}.affine", cfg.hidden_dim, K * cfg.bottleneck_dim[i], 1)
-    add("prefinal-l", cfg.prefinal_small_dim, cfg.hidden_dim, 0, orth=-1.0)
-    for hn in ("chain", "xent"):
-        add(f"prefinal-{hn}.affine", cfg.hidden_dim, cfg.prefinal_small_dim, 1)
-        add(f"prefinal-{hn}.linear", cfg.prefinal_small_dim, cfg.hidden_dim, 0, orth=-1.0)
-        add("output.affine" if hn == "chain" else "output-xent.affine", cfg.num_pdfs, cfg.prefinal_small_dim, 1,
-            lrf=1.0 if hn == "chain" else 5.0, l2=0.002, mc=1.5)
+def parity_and_cpu_baseline(pkg, args, want_baseline=True):
+    """A bounded sample of the SAME workload (same net at full width, chunk 150, --cpu-sequences sequences, same denominator
+    graph family): (1) one training step on the GPU through the C-ABI against the double-accumulating CPU oracle -- objective
+    and parameter gradient, asserted against BASELINE.json's bars; (2) the float/OpenMP build of the oracle timed on this
+    box's host cores (2 warm-ups, median of 5), all usable cores and one thread."""
     import numpy as np
-    rng = np.random.default_rng(0)
-    params = (rng.standard_normal(begin) * 0.02).astype(np.float32)
-    net = OracleNet(pkg, cfg, comps, fast=True)
-    feats = rng.standard_normal((net.num_t_in * B, cfg.feat_dim)).astype(np.float32)
-    iv = rng.standard_normal((B, cfg.ivector_dim)).astype(np.float32)
+    import torch
+    from tests.oracle_net import OracleNet, component_table
+    B, T = args.cpu_sequences, 150
+    cfg = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B, use_natural_gradient=args.natural_gradient, **workload_kwargs(args))
+    net = pkg.trainer.ChainNet(cfg)
+    comps, num_params = component_table(cfg)
+    assert num_params == net.num_params and [c["begin"] for c in comps] == [c["begin"] for c in net.components]
+    params = net.init_params_numpy(seed=0, output_stddev=0.05)
+    net.set_params(params)
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=100)
     den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
     sup = pkg.synth.make_supervision_from_den(den, B, T // 3, num_paths=2, seed=2)
-    t0 = time.time()
-    res, grads, _ = net.forward_backward(params, feats, iv, den, sup, step=0)
-    net.update(params, grads, 1e-3, float(B), 0)
-    dt = time.time() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    out = {"value": round(B * T / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": f"one full training step (natural gradient {'on' if args.natural_gradient else 'off'}) of the same 7q net on {B} sequences x "
-                     f"{T} frames ({dt:.1f} s), CPU restatement of the reference path (oracle/, OpenMP float build), not Kaldi"}
+    draws = np.random.default_rng(5).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(np.float32)
+    net.set_random_draws(draws)
+    r = net.forward_backward(torch.from_numpy(feats).cuda(), torch.from_numpy(iv).cuda(), pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup), step=0)
+    torch.cuda.synchronize()
+    r, g = r.cpu().numpy(), net.grads.cpu().numpy()
+    # ReLU outputs of the GPU step: a pre-activation within rounding of zero flips its derivative mask between two correct
+    # float implementations (and one flip among ~10^6 elements is ~1e-3 of a layer's derivative norm); the oracle takes those
+    # ties over -- after checking that they ARE ties -- and counts them
+    relu_names = ["tdnn1.relu"] + ["tdnnf%d.relu" % (l + 2) for l in range(cfg.num_layers)] + ["prefinal-chain.relu", "prefinal-xent.relu"]
+    relus = {k: net.activation(k).cpu().numpy() for k in relu_names}
+    net.close()
+    ref = OracleNet(pkg, cfg, comps)  # double-accumulating build
+    res_ref, g_ref, _ = ref.forward_backward(params, feats, iv, den, sup, step=0, draws=draws, relu_like=relus)
+    objf_rel = abs(r[0] - res_ref["objf"]) / abs(res_ref["objf"])
+    grad_rel = float(np.linalg.norm(g.astype(np.float64) - g_ref) / np.linalg.norm(g_ref.astype(np.float64)))
+    gtol = GRAD_TOL_NG if args.natural_gradient else GRAD_TOL
+    parity = {"objf_rel": float(f"{objf_rel:.3e}"), "grad_rel_l2": float(f"{grad_rel:.3e}"), "objf_tol": OBJF_TOL, "grad_tol": gtol,
+              "ok": bool(r[5] == 1.0 and objf_rel < OBJF_TOL and grad_rel < gtol and np.isfinite(g).all()),
+              "objf_hip": float(r[0]), "objf_oracle": float(res_ref["objf"]),
+              "relu_ties": int(sum(ref.relu_ties.values())), "relu_elements": int(sum(v.size for v in relus.values())),
+              "sample": f"one training step (natural gradient {'on' if args.natural_gradient else 'off'}) of the full-width net on {B} sequences x {T} frames, "
+                        f"{args.den_states}-state denominator graph; HIP through the C-ABI against oracle/ (double-accumulating CPU restatement, parity unpinned vs Kaldi)"}
+    if not want_baseline:
+        return parity, None
+
+    gomp = C.CDLL("libgomp.so.1")
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if os.environ.get("OMP_NUM_THREADS"):
+        avail = min(avail, int(os.environ["OMP_NUM_THREADS"]))
+
+    def timed_steps(B_s, threads, warm, timed, seed):
+        gomp.omp_set_num_threads(threads)
+        cfg_s = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B_s, use_natural_gradient=args.natural_gradient, **workload_kwargs(args))
+        o = OracleNet(pkg, cfg_s, comps, fast=True)
+        rng = np.random.default_rng(seed)
+        f = rng.standard_normal((o.num_t_in * B_s, cfg_s.feat_dim)).astype(np.float32)
+        v = rng.standard_normal((B_s, cfg_s.ivector_dim)).astype(np.float32)
+        sp = pkg.synth.make_supervision_from_den(den, B_s, T // 3, num_paths=2, seed=seed)
+        p, ts = params.copy(), []
+        for i in range(warm + timed):
+            t0 = time.perf_counter()
+            _, gg, _ = o.forward_backward(p, f, v, den, sp, step=i, draws=draws)
+            p = o.update(p, gg, 1e-3, float(B_s), i)
+            ts.append(time.perf_counter() - t0)
+        return ts[warm:]
+
+    # thread count: the oracle's OpenMP loops stop scaling long before 256 threads on matrices this small, so one step is
+    # timed at a few counts and the timed runs use the fastest
+    cands = sorted({c for c in (avail, 128, 64, 32, 16) if c <= avail}, reverse=True)
+    probe = {c: timed_steps(B, c, 1, 1, 7)[0] for c in cands} if len(cands) > 1 else {avail: 0.0}
+    cores = min(probe, key=probe.get)
+    ts = timed_steps(B, cores, 2, 5, 7)
+    med = statistics.median(ts)
+    out = {"value": round(B * T / med, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"the same training step (natural gradient {'on' if args.natural_gradient else 'off'}, forward + objective + backward + update) of the "
+                     f"full-width net on {B} sequences x {T} frames: median of 5 after 2 warm-ups ({med:.2f} s per step, min {min(ts):.2f} max {max(ts):.2f}); "
+                     f"{cores} OpenMP threads of {avail} usable (fastest of {sorted(probe)} on a probe step); CPU restatement of the reference path "
+                     f"(oracle/, float build), not Kaldi"}
     # stock Kaldi CPU nnet3 runs one thread per job ("nnet3 does not yet support multiple threads", train.py:251-252)
-    try:
-        gomp = C.CDLL("libgomp.so.1")
-        gomp.omp_set_num_threads(1)
-        B1 = 1
-        cfg1 = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B1, use_natural_gradient=args.natural_gradient)
-        net1 = OracleNet(pkg, cfg1, comps, fast=True)
-        f1 = rng.standard_normal((net1.num_t_in * B1, cfg1.feat_dim)).astype(np.float32)
-        sup1 = pkg.synth.make_supervision_from_den(den, B1, T // 3, num_paths=2, seed=3)
-        t0 = time.time()
-        _, g1, _ = net1.forward_backward(params, f1, iv[:B1], den, sup1, step=0)
-        net1.update(params, g1, 1e-3, float(B1), 0)
-        dt1 = time.time() - t0
-        gomp.omp_set_num_threads(cores)
-        out["single_thread"] = {"value": round(B1 * T / dt1, 2), "unit": "frames/s", "cores": 1,
-                                "sample": f"the same step on {B1} sequences x {T} frames, one thread ({dt1:.1f} s)"}
-    except OSError:
-        pass
-    return out
+    t1 = timed_steps(1, 1, 1, 3, 9)
+    m1 = statistics.median(t1)
+    out["single_thread"] = {"value": round(T / m1, 2), "unit": "frames/s", "cores": 1,
+                            "sample": f"the same step on 1 sequence x {T} frames, one thread: median of 3 after 1 warm-up ({m1:.2f} s per step)"}
+    gomp.omp_set_num_threads(avail)
+    return parity, out
 
 
 def workload_text(args):
@@ -107,6 +150,65 @@ def workload_text(args):
             "minibatch), otherwise as configs[1]; " + tail)
 
 
+class Job:
+    """One replica of the trainer on this rank's GPU with its own synthetic egs resident in HBM."""
+
+    def __init__(self, pkg, args, chunk, sequences, den_states, rank, world, gemm=None, first_sequence=0):
+        import torch
+        self.pkg, self.args, self.world = pkg, args, world
+        gemm = args.gemm if gemm is None else gemm
+        self.cfg = pkg.trainer.make_config(frames_per_chunk=chunk, num_sequences=sequences, use_natural_gradient=args.natural_gradient,
+                                           gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[gemm], use_dropout=int(args.dropout > 0),
+                                           **workload_kwargs(args))
+        self.net = pkg.trainer.ChainNet(self.cfg)
+        if args.dropout > 0:
+            self.net.set_dropout_proportion(args.dropout)
+        # identical initial model on every rank (seed), different egs per rank (data parallel over sequences)
+        self.net.set_params(self.net.init_params_numpy(seed=0, output_stddev=0.05))
+        feats, iv = pkg.trainer.synthetic_egs(self.net, seed=100 + rank)
+        self.den = pkg.synth.make_den_graph(den_states, self.cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
+        sup = pkg.synth.make_supervision_from_den(self.den, sequences, chunk // 3, num_paths=2, seed=200 + rank)
+        self.dg, self.ds = pkg.hipabi.DenGraph(self.den), pkg.hipabi.Supervision(sup)
+        self.fd, self.ivd = torch.from_numpy(feats).cuda(), torch.from_numpy(iv).cuda()
+        # Effective learning rate.  The gradient buffers are SUMMED over ranks, which to first order is Kaldi's scheme of
+        # num_jobs jobs at learning rate lr_eff x num_jobs followed by model averaging (common.py:618): mean_j(lr_eff J g_j) =
+        # lr_eff sum_j g_j -- so the summed gradient takes lr_eff itself, NOT lr_eff x num_jobs (DESIGN.md 6).
+        self.lr = pkg.trainer.learning_rate(0, 1, 100, 0, 100)
+        # l2 scale = GetNumNvalues x l2_regularize_factor (= 1 / num_jobs): weak scaling = every rank is a Kaldi job with its own
+        # minibatch -> its sequence count; strong scaling = ONE minibatch sharded over the ranks -> the global sequence count
+        self.l2_scale = float(sequences * (world if args.scaling == "strong" else 1))
+        self.gen = torch.Generator(device="cuda")
+        self.gen.manual_seed(1234)  # same architecture sample on every rank (SURVEY.md 8(e): seed-shared draws)
+        self.i = 0
+
+    def step(self):
+        self.net.set_random_draws(generator=self.gen)
+        self.net.forward_backward(self.fd, self.ivd, self.dg, self.ds, step=self.i)
+        self.net.allreduce_grads()
+        self.net.update(self.lr, l2_regularize_scale=self.l2_scale, step=self.i)
+        self.i += 1
+
+    def run(self, burn, warmup, steps, sync, profile=False):
+        for _ in range(burn + warmup):
+            self.step()
+        sync()
+        lib = self.pkg.hipabi.load()
+        if profile:
+            self.pkg.hipabi.check(lib.tdnnf_profile_enable(1))
+            sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        sync()
+        dt = time.perf_counter() - t0
+        if profile:
+            self.pkg.hipabi.check(lib.tdnnf_profile_enable(0))
+        return dt
+
+    def close(self):
+        self.net.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,11 +219,16 @@ def main():
                          "first 10 calls, which refresh on EVERY call (OnlineNaturalGradient's num_initial_updates); afterwards every 4th "
                          "does, and that steady state -- refresh steps included -- is what is timed.  0: time a fresh process's first steps")
     ap.add_argument("--chunk", type=int, default=1500, help="frames per chunk (north_star: 1500-frame chunks)")
-    ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU")
+    ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU (--scaling weak) or per node (--scaling strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): every GPU runs --minibatch sequences, the global batch grows with N; strong: ONE minibatch of "
+                         "--minibatch sequences is sharded, rank g takes minibatch / N of them (SURVEY.md 8(e))")
     ap.add_argument("--den-states", type=int, default=4000)
     ap.add_argument("--den-degree", type=float, default=12.0)
     ap.add_argument("--cpu-sequences", type=int, default=16)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU oracle leg (the parity check stays)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the HIP-against-oracle check of the bounded sample as well")
+    ap.add_argument("--no-also", action="store_true", help="skip the further line items (recipe egs shape, 10 000 / 30 000-state denominator graphs)")
     ap.add_argument("--workload", default="7q", choices=["7q", "darts-offset", "bn-supernet"],
                     help="7q = BASELINE configs[1] (default, the metric's config); darts-offset = configs[3], the K-tap offset "
                          "supernet of run_TDNN_DARTSV3_fbk_stride_pretrain.sh in pretrain (uniform-sample) mode; bn-supernet = "
@@ -143,7 +250,6 @@ def main():
                          "updatable component's gradient; 0 = raw-gradient SGD step")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     import __graft_entry__ as ge
@@ -168,35 +274,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
-    extra = {}
-    if args.workload == "darts-offset":
-        extra = dict(darts_num_offsets=args.darts_offsets)
-    elif args.workload == "bn-supernet":
-        extra = dict(bn_choice_dims=pkg.trainer.BN_CHOICE_DIMS if args.bn_choices == "reference" else [80, 80, 80, 80], bn_mode=pkg.trainer.BN_ONEHOT)
-    cfg = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch,
-                                  use_natural_gradient=args.natural_gradient, gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.gemm],
-                                  use_dropout=int(args.dropout > 0), **extra)
-    net = pkg.trainer.ChainNet(cfg)
-    if args.dropout > 0:
-        net.set_dropout_proportion(args.dropout)
-    # identical initial model on every rank (seed), different egs per rank (data parallel over sequences)
-    net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
-    feats, iv = pkg.trainer.synthetic_egs(net, seed=100 + rank)
-    den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
-    sup = pkg.synth.make_supervision_from_den(den, cfg.num_sequences, args.chunk // 3, num_paths=2, seed=200 + rank)
-    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
-    fd, ivd = torch.from_numpy(feats).cuda(), torch.from_numpy(iv).cuda()
-    lr = pkg.trainer.learning_rate(0, world, 100, 0, 100)  # 2.5e-4 * num_jobs
-
-    gen = torch.Generator(device="cuda")
-    gen.manual_seed(1234)  # same architecture sample on every rank (seed-shared draws)
-
-    def step(i):
-        net.set_random_draws(generator=gen)
-        net.forward_backward(fd, ivd, dg, ds, step=i)
-        net.allreduce_grads()
-        # l2 scale: GetNumNvalues * l2_regularize_factor(=1/num_jobs) -> per-GPU sequence count
-        net.update(lr, l2_regularize_scale=float(cfg.num_sequences), step=i)
+    if args.scaling == "strong":
+        b0, b1 = pkg.trainer.shard_sequences(args.minibatch, rank, world)
+        if args.minibatch % world:
+            raise SystemExit(f"--scaling strong: {args.minibatch} sequences do not divide over {world} ranks")
+        seqs = b1 - b0
+    else:
+        seqs = args.minibatch
 
     def sync():
         torch.cuda.synchronize()
@@ -205,84 +289,99 @@ def main():
             torch.cuda.synchronize()
 
     burn = args.ng_burn_in if args.natural_gradient else 0
-    for i in range(burn + args.warmup):
-        step(i)
-    sync()
-    pkg.hipabi.check(lib.tdnnf_profile_enable(1))
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(burn + args.warmup + i)
-    sync()
-    dt = time.perf_counter() - t0
-    pkg.hipabi.check(lib.tdnnf_profile_enable(0))
+    job = Job(pkg, args, args.chunk, seqs, args.den_states, rank, world)
+    cfg = job.cfg
+    dt = job.run(burn, args.warmup, args.steps, sync, profile=True)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    res = net.results.cpu().numpy()
+    res = job.net.results.cpu().numpy()
+    den_arcs = int(len(job.den["src"]))
 
     # live roofline of the dominant kernel class (HIP events recorded on the launch stream)
     classes = []
     for k in range(4):
-        n, ms, fl = C.c_double(), C.c_double(), C.c_double()
+        n, ms, fl, by = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         pkg.hipabi.check(lib.tdnnf_profile_read(k, C.byref(n), C.byref(ms), C.byref(fl)))
-        classes.append(dict(name=lib.tdnnf_profile_class_name(k).decode(), launches=n.value, ms=ms.value, flops=fl.value))
+        pkg.hipabi.check(lib.tdnnf_profile_read_bytes(k, C.byref(by)))
+        classes.append(dict(name=lib.tdnnf_profile_class_name(k).decode(), launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value))
     dom = max(classes[:3], key=lambda c: c["ms"])  # the TDNN-F factored GEMMs (class 3 = natural-gradient statistics)
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    # HBM traffic per launch from the PMC passes of THIS command (tools/make_profiles.py writes the file; null when the
+    # file is not from this round's kernels)
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, TRAFFIC_FILE)
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dom["name"], {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
+            traffic_src = TRAFFIC_FILE
         except Exception:
             traffic = None
+    alg_per_launch = dom["bytes"] / max(dom["launches"], 1)
+    job.close()
 
     if rank == 0:
-        frames = world * cfg.num_sequences * args.chunk * args.steps
+        frames = world * seqs * args.chunk * args.steps
         out = {
             "metric": "LF-MMI training frames/sec per node (SWBD 7q TDNN-F)",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, 2 planes / 3 products, f32 accumulate)",
                                           "bf16x6": "bf16x6 (split-bf16 MFMA, 3 planes / 6 products, f32 accumulate; f32-equivalent)"}[args.gemm], "data": "synthetic",
             "config": {"workload": workload_text(args),
-                       "frames_per_chunk": args.chunk, "sequences_per_gpu": cfg.num_sequences, "global_batch": world * cfg.num_sequences,
-                       "den_graph": {"states": args.den_states, "arcs": int(len(den["src"]))},
+                       "frames_per_chunk": args.chunk, "sequences_per_gpu": seqs, "global_batch": world * seqs,
+                       "den_graph": {"states": args.den_states, "arcs": den_arcs},
                        "natural_gradient": {"on": bool(args.natural_gradient), "rank_in": 20, "rank_out": 80, "update_period": 4,
                                             "setup_minibatches_before_warmup": burn,
                                             "refresh_steps_in_timed_region": sum(1 for t in range(burn + args.warmup, burn + args.warmup + args.steps)
                                                                                  if t <= 10 or (t - 10) % 4 == 0) if args.natural_gradient else 0},
                        "parallelism": f"dp{world}", "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": round(alg_per_launch, 1),
+                         "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic and alg_per_launch else None,
                          "avg_launch_ms": round(dom["ms"] / max(dom["launches"], 1), 4), "launches": int(dom["launches"]),
                          "all_kernels": [{"kernel": c["name"], "launches": int(c["launches"]), "ms": round(c["ms"], 3),
-                                          "tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2) if c["ms"] > 0 else 0.0}
+                                          "tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2) if c["ms"] > 0 else 0.0,
+                                          "algorithmic_gb_per_s": round(c["bytes"] / (c["ms"] * 1e-3) / 1e9, 1) if c["ms"] > 0 else 0.0,
+                                          "flops_per_step": round(c["flops"] / args.steps, 1), "algorithmic_bytes_per_step": round(c["bytes"] / args.steps, 1)}
                                          for c in classes]},
         }
+
+        def line_item(name, chunk, sequences, den_states, gemm=None, steps=None):
+            j = Job(pkg, args, chunk, sequences, den_states, rank, world, gemm=gemm)
+            k = args.steps if steps is None else steps
+            d = j.run(burn, args.warmup, k, lambda: torch.cuda.synchronize())
+            arcs = int(len(j.den["src"]))
+            j.close()
+            torch.cuda.empty_cache()
+            return {"what": name, "value": round(sequences * chunk * k / d, 1), "unit": "frames/s", "ms_per_step": round(1e3 * d / k, 3),
+                    "frames_per_chunk": chunk, "sequences": sequences, "den_graph": {"states": den_states, "arcs": arcs}}
+
         if world == 1 and args.gemm == "f32" and not args.no_alt:
             # the same step with the optional split-bf16 GEMM arithmetic (not the headline: its gradient parity sits AT the
             # 1e-3 bar), same workload, same steps
-            net.close()
-            cfg2 = pkg.trainer.make_config(frames_per_chunk=args.chunk, num_sequences=args.minibatch, use_natural_gradient=args.natural_gradient,
-                                           gemm_precision=1, **extra)
-            net = pkg.trainer.ChainNet(cfg2)
-            net.set_params(net.init_params_numpy(seed=0, output_stddev=0.05))
-            for i in range(burn + args.warmup):
-                step(i)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for i in range(args.steps):
-                step(burn + args.warmup + i)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            out["alt"] = {"gemm": "bf16x3 (split-bf16 MFMA, f32 accumulate; --gemm bf16x3)", "value": round(frames / dt2, 1), "unit": "frames/s",
-                          "ms_per_step": round(1e3 * dt2 / args.steps, 3)}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, args)
+            it = line_item("--gemm bf16x3", args.chunk, seqs, args.den_states, gemm="bf16x3")
+            out["alt"] = {"gemm": "bf16x3 (split-bf16 MFMA, f32 accumulate; --gemm bf16x3)", "value": it["value"], "unit": "frames/s",
+                          "ms_per_step": it["ms_per_step"]}
+        if world == 1 and not args.no_also:
+            # further line items, same net and step: the reference's own egs shape (chunk 150 x 64, ...pretrain.sh:46,197) and
+            # SWBD-scale denominator graphs (10 000 and 30 000 states)
+            out["also"] = [line_item("the recipes' egs shape (--chunk 150 --minibatch 64)", 150, 64, args.den_states),
+                           line_item("10 000-state denominator graph (--den-states 10000)", args.chunk, seqs, 10000, steps=4),
+                           line_item("30 000-state denominator graph (--den-states 30000)", args.chunk, seqs, 30000, steps=4)]
+        ok = True
+        if world == 1 and not args.no_parity:
+            parity, base = parity_and_cpu_baseline(pkg, args, want_baseline=not args.no_cpu_baseline)
+            out["parity"] = parity
+            ok = parity["ok"]
+            if base is not None:
+                out["cpu_baseline"] = base
         print(json.dumps(out), flush=True)
-    net.close()
+        if not ok:
+            raise SystemExit("bench.py: the HIP step does not match the oracle on the parity sample: " + json.dumps(out["parity"]))
     if world > 1:
         dist.destroy_process_group()
 

@@ -45,6 +45,7 @@ typedef struct {
 } tdnnf_mat;
 
 typedef void *tdnnf_stream;
+typedef struct tdnnf_ng tdnnf_ng; /* OnlineNaturalGradient state (A8, below) */
 
 const char *tdnnf_last_error(void);
 int tdnnf_abi_version(void);
@@ -108,6 +109,31 @@ int tdnnf_tdnn_darts_alpha_update(const float *tap_grad_dev, int ldg, const floa
                                   int flags, int share_index, float temp_proportion, float lr,
                                   float *alpha_acc_dev, double *tap_dots_dev /* K doubles, receives s_i */,
                                   tdnnf_stream stream);
+/* (in TDNNF_DARTS_UNIFORM_SAMPLE mode no gradient is added -- the reference computes and discards it, :502-507 --
+   only the trailing scalings :565-590 run; tap_grad_dev may then be NULL) */
+
+/* UpdateNaturalGradient :457-626 -- the branch Backprop takes whenever use_natural_gradient_ is set and the component is
+   not a gradient holder (:427-430), i.e. in every recipe.  Literal order of the reference: architecture-logit update
+   (:490-590, as tdnnf_tdnn_darts_alpha_update), in_value_temp = [c_i X_i ..., 1] (:466-532; the share tap unscaled
+   unless free_select, a zero-coefficient tap left zero), out_deriv_temp = out_deriv (:592), both preconditioned in
+   place by the caller's OnlineNaturalGradient objects (:598-599), then with local_lrate = in_scale * out_scale *
+   learning_rate: linear_params_ += local_lrate out_deriv_temp^T in_value_temp[:, :K Di] (:621-624) and
+   bias_params_[K:] += local_lrate out_deriv_temp^T in_value_temp[:, K Di] (:606-616).
+   Plain TdnnComponent (UPSTREAM): coef_memo_dev = eff_coef_dev = alpha_acc_dev = NULL (linear_params_dev unused).
+   bias_acc_dev (Do floats = to_update->bias_params_ + K, or NULL when the component has no bias: no ones column),
+   alpha_acc_dev (K floats = to_update->bias_params_).  coef_memo_dev / eff_coef_dev: the two halves of the memo
+   tdnnf_tdnn_darts_coef wrote in Propagate.  learning_rate == 0 returns at once (:423-424).  Nothing synchronises:
+   the two scales stay on the device (tdnnf_ng_scale_dev). */
+size_t tdnnf_tdnn_update_natural_gradient_workspace_bytes(int Do, int Di, int K, int num_rows, int has_bias);
+int tdnnf_tdnn_update_natural_gradient(const tdnnf_tdnn_indexes *indexes, const tdnnf_mat *in_value,
+                                       const tdnnf_mat *out_deriv, int Do, int Di,
+                                       const float *linear_params_dev, int ldw_params,
+                                       const float *coef_memo_dev, const float *eff_coef_dev, int flags,
+                                       int share_index, float temp_proportion,
+                                       tdnnf_ng *preconditioner_in, tdnnf_ng *preconditioner_out,
+                                       float learning_rate, float *W_acc_dev, int ldw, float *bias_acc_dev,
+                                       float *alpha_acc_dev, void *workspace_dev, size_t workspace_bytes,
+                                       tdnnf_stream stream);
 
 /* ======================================================================= A3/A4
  * BatchNormComponent / BatchNormTestComponent (src/nnet3/nnet-normalize-component.cc) */
@@ -149,6 +175,11 @@ int tdnnf_softmax_flops_backprop(const tdnnf_mat *out_value, tdnnf_mat *out_deri
                                  tdnnf_mat *in_deriv, tdnnf_stream stream);
 /* OnehotFunctionComponent::Propagate :9504-9519 (one uniform draw, device) */
 int tdnnf_onehot_propagate(const float *sample_u_dev, tdnnf_mat *out, tdnnf_stream stream);
+/* OnehotFunctionComponent::Backprop :9521-9552, non-natural-gradient branch (the recipes' configuration
+   "is-updatable=true use-natural-gradient=false"): output_ += lr * colsum(out_deriv); no input derivative.
+   workspace: tdnnf_colreduce_workspace_bytes(rows, cols). */
+int tdnnf_onehot_backprop(const tdnnf_mat *out_deriv, float lr, float *output_acc_dev, void *workspace_dev,
+                          size_t workspace_bytes, tdnnf_stream stream);
 /* CopyNComponent :4843-4867 (AddMatBlocks: both directions ADD) */
 int tdnnf_copyn_propagate(const tdnnf_mat *in, float scale, tdnnf_mat *out, tdnnf_stream stream);
 int tdnnf_copyn_backprop(const tdnnf_mat *out_deriv, float scale, tdnnf_mat *in_deriv, tdnnf_stream stream);
@@ -181,6 +212,14 @@ int tdnnf_affine_backprop(const tdnnf_mat *out_deriv, const float *W_dev, int ld
 int tdnnf_affine_update_simple(const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, float lr, float *W_acc_dev,
                                int ldw, float *bias_acc_dev, void *workspace_dev, size_t workspace_bytes,
                                tdnnf_stream);
+/* NaturalGradientAffineComponent::Update :2980-3024 (bias_acc_dev != NULL) and the natural-gradient branch of
+   LinearComponent::Backprop :3240-3243 (bias_acc_dev == NULL: no ones column): [X, 1] and a copy of out_deriv are
+   preconditioned by the caller's two OnlineNaturalGradient objects, W += lr a b dY'^T X', bias += lr a b dY'^T 1'. */
+size_t tdnnf_affine_update_natural_gradient_workspace_bytes(int Do, int Di, int num_rows, int has_bias);
+int tdnnf_affine_update_natural_gradient(const tdnnf_mat *in_value, const tdnnf_mat *out_deriv,
+                                         tdnnf_ng *preconditioner_in, tdnnf_ng *preconditioner_out,
+                                         float learning_rate, float *W_acc_dev, int ldw, float *bias_acc_dev,
+                                         void *workspace_dev, size_t workspace_bytes, tdnnf_stream);
 /* LogSoftmaxComponent :3607-3632 */
 int tdnnf_log_softmax_propagate(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_stream);
 int tdnnf_log_softmax_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_deriv, tdnnf_mat *in_deriv,
@@ -230,13 +269,14 @@ int tdnnf_chain_objf_and_deriv(const tdnnf_den_graph *, const tdnnf_supervision 
 /* ========================================================================== A8
  * OnlineNaturalGradient::PreconditionDirections (UPSTREAM; call sites
  * src/nnet3/nnet-tdnn-component.cc:598-599, nnet-simple-component.cc:3001-3002). */
-typedef struct tdnnf_ng tdnnf_ng;
 int tdnnf_ng_create(int rank, int update_period, float num_samples_history, float alpha, tdnnf_ng **out);
 void tdnnf_ng_destroy(tdnnf_ng *);
 /* X is modified in place; *scale_host (may be NULL) receives the scalar, which costs a stream synchronisation.
    The R x R eigen-problem of a refresh step is solved on a host worker thread and W_{t+1} is installed at the
    next call on the same object, so a call with scale_host == NULL never blocks.  rank <= 128. */
 int tdnnf_ng_precondition(tdnnf_ng *, tdnnf_mat *X, float *scale_host, tdnnf_stream);
+/* device float holding the scale of the object's last tdnnf_ng_precondition call (NULL before the first call) */
+const float *tdnnf_ng_scale_dev(const tdnnf_ng *);
 
 /* ========================================================================== A9
  * src/nnet3/nnet-utils.cc */
@@ -453,6 +493,11 @@ int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_
    No GPU needed.  *needed (optional) receives the size including the terminating 0; out may be null with capacity 0 to
    query it. */
 int tdnnf_net_config_text(const tdnnf_net_config *cfg, char *out, size_t capacity, size_t *needed);
+/* debugging / parity: on != 0 makes the following forward_backward calls keep copies of the backward pass's derivative
+   matrices (which otherwise live in recycled scratch): "<layer>.noop.deriv" (w.r.t. the layer output), "<layer>.affine.deriv",
+   "<layer>.linear.deriv" (w.r.t. those components' outputs), "prefinal-l.deriv", "prefinal-{chain,xent}.{batchnorm2,linear,
+   batchnorm1,affine}.deriv", "output-xent.deriv"; served by tdnnf_net_get_activation.  Costs memory and copies: tests only. */
+int tdnnf_net_set_capture(tdnnf_net *, int on);
 /* debugging / parity: copy an internal activation by name ("tdnnf2.linear", "output", ...) into out */
 int tdnnf_net_get_activation(const tdnnf_net *, const char *name, tdnnf_mat *out, tdnnf_stream);
 int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, int *cols);
@@ -463,6 +508,10 @@ int tdnnf_net_activation_dims(const tdnnf_net *, const char *name, int *rows, in
  * 2 = wgrad, 3 = the skinny GEMMs of the natural-gradient statistics.  tdnnf_profile_read synchronises the recorded events and returns totals since enable. */
 int tdnnf_profile_enable(int on);
 int tdnnf_profile_read(int kernel_class, double *launches, double *total_ms, double *total_flops);
+/* Algorithmic HBM bytes of the class's launches since enable, computed from the launch shapes: every operand element
+   touched once -- 4 (distinct input rows x K-length + weight block + output rows x N [x 2 when added to]) per GEMM
+   (e (N_in Di + K Di Do + N Do)); measured PMC traffic divided by this is the wasted-re-read ratio. */
+int tdnnf_profile_read_bytes(int kernel_class, double *algorithmic_bytes);
 const char *tdnnf_profile_class_name(int kernel_class);
 
 #ifdef __cplusplus

@@ -77,18 +77,34 @@ inline void TdnnDartsPropagate(const TdnnDartsState &c, const tdnnf_tdnn_indexes
   Check(tdnnf_tdnn_propagate(&ix, &vin, c.linear_params, c.ldw, c.Do, c.Di, bias, memo_dev + c.K, init_mode, &vout, stream));
 }
 
-// Backprop :335-431 (data part) and UpdateSimple :433-455 into `to_update`'s accumulators.
+// The component's two OnlineNaturalGradient objects (preconditioner_in_ / preconditioner_out_ of the Kaldi class become
+// two tdnnf_ng handles created once with the component's rank / update-period / history / alpha, nnet-tdnn-component.cc:183-210).
+struct NaturalGradient {
+  tdnnf_ng *in;
+  tdnnf_ng *out;
+};
+
+// Backprop :335-431: data part :366-416, then (:418-430) "if (to_update->is_gradient_ || !to_update->use_natural_gradient_)
+// UpdateSimple(...) else UpdateNaturalGradient(...)".  ng == nullptr selects UpdateSimple (:433-455); otherwise
+// UpdateNaturalGradient :457-626 with the component's preconditioners.  to_update_bias is to_update->bias_params_ (K + Do).
+// workspace: tdnnf_tdnn_update_workspace_bytes (simple) / tdnnf_tdnn_update_natural_gradient_workspace_bytes (natural gradient).
 template <class CuMat>
 inline void TdnnDartsBackprop(const TdnnDartsState &c, const tdnnf_tdnn_indexes &ix, const CuMat &in_value,
                               const CuMat &out_deriv, const float *memo_dev, CuMat *in_deriv /* may be null */,
                               float learning_rate, float *to_update_linear /* null: no update */, float *to_update_bias,
-                              void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream) {
+                              void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream, const NaturalGradient *ng = nullptr) {
   tdnnf_mat vdy = View(out_deriv), vx = View(in_value);
   if (in_deriv) {
     tdnnf_mat vdx = View(*in_deriv);
     Check(tdnnf_tdnn_backprop_data(&ix, &vdy, c.linear_params, c.ldw, c.Do, c.Di, memo_dev + c.K, &vdx, stream));
   }
-  if (to_update_linear && learning_rate != 0.0f)  // :423-427
+  if (!to_update_linear || learning_rate == 0.0f) return;  // :418-424
+  if (ng)
+    Check(tdnnf_tdnn_update_natural_gradient(&ix, &vx, &vdy, c.Do, c.Di, c.linear_params, c.ldw, memo_dev, memo_dev + c.K, c.flags,
+                                             c.share_index, c.temp_proportion, ng->in, ng->out, learning_rate, to_update_linear, c.ldw,
+                                             to_update_bias ? to_update_bias + c.K : nullptr, to_update_bias, workspace_dev,
+                                             workspace_bytes, stream));
+  else
     Check(tdnnf_tdnn_update_simple(&ix, &vx, &vdy, c.Do, c.Di, memo_dev + c.K, learning_rate, to_update_linear, c.ldw,
                                    to_update_bias ? to_update_bias + c.K : nullptr, workspace_dev, workspace_bytes, stream));
 }
@@ -99,6 +115,25 @@ inline void TdnnPropagate(const tdnnf_tdnn_indexes &ix, const CuMat &in, const f
                           const float *bias /* Do or null */, CuMat *out, tdnnf_stream stream) {
   tdnnf_mat vin = View(in), vout = View(*out);
   Check(tdnnf_tdnn_propagate(&ix, &vin, linear_params, ldw, Do, Di, bias, nullptr, bias ? 1 : 0, &vout, stream));
+}
+// TdnnComponent::Backprop (UPSTREAM): in_deriv += out_deriv W_i on the tap views, then UpdateSimple or UpdateNaturalGradient
+template <class CuMat>
+inline void TdnnBackprop(const tdnnf_tdnn_indexes &ix, const CuMat &in_value, const CuMat &out_deriv, const float *linear_params, int ldw,
+                         int Do, int Di, CuMat *in_deriv /* may be null */, float learning_rate, float *to_update_linear /* null: no update */,
+                         float *to_update_bias /* Do or null */, void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream,
+                         const NaturalGradient *ng = nullptr) {
+  tdnnf_mat vdy = View(out_deriv), vx = View(in_value);
+  if (in_deriv) {
+    tdnnf_mat vdx = View(*in_deriv);
+    Check(tdnnf_tdnn_backprop_data(&ix, &vdy, linear_params, ldw, Do, Di, nullptr, &vdx, stream));
+  }
+  if (!to_update_linear || learning_rate == 0.0f) return;
+  if (ng)
+    Check(tdnnf_tdnn_update_natural_gradient(&ix, &vx, &vdy, Do, Di, nullptr, 0, nullptr, nullptr, 0, 0, 1.0f, ng->in, ng->out, learning_rate,
+                                             to_update_linear, ldw, to_update_bias, nullptr, workspace_dev, workspace_bytes, stream));
+  else
+    Check(tdnnf_tdnn_update_simple(&ix, &vx, &vdy, Do, Di, nullptr, learning_rate, to_update_linear, ldw, to_update_bias, workspace_dev,
+                                   workspace_bytes, stream));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -141,6 +176,153 @@ inline void SoftmaxFlopsBackprop(const CuMat &out_value, CuMat *out_deriv /* mut
                                  const float *flops_dev, int dim, float temp_proportion, CuMat *in_deriv, tdnnf_stream stream) {
   tdnnf_mat vp = View(out_value), vdp = View(*out_deriv), vdx = View(*in_deriv);
   Check(tdnnf_softmax_flops_backprop(&vp, &vdp, scale, flops_dev, dim, temp_proportion, &vdx, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// BatchNorm statistics: StoreStats nnet-normalize-component.cc:551-589 (stats_dev = [count, sum[D], sumsq[D]] doubles),
+// BatchNormTestComponent::ComputeDerived :682-715
+inline void BatchNormStoreStats(const float *memo_dev, int dim, int num_frames, double *stats_dev, tdnnf_stream stream) {
+  Check(tdnnf_batchnorm_store_stats(memo_dev, dim, num_frames, stats_dev, stream));
+}
+inline void BatchNormComputeDerived(const double *stats_dev, int dim, float epsilon, float target_rms, float *scale_dev, float *offset_dev,
+                                    tdnnf_stream stream) {
+  Check(tdnnf_batchnorm_compute_derived(stats_dev, dim, epsilon, target_rms, scale_dev, offset_dev, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// OnehotFunctionComponent (nnet-simple-component.cc:9504-9552): Propagate draws ONE uniform and replicates the one-hot row;
+// Backprop has no input derivative and (is-updatable=true use-natural-gradient=false) adds lr * colsum(out_deriv) to output_.
+template <class CuMat>
+inline void OnehotPropagate(const float *uniform_draw_dev, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vout = View(*out);
+  Check(tdnnf_onehot_propagate(uniform_draw_dev, &vout, stream));
+}
+template <class CuMat>
+inline void OnehotBackprop(const CuMat &out_deriv, float learning_rate, float *to_update_output, void *ws, size_t ws_bytes, tdnnf_stream stream) {
+  tdnnf_mat vd = View(out_deriv);
+  Check(tdnnf_onehot_backprop(&vd, learning_rate, to_update_output, ws, ws_bytes, stream));
+}
+// CopyNComponent :4843-4867 (both directions add)
+template <class CuMat>
+inline void CopyNPropagate(const CuMat &in, float scale, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vin = View(in), vout = View(*out);
+  Check(tdnnf_copyn_propagate(&vin, scale, &vout, stream));
+}
+template <class CuMat>
+inline void CopyNBackprop(const CuMat &out_deriv, float scale, CuMat *in_deriv, tdnnf_stream stream) {
+  tdnnf_mat vd = View(out_deriv), vdx = View(*in_deriv);
+  Check(tdnnf_copyn_backprop(&vd, scale, &vdx, stream));
+}
+// ConstantFunctionComponent :2602-2642 (the NAS-modified non-natural-gradient branch: output_ += 5 lr colsum(out_deriv))
+template <class CuMat>
+inline void ConstantFunctionPropagate(const float *output_dev, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vout = View(*out);
+  Check(tdnnf_constant_function_propagate(output_dev, &vout, stream));
+}
+template <class CuMat>
+inline void ConstantFunctionBackprop(const CuMat &out_deriv, float learning_rate, float *to_update_output, void *ws, size_t ws_bytes,
+                                     tdnnf_stream stream) {
+  tdnnf_mat vd = View(out_deriv);
+  Check(tdnnf_constant_function_backprop(&vd, learning_rate, to_update_output, ws, ws_bytes, stream));
+}
+// ElementwiseProductComponent :256-299
+template <class CuMat>
+inline void ElementwiseProductPropagate(const CuMat &in, int output_dim, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vin = View(in), vout = View(*out);
+  Check(tdnnf_elementwise_product_propagate(&vin, output_dim, &vout, stream));
+}
+template <class CuMat>
+inline void ElementwiseProductBackprop(const CuMat &in_value, const CuMat &out_deriv, int output_dim, CuMat *in_deriv, tdnnf_stream stream) {
+  tdnnf_mat vx = View(in_value), vd = View(out_deriv), vdx = View(*in_deriv);
+  Check(tdnnf_elementwise_product_backprop(&vx, &vd, output_dim, &vdx, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// RectifiedLinearComponent :958-1091.  stats_dev = [count, value_sum[D], deriv_sum[D]] doubles (NonlinearComponent's
+// value_sum_ / deriv_sum_ / count_); the caller keeps the reference's coin flips (StoreStats w.p. 1/2 :1084, RepairGradients
+// w.p. self_repair probability :1017) and calls Repair / StoreStats accordingly.
+template <class CuMat>
+inline void ReluPropagate(const CuMat &in, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vin = View(in), vout = View(*out);
+  Check(tdnnf_relu_propagate(&vin, &vout, stream));
+}
+template <class CuMat>
+inline void ReluBackprop(const CuMat &out_value, const CuMat &out_deriv, CuMat *in_deriv, tdnnf_stream stream) {
+  tdnnf_mat vy = View(out_value), vd = View(out_deriv), vdx = View(*in_deriv);
+  Check(tdnnf_relu_backprop(&vy, &vd, &vdx, stream));
+}
+template <class CuMat>
+inline void ReluRepairGradients(const double *stats_dev, int dim, float self_repair_scale, float lower, float upper, CuMat *in_deriv,
+                                tdnnf_stream stream) {
+  tdnnf_mat vdx = View(*in_deriv);
+  Check(tdnnf_relu_repair(stats_dev, dim, self_repair_scale, lower, upper, &vdx, stream));
+}
+template <class CuMat>
+inline void ReluStoreStats(const CuMat &out_value, double *stats_dev, void *ws, size_t ws_bytes, tdnnf_stream stream) {
+  tdnnf_mat vy = View(out_value);
+  Check(tdnnf_relu_store_stats(&vy, stats_dev, ws, ws_bytes, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// AffineComponent :1235-1279 / NaturalGradientAffineComponent::Update :2980-3024 / LinearComponent :3211-3254 (bias == null)
+template <class CuMat>
+inline void AffinePropagate(const CuMat &in, const float *linear_params, int ldw, const float *bias /* null: LinearComponent */, int output_dim,
+                            CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vin = View(in), vout = View(*out);
+  Check(tdnnf_affine_propagate(&vin, linear_params, ldw, bias, output_dim, &vout, stream));
+}
+// Backprop :1253-1279: in_deriv = out_deriv W (overwrites; may be null), then the update of `to_update` -- UpdateSimple :1246-1251
+// when ng == nullptr (is_gradient_ or use-natural-gradient=false), else the natural-gradient Update.
+// workspace: tdnnf_tdnn_update_workspace_bytes(Do, Di, 1, rows) / tdnnf_affine_update_natural_gradient_workspace_bytes.
+template <class CuMat>
+inline void AffineBackprop(const CuMat &in_value, const CuMat &out_deriv, const float *linear_params, int ldw, CuMat *in_deriv,
+                           float learning_rate, float *to_update_linear /* null: no update */, float *to_update_bias /* null: Linear */,
+                           void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream, const NaturalGradient *ng = nullptr) {
+  tdnnf_mat vx = View(in_value), vdy = View(out_deriv);
+  if (in_deriv) {
+    tdnnf_mat vdx = View(*in_deriv);
+    Check(tdnnf_affine_backprop(&vdy, linear_params, ldw, vx.cols, &vdx, stream));
+  }
+  if (!to_update_linear || learning_rate == 0.0f) return;
+  if (ng)
+    Check(tdnnf_affine_update_natural_gradient(&vx, &vdy, ng->in, ng->out, learning_rate, to_update_linear, ldw, to_update_bias, workspace_dev,
+                                               workspace_bytes, stream));
+  else
+    Check(tdnnf_affine_update_simple(&vx, &vdy, learning_rate, to_update_linear, ldw, to_update_bias, workspace_dev, workspace_bytes, stream));
+}
+
+// LogSoftmaxComponent :3607-3632
+template <class CuMat>
+inline void LogSoftmaxPropagate(const CuMat &in, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vin = View(in), vout = View(*out);
+  Check(tdnnf_log_softmax_propagate(&vin, &vout, stream));
+}
+template <class CuMat>
+inline void LogSoftmaxBackprop(const CuMat &out_value, const CuMat &out_deriv, CuMat *in_deriv, tdnnf_stream stream) {
+  tdnnf_mat vy = View(out_value), vd = View(out_deriv), vdx = View(*in_deriv);
+  Check(tdnnf_log_softmax_backprop(&vy, &vd, &vdx, stream));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// chain::ComputeChainObjfAndDeriv (UPSTREAM; what NnetChainTrainer::ProcessOutputs calls).  results_dev: 8 device doubles
+// (tdnnf_hip.h); xent_output / xent_deriv may be null.  workspace: tdnnf_chain_workspace_bytes(graph, num_sequences, frames).
+template <class CuMat>
+inline void ChainObjfAndDeriv(const tdnnf_den_graph *den_graph, const tdnnf_supervision *supervision, const CuMat &nnet_output,
+                              const CuMat *xent_output, float leaky_hmm_coefficient, float l2_regularize, float xent_regularize,
+                              double *results_dev, CuMat *nnet_output_deriv, CuMat *xent_deriv, void *workspace_dev, size_t workspace_bytes,
+                              tdnnf_stream stream) {
+  tdnnf_mat vy = View(nnet_output), vd = View(*nnet_output_deriv), vx, vdx;
+  if (xent_output) vx = View(*xent_output);
+  if (xent_deriv) vdx = View(*xent_deriv);
+  Check(tdnnf_chain_objf_and_deriv(den_graph, supervision, &vy, xent_output ? &vx : nullptr, leaky_hmm_coefficient, l2_regularize,
+                                   xent_regularize, results_dev, &vd, xent_deriv ? &vdx : nullptr, workspace_dev, workspace_bytes, stream));
+}
+
+// ConstrainOrthonormalInternal nnet-utils.cc:914-1032 on a CuMatrixBase with rows <= cols (pass the transpose otherwise, :1068-1075)
+template <class CuMat>
+inline void ConstrainOrthonormal(float scale, CuMat *M, void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream) {
+  tdnnf_mat vm = View(*M);
+  Check(tdnnf_constrain_orthonormal(scale, vm.data, vm.rows, vm.cols, vm.stride, workspace_dev, workspace_bytes, stream));
 }
 
 }  // namespace tdnnf_adapter

@@ -265,6 +265,7 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
   for (int n = 0; n < N; n++)
     for (int r = 0; r < R; r++) {
       double a = 0;
+#pragma omp simd reduction(+ : a)
       for (int k = 0; k < D; k++) a += (double)X->data[(long)X->stride * n + k] * W[(size_t)r * D + k];
       H[(size_t)n * R + r] = (float)a;
     }
@@ -278,6 +279,7 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
       for (int n = 0; n < N; n++) {
         const double h = H[(size_t)n * R + r];
         const float *x = X->data + (long)X->stride * n;
+#pragma omp simd
         for (int k = 0; k < D; k++) acc[k] += h * x[k];
       }
       for (int k = 0; k < D; k++) J[(size_t)r * D + k] = (float)acc[k];
@@ -302,6 +304,7 @@ static void ng_precondition_internal(oracle_ng *ng, omat *X, int updating,
     for (int r = 0; r < R; r++) {
       const double h = H[(size_t)n * R + r];
       const float *w = W + (size_t)r * D;
+#pragma omp simd
       for (int k = 0; k < D; k++) acc[k] += h * w[k];
     }
     float *x = X->data + (long)X->stride * n;

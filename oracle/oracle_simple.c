@@ -215,6 +215,7 @@ void oracle_affine_propagate(const omat *in, const float *W, int ldw,
   for (int r = 0; r < in->rows; r++)
     for (int o = 0; o < Do; o++) {
       acc_t a = 0;
+#pragma omp simd reduction(+ : a)
       for (int d = 0; d < Di; d++) a += (acc_t)AT(in, r, d) * (acc_t)W[(long)ldw * o + d];
       AT(out, r, o) = (float)((acc_t)(bias ? bias[o] : 0.0f) + a);
     }
@@ -225,12 +226,17 @@ void oracle_affine_backprop(const omat *out_deriv, const float *W, int ldw,
                             int Di, omat *in_deriv) {
   int Do = out_deriv->cols;
 #pragma omp parallel for schedule(static)
-  for (int r = 0; r < out_deriv->rows; r++)
-    for (int d = 0; d < Di; d++) {
-      acc_t a = 0;
-      for (int o = 0; o < Do; o++) a += (acc_t)AT(out_deriv, r, o) * (acc_t)W[(long)ldw * o + d];
-      AT(in_deriv, r, d) = (float)a;
+  for (int r = 0; r < out_deriv->rows; r++) {
+    acc_t a[Di]; /* a[d] = sum_o dY[r][o] W[o][d], o ascending (W walked row by row) */
+    for (int d = 0; d < Di; d++) a[d] = 0;
+    for (int o = 0; o < Do; o++) {
+      const acc_t g = (acc_t)AT(out_deriv, r, o);
+      const float *w = W + (long)ldw * o;
+#pragma omp simd
+      for (int d = 0; d < Di; d++) a[d] += g * (acc_t)w[d];
     }
+    for (int d = 0; d < Di; d++) AT(in_deriv, r, d) = (float)a[d];
+  }
 }
 
 /* UpdateSimple :1246-1251 */
@@ -245,11 +251,16 @@ void oracle_affine_update_simple(const omat *in_value, const omat *out_deriv,
       for (int r = 0; r < N; r++) s += AT(out_deriv, r, o);
       bias_acc[o] = (float)((acc_t)bias_acc[o] + (acc_t)lr * s);
     }
-    for (int d = 0; d < Di; d++) {
-      acc_t s = 0;
-      for (int r = 0; r < N; r++) s += (acc_t)AT(out_deriv, r, o) * (acc_t)AT(in_value, r, d);
-      W_acc[(long)ldw * o + d] = (float)((acc_t)W_acc[(long)ldw * o + d] + (acc_t)lr * s);
+    acc_t *s = (acc_t *)calloc(Di, sizeof(acc_t)); /* s[d] = sum_r dY[r][o] X[r][d], r ascending */
+    for (int r = 0; r < N; r++) {
+      const acc_t g = (acc_t)AT(out_deriv, r, o);
+      const float *x = in_value->data + (long)in_value->stride * r;
+#pragma omp simd
+      for (int d = 0; d < Di; d++) s[d] += g * (acc_t)x[d];
     }
+    for (int d = 0; d < Di; d++)
+      W_acc[(long)ldw * o + d] = (float)((acc_t)W_acc[(long)ldw * o + d] + (acc_t)lr * s[d]);
+    free(s);
   }
 }
 

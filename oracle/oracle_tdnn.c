@@ -103,6 +103,7 @@ void oracle_tdnn_propagate(const omat *in, const float *W, int ldw, int Do,
         const float *x = in_row(in, row_stride, row_offsets[i], r);
         const float *w = W + (long)ldw * o + (long)i * Di;
         acc_t t = 0;
+#pragma omp simd reduction(+ : t)
         for (int d = 0; d < Di; d++) t += (acc_t)x[d] * (acc_t)w[d];
         a += (acc_t)c * t; /* AddMatMat(c_i, in_part, kNoTrans, W_i, kTrans, 1.0) :302-324 */
       }
@@ -127,12 +128,16 @@ void oracle_tdnn_backprop_data(const omat *out_deriv, const float *W, int ldw,
       const float *dy = out_deriv->data + (long)out_deriv->stride * r;
       float *dx = in_deriv->data +
                   (long)in_deriv->stride * ((long)row_offsets[i] + (long)r * row_stride);
-      for (int d = 0; d < Di; d++) {
-        acc_t t = 0;
-        for (int o = 0; o < Do; o++)
-          t += (acc_t)dy[o] * (acc_t)W[(long)ldw * o + (long)i * Di + d];
-        dx[d] = (float)((acc_t)dx[d] + (acc_t)c * t);
+      /* t[d] = sum_o dy[o] W_i[o][d], o ascending for every d (W walked row by row) */
+      acc_t t[Di];
+      for (int d = 0; d < Di; d++) t[d] = 0;
+      for (int o = 0; o < Do; o++) {
+        const acc_t g = (acc_t)dy[o];
+        const float *w = W + (long)ldw * o + (long)i * Di;
+#pragma omp simd
+        for (int d = 0; d < Di; d++) t[d] += g * (acc_t)w[d];
       }
+      for (int d = 0; d < Di; d++) dx[d] = (float)((acc_t)dx[d] + (acc_t)c * t[d]);
     }
   }
 }
@@ -163,6 +168,7 @@ void oracle_tdnn_update_simple(const omat *in_value, const omat *out_deriv,
       for (int r = 0; r < N; r++) {
         acc_t dy = out_deriv->data[(long)out_deriv->stride * r + o];
         const float *x = in_row(in_value, row_stride, row_offsets[i], r);
+#pragma omp simd
         for (int d = 0; d < Di; d++) tmp[d] += dy * (acc_t)x[d];
       }
       float *w = W_acc + (long)ldw * o + (long)i * Di;

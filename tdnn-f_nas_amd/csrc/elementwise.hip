@@ -843,6 +843,21 @@ int tdnnf_constant_function_backprop(const tdnnf_mat *out_deriv, float lr, float
   return TDNNF_OK;
 }
 
+// OnehotFunctionComponent::Backprop nnet-simple-component.cc:9521-9552, the branch the recipes configure
+// ("is-updatable=true use-natural-gradient=false", generate_bottleneckCB8share_onehottrain_config.py:12):
+// output_.AddRowSumMat(learning_rate, out_deriv); the component has no input derivative
+int tdnnf_onehot_backprop(const tdnnf_mat *out_deriv, float lr, float *output_acc, void *ws, size_t ws_bytes, tdnnf_stream stream) {
+  TDNNF_REQUIRE(mat_ok(out_deriv) && output_acc, "onehot_backprop: bad arguments");
+  if (out_deriv->rows == 0) return TDNNF_OK;
+  TDNNF_REQUIRE(ws && ws_bytes >= colreduce_bytes(out_deriv->rows, out_deriv->cols), "onehot_backprop: workspace too small");
+  MatView a = view(out_deriv);
+  ColReducePlan pl = colreduce_plan(a.rows, a.cols);
+  TDNNF_HIP(colreduce_partial(0, a, a, (float *)ws, (hipStream_t)stream));
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3(finalize_grid(a.cols)), dim3(kFinThreads), 0, (hipStream_t)stream, (const float *)ws, pl.chunks, a.cols, lr, output_acc);
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
 int tdnnf_flops_constraint_backprop(const float *flops, float scale, int rows_in, int cols_in, tdnnf_mat *in_deriv, tdnnf_stream stream) {
   TDNNF_REQUIRE(flops && mat_ok(in_deriv) && rows_in > 0 && cols_in > 0, "flops_constraint_backprop: bad arguments");
   if (in_deriv->rows * in_deriv->cols == 0) return TDNNF_OK;
@@ -978,9 +993,12 @@ int tdnnf_tdnn_darts_coef(const float *log_alpha, int K, int flags, float temp, 
 int tdnnf_tdnn_darts_alpha_update(const float *tap_grad, int ldg, const float *W, int ldw, int Do, int Di, int K,
                                   const float *coef_memo, int flags, int share_index, float temp, float lr,
                                   float *alpha_acc, double *tap_dots, tdnnf_stream stream) {
-  TDNNF_REQUIRE(tap_grad && W && coef_memo && alpha_acc && tap_dots, "tdnn_darts_alpha_update: null pointer (tap_dots_dev is required scratch of K doubles)");
+  // uniform-sample mode adds no gradient (the reference computes and discards it, :502-507): only the scalings run and
+  // tap_grad may be null
+  const bool uniform = (flags & TDNNF_DARTS_UNIFORM_SAMPLE) != 0;
+  TDNNF_REQUIRE((tap_grad || uniform) && W && coef_memo && alpha_acc && tap_dots, "tdnn_darts_alpha_update: null pointer (tap_dots_dev is required scratch of K doubles)");
   TDNNF_REQUIRE(K >= 1 && K <= TDNNF_MAX_OFFSETS && Do > 0 && Di > 0 && ldg >= K * Di && ldw >= K * Di, "tdnn_darts_alpha_update: bad dimensions");
-  hipLaunchKernelGGL(tap_dots_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, tap_grad, ldg, W, ldw, Do, Di, tap_dots);
+  if (tap_grad) hipLaunchKernelGGL(tap_dots_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, tap_grad, ldg, W, ldw, Do, Di, tap_dots);
   hipLaunchKernelGGL(alpha_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tap_dots, coef_memo, K, flags, share_index, temp, lr, alpha_acc);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;

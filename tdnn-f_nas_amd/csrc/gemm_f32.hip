@@ -35,11 +35,14 @@ struct ProfClass {
   std::vector<hipEvent_t> ev;  // pairs
   size_t used = 0;
   double flops = 0;
+  double bytes = 0;  // algorithmic HBM bytes: every operand element touched once
 };
 static ProfClass g_prof[4] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32"}, {"ng_skinny_gemm_f32"}};
 static bool g_prof_on = false;
 static int g_prof_override = -1;
 static double g_prof_flops_scale = 1.0;
+static double g_prof_next_bytes = 0;  // algorithmic bytes of the whole GEMM the next ProfScope(s) belong to (set by rows_gemm / wgrad)
+static double g_prof_next_flops = 0;
 ProfFlopsScale::ProfFlopsScale(double f) : prev(g_prof_flops_scale) { g_prof_flops_scale = f; }
 ProfFlopsScale::~ProfFlopsScale() { g_prof_flops_scale = prev; }
 namespace {
@@ -86,6 +89,8 @@ struct ProfScope {
     if (p.used + 2 > p.ev.size()) return;
     c = &p;
     p.flops += flops * g_prof_flops_scale;
+    // a launch that covers a fraction of the GEMM's rows (main + split-K tail) gets that fraction of its bytes
+    if (g_prof_next_flops > 0) p.bytes += g_prof_next_bytes * (flops / g_prof_next_flops);
     hipEventRecord(p.ev[p.used], s);
   }
   ~ProfScope() {
@@ -1126,6 +1131,31 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     const int lo = a.seg[i].m_lo > 0 ? a.seg[i].m_lo : 0, hi = a.seg[i].m_hi < a.M ? a.seg[i].m_hi : a.M;
     if (hi > lo) flops += 2.0 * (hi - lo) * a.N * a.seg[i].klen;
   }
+  if (g_prof_on) {
+    // algorithmic bytes, each operand element once: the distinct A rows the segments read (taps of one matrix are row
+    // shifts of it, so they share rows), the B blocks, the C tile written (and read when it is added to), the addend
+    double a_elems = 0, b_elems = 0;
+    bool taps = true;  // all segments: same reduction length, A offsets whole rows apart -> one matrix, shifted
+    for (int i = 1; i < a.nseg; i++)
+      taps = taps && a.seg[i].klen == a.seg[0].klen && a.lda > 0 && (a.seg[i].a_off - a.seg[0].a_off) % a.lda == 0;
+    if (taps) {
+      long long lo = a.seg[0].a_off, hi = a.seg[0].a_off;
+      for (int i = 1; i < a.nseg; i++) {
+        lo = std::min(lo, a.seg[i].a_off);
+        hi = std::max(hi, a.seg[i].a_off);
+      }
+      a_elems = ((double)a.M + (double)(hi - lo) / (double)a.lda) * a.seg[0].klen;
+    }
+    for (int i = 0; i < a.nseg; i++) {
+      const int lo = a.seg[i].m_lo > 0 ? a.seg[i].m_lo : 0, hi = a.seg[i].m_hi < a.M ? a.seg[i].m_hi : a.M;
+      if (!taps && hi > lo) a_elems += (double)(hi - lo) * a.seg[i].klen;
+      b_elems += (double)a.seg[i].klen * a.N;
+    }
+    double c_elems = (double)a.M * a.N * (a.init_mode == 0 ? 2.0 : 1.0);
+    if (a.add) c_elems += (double)(std::min(a.add_hi, a.M) - std::max(a.add_lo, 0)) * a.N;
+    g_prof_next_bytes = 4.0 * (a_elems + b_elems + c_elems);
+    g_prof_next_flops = flops;
+  }
   if (a.prec == 0) a.prec = g_gemm_prec;
   if (a.prec == 2) a.prec = 0;  // 2 = exact f32 regardless of the default
   {
@@ -1749,6 +1779,16 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   const size_t lds = sizeof(float) * 2 * (32 * (wt.BM + 4) + 32 * (wt.BN + 4));
   {
     ProfFlopsScale exact(ktaps != a.K ? 1.0 : g_prof_flops_scale);  // a compacted launch already counts only its taps
+    if (g_prof_on) {  // algorithmic bytes: dY once, the distinct input rows once, the gradient block written (and read)
+      int lo = a.row_offsets[0], hi = a.row_offsets[0];
+      for (int i = 1; i < a.K; i++) {
+        lo = std::min(lo, a.row_offsets[i]);
+        hi = std::max(hi, a.row_offsets[i]);
+      }
+      g_prof_next_flops = 2.0 * a.N * a.Do * ktaps * a.Di;
+      g_prof_next_bytes = 4.0 * ((double)a.N * a.Do + std::min((double)a.N * ktaps, (double)a.N * a.row_stride + (hi - lo)) * a.Di +
+                                 (double)a.Do * ktaps * a.Di * (a.accumulate ? 2.0 : 1.0));
+    }
     ProfScope ps(2, 2.0 * a.N * a.Do * ktaps * a.Di, s);
 #define WG_LAUNCH_T(WM, WN, TM, TN, TAG)                                                                                            \
   {                                                                                                                                \
@@ -1827,6 +1867,7 @@ int tdnnf_profile_enable(int on) {
       }
       p.used = 0;
       p.flops = 0;
+      p.bytes = 0;
     }
   }
   g_prof_on = on != 0;
@@ -1846,6 +1887,11 @@ int tdnnf_profile_read(int cls, double *launches, double *total_ms, double *tota
   if (launches) *launches = (double)(p.used / 2);
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = p.flops;
+  return TDNNF_OK;
+}
+int tdnnf_profile_read_bytes(int cls, double *algorithmic_bytes) {
+  if (cls < 0 || cls > 3 || !algorithmic_bytes) return TDNNF_EINVAL;
+  *algorithmic_bytes = tdnnf::g_prof[cls].bytes;
   return TDNNF_OK;
 }
 const char *tdnnf_profile_class_name(int cls) { return cls >= 0 && cls <= 3 ? tdnnf::g_prof[cls].name : ""; }

@@ -122,6 +122,10 @@ struct tdnnf_net {
   void *chain_ws;
   size_t chain_ws_bytes;
   std::vector<std::pair<std::string, tdnnf_mat>> named;
+  // debugging / parity (tdnnf_net_set_capture): copies of the backward pass's derivative matrices, which live in recycled
+  // scratch buffers, kept under names ("tdnnf5.affine.deriv", ...) that tdnnf_net_get_activation serves
+  bool capture_on = false;
+  std::vector<float *> captured;
 };
 
 namespace tdnnf {

@@ -818,6 +818,8 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   if (!n->layers.empty() && !n->layers[0].perm)  // what the last backward step left: d objective / d tdnnf2.linear (debugging aid)
     name("tdnnf2.linear.deriv", n->d_small, n->layers[0].lin.rows_out, n->layers[0].bn);
   name("prefinal-l", n->prefinal_l_out, n->Tout * B, S);
+  name("prefinal-chain.relu", n->head[0].aff_relu, n->Tout * B, Hd);
+  name("prefinal-xent.relu", n->head[1].aff_relu, n->Tout * B, Hd);
   name("output", n->head[0].y, n->Tout * B, P);
   name("output-xent", n->xent_logsoftmax, n->Tout * B, P);
   name("output.deriv", n->d_y, n->Tout * B, P);
@@ -835,6 +837,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   }
   hipFree(n->arena);
   hipFree(n->chain_ws);
+  for (float *p : n->captured) hipFree(p);
   if (n->s2) hipStreamDestroy(n->s2);
   if (n->ev_fork) hipEventDestroy(n->ev_fork);
   if (n->ev_den) hipEventDestroy(n->ev_den);
@@ -949,6 +952,12 @@ int tdnnf_net_set_buffers(tdnnf_net *n, float *params, float *grads) {
                 "net_set_buffers: buffers must be non-null and 16-byte aligned");
   n->params = params;
   n->grads = grads;
+  return TDNNF_OK;
+}
+
+int tdnnf_net_set_capture(tdnnf_net *n, int on) {
+  TDNNF_REQUIRE(n, "net_set_capture: null net");
+  n->capture_on = on != 0;
   return TDNNF_OK;
 }
 
@@ -1142,6 +1151,22 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // passes; also yields the bias gradient of the affine layer in front of the ReLU.
   // With natural gradient the same sweep also forms the output-side statistic H = dY Wy^T of the affine component in front
   // of the ReLU (fused.h NgFuse): into the buffer set the component's param_grad call, which must come next, will take.
+  // parity aid: keep a copy of a derivative matrix under `name` (tdnnf_net_set_capture); the originals are recycled scratch
+  auto capture = [&](const std::string &name, const tdnnf_mat &m) -> int {
+    if (!n->capture_on) return TDNNF_OK;
+    tdnnf_mat *dst = nullptr;
+    for (auto &kv : n->named)
+      if (kv.first == name) dst = &kv.second;
+    if (!dst) {
+      float *p = nullptr;
+      TDNNF_HIP(hipMalloc((void **)&p, sizeof(float) * (size_t)std::max(1, m.rows) * ldpad(m.cols)));
+      n->captured.push_back(p);
+      n->named.push_back({name, M(p, m.rows, m.cols)});
+      dst = &n->named.back().second;
+    }
+    TDNNF_REQUIRE(dst->rows == m.rows && dst->cols == m.cols, "net_forward_backward: captured %s changed shape", name.c_str());
+    return tdnnf_sum_scaled(&m, 1.0f, nullptr, 0.f, dst, s);
+  };
   int fused_comp = -1;
   tdnnf_net::NgSet *fused_set = nullptr;
   auto out_stats_fuse = [&](int comp, MatView xv, MatView dzv, MatView dv, NgFuse &f) -> int {  // 1: f is to be passed on
@@ -1254,13 +1279,19 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat dout = h == 0 ? dy : dx;
     tdnnf_mat b2 = M(H.bn2_out, No, S), b1 = M(H.bn1_out, No, Hd);
     tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
+    const std::string hname = h == 0 ? "prefinal-chain" : "prefinal-xent";
+    if (h == 1) CK(capture("output-xent.deriv", dout));
     CK(param_grad(H.c_output, ix1, 1, S, P, &b2, &dout, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
+    CK(capture(hname + ".batchnorm2.deriv", d_b2));
     if (cv) CK(tdnnf_batchnorm_test_backprop(&d_b2, H.bn2_memo + 2 * S, &d_b2, s));
     else CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
+    CK(capture(hname + ".linear.deriv", d_b2));
     CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
+    CK(capture(hname + ".batchnorm1.deriv", d_b1));
     CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine));  // dA -> d affine out
+    CK(capture(hname + ".affine.deriv", d_b1));
     CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
@@ -1270,6 +1301,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_add_scaled(&tmp, 1.0f, &d_pl, s));
     }
   }
+  CK(capture("prefinal-l.deriv", d_pl));
   CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0, false));
   float *d_cur = n->dA, *d_next = n->dB;  // d_cur: deriv w.r.t. the current layer's output (noop)
   {
@@ -1282,6 +1314,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const int no = L.aff.rows_out, nl = L.lin.rows_out, ni = N_of(L.gin, B);
     // d_cur is needed again for the bypass term, so the derivative w.r.t. the affine output goes to dC
     tdnnf_mat d_out = M(d_cur, no, Hd), d_aff = M(n->dC, no, Hd);
+    const std::string lname = "tdnnf" + std::to_string(l + 2);
+    CK(capture(lname + ".noop.deriv", d_out));
     {
       const bool store = coin() || step == 0;
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
@@ -1292,6 +1326,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
                             view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr));
     }
+    CK(capture(lname + ".affine.deriv", d_aff));
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
     tdnnf_mat aff_in = L.perm ? M(L.lin_perm, nl, L.bn) : (L.c_arch >= 0 ? M(L.lin_masked, nl, L.bn) : lin);
     const float *lin_eff = L.lin.darts ? L.lin.memo + TDNNF_MAX_OFFSETS : nullptr;
@@ -1339,6 +1374,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       hipLaunchKernelGGL(bn_choice_backward_kernel, dim3(1), dim3(256), 0, s, bn_choice(c), (const float *)n->ws, chunks, L.arch_p, Wg(n, L.c_arch));
       hipLaunchKernelGGL(col_scale_kernel, dim3(grid_for((long long)nl * L.bn, 256)), dim3(256), 0, s, view(&d_lin), L.arch_mask, view(&d_lin));
     }
+    CK(capture(lname + ".linear.deriv", d_lin));
     tdnnf_mat in = M(in_act, ni, Hd);
     // (the never-added bias of a DARTS .linear is still updated by the reference, :614 -- Bg() is null for plain layers)
     CK(tdnn_wgrad(L.lin, &in, &d_lin, lin_eff, false));

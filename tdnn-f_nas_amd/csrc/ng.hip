@@ -620,6 +620,8 @@ using namespace tdnnf;
 
 extern "C" {
 
+const float *tdnnf_ng_scale_dev(const tdnnf_ng *ng) { return ng && ng->dev ? ng->scale_f : nullptr; }
+
 int tdnnf_ng_create(int rank, int update_period, float num_samples_history, float alpha, tdnnf_ng **out) {
   TDNNF_REQUIRE(out && rank >= 0 && update_period >= 1 && num_samples_history > 0 && alpha >= 0, "ng_create: bad configuration");
   tdnnf_ng *ng = new tdnnf_ng();

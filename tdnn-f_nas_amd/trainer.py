@@ -237,6 +237,10 @@ class ChainNet:
             l2_regularize_scale = float(self.cfg.num_sequences)
         hipabi.check(self.lib.tdnnf_net_update(self.h, float(learning_rate), float(l2_regularize_scale), int(step), hipabi.stream()))
 
+    def set_capture(self, on=True):
+        """Parity aid: keep copies of the backward pass's derivative matrices (tdnnf_net_set_capture); read them with activation()."""
+        hipabi.check(self.lib.tdnnf_net_set_capture(self.h, int(bool(on))))
+
     def activation(self, name):
         import torch
         r, c = C.c_int(), C.c_int()

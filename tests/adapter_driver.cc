@@ -1,0 +1,297 @@
+// adapter_driver.cc -- a stand-in for the Kaldi side of the boundary, used by tests/test_gpu_adapter.py.
+//
+// It drives the nnet3 components of the hot path ONLY through include/tdnnf_nnet3_adapter.h, the way the edited
+// Component::Propagate / Backprop bodies of INTEGRATION.md would, over a CuMatrixBase<float> stand-in that owns hipMalloc
+// memory (Data / NumRows / NumCols / Stride, row stride padded like Kaldi's pitched allocations).  Inputs and outputs travel
+// as files of named float matrices; the test compares the outputs with the CPU oracle.
+// Build: hipcc -std=c++17 -I include tests/adapter_driver.cc -L tdnn-f_nas_amd -ltdnnf_hip
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "tdnnf_nnet3_adapter.h"
+
+#define HIPCK(e)                                                                      \
+  do {                                                                                \
+    hipError_t err__ = (e);                                                           \
+    if (err__ != hipSuccess) {                                                        \
+      std::fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(err__));                 \
+      std::exit(3);                                                                   \
+    }                                                                                 \
+  } while (0)
+
+struct HostMat {
+  int rows = 0, cols = 0;
+  std::vector<float> v;
+  float at(int i) const { return v[i]; }
+};
+typedef std::map<std::string, HostMat> Blob;
+
+static Blob read_blob(const char *path) {
+  Blob b;
+  FILE *f = std::fopen(path, "rb");
+  if (!f) { std::perror(path); std::exit(2); }
+  int n = 0;
+  while (std::fread(&n, 4, 1, f) == 1) {
+    std::string name(n, ' ');
+    HostMat m;
+    if (std::fread(&name[0], 1, n, f) != (size_t)n || std::fread(&m.rows, 4, 1, f) != 1 || std::fread(&m.cols, 4, 1, f) != 1) std::exit(2);
+    m.v.resize((size_t)m.rows * m.cols);
+    if (!m.v.empty() && std::fread(m.v.data(), 4, m.v.size(), f) != m.v.size()) std::exit(2);
+    b[name] = m;
+  }
+  std::fclose(f);
+  return b;
+}
+static void write_mat(FILE *f, const std::string &name, const HostMat &m) {
+  int n = (int)name.size();
+  std::fwrite(&n, 4, 1, f);
+  std::fwrite(name.data(), 1, n, f);
+  std::fwrite(&m.rows, 4, 1, f);
+  std::fwrite(&m.cols, 4, 1, f);
+  if (!m.v.empty()) std::fwrite(m.v.data(), 4, m.v.size(), f);
+}
+
+// kaldi::CuMatrix<float> stand-in: pitched device memory, the three accessors the adapter uses
+class CuMatrixStub {
+ public:
+  CuMatrixStub(int rows, int cols, float fill = 0.f) : r_(rows), c_(cols), s_(((cols + 3) & ~3) + 4) {
+    HIPCK(hipMalloc((void **)&d_, sizeof(float) * (size_t)std::max(1, r_) * s_));
+    std::vector<float> h((size_t)std::max(1, r_) * s_, fill);
+    HIPCK(hipMemcpy(d_, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+  }
+  explicit CuMatrixStub(const HostMat &m) : CuMatrixStub(m.rows, m.cols) {
+    if (!m.v.empty()) HIPCK(hipMemcpy2D(d_, sizeof(float) * s_, m.v.data(), sizeof(float) * c_, sizeof(float) * c_, r_, hipMemcpyHostToDevice));
+  }
+  ~CuMatrixStub() { (void)hipFree(d_); }
+  CuMatrixStub(const CuMatrixStub &) = delete;
+  const float *Data() const { return d_; }
+  float *Data() { return d_; }
+  int NumRows() const { return r_; }
+  int NumCols() const { return c_; }
+  int Stride() const { return s_; }
+  HostMat Host() const {
+    HostMat m;
+    m.rows = r_;
+    m.cols = c_;
+    m.v.resize((size_t)r_ * c_);
+    HIPCK(hipDeviceSynchronize());
+    if (!m.v.empty()) HIPCK(hipMemcpy2D(m.v.data(), sizeof(float) * c_, d_, sizeof(float) * s_, sizeof(float) * c_, r_, hipMemcpyDeviceToHost));
+    return m;
+  }
+
+ private:
+  float *d_ = nullptr;
+  int r_, c_, s_;
+};
+// kaldi::CuVector<float> stand-in (dense)
+struct CuVectorStub {
+  float *d = nullptr;
+  int n;
+  explicit CuVectorStub(int dim, float fill = 0.f) : n(dim) {
+    HIPCK(hipMalloc((void **)&d, sizeof(float) * std::max(1, n)));
+    std::vector<float> h(std::max(1, n), fill);
+    HIPCK(hipMemcpy(d, h.data(), sizeof(float) * h.size(), hipMemcpyHostToDevice));
+  }
+  explicit CuVectorStub(const HostMat &m) : CuVectorStub((int)m.v.size()) {
+    if (n) HIPCK(hipMemcpy(d, m.v.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+  }
+  ~CuVectorStub() { (void)hipFree(d); }
+  CuVectorStub(const CuVectorStub &) = delete;
+  HostMat Host() const {
+    HostMat m;
+    m.rows = 1;
+    m.cols = n;
+    m.v.resize(n);
+    HIPCK(hipDeviceSynchronize());
+    if (n) HIPCK(hipMemcpy(m.v.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost));
+    return m;
+  }
+};
+struct DevBytes {
+  void *p = nullptr;
+  size_t n;
+  explicit DevBytes(size_t bytes) : n(bytes) {
+    HIPCK(hipMalloc(&p, std::max<size_t>(n, 256)));
+    HIPCK(hipMemset(p, 0, std::max<size_t>(n, 256)));
+  }
+  ~DevBytes() { (void)hipFree(p); }
+};
+static HostMat doubles_to_host(const double *dev, int n) {
+  std::vector<double> h(n);
+  HIPCK(hipDeviceSynchronize());
+  HIPCK(hipMemcpy(h.data(), dev, sizeof(double) * n, hipMemcpyDeviceToHost));
+  HostMat m;
+  m.rows = 1;
+  m.cols = n;
+  m.v.assign(h.begin(), h.end());
+  return m;
+}
+
+using namespace tdnnf_adapter;
+
+static NaturalGradient make_ng(int dim_in, int dim_out) {  // ranks / period / history / alpha of nnet-tdnn-component.cc:183-210
+  NaturalGradient ng;
+  Check(tdnnf_ng_create(std::min(20, (dim_in + 1) / 2), 4, 2000.0f, 4.0f, &ng.in));
+  Check(tdnnf_ng_create(std::min(80, (dim_out + 1) / 2), 4, 2000.0f, 4.0f, &ng.out));
+  return ng;
+}
+
+// A Tdnn[DARTSV3]Component over `steps` minibatches: Propagate, Backprop (data part + UpdateNaturalGradient into a zeroed
+// delta-nnet component), the way NnetComputer would call them.  cfg = [K, Di, Do, row_stride, flags (-1: plain TdnnComponent),
+// temp_proportion, lr, steps, offsets1_positive, row_offsets...]
+static void run_tdnn(const Blob &in, FILE *out) {
+  const HostMat &cfg = in.at("cfg");
+  const int K = (int)cfg.at(0), Di = (int)cfg.at(1), Do = (int)cfg.at(2), rho = (int)cfg.at(3), flags = (int)cfg.at(4), steps = (int)cfg.at(7);
+  const float temp = cfg.at(5), lr = cfg.at(6);
+  const bool darts = flags >= 0, off1pos = cfg.at(8) != 0.f;
+  std::vector<int> ro(K);
+  for (int i = 0; i < K; i++) ro[i] = (int)cfg.at(9 + i);
+  tdnnf_tdnn_indexes ix = Indexes(rho, ro);
+  CuMatrixStub W(in.at("W"));
+  CuVectorStub bias(in.at("bias"));  // DARTS: K + Do (logits first); plain: Do
+  NaturalGradient ng = make_ng(K * Di + 1, Do);
+  for (int t = 0; t < steps; t++) {
+    const std::string sfx = std::to_string(t);
+    CuMatrixStub x(in.at("x" + sfx)), dy(in.at("dy" + sfx));
+    const int N = dy.NumRows();
+    CuMatrixStub y(N, Do), dx(x.NumRows(), Di);
+    CuMatrixStub W_acc(Do, K * Di);
+    CuVectorStub b_acc(bias.n);
+    DevBytes ws(tdnnf_tdnn_update_natural_gradient_workspace_bytes(Do, Di, K, N, 1));
+    if (darts) {
+      TdnnDartsState st = {K, Di, Do, W.Stride(), W.Data(), bias.d, flags, temp, off1pos ? 0 : K - 1, off1pos};
+      CuVectorStub draws(in.at("draws" + sfx)), memo(2 * K);
+      TdnnDartsPropagate(st, ix, x, &y, draws.d, memo.d, nullptr);
+      TdnnDartsBackprop(st, ix, x, dy, memo.d, &dx, lr, W_acc.Data(), b_acc.d, ws.p, ws.n, nullptr, &ng);
+      // the accumulator's row stride is its own (to_update->linear_params_.Stride()): the adapter passes c.ldw = W.Stride()
+      write_mat(out, "memo" + sfx, memo.Host());
+    } else {
+      TdnnPropagate(ix, x, W.Data(), W.Stride(), Do, Di, bias.d, &y, nullptr);
+      TdnnBackprop(ix, x, dy, W.Data(), W.Stride(), Do, Di, &dx, lr, W_acc.Data(), b_acc.d, ws.p, ws.n, nullptr, &ng);
+    }
+    write_mat(out, "y" + sfx, y.Host());
+    write_mat(out, "dx" + sfx, dx.Host());
+    write_mat(out, "W_acc" + sfx, W_acc.Host());
+    write_mat(out, "b_acc" + sfx, b_acc.Host());
+  }
+  tdnnf_ng_destroy(ng.in);
+  tdnnf_ng_destroy(ng.out);
+}
+
+// NaturalGradientAffine -> RectifiedLinear -> BatchNorm -> Linear -> LogSoftmax and back, `steps` minibatches.
+// cfg = [steps, lr, self_repair_scale]
+static void run_stack(const Blob &in, FILE *out) {
+  const HostMat &cfg = in.at("cfg");
+  const int steps = (int)cfg.at(0);
+  const float lr = cfg.at(1), repair = cfg.at(2);
+  CuMatrixStub Wa(in.at("Wa")), Wl(in.at("Wl"));
+  CuVectorStub ba(in.at("ba"));
+  const int Di = Wa.NumCols(), H = Wa.NumRows(), P = Wl.NumRows();
+  NaturalGradient nga = make_ng(Di + 1, H), ngl = make_ng(H, P);
+  DevBytes relu_stats(sizeof(double) * (1 + 2 * H)), bn_stats(sizeof(double) * (1 + 2 * H));
+  for (int t = 0; t < steps; t++) {
+    const std::string sfx = std::to_string(t);
+    CuMatrixStub x(in.at("x" + sfx)), dlsm(in.at("d" + sfx));
+    const int N = x.NumRows();
+    CuMatrixStub a(N, H), r(N, H), z(N, H), l(N, P), lsm(N, P);
+    CuVectorStub memo(5 * H);
+    DevBytes cws(tdnnf_colreduce_workspace_bytes(N, std::max(H, P)));
+    AffinePropagate(x, Wa.Data(), Wa.Stride(), ba.d, H, &a, nullptr);
+    ReluPropagate(a, &r, nullptr);
+    ReluStoreStats(r, (double *)relu_stats.p, cws.p, cws.n, nullptr);
+    BatchNormPropagate(r, 1.0e-3f, 1.0f, &z, memo.d, cws.p, cws.n, nullptr);
+    BatchNormStoreStats(memo.d, H, N, (double *)bn_stats.p, nullptr);
+    AffinePropagate(z, Wl.Data(), Wl.Stride(), (const float *)nullptr, P, &l, nullptr);
+    LogSoftmaxPropagate(l, &lsm, nullptr);
+    // backward
+    CuMatrixStub dl(N, P), dz(N, H), dr(N, H), da(N, H), dxm(N, Di);
+    CuMatrixStub Wl_acc(P, H), Wa_acc(H, Di);
+    CuVectorStub ba_acc(H);
+    LogSoftmaxBackprop(lsm, dlsm, &dl, nullptr);
+    DevBytes wsl(tdnnf_affine_update_natural_gradient_workspace_bytes(P, H, N, 0)), wsa(tdnnf_affine_update_natural_gradient_workspace_bytes(H, Di, N, 1));
+    AffineBackprop(z, dl, Wl.Data(), Wl.Stride(), &dz, lr, Wl_acc.Data(), (float *)nullptr, wsl.p, wsl.n, nullptr, &ngl);
+    BatchNormBackprop(z, dz, 1.0f, memo.d, &dr, cws.p, cws.n, nullptr);
+    ReluBackprop(r, dr, &da, nullptr);
+    ReluRepairGradients((const double *)relu_stats.p, H, repair, 0.05f, 0.95f, &da, nullptr);
+    AffineBackprop(x, da, Wa.Data(), Wa.Stride(), &dxm, lr, Wa_acc.Data(), ba_acc.d, wsa.p, wsa.n, nullptr, &nga);
+    write_mat(out, "lsm" + sfx, lsm.Host());
+    write_mat(out, "z" + sfx, z.Host());
+    write_mat(out, "dx" + sfx, dxm.Host());
+    write_mat(out, "da" + sfx, da.Host());
+    write_mat(out, "Wl_acc" + sfx, Wl_acc.Host());
+    write_mat(out, "Wa_acc" + sfx, Wa_acc.Host());
+    write_mat(out, "ba_acc" + sfx, ba_acc.Host());
+  }
+  write_mat(out, "relu_stats", doubles_to_host((const double *)relu_stats.p, 1 + 2 * H));
+  write_mat(out, "bn_stats", doubles_to_host((const double *)bn_stats.p, 1 + 2 * H));
+  for (tdnnf_ng *g : {nga.in, nga.out, ngl.in, ngl.out}) tdnnf_ng_destroy(g);
+}
+
+// The DARTS mixing components of one bottleneck-supernet layer, wired as generate_bottleneckCB8share_onehottrain_config.py /
+// add_flopsconstraint.py do for ONE block: alpha -> ConstantFunction -> GumbelSoftmaxFlops -> (column k) CopyN ->
+// ElementwiseProduct with the block of the linear output; and the Onehot variant.  cfg = [N, C, d, k, flops_scale, temp, lr]
+static void run_mixing(const Blob &in, FILE *out) {
+  const HostMat &cfg = in.at("cfg");
+  const int N = (int)cfg.at(0), Cn = (int)cfg.at(1), d = (int)cfg.at(2);
+  const float fscale = cfg.at(4), temp = cfg.at(5), lr = cfg.at(6);
+  CuVectorStub alpha(in.at("alpha")), u(in.at("u")), flops(in.at("flops")), draw(in.at("draw"));
+  CuMatrixStub lin(in.at("lin")), dmask(in.at("dmasked")), sk(in.at("sk")), dP_in(in.at("dP"));
+  DevBytes cws(tdnnf_colreduce_workspace_bytes(N, std::max(Cn, 2 * d)));
+  CuMatrixStub A(N, Cn), P(N, Cn), cop(N, d), ew_in(N, 2 * d), masked(N, d);
+  ConstantFunctionPropagate(alpha.d, &A, nullptr);
+  SoftmaxFlopsPropagate(A, u.d, temp, &P, nullptr);
+  CopyNPropagate(sk, 1.0f, &cop, nullptr);
+  {  // Append(copyn, linear block) is descriptor plumbing: two strided copies on the caller's side
+    HIPCK(hipMemcpy2D(ew_in.Data(), sizeof(float) * ew_in.Stride(), cop.Data(), sizeof(float) * cop.Stride(), sizeof(float) * d, N, hipMemcpyDeviceToDevice));
+    HIPCK(hipMemcpy2D(ew_in.Data() + d, sizeof(float) * ew_in.Stride(), lin.Data(), sizeof(float) * lin.Stride(), sizeof(float) * d, N, hipMemcpyDeviceToDevice));
+  }
+  ElementwiseProductPropagate(ew_in, d, &masked, nullptr);
+  CuMatrixStub d_ew(N, 2 * d), d_sk(N, 1), dA(N, Cn);
+  ElementwiseProductBackprop(ew_in, dmask, d, &d_ew, nullptr);
+  CuMatrixStub d_cop(N, d);
+  HIPCK(hipMemcpy2D(d_cop.Data(), sizeof(float) * d_cop.Stride(), d_ew.Data(), sizeof(float) * d_ew.Stride(), sizeof(float) * d, N, hipMemcpyDeviceToDevice));
+  CopyNBackprop(d_cop, 1.0f, &d_sk, nullptr);
+  SoftmaxFlopsBackprop(P, &dP_in, fscale, flops.d, Cn, temp, &dA, nullptr);
+  CuVectorStub alpha_acc(Cn), onehot_acc(Cn);
+  ConstantFunctionBackprop(dA, lr, alpha_acc.d, cws.p, cws.n, nullptr);
+  CuMatrixStub oh(N, Cn);
+  OnehotPropagate(draw.d, &oh, nullptr);
+  OnehotBackprop(dP_in, lr, onehot_acc.d, cws.p, cws.n, nullptr);
+  write_mat(out, "P", P.Host());
+  write_mat(out, "masked", masked.Host());
+  write_mat(out, "d_ew", d_ew.Host());
+  write_mat(out, "d_sk", d_sk.Host());
+  write_mat(out, "dA", dA.Host());
+  write_mat(out, "dP_after", dP_in.Host());
+  write_mat(out, "alpha_acc", alpha_acc.Host());
+  write_mat(out, "onehot", oh.Host());
+  write_mat(out, "onehot_acc", onehot_acc.Host());
+}
+
+int main(int argc, char **argv) {
+  if (argc != 4) {
+    std::fprintf(stderr, "usage: adapter_driver tdnn|stack|mixing in.bin out.bin\n");
+    return 2;
+  }
+  try {
+    Blob in = read_blob(argv[2]);
+    FILE *out = std::fopen(argv[3], "wb");
+    if (!out) { std::perror(argv[3]); return 2; }
+    const std::string what = argv[1];
+    if (what == "tdnn") run_tdnn(in, out);
+    else if (what == "stack") run_stack(in, out);
+    else if (what == "mixing") run_mixing(in, out);
+    else return 2;
+    std::fclose(out);
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "adapter_driver: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -21,6 +21,50 @@ def decision(step, k):
     return (z ^ (z >> 31)) >> 8
 
 
+def component_table(cfg):
+    """The trainer's component table (name, offset into the flat parameter vector, shape, optimizer settings) for a
+    NetConfig, derived here independently of the library (which reports its own through tdnnf_net_component_info; the
+    -m gpu tests hold the two equal).  nnet3 config order: lda, tdnn1.affine, per tdnnf layer [X.softmax | X.alpha,]
+    X.linear, X.affine, prefinal-l, per head prefinal-H.affine, prefinal-H.linear, output[-xent].affine
+    (run_tdnn_fbk_40_iv_sp_7q.sh:160-186; generate_config.py:25-26 forces the DARTS bias on;
+    generate_bottleneckCB8share_onehottrain_config.py:10-38 adds the C-vector components).  Returns (components, num_params)."""
+    comps, begin = [], 0
+    lda_dim = 3 * cfg.feat_dim + cfg.ivector_dim
+    Hd, S, Kd, C_bn = cfg.hidden_dim, cfg.prefinal_small_dim, int(cfg.darts_num_offsets), int(cfg.bn_num_choices)
+
+    def add(name, rows, cols, hb, lrf=1.0, l2=None, mc=None, orth=0.0, num_alpha=0, plain=False):
+        nonlocal begin
+        comps.append(dict(name=name, begin=begin, rows=rows, cols=cols, has_bias=hb, lr_factor=lrf,
+                          l2=float(np.float32(cfg.l2_hidden if l2 is None else l2)),
+                          max_change=float(np.float32(cfg.max_change_hidden if mc is None else mc)),
+                          orthonormal=orth, num_alpha=num_alpha, plain=plain))
+        begin = (begin + rows * cols + num_alpha + (rows if hb else 0) + 3) // 4 * 4
+
+    add("lda", lda_dim, lda_dim, 1, lrf=0.0, l2=0.0, mc=0.0)
+    add("tdnn1.affine", Hd, lda_dim, 1)
+    for i in range(cfg.num_layers):
+        nm = f"tdnnf{i + 2}"
+        a = cfg.offset_left[i] if cfg.use_layer_offsets else cfg.time_stride[i]
+        b = cfg.offset_right[i] if cfg.use_layer_offsets else cfg.time_stride[i]
+        Kl, Ka = (Kd, Kd) if Kd >= 2 else (2 if a > 0 else 1, 2 if b > 0 else 1)
+        if C_bn:
+            add(nm + (".softmax" if cfg.bn_mode == 0 else ".alpha"), C_bn, 1, 0, l2=0.0, mc=0.0, plain=True)
+        add(nm + ".linear", cfg.bottleneck_dim[i], Kl * Hd, 1 if Kd >= 2 else 0, orth=0.0 if Kd >= 2 else -1.0, num_alpha=Kd if Kd >= 2 else 0)
+        add(nm + ".affine", Hd, Ka * cfg.bottleneck_dim[i], 1, num_alpha=Kd if Kd >= 2 else 0)
+    add("prefinal-l", S, Hd, 0, orth=-1.0)
+    for h, hn in enumerate(("chain", "xent")):
+        add(f"prefinal-{hn}.affine", Hd, S, 1)
+        add(f"prefinal-{hn}.linear", S, Hd, 0, orth=-1.0)
+        lrf = float(np.float32(0.5) / np.float32(cfg.xent_regularize)) if h == 1 and cfg.xent_regularize > 0 else 1.0
+        add("output.affine" if h == 0 else "output-xent.affine", cfg.num_pdfs, S, 1, lrf=lrf, l2=cfg.l2_output, mc=cfg.max_change_output)
+    if cfg.cv_update:  # run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-142
+        for c in comps:
+            c["lr_factor"] = 1.0 if c["plain"] else (float(np.float32(1.0e-4)) if c["num_alpha"] > 0 else 0.0)
+    for c in comps:
+        del c["plain"]
+    return comps, begin
+
+
 class OracleNet:
     def __init__(self, pkg, cfg, components, fast=False):
         self.pkg, self.cfg = pkg, cfg
@@ -325,11 +369,32 @@ class OracleNet:
         return (tau[:, None] * self.B + np.arange(self.B)[None, :]).ravel()
 
     # ------------------------------------------------------------ one minibatch
-    def forward_backward(self, params, feats, ivectors, den, sup, step=0, fixed_xent_post=None, forward_only=False, draws=None):
+    def forward_backward(self, params, feats, ivectors, den, sup, step=0, fixed_xent_post=None, forward_only=False, draws=None, relu_like=None):
         cfg, B, Lb = self.cfg, self.B, self.L
         p = params
         grads = np.zeros_like(p)
         acts = {}
+        self.relu_ties = {}
+
+        def relu_of(name, a):
+            """ReLU.  relu_like (optional): {name: another implementation's ReLU output of the same matrix}.  A pre-activation
+            within rounding of zero comes out 0 on one side and ~1e-8 on the other; the forward values agree, but the
+            derivative mask flips, and ONE flipped element of typical size moves the derivative's L2 norm by ~1/sqrt(#elements)
+            (1e-3 at 10^6 elements).  Such ties are not a difference in arithmetic: they are taken over from relu_like
+            (only where this side's pre-activation is itself within rounding of zero) and counted in self.relu_ties."""
+            r = np.maximum(a, 0)
+            if relu_like is not None and name in relu_like:
+                other = relu_like[name]
+                mism = (r > 0) != (other > 0)
+                n = int(mism.sum())
+                if n:
+                    tol = 1e-4 * float(np.sqrt((a.astype(np.float64) ** 2).mean()))  # forward values agree to ~1e-5 of the rms by the last layers
+                    worst = float(np.abs(a[mism]).max())
+                    assert worst <= tol, "%s: ReLU masks differ at %d elements whose pre-activations are NOT ties (|a| up to %.3e, tolerance %.3e)" % (name, n, worst, tol)
+                    r[mism] = other[mism]
+                self.relu_ties[name] = n
+            return r
+
         g0 = self.g_lda
         N0 = g0[2] * B
         fd = cfg.feat_dim
@@ -346,7 +411,7 @@ class OracleNet:
         W1, b1 = np.ascontiguousarray(self.W(p, "tdnn1.affine")), np.ascontiguousarray(self.b(p, "tdnn1.affine"))
         t1 = np.zeros((N0, cfg.hidden_dim), F)
         Lb.oracle_affine_propagate(ora.omat(lda), ora.fptr(W1), W1.shape[1], ora.fptr(b1), W1.shape[0], ora.omat(t1))
-        t1_relu = np.maximum(t1, 0)
+        t1_relu = relu_of("tdnn1.relu", t1)
         t1_bn, t1_memo = self._bn_fwd("tdnn1", t1_relu)
         masks = self._dropout_masks(draws) if draws is not None else None
         t1_bn_pre = t1_bn
@@ -379,7 +444,7 @@ class OracleNet:
                 lin_used, arch = self._arch_fwd(p, nm, lin, draws, per * i)
             aff_in = self._to_rho(lin_used, rho) if rho > 1 else lin_used
             aff = self._tdnn_fwd(aff_in, Waff, baff, aff_off, Ly["lin"], Ly["out"], eff=da["eff"] if da else None)
-            relu = np.maximum(aff, 0)
+            relu = relu_of(nm + ".relu", aff)
             bn, memo = self._bn_fwd(nm, relu)
             bn_pre = bn
             if masks is not None:
@@ -403,7 +468,7 @@ class OracleNet:
             Wo, bo = np.ascontiguousarray(self.W(p, on)), np.ascontiguousarray(self.b(p, on))
             a = np.zeros((No, Wa.shape[0]), F)
             Lb.oracle_affine_propagate(ora.omat(pl), ora.fptr(Wa), Wa.shape[1], ora.fptr(ba), Wa.shape[0], ora.omat(a))
-            ar = np.maximum(a, 0)
+            ar = relu_of(f"prefinal-{hn}.relu", a)
             b1o, m1 = self._bn_fwd(hn + "1", ar)
             lo = np.zeros((No, Wn.shape[0]), F)
             Lb.oracle_affine_propagate(ora.omat(b1o), ora.fptr(Wn), Wn.shape[1], None, Wn.shape[0], ora.omat(lo))
@@ -491,8 +556,12 @@ class OracleNet:
             d_b1 = affine_bwd(Hd["b1"], d_lo, Hd["Wn"], f"prefinal-{Hd['hn']}.linear")
             d_ar = self._bn_bwd(Hd["b1"], d_b1, Hd["m1"])
             d_a = relu_bwd("head" + Hd["hn"], Hd["ar"], d_ar)
+            hname = f"prefinal-{Hd['hn']}"  # derivatives by the names tdnnf_net_set_capture keeps them under
+            acts[hname + ".batchnorm2.deriv"], acts[hname + ".linear.deriv"] = d_b2, d_lo
+            acts[hname + ".batchnorm1.deriv"], acts[hname + ".affine.deriv"] = d_b1, d_a
             d = affine_bwd(pl, d_a, Hd["Wa"], f"prefinal-{Hd['hn']}.affine")
             d_pl = d if d_pl is None else (d_pl + d).astype(F)
+        acts["output-xent.deriv"], acts["prefinal-l.deriv"] = dlsm, d_pl
         d_cur = affine_bwd(prev, d_pl, Wpl, "prefinal-l")
         for i in reversed(range(len(self.layers))):
             Ly, st = self.layers[i], store[i]
@@ -500,6 +569,7 @@ class OracleNet:
             d_bn = d_cur if masks is None else (d_cur * self._mask_rows(masks[i + 1], d_cur.shape[0])).astype(F)
             d_relu = self._bn_bwd(st["bn"], d_bn, st["memo"])
             d_aff = relu_bwd(nm, st["relu"], d_relu)
+            acts[nm + ".noop.deriv"], acts[nm + ".affine.deriv"] = d_cur, d_aff
             Wg, bgv = np.ascontiguousarray(Gw(nm + ".affine")), Gb(nm + ".affine")
             bg = np.ascontiguousarray(bgv)
             da, dl = st["da"], st["dl"]
@@ -514,6 +584,7 @@ class OracleNet:
             if st["arch"] is not None:
                 an = nm + (".softmax" if cfg.bn_mode == 0 else ".alpha")
                 d_lin = self._arch_bwd(nm, st["arch"], d_lin, Gw(an).reshape(-1))
+            acts[nm + ".linear.deriv"] = d_lin
             Wg = np.ascontiguousarray(Gw(nm + ".linear"))
             blin = np.ascontiguousarray(Gb(nm + ".linear")) if dl else None  # DARTS .linear: inert bias, still updated
             d_in = self._tdnn_bwd(st["inp"], d_lin, st["Wlin"], Wg, blin, st["lin_off"], Ly["inn"], Ly["lin"],

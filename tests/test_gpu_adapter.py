@@ -1,0 +1,227 @@
+"""-m gpu: the Kaldi-side adapter (include/tdnnf_nnet3_adapter.h) exercised from C++.
+
+tests/adapter_driver.cc is compiled against the adapter header with a CuMatrixBase<float> stand-in over hipMalloc memory
+and drives every component family of the hot path the way the edited Propagate / Backprop bodies of INTEGRATION.md would,
+including the natural-gradient branch every recipe takes (UpdateNaturalGradient nnet-tdnn-component.cc:457-626,
+NaturalGradientAffineComponent::Update nnet-simple-component.cc:2980-3024).  The outputs are compared with the oracle's
+literal formulation."""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.gpu_util import F, rel_l2
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_blob(path, arrays):
+    with open(path, "wb") as f:
+        for name, a in arrays.items():
+            a = np.atleast_2d(np.asarray(a, F))
+            f.write(struct.pack("<i", len(name)) + name.encode() + struct.pack("<ii", *a.shape) + np.ascontiguousarray(a).tobytes())
+
+
+def read_blob(path):
+    out, raw, o = {}, open(path, "rb").read(), 0
+    while o < len(raw):
+        n, = struct.unpack_from("<i", raw, o)
+        name = raw[o + 4:o + 4 + n].decode()
+        r, c = struct.unpack_from("<ii", raw, o + 4 + n)
+        o += 12 + n
+        out[name] = np.frombuffer(raw, F, r * c, o).reshape(r, c).copy()
+        o += 4 * r * c
+    return out
+
+
+@pytest.fixture(scope="module")
+def driver(pkg, tmp_path_factory):
+    exe = tmp_path_factory.mktemp("adapter") / "adapter_driver"
+    lib_dir = os.path.dirname(pkg.hipabi.LIB_PATH)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "adapter_driver.cc"),
+                           "-L", lib_dir, "-ltdnnf_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+
+    def run(what, arrays, tmp_path):
+        fin, fout = tmp_path / (what + "_in.bin"), tmp_path / (what + "_out.bin")
+        write_blob(fin, arrays)
+        p = subprocess.run([str(exe), what, str(fin), str(fout)], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        return read_blob(fout)
+
+    return run
+
+
+def _rand(rng, *shape):
+    return rng.standard_normal(shape).astype(F)
+
+
+def _ng_update(L, ora, X, dy, ngi, ngo, lr, Wacc, bacc):
+    """NaturalGradientAffineComponent::Update on an already spliced X (with the ones column when bacc is given)"""
+    Y = dy.copy()
+    a, b = C.c_float(1.0), C.c_float(1.0)
+    L.oracle_ng_precondition(ngi, ora.omat(X), C.byref(a))
+    L.oracle_ng_precondition(ngo, ora.omat(Y), C.byref(b))
+    sc = F(a.value * b.value) * F(lr)
+    nW = Wacc.shape[1]
+    Xw = np.ascontiguousarray(X[:, :nW])
+    L.oracle_affine_update_simple(ora.omat(Xw), ora.omat(Y), float(sc), ora.fptr(Wacc), nW, None)
+    if bacc is not None:
+        bacc += (sc * (Y.astype(np.float64) * X[:, -1:].astype(np.float64)).sum(0)).astype(F)
+
+
+@pytest.mark.parametrize("flags", [-1, 0, 1 | 16, 4], ids=["plain-TdnnComponent", "darts-softmax", "darts-gumbel-updatealpha", "darts-uniform-pretrain"])
+def test_tdnn_components_through_the_adapter(driver, ora, pkg, tmp_path, flags):
+    L = ora.lib()
+    rng = np.random.default_rng(50 + flags)
+    darts = flags >= 0
+    offs = [0, 1, 2] if darts else [-3, 0]
+    K, B, nt, Di, Do, steps, lr, temp = len(offs), 8, 20, 48, 64, 3, 0.02, 0.8
+    rho, ro, rows_in, N = pkg.synth.tdnn_indexes(offs, nt, B)
+    W = (_rand(rng, Do, K * Di) / np.sqrt(K * Di)).astype(F)
+    bias = _rand(rng, (K if darts else 0) + Do) * 0.5
+    arrays = {"cfg": [K, Di, Do, rho, flags, temp, lr, steps, float(offs[1] > 0)] + [float(v) for v in ro], "W": W, "bias": bias}
+    bx, by = _rand(rng, 5, Di), _rand(rng, 6, Do)
+    data = []
+    for t in range(steps):
+        x = (_rand(rng, rows_in, 5) @ bx + 0.4 * _rand(rng, rows_in, Di)).astype(F)
+        dy = (_rand(rng, N, 6) @ by + 0.4 * _rand(rng, N, Do)).astype(F)
+        draws = rng.uniform(0.05, 0.95, K + 1).astype(F)
+        arrays.update({f"x{t}": x, f"dy{t}": dy, f"draws{t}": draws})
+        data.append((x, dy, draws))
+    got = driver("tdnn", arrays, tmp_path)
+    Dx = K * Di + 1
+    ngi, ngo = L.oracle_ng_create(min(20, (Dx + 1) // 2), 4, 2000.0, 4.0), L.oracle_ng_create(min(80, (Do + 1) // 2), 4, 2000.0, 4.0)
+    share = 0 if offs[1] > 0 else K - 1
+    for t, (x, dy, draws) in enumerate(data):
+        coef = eff = None
+        if darts:
+            coef, eff = np.zeros(K, F), np.zeros(K, F)
+            la = np.ascontiguousarray(bias[:K])
+            L.oracle_tdnn_darts_coef(ora.fptr(la), K, flags, temp, ora.fptr(np.ascontiguousarray(draws[:K])), float(draws[K]), ora.fptr(coef))
+            L.oracle_tdnn_darts_effective_coef(ora.fptr(coef), K, flags, share, ora.fptr(eff))
+            assert np.allclose(got[f"memo{t}"].ravel(), np.concatenate([coef, eff]), rtol=1e-5, atol=1e-7)
+        real_bias = np.ascontiguousarray(bias[K:] if darts else bias)
+        y = np.zeros((N, Do), F)
+        # DARTS: bias rows only when offsets[1] > 0 (here: yes); plain: always
+        L.oracle_tdnn_propagate(ora.omat(x), ora.fptr(W), K * Di, Do, Di, K, rho, ora.iptr(ro), ora.fptr(real_bias), ora.fptr(eff) if darts else None, 1, ora.omat(y))
+        assert rel_l2(got[f"y{t}"], y) < 2e-5
+        dx = np.zeros((rows_in, Di), F)
+        L.oracle_tdnn_backprop_data(ora.omat(dy), ora.fptr(W), K * Di, Do, Di, K, rho, ora.iptr(ro), ora.fptr(eff) if darts else None, ora.omat(dx))
+        assert rel_l2(got[f"dx{t}"], dx) < 2e-5
+        W_acc, b_acc = np.zeros_like(W), np.zeros_like(bias)
+        if darts:
+            s = np.zeros(K)
+            if not (flags & 4):
+                L.oracle_tdnn_darts_tap_dots(ora.omat(x), ora.omat(dy), ora.fptr(W), K * Di, Do, Di, K, rho, ora.iptr(ro), ora.dptr(s))
+            aacc = np.zeros(K, F)
+            L.oracle_tdnn_darts_alpha_update(ora.dptr(s), ora.fptr(coef), K, flags, share, temp, lr, ora.fptr(aacc))
+            b_acc[:K] = aacc
+        X = np.zeros((N, Dx), F)
+        L.oracle_tdnn_splice(ora.omat(x), N, Di, K, rho, ora.iptr(ro), ora.fptr(eff) if darts else None, 1, ora.omat(X))
+        bview = np.zeros(Do, F)
+        _ng_update(L, ora, X, dy, ngi, ngo, lr, W_acc, bview)
+        b_acc[(K if darts else 0):] = bview
+        assert rel_l2(got[f"W_acc{t}"], W_acc) < 5e-3, (t, rel_l2(got[f"W_acc{t}"], W_acc))
+        assert rel_l2(got[f"b_acc{t}"].ravel()[(K if darts else 0):], bview) < 5e-3
+        if darts:
+            assert rel_l2(got[f"b_acc{t}"].ravel()[:K], b_acc[:K]) < 1e-4 or not np.any(b_acc[:K])
+    L.oracle_ng_destroy(ngi)
+    L.oracle_ng_destroy(ngo)
+
+
+def test_affine_relu_batchnorm_linear_logsoftmax_through_the_adapter(driver, ora, tmp_path):
+    L = ora.lib()
+    rng = np.random.default_rng(77)
+    N, Di, H, P, steps, lr, repair = 384, 40, 96, 50, 3, 0.05, 1e-3
+    Wa, ba, Wl = (_rand(rng, H, Di) / np.sqrt(Di)).astype(F), _rand(rng, H), (_rand(rng, P, H) / np.sqrt(H)).astype(F)
+    ba[:4] = -30.0  # dead units: self-repair has something to do
+    arrays = {"cfg": [steps, lr, repair], "Wa": Wa, "ba": ba, "Wl": Wl}
+    data = []
+    for t in range(steps):
+        x, d = _rand(rng, N, Di), _rand(rng, N, P)
+        arrays.update({f"x{t}": x, f"d{t}": d})
+        data.append((x, d))
+    got = driver("stack", arrays, tmp_path)
+    nga = (L.oracle_ng_create(min(20, (Di + 2) // 2), 4, 2000.0, 4.0), L.oracle_ng_create(min(80, (H + 1) // 2), 4, 2000.0, 4.0))
+    ngl = (L.oracle_ng_create(min(20, (H + 1) // 2), 4, 2000.0, 4.0), L.oracle_ng_create(min(80, (P + 1) // 2), 4, 2000.0, 4.0))
+    vs, ds, cnt = np.zeros(H), np.zeros(H), C.c_double(0.0)
+    bcnt, bsum, bsq = C.c_double(0.0), np.zeros(H), np.zeros(H)
+    for t, (x, d) in enumerate(data):
+        a = np.zeros((N, H), F)
+        L.oracle_affine_propagate(ora.omat(x), ora.fptr(Wa), Di, ora.fptr(ba), H, ora.omat(a))
+        r = np.maximum(a, 0)
+        L.oracle_relu_store_stats(ora.omat(r), ora.dptr(vs), ora.dptr(ds), C.byref(cnt))
+        z, memo = np.zeros_like(r), np.zeros((5, H), F)
+        L.oracle_batchnorm_propagate(ora.omat(r), 1e-3, 1.0, ora.omat(z), ora.fptr(memo))
+        L.oracle_batchnorm_store_stats(ora.fptr(memo), H, N, C.byref(bcnt), ora.dptr(bsum), ora.dptr(bsq))
+        l, lsm = np.zeros((N, P), F), np.zeros((N, P), F)
+        L.oracle_affine_propagate(ora.omat(z), ora.fptr(Wl), H, None, P, ora.omat(l))
+        L.oracle_log_softmax_propagate(ora.omat(l), ora.omat(lsm))
+        assert rel_l2(got[f"z{t}"], z) < 2e-5 and rel_l2(got[f"lsm{t}"], lsm) < 2e-5
+        dl = np.zeros_like(d)
+        L.oracle_log_softmax_backprop(ora.omat(lsm), ora.omat(d), ora.omat(dl))
+        dz = np.zeros((N, H), F)
+        L.oracle_affine_backprop(ora.omat(dl), ora.fptr(Wl), H, H, ora.omat(dz))
+        Wl_acc = np.zeros_like(Wl)
+        _ng_update(L, ora, z.copy(), dl, ngl[0], ngl[1], lr, Wl_acc, None)
+        dr = np.zeros_like(dz)
+        L.oracle_batchnorm_backprop(ora.omat(z), ora.omat(dz), 1.0, ora.fptr(memo), ora.omat(dr))
+        da = ((r > 0) * dr).astype(F)
+        L.oracle_relu_repair(ora.dptr(ds), cnt.value, H, repair, 0.05, 0.95, ora.omat(da))
+        assert rel_l2(got[f"da{t}"], da) < 5e-5
+        dx = np.zeros((N, Di), F)
+        L.oracle_affine_backprop(ora.omat(da), ora.fptr(Wa), Di, Di, ora.omat(dx))
+        assert rel_l2(got[f"dx{t}"], dx) < 5e-5
+        Wa_acc, ba_acc = np.zeros_like(Wa), np.zeros(H, F)
+        X = np.ones((N, Di + 1), F)
+        X[:, :Di] = x
+        _ng_update(L, ora, X, da, nga[0], nga[1], lr, Wa_acc, ba_acc)
+        assert rel_l2(got[f"Wl_acc{t}"], Wl_acc) < 5e-3, t
+        assert rel_l2(got[f"Wa_acc{t}"], Wa_acc) < 5e-3, t
+        assert rel_l2(got[f"ba_acc{t}"].ravel(), ba_acc) < 5e-3, t
+    assert rel_l2(got["relu_stats"].ravel(), np.concatenate([[cnt.value], vs, ds])) < 1e-5
+    assert rel_l2(got["bn_stats"].ravel(), np.concatenate([[bcnt.value], bsum, bsq])) < 1e-5
+    for g in nga + ngl:
+        L.oracle_ng_destroy(g)
+
+
+def test_darts_mixing_components_through_the_adapter(driver, ora, tmp_path):
+    L = ora.lib()
+    rng = np.random.default_rng(91)
+    N, Cn, d, temp, fscale, lr = 600, 8, 40, 0.7, 2.0, 0.1
+    alpha, u = _rand(rng, Cn) * 0.6, rng.uniform(0.05, 0.95, Cn).astype(F)
+    flops = -np.cumsum([25, 25, 30, 20, 20, 40, 40, 40]).astype(F)
+    lin, dmasked, sk, dP = _rand(rng, N, d), _rand(rng, N, d), rng.uniform(0.1, 1.0, (N, 1)).astype(F), _rand(rng, N, Cn)
+    draw = np.asarray([0.4], F)
+    got = driver("mixing", {"cfg": [N, Cn, d, 0, fscale, temp, lr], "alpha": alpha, "u": u, "flops": flops, "draw": draw, "lin": lin,
+                            "dmasked": dmasked, "sk": sk, "dP": dP}, tmp_path)
+    A, P = np.zeros((N, Cn), F), np.zeros((N, Cn), F)
+    L.oracle_constant_function_propagate(ora.fptr(alpha), ora.omat(A))
+    L.oracle_softmax_flops_propagate(ora.omat(A), ora.fptr(u), temp, ora.omat(P))
+    assert rel_l2(got["P"], P) < 1e-5
+    cop = np.zeros((N, d), F)
+    L.oracle_copyn_propagate(ora.omat(sk), 1.0, ora.omat(cop))
+    ew_in = np.ascontiguousarray(np.concatenate([cop, lin], axis=1))
+    masked = np.zeros((N, d), F)
+    L.oracle_elementwise_product_propagate(ora.omat(ew_in), d, ora.omat(masked))
+    assert rel_l2(got["masked"], masked) < 1e-6
+    d_ew = np.zeros((N, 2 * d), F)
+    L.oracle_elementwise_product_backprop(ora.omat(ew_in), ora.omat(dmasked), d, ora.omat(d_ew))
+    assert rel_l2(got["d_ew"], d_ew) < 1e-6
+    d_sk, d_cop = np.zeros((N, 1), F), np.ascontiguousarray(d_ew[:, :d])  # (named: omat() keeps no reference)
+    L.oracle_copyn_backprop(ora.omat(d_cop), 1.0, ora.omat(d_sk))
+    assert rel_l2(got["d_sk"], d_sk) < 1e-5
+    dP2, dA = dP.copy(), np.zeros((N, Cn), F)
+    L.oracle_softmax_flops_backprop(ora.omat(P), ora.omat(dP2), fscale, ora.fptr(flops), Cn, temp, ora.omat(dA))
+    assert rel_l2(got["dP_after"], dP2) < 1e-6 and rel_l2(got["dA"], dA) < 1e-4
+    acc = np.zeros(Cn, F)
+    L.oracle_constant_function_backprop(ora.omat(dA), lr, ora.fptr(acc))
+    assert rel_l2(got["alpha_acc"].ravel(), acc) < 1e-4
+    oh = np.zeros((N, Cn), F)
+    L.oracle_onehot_propagate(float(draw[0]), ora.omat(oh))
+    assert np.array_equal(got["onehot"], oh) and oh.sum() == N
+    assert rel_l2(got["onehot_acc"].ravel(), lr * dP2.astype(np.float64).sum(0)) < 1e-5

@@ -1,0 +1,244 @@
+"""-m gpu: the BASELINE configs at their REAL dimensions.
+
+The whole-net cases of tests/test_gpu_net.py are toys (hidden <= 192); kernel selection in the library depends on
+the sizes (128 x 160 against 128 x 128 tiles, split-K tails and their reduces, the fused BatchNorm statistics of the
+GEMM epilogue, the fused natural-gradient sweep, persistent against wide denominator), so the code paths bench.py
+runs are pinned here:
+
+  (a) full-width nets (hidden 1536, bottleneck 160 / 240 / 320, 14 layers, 6034 pdfs, 4 000-state denominator graph) at
+      chunk 150 x 8 sequences against the double-accumulating oracle: objective 1e-4 relative, gradient L2 1e-3
+      (5e-3 with natural gradient: the preconditioners' eigen-decompositions feed small differences back), per component.
+      Graphs: run_tdnn_fbk_40_iv_sp_7q.sh:160-186, run_tdnn_7q_fbk_40_manual.sh --offset 6,
+      run_TDNN_DARTSV3_fbk_stride_pretrain.sh:143-156 (K = 7, W 160 x 10752),
+      generate_bottleneckCB8share_onehottrain_config.py:24-38 (240 wide) and BASELINE configs[4] (320 wide).
+  (b) BASELINE configs[0] at its stated size: 128 x 150 frames, 40 -> 160 -> 1536, offsets {-1, 0, 1}.
+  (c) size-independent properties at chunk 1500 x 128 sequences (the bench shape), where the oracle would take hours.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import F, Hip, dev, host, rel_l2
+from tests.oracle_net import OracleNet, component_table
+
+pytestmark = pytest.mark.gpu
+
+BN8 = [25, 25, 30, 20, 20, 40, 40, 40]  # generate_bottleneckCB8share_onehottrain_config.py:24-38
+FULL = [
+    ("7q", dict()),
+    ("7q-NG", dict(use_natural_gradient=1)),
+    ("manual-offset6-NG", dict(strides=[1, 1, 1, 0] + [6] * 10, use_natural_gradient=1)),
+    ("darts-offset-k7-pretrain-NG", dict(darts_num_offsets=7, darts_flags=4, use_natural_gradient=1)),
+    ("darts-offset-k7-gumbel-cvupdate-flags", dict(darts_num_offsets=7, darts_flags=1 | 16, darts_temp_proportion=0.6)),
+    ("bn-supernet-240-onehot-NG", dict(bn_choice_dims=BN8, bn_mode=0, use_natural_gradient=1)),
+    ("bn-supernet-320-gumbel-flops", dict(bn_choice_dims=[80, 80, 80, 80], bn_mode=2, bn_flops_scale=1.0, bn_temp_proportion=0.8)),
+]
+
+
+def full_size_egs(pkg, net, cfg, den_states=4000, seed=0):
+    feats, iv = pkg.trainer.synthetic_egs(net, seed=100 + seed)
+    den = pkg.synth.make_den_graph(den_states, cfg.num_pdfs, mean_out_degree=12.0, seed=1)
+    sup = pkg.synth.make_supervision_from_den(den, cfg.num_sequences, cfg.frames_per_chunk // 3, num_paths=2, seed=200 + seed)
+    return feats, iv, den, sup
+
+
+def relu_outputs(net, cfg):
+    """Every ReLU output of the step the net just ran, by the oracle's names: the oracle takes the derivative masks of
+    elements whose pre-activation is within rounding of zero from here (tests/oracle_net.py: relu_of)."""
+    names = ["tdnn1.relu"] + ["tdnnf%d.relu" % (l + 2) for l in range(cfg.num_layers)] + ["prefinal-chain.relu", "prefinal-xent.relu"]
+    return {k: host(net.activation(k)) for k in names}
+
+
+def component_slice(c):
+    return slice(c["begin"], c["begin"] + c["rows"] * c["cols"] + c["num_alpha"] + (c["rows"] if c["has_bias"] else 0))
+
+
+@pytest.mark.parametrize("name,kw", FULL, ids=[c[0] for c in FULL])
+def test_full_width_net_step_matches_oracle(pkg, name, kw):
+    cfg = pkg.trainer.make_config(frames_per_chunk=150, num_sequences=8, **kw)
+    assert cfg.hidden_dim == 1536 and cfg.num_pdfs == 6034 and cfg.num_layers == 14
+    net = pkg.trainer.ChainNet(cfg)
+    # the oracle's own component table (derived from the config alone) is the library's
+    table, num_params = component_table(cfg)
+    assert num_params == net.num_params
+    for a, b in zip(table, net.components):
+        assert all(a[k] == b[k] for k in ("name", "begin", "rows", "cols", "has_bias", "num_alpha", "orthonormal")), (a, b)
+        assert all(abs(a[k] - b[k]) <= 1e-6 * abs(b[k]) for k in ("lr_factor", "l2", "max_change")), (a, b)
+    params = net.init_params_numpy(seed=0, output_stddev=0.05)
+    rng = np.random.default_rng(17)
+    for c in net.components:  # non-trivial architecture parameters
+        n = c["rows"] * c["cols"]
+        if c["num_alpha"]:
+            params[c["begin"] + n:c["begin"] + n + c["num_alpha"]] = rng.standard_normal(c["num_alpha"]).astype(F) * 0.5
+        if c["name"].endswith((".alpha", ".softmax")):
+            params[c["begin"]:c["begin"] + c["rows"]] = rng.standard_normal(c["rows"]).astype(F) * 0.7
+    net.set_params(params)
+    ref = OracleNet(pkg, cfg, table)
+    assert ref.num_t_in == net.num_t_in
+    feats, iv, den, sup = full_size_egs(pkg, net, cfg)
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    fd, ivd = dev(feats), dev(iv)
+    ng = bool(cfg.use_natural_gradient)
+    for step in (0, 1):
+        draws = np.random.default_rng(100 + step).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(F)
+        net.set_random_draws(draws)
+        net.grads.zero_()
+        r = host(net.forward_backward(fd, ivd, dg, ds, step=step)).copy()
+        # (25 million ReLU elements per step: a handful of pre-activations land within rounding of zero, and one flipped
+        #  derivative mask alone moves a layer's derivative by ~1e-3 relative -- ties are taken over and counted, not compared)
+        res_ref, g_ref, acts = ref.forward_backward(params, feats, iv, den, sup, step=step, draws=draws, relu_like=relu_outputs(net, cfg))
+        ties = sum(ref.relu_ties.values())
+        assert ties <= 64, ref.relu_ties
+        for key in ["tdnn1.batchnorm", "tdnnf2.linear", "tdnnf8.noop", "tdnnf15.noop", "prefinal-l", "output", "output-xent", "output.deriv"]:
+            e = rel_l2(host(net.activation(key)), acts[key])
+            assert e < 1e-4, (key, e)
+        assert r[5] == 1.0 and r[2] == res_ref["weight"]
+        assert abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"]), (r[0], res_ref["objf"])
+        assert abs(r[6] - res_ref["xent_objf"]) < 1e-4 * abs(res_ref["xent_objf"])
+        g = host(net.grads)
+        assert np.isfinite(g).all()
+        gtol = 5e-3 if ng else 1e-3
+        assert rel_l2(g, g_ref) < gtol, rel_l2(g, g_ref)
+        for c in net.components[1:]:
+            sl = component_slice(c)
+            if np.linalg.norm(g_ref[sl]) > 0:
+                assert rel_l2(g[sl], g_ref[sl]) < 2 * gtol, (c["name"], rel_l2(g[sl], g_ref[sl]))
+        p_ref = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
+        net.update(1e-3, step=step)
+        p = host(net.params)
+        assert rel_l2(p - params, p_ref - params) < (1e-2 if ng else 2e-3), rel_l2(p - params, p_ref - params)
+        params = p_ref
+        net.set_params(params)
+    net.close()
+
+
+@pytest.mark.parametrize("K", [1, 3], ids=["affine-k1", "affine-k3"])
+def test_config0_affine_at_its_stated_size(pkg, ora, K):
+    """BASELINE configs[0], second component: in 160 -> out 1536 on 128 x 150 frames (19 200 output rows); the config text
+    leaves the affine's taps open, so both readings: one tap, and offsets {-1, 0, 1} (K*Di = 480)."""
+    hip = Hip(pkg)
+    L = ora.lib()
+    rng = np.random.default_rng(40 + K)
+    offs = [0] if K == 1 else [-1, 0, 1]
+    B, nt, Di, Do = 128, 150, 160, 1536
+    rho, ro, rows_in, N = pkg.synth.tdnn_indexes(offs, nt, B)
+    assert N == 19200
+    x = rng.standard_normal((rows_in, Di)).astype(F)
+    W = (rng.standard_normal((Do, K * Di)) / np.sqrt(K * Di)).astype(F)
+    b = rng.standard_normal(Do).astype(F)
+    dy = rng.standard_normal((N, Do)).astype(F)
+    ix = pkg.hipabi.indexes(rho, ro)
+    y_ref = np.zeros((N, Do), F)
+    L.oracle_tdnn_propagate(ora.omat(x), ora.fptr(W), K * Di, Do, Di, K, rho, ora.iptr(ro), ora.fptr(b), None, 1, ora.omat(y_ref))
+    xd, Wd, bd, dyd = dev(x), dev(W), dev(b), dev(dy)
+    yd = torch.zeros(N, Do, device="cuda")
+    hip.tdnn_propagate(C.byref(ix), xd, hip.vec(Wd), K * Di, Do, Di, hip.vec(bd), None, 1, yd, hip.stream())
+    assert rel_l2(host(yd), y_ref) < 2e-5
+    dx_ref = np.zeros((rows_in, Di), F)
+    L.oracle_tdnn_backprop_data(ora.omat(dy), ora.fptr(W), K * Di, Do, Di, K, rho, ora.iptr(ro), None, ora.omat(dx_ref))
+    dxd = torch.zeros(rows_in, Di, device="cuda")
+    hip.tdnn_backprop_data(C.byref(ix), dyd, hip.vec(Wd), K * Di, Do, Di, None, dxd, hip.stream())
+    assert rel_l2(host(dxd), dx_ref) < 2e-5
+    G_ref, gb_ref = np.zeros_like(W), np.zeros_like(b)
+    L.oracle_tdnn_update_simple(ora.omat(x), ora.omat(dy), Do, Di, K, rho, ora.iptr(ro), None, 1.0, ora.fptr(G_ref), K * Di, ora.fptr(gb_ref))
+    G, gb = torch.zeros(Do, K * Di, device="cuda"), torch.zeros(Do, device="cuda")
+    nb = hip.tdnn_update_workspace_bytes(Do, Di, K, N)
+    ws = hip.ws(nb)
+    hip.tdnn_update_simple(C.byref(ix), xd, dyd, Do, Di, None, 1.0, hip.vec(G), K * Di, hip.vec(gb), hip.vec(ws), nb, hip.stream())
+    assert rel_l2(host(G), G_ref) < 2e-5 and rel_l2(host(gb), gb_ref) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (c) properties at the bench shape: chunk 1500 x 128 sequences
+BENCH_KW = dict(frames_per_chunk=1500, num_sequences=128)
+
+
+@pytest.fixture(scope="module")
+def bench_egs(pkg):
+    cfg = pkg.trainer.make_config(**BENCH_KW)
+    net = pkg.trainer.ChainNet(pkg.trainer.make_config(frames_per_chunk=1500, num_sequences=1))  # only for the input window
+    nt = net.num_t_in
+    net.close()
+    rng = np.random.default_rng(100)
+    feats = rng.standard_normal((nt * cfg.num_sequences, cfg.feat_dim)).astype(F)
+    iv = rng.standard_normal((cfg.num_sequences, cfg.ivector_dim)).astype(F)
+    den = pkg.synth.make_den_graph(4000, cfg.num_pdfs, mean_out_degree=12.0, seed=1)
+    sup = pkg.synth.make_supervision_from_den(den, cfg.num_sequences, 500, num_paths=2, seed=200)
+    return dev(feats), dev(iv), den, sup
+
+
+def run_bench_shape(pkg, egs, steps, seed_params=0, **kw):
+    """`steps` training steps of the bench workload; returns per step (results, gradient) and the last output derivative's
+    per-frame sums."""
+    fd, ivd, den, sup = egs
+    cfg = pkg.trainer.make_config(**dict(BENCH_KW, **kw))
+    net = pkg.trainer.ChainNet(cfg)
+    net.set_params(net.init_params_numpy(seed=seed_params, output_stddev=0.05))
+    dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+    out = []
+    for i in range(steps):
+        r = host(net.forward_backward(fd, ivd, dg, ds, step=i)).copy()
+        out.append((r, net.grads.clone()))
+        net.update(2.5e-4, step=i)
+    extra = dict(deriv_row_sums=net.activation("output.deriv").double().sum(1), deriv_abs=float(net.activation("output.deriv").abs().max()))
+    net.close()
+    torch.cuda.empty_cache()
+    return out, extra
+
+
+def test_bench_shape_properties_and_reproducibility(pkg, bench_egs):
+    """T = 1500 x B = 128, natural gradient on (the bench step): finite everything, the chain derivative of every frame
+    sums to zero (numerator and denominator posteriors each sum to one per (frame, sequence)), two runs are bit-identical."""
+    a, ea = run_bench_shape(pkg, bench_egs, 3, use_natural_gradient=1)
+    b, _ = run_bench_shape(pkg, bench_egs, 3, use_natural_gradient=1)
+    for (ra, ga), (rb, gb) in zip(a, b):
+        assert ra[5] == 1.0 and np.isfinite(ra).all() and bool(torch.isfinite(ga).all())
+        assert ra[2] == 128 * 500.0
+        assert -1.0 < ra[0] / ra[2] < 0.0  # supervision paths are paths of the denominator graph: objf per frame is negative
+        assert np.array_equal(ra, rb)
+        assert torch.equal(ga, gb), "two runs of the same steps differ"
+    rs = ea["deriv_row_sums"]
+    assert rs.numel() == 128 * 500 and ea["deriv_abs"] > 1e-3
+    assert float(rs.abs().max()) < 2e-4, float(rs.abs().max())  # sum_pdf (gamma_num - gamma_den) = 1 - 1
+
+
+def test_bench_shape_fused_statistics_against_separate_passes(pkg, bench_egs, monkeypatch):
+    monkeypatch.setenv("TDNNF_NG_FUSE", "0")
+    sep, _ = run_bench_shape(pkg, bench_egs, 3, use_natural_gradient=1)
+    monkeypatch.delenv("TDNNF_NG_FUSE")
+    fus, _ = run_bench_shape(pkg, bench_egs, 3, use_natural_gradient=1)
+    for i, ((ra, ga), (rb, gb)) in enumerate(zip(fus, sep)):
+        assert abs(ra[0] - rb[0]) <= 1e-5 * (abs(rb[3]) + abs(rb[4])), (i, ra, rb)
+        e = float((ga - gb).double().norm() / gb.double().norm())
+        assert e < 2e-4, (i, e)
+
+
+def test_bench_shape_split_bf16_six_products_against_f32(pkg, bench_egs):
+    """gemm_precision 2 (three bf16 planes, six products) is held to the f32 bars against the exact-f32 path at full size."""
+    f32, _ = run_bench_shape(pkg, bench_egs, 1)
+    x6, _ = run_bench_shape(pkg, bench_egs, 1, gemm_precision=2)
+    (ra, ga), (rb, gb) = x6[0], f32[0]
+    assert abs(ra[0] - rb[0]) < 1e-4 * abs(rb[0]), (ra[0], rb[0])
+    e = float((ga - gb).double().norm() / gb.double().norm())
+    assert e < 1e-3, e
+
+
+def test_bench_shape_denominator_forms_agree(pkg, bench_egs):
+    """Persistent (LDS-resident state vectors) against wide (one launch per frame over all sequences) denominator on the
+    bench's 4 000-state graph at 128 x 500 frames."""
+    lib = pkg.hipabi.load()
+    res = {}
+    try:
+        for mode in (1, 2):
+            pkg.hipabi.check(lib.tdnnf_chain_set_denominator_mode(mode))
+            res[mode], _ = run_bench_shape(pkg, bench_egs, 1)
+    finally:
+        pkg.hipabi.check(lib.tdnnf_chain_set_denominator_mode(0))
+    (ra, ga), (rb, gb) = res[1][0], res[2][0]
+    assert ra[5] == 1.0 and rb[5] == 1.0
+    assert abs(ra[4] - rb[4]) < 1e-6 * abs(rb[4]), (ra[4], rb[4])  # denominator log-prob
+    e = float((ga - gb).double().norm() / gb.double().norm())
+    assert e < 1e-4, e
