@@ -415,11 +415,15 @@ __global__ __launch_bounds__(256) void den_wide_gamma_kernel(DenDev g, int B, in
   }
 }
 
-__device__ __forceinline__ float log_add(float a, float b) {
+// The numerator recursion runs in the log domain, where the values grow with the frame index (log alpha ~ -8 t): at 500
+// frames a float's 24 bits leave an absolute error of ~2e-4 in the exponent of a posterior, 2e-3 in the posteriors of a
+// 1500-frame chunk (measured: frame sums of gamma_num off by up to 2.2e-3, derivative 6.8e-4 from a float64 evaluation).  Doubles:
+// one wave per sequence walks a few states per frame, the arithmetic is free.
+__device__ __forceinline__ double log_add(double a, double b) {
   if (a == -INFINITY) return b;
   if (b == -INFINITY) return a;
-  const float m = fmaxf(a, b), d = fminf(a, b) - m;
-  return m + log1pf(expf(d));
+  const double m = fmax(a, b), d = fmin(a, b) - m;
+  return m + log1p(exp(d));
 }
 
 struct SupDev {
@@ -434,7 +438,7 @@ struct SupDev {
 };
 
 // one wave per sequence.  la/lb: global scratch indexed by global state id.
-__global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, MatView xent_out, float *la, float *lb,
+__global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, MatView xent_out, double *la, double *lb,
                                                        double *num_logprob, double *xent_objf, MatView deriv,
                                                        MatView xent_deriv, float xent_scale, int phases) {
   // phases bit 0: forward-backward recursion (la, lb, total) + xent posteriors / objective;
@@ -442,37 +446,37 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
   const int s = blockIdx.x, lane = threadIdx.x, B = sp.B, T = sp.T;
   const int *fsb = sp.frame_state_begin + (size_t)s * (T + 2);
   const int s0 = sp.seq_state_begin[s], s1 = sp.seq_state_begin[s + 1];
-  float tot = -INFINITY;
+  double tot = -INFINITY;
   if (phases & 1) {
-  for (int i = s0 + lane; i < s1; i += 64) la[i] = (i == s0) ? 0.f : -INFINITY;
+  for (int i = s0 + lane; i < s1; i += 64) la[i] = (i == s0) ? 0.0 : -INFINITY;
   __syncthreads();
   for (int t = 1; t <= T; t++) {  // states entered at time t
     for (int st = fsb[t] + lane; st < fsb[t + 1]; st += 64) {
-      float v = -INFINITY;
+      double v = -INFINITY;
       for (int a = sp.in_begin[st]; a < sp.in_begin[st + 1]; a++)
-        v = log_add(v, la[sp.in_src[a]] + sp.in_lp[a] + y.data[(size_t)((t - 1) * B + s) * y.stride + sp.in_pdf[a]]);
+        v = log_add(v, la[sp.in_src[a]] + ((double)sp.in_lp[a] + (double)y.data[(size_t)((t - 1) * B + s) * y.stride + sp.in_pdf[a]]));
       la[st] = v;
     }
     __syncthreads();
   }
   for (int st = fsb[T] + lane; st < fsb[T + 1]; st += 64) {
     const float f = sp.final_logprob[st];
-    lb[st] = f;
-    if (f != -INFINITY) tot = log_add(tot, la[st] + f);
+    lb[st] = (double)f;
+    if (f != -INFINITY) tot = log_add(tot, la[st] + (double)f);
   }
   for (int o = 32; o > 0; o >>= 1) tot = log_add(tot, __shfl_xor(tot, o, 64));
   __syncthreads();
   for (int t = T - 1; t >= 0; t--) {
     for (int st = fsb[t] + lane; st < fsb[t + 1]; st += 64) {
-      float v = -INFINITY;
+      double v = -INFINITY;
       for (int a = sp.out_begin[st]; a < sp.out_begin[st + 1]; a++)
-        v = log_add(v, sp.out_lp[a] + y.data[(size_t)(t * B + s) * y.stride + sp.out_pdf[a]] + lb[sp.out_dst[a]]);
+        v = log_add(v, ((double)sp.out_lp[a] + (double)y.data[(size_t)(t * B + s) * y.stride + sp.out_pdf[a]]) + lb[sp.out_dst[a]]);
       lb[st] = v;
     }
     __syncthreads();
   }
   } else {
-    tot = (float)num_logprob[s];
+    tot = num_logprob[s];
   }
   const bool do_xent = (phases & 1) != 0, do_deriv = (phases & 2) != 0;
   // posteriors: lane = frame (distinct output rows per lane, fixed arc order -> deterministic)
@@ -482,8 +486,8 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
     for (int st = fsb[t]; st < fsb[t + 1]; st++)
       for (int a = sp.out_begin[st]; a < sp.out_begin[st + 1]; a++) {
         const int pdf = sp.out_pdf[a];
-        const float ll = sp.out_lp[a] + y.data[row * y.stride + pdf];
-        const float gam = sp.weight * expf(la[st] + ll + lb[sp.out_dst[a]] - tot);
+        const double ll = (double)sp.out_lp[a] + (double)y.data[row * y.stride + pdf];
+        const float gam = sp.weight * (float)exp(la[st] + ll + lb[sp.out_dst[a]] - tot);
         if (do_deriv && deriv.data) deriv.data[row * deriv.stride + pdf] += gam;
         if (do_xent && xent_deriv.data) xent_deriv.data[row * xent_deriv.stride + pdf] += xent_scale * gam;
         if (do_xent && xent_out.data) xo += (double)gam * (double)xent_out.data[row * xent_out.stride + pdf];
@@ -492,7 +496,7 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
   if (do_xent) {
     for (int o = 32; o > 0; o >>= 1) xo += __shfl_xor(xo, o, 64);
     if (lane == 0) {
-      num_logprob[s] = (double)tot;
+      num_logprob[s] = tot;
       xent_objf[s] = xo;
     }
   }
@@ -625,7 +629,7 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
   p.asum_floats = (size_t)B * (T + 4);  // wide: A(0..T), tot, and two rows of init-weighted beta sums
   // wide: beta_dash double buffer, partial rows, and x = exp(clamp(y)) / the derivative, sequence-minor (T x P x B)
   p.gstate_floats = p.wide ? (size_t)B * (2 * p.Hs + p.wide_blocks) + (size_t)T * g->P * B : (p.lds_state ? 0 : (size_t)B * 3 * p.Hs);
-  p.la_floats = 2 * (size_t)num_states_sup;
+  p.la_floats = 4 * (size_t)num_states_sup + 2;  // two arrays of DOUBLES (log alpha, log beta of the numerator), 8-byte aligned
   return p;
 }
 
@@ -798,7 +802,8 @@ namespace {
 struct ChainBufs {
   ChainPlan p;
   double *den_lp, *num_lp, *xent, *l2sum;
-  float *alpha, *asum, *gstate, *la, *lb;
+  float *alpha, *asum, *gstate;
+  double *la, *lb;  // numerator log alpha / log beta
 };
 ChainBufs chain_bufs(const tdnnf_den_graph *g, int B, int T, void *ws) {
   ChainBufs b;
@@ -810,8 +815,8 @@ ChainBufs chain_bufs(const tdnnf_den_graph *g, int B, int T, void *ws) {
   b.alpha = (float *)(b.l2sum + 2);
   b.asum = b.alpha + b.p.alpha_floats;
   b.gstate = b.asum + b.p.asum_floats;
-  b.la = b.gstate + b.p.gstate_floats;
-  b.lb = b.la + b.p.la_floats / 2;
+  b.la = (double *)(((uintptr_t)(b.gstate + b.p.gstate_floats) + 7) & ~(uintptr_t)7);
+  b.lb = b.la + (b.p.la_floats - 2) / 4;
   return b;
 }
 SupDev sup_dev(const tdnnf_supervision *sp) {

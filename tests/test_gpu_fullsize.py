@@ -170,9 +170,10 @@ def bench_egs(pkg):
     return dev(feats), dev(iv), den, sup
 
 
-def run_bench_shape(pkg, egs, steps, seed_params=0, **kw):
-    """`steps` training steps of the bench workload; returns per step (results, gradient) and the last output derivative's
-    per-frame sums."""
+def run_bench_shape(pkg, egs, steps, seed_params=0, update=True, keep=(), **kw):
+    """`steps` training steps of the bench workload; returns per step (results, gradient) and, of the last step, the output
+    derivative's per-frame sums and the activations named in `keep`.  update=False: the parameters stay put (the gradient
+    buffer is zeroed instead), so that every step of two variants starts from the same state."""
     fd, ivd, den, sup = egs
     cfg = pkg.trainer.make_config(**dict(BENCH_KW, **kw))
     net = pkg.trainer.ChainNet(cfg)
@@ -182,8 +183,14 @@ def run_bench_shape(pkg, egs, steps, seed_params=0, **kw):
     for i in range(steps):
         r = host(net.forward_backward(fd, ivd, dg, ds, step=i)).copy()
         out.append((r, net.grads.clone()))
-        net.update(2.5e-4, step=i)
-    extra = dict(deriv_row_sums=net.activation("output.deriv").double().sum(1), deriv_abs=float(net.activation("output.deriv").abs().max()))
+        if update:
+            net.update(2.5e-4, step=i)
+        else:
+            net.grads.zero_()
+    extra = dict(deriv_row_sums=net.activation("output.deriv").double().sum(1), deriv_abs=float(net.activation("output.deriv").abs().max()),
+                 components=net.components)
+    for k in keep:
+        extra[k] = net.activation(k)
     net.close()
     torch.cuda.empty_cache()
     return out, extra
@@ -197,33 +204,57 @@ def test_bench_shape_properties_and_reproducibility(pkg, bench_egs):
     for (ra, ga), (rb, gb) in zip(a, b):
         assert ra[5] == 1.0 and np.isfinite(ra).all() and bool(torch.isfinite(ga).all())
         assert ra[2] == 128 * 500.0
-        assert -1.0 < ra[0] / ra[2] < 0.0  # supervision paths are paths of the denominator graph: objf per frame is negative
+        assert -20.0 < ra[0] / ra[2] < 0.0  # supervision paths are paths of the denominator graph: objf per frame is negative
         assert np.array_equal(ra, rb)
         assert torch.equal(ga, gb), "two runs of the same steps differ"
     rs = ea["deriv_row_sums"]
     assert rs.numel() == 128 * 500 and ea["deriv_abs"] > 1e-3
-    assert float(rs.abs().max()) < 2e-4, float(rs.abs().max())  # sum_pdf (gamma_num - gamma_den) = 1 - 1
+    assert float(rs.abs().max()) < 1e-4, float(rs.abs().max())  # sum_pdf (gamma_num - gamma_den) = 1 - 1 on every one of the 64 000 frames
 
 
 def test_bench_shape_fused_statistics_against_separate_passes(pkg, bench_egs, monkeypatch):
+    """TDNNF_NG_FUSE=0 (the output-side statistic by its own GEMM) against the default (formed by the BatchNorm/ReLU backward
+    sweep) at the bench shape.  The parameters are held fixed, so every step of both variants sees the same activations and
+    the preconditioners evolve from the same inputs: what differs is the summation order of H = dY Wy^T."""
     monkeypatch.setenv("TDNNF_NG_FUSE", "0")
-    sep, _ = run_bench_shape(pkg, bench_egs, 3, use_natural_gradient=1)
+    sep, _ = run_bench_shape(pkg, bench_egs, 4, update=False, use_natural_gradient=1)
     monkeypatch.delenv("TDNNF_NG_FUSE")
-    fus, _ = run_bench_shape(pkg, bench_egs, 3, use_natural_gradient=1)
+    fus, _ = run_bench_shape(pkg, bench_egs, 4, update=False, use_natural_gradient=1)
+    assert torch.equal(fus[0][1], sep[0][1])  # the first minibatch initialises the preconditioners: nothing to fuse yet
     for i, ((ra, ga), (rb, gb)) in enumerate(zip(fus, sep)):
-        assert abs(ra[0] - rb[0]) <= 1e-5 * (abs(rb[3]) + abs(rb[4])), (i, ra, rb)
+        assert np.array_equal(ra, rb), (i, ra, rb)  # forward pass and objective do not depend on the switch
         e = float((ga - gb).double().norm() / gb.double().norm())
         assert e < 2e-4, (i, e)
+    assert any(not torch.equal(ga, gb) for (_, ga), (_, gb) in zip(fus[1:], sep[1:]))  # the switch did switch
 
 
 def test_bench_shape_split_bf16_six_products_against_f32(pkg, bench_egs):
-    """gemm_precision 2 (three bf16 planes, six products) is held to the f32 bars against the exact-f32 path at full size."""
-    f32, _ = run_bench_shape(pkg, bench_egs, 1)
-    x6, _ = run_bench_shape(pkg, bench_egs, 1, gemm_precision=2)
+    """gemm_precision 2 (three bf16 planes, six products) against exact f32 at the bench shape.  Forward values agree to f32
+    rounding; but with 295 million ReLU elements per full-rate layer, ~1e-7 differences in the pre-activations flip the
+    derivative mask of the few hundred elements that sit within rounding of zero, and each flip is a typical-size element of
+    the derivative (tools/fullsize_diag.py: ONE flip among 614 000 elements = 4.7e-4 of that matrix's norm).  So: the masks
+    may differ only at ties; the components between the loss and the first ReLU backward (no mask involved) are held to the
+    1e-3 bar; the whole gradient to the size of that tie noise."""
+    keep = ["tdnnf2.relu", "tdnnf9.relu", "tdnnf15.relu", "prefinal-chain.relu"]
+    f32, ef = run_bench_shape(pkg, bench_egs, 1, keep=keep)
+    x6, ex = run_bench_shape(pkg, bench_egs, 1, keep=keep, gemm_precision=2)
     (ra, ga), (rb, gb) = x6[0], f32[0]
     assert abs(ra[0] - rb[0]) < 1e-4 * abs(rb[0]), (ra[0], rb[0])
+    for k in keep:
+        a, b = ex[k], ef[k]
+        assert float((a - b).double().norm() / b.double().norm()) < 5e-5, k  # f32-equivalent arithmetic, 15 layers deep
+        mism = (a > 0) != (b > 0)
+        n, rms = int(mism.sum()), float(b.double().pow(2).mean().sqrt())
+        assert n < 2e-5 * a.numel(), (k, n)
+        if n:
+            assert float(torch.maximum(a, b)[mism].max()) < 1e-4 * rms, (k, n)  # they ARE ties
+    comps = {c["name"]: c for c in ef["components"]}
+    for name in ("output.affine", "prefinal-chain.linear", "output-xent.affine", "prefinal-xent.linear"):
+        sl = component_slice(comps[name])
+        e = float((ga[sl] - gb[sl]).double().norm() / gb[sl].double().norm())
+        assert e < 1e-3, (name, e)
     e = float((ga - gb).double().norm() / gb.double().norm())
-    assert e < 1e-3, e
+    assert e < 3e-2, e
 
 
 def test_bench_shape_denominator_forms_agree(pkg, bench_egs):
@@ -242,3 +273,36 @@ def test_bench_shape_denominator_forms_agree(pkg, bench_egs):
     assert abs(ra[4] - rb[4]) < 1e-6 * abs(rb[4]), (ra[4], rb[4])  # denominator log-prob
     e = float((ga - gb).double().norm() / gb.double().norm())
     assert e < 1e-4, e
+
+
+@pytest.mark.parametrize("mode", [1, 2], ids=["persistent", "wide"])
+def test_chain_objective_at_500_frames_matches_oracle(pkg, ora, mode):
+    """chain::ComputeChainObjfAndDeriv at the length of a 1500-frame chunk (500 output frames), 6034 pdfs, the bench's
+    4 000-state graph, supervision paths drawn from the denominator graph: errors of a log-domain recursion grow with the
+    frame index (a float numerator was 6.8e-4 off here and its frame posteriors summed to 1 +- 2.2e-3: it runs in double now)."""
+    hip = Hip(pkg)
+    L = ora.lib()
+    H, P, B, T = 4000, 6034, 8, 500
+    g = pkg.synth.make_den_graph(H, P, mean_out_degree=12.0, seed=1)
+    sup = pkg.synth.make_supervision_from_den(g, B, T, num_paths=2, seed=T)
+    y = np.random.default_rng(T).standard_normal((T * B, P)).astype(F)
+    gs, ss = ora.den_graph_struct(g), ora.supervision_struct(sup)
+    objf, l2t, w = C.c_double(), C.c_double(), C.c_double()
+    d_ref, xd_ref = np.zeros_like(y), np.zeros_like(y)
+    assert L.oracle_chain_objf_and_deriv(C.byref(gs), C.byref(ss), ora.omat(y), 0.1, 0.0, 0.1, C.byref(objf), C.byref(l2t), C.byref(w),
+                                         ora.omat(d_ref), ora.omat(xd_ref)) == 1
+    pkg.hipabi.check(pkg.hipabi.load().tdnnf_chain_set_denominator_mode(mode))
+    try:
+        dg, ds = pkg.hipabi.DenGraph(g), pkg.hipabi.Supervision(sup)
+        nb = hip.chain_workspace_bytes(dg.h, B, T)
+        ws = hip.ws(nb)
+        res = torch.zeros(8, dtype=torch.float64, device="cuda")
+        dd, xdd = torch.zeros(T * B, P, device="cuda"), torch.zeros(T * B, P, device="cuda")
+        hip.chain_objf_and_deriv(dg.h, ds.h, dev(y), None, 0.1, 0.0, 0.1, hip.vec(res), dd, xdd, hip.vec(ws), nb, hip.stream())
+    finally:
+        pkg.hipabi.load().tdnnf_chain_set_denominator_mode(0)
+    r, d, xd = host(res), host(dd).astype(np.float64), host(xdd).astype(np.float64) / 0.1
+    assert r[5] == 1.0 and abs(r[0] - objf.value) < 1e-6 * abs(objf.value)
+    assert rel_l2(d, d_ref) < 2e-5, rel_l2(d, d_ref)
+    assert rel_l2(xd, xd_ref) < 2e-5
+    assert np.abs(xd.sum(1) - 1).max() < 2e-5 and np.abs((xd - d).sum(1) - 1).max() < 2e-5  # numerator, denominator posteriors per frame
