@@ -179,12 +179,16 @@ class Job:
         self.l2_scale = float(sequences * (world if args.scaling == "strong" else 1))
         self.gen = torch.Generator(device="cuda")
         self.gen.manual_seed(1234)  # same architecture sample on every rank (seed-shared draws)
+        self.comm = torch.cuda.Stream() if world > 1 and not args.no_overlap else None
         self.i = 0
 
     def step(self):
         self.net.set_random_draws(generator=self.gen)
         self.net.forward_backward(self.fd, self.ivd, self.dg, self.ds, step=self.i)
-        self.net.allreduce_grads()
+        if self.comm is not None:  # one collective per gradient bucket, each behind its "bucket final" event: overlaps the backward pass
+            self.net.allreduce_grads_overlapped(self.comm)
+        else:
+            self.net.allreduce_grads()
         self.net.update(self.lr, l2_regularize_scale=self.l2_scale, step=self.i)
         self.i += 1
 
@@ -223,6 +227,8 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU runs --minibatch sequences, the global batch grows with N; strong: ONE minibatch of "
                          "--minibatch sequences is sharded, rank g takes minibatch / N of them (SURVEY.md 8(e))")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce of the whole gradient buffer after the backward pass instead of "
+                                                               "one per bucket overlapped with it")
     ap.add_argument("--den-states", type=int, default=4000)
     ap.add_argument("--den-degree", type=float, default=12.0)
     ap.add_argument("--cpu-sequences", type=int, default=16)
@@ -337,7 +343,8 @@ def main():
                                             "setup_minibatches_before_warmup": burn,
                                             "refresh_steps_in_timed_region": sum(1 for t in range(burn + args.warmup, burn + args.warmup + args.steps)
                                                                                  if t <= 10 or (t - 10) % 4 == 0) if args.natural_gradient else 0},
-                       "parallelism": f"dp{world}", "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
+                       "parallelism": f"dp{world}", "allreduce": None if world == 1 else ("one collective after backward" if args.no_overlap else
+                                                                                           "per gradient bucket, overlapped with backward"), "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": round(alg_per_launch, 1),

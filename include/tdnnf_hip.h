@@ -454,6 +454,15 @@ int tdnnf_net_set_buffers(tdnnf_net *, float *params_dev, float *grads_dev);
    (ReLU stats / self-repair coin flips). */
 int tdnnf_net_forward_backward(tdnnf_net *, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *,
                                const tdnnf_supervision *, double *results_dev, long long step, tdnnf_stream);
+/* Data-parallel callers may overlap the gradient all-reduce with the backward pass: the flat gradient buffer is final
+   bucket by bucket -- contiguous ranges, whole layers, >= 16 MB where the model allows, in the order backward finishes
+   them (heads + prefinal-l first, then tdnnf layers from the top down, tdnn1 last; together they cover the buffer).
+   tdnnf_net_forward_backward records an event per bucket once grads[begin, end) holds this minibatch's contribution;
+   tdnnf_net_wait_grad_bucket makes `stream` wait for it (hipStreamWaitEvent), so a collective enqueued there afterwards
+   runs beside the rest of the backward pass.  (forward_backward's own stream is complete, as before, when it returns.) */
+int tdnnf_net_num_grad_buckets(const tdnnf_net *);
+int tdnnf_net_grad_bucket(const tdnnf_net *, int index, long long *begin, long long *end);
+int tdnnf_net_wait_grad_bucket(const tdnnf_net *, int index, tdnnf_stream stream);
 /* delta = lr_c*(grad) - 2*l2_scale*lr_c*l2_c*params; max-change; params += delta; grads = 0; orthonormal
    constraint on the scheduled quarter of the constrained matrices; batchnorm stats *= batchnorm_stats_scale. */
 int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale, long long step, tdnnf_stream);

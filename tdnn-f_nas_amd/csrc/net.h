@@ -122,6 +122,14 @@ struct tdnnf_net {
   void *chain_ws;
   size_t chain_ws_bytes;
   std::vector<std::pair<std::string, tdnnf_mat>> named;
+  // Gradient buckets for a data-parallel caller (tdnnf_net_grad_bucket): contiguous ranges of the flat gradient buffer in the
+  // order the backward pass finishes them; `ready` is recorded once the range is final in `grads`
+  struct GradBucket {
+    long long begin, end;
+    int close_key;  // closed after: -2 prefinal-l (heads + prefinal-l), l >= 0 tdnnf layer l, -1 tdnn1 (the rest)
+    hipEvent_t ready, handoff;
+  };
+  std::vector<GradBucket> buckets;
   // debugging / parity (tdnnf_net_set_capture): copies of the backward pass's derivative matrices, which live in recycled
   // scratch buffers, kept under names ("tdnnf5.affine.deriv", ...) that tdnnf_net_get_activation serves
   bool capture_on = false;

@@ -766,6 +766,29 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
       }
     }
   }
+  // ---- gradient buckets: whole layers, cut from the top of the flat buffer downwards (= the order backward finishes them)
+  {
+    const long long target = 4LL << 20;  // >= 16 MB of fp32 per collective (xGMI rings want large messages), layers kept whole
+    auto first_comp_of_layer = [&](int l) { return n->layers[l].c_arch >= 0 ? n->layers[l].c_arch : n->layers[l].lin.comp; };
+    long long end = n->num_params;
+    tdnnf_net::GradBucket b{n->comps[n->c_prefinal_l].begin, end, -2, nullptr, nullptr};
+    n->buckets.push_back(b);
+    end = b.begin;
+    for (int l = c.num_layers - 1; l >= 0; l--) {
+      const long long begin = n->comps[first_comp_of_layer(l)].begin;
+      if (end - begin >= target) {
+        n->buckets.push_back(tdnnf_net::GradBucket{begin, end, l, nullptr, nullptr});
+        end = begin;
+      }
+    }
+    n->buckets.push_back(tdnnf_net::GradBucket{0, end, -1, nullptr, nullptr});
+    for (auto &gb : n->buckets)
+      if (hipEventCreateWithFlags(&gb.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&gb.handoff, hipEventDisableTiming) != hipSuccess) {
+        set_error("net_create: cannot create events");
+        delete n;
+        return TDNNF_EHIP;
+      }
+  }
   // ---- activations
   Arena sizing;
   layout_arena(n, sizing);
@@ -838,6 +861,10 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   hipFree(n->arena);
   hipFree(n->chain_ws);
   for (float *p : n->captured) hipFree(p);
+  for (auto &gb : n->buckets) {
+    if (gb.ready) hipEventDestroy(gb.ready);
+    if (gb.handoff) hipEventDestroy(gb.handoff);
+  }
   if (n->s2) hipStreamDestroy(n->s2);
   if (n->ev_fork) hipEventDestroy(n->ev_fork);
   if (n->ev_den) hipEventDestroy(n->ev_den);
@@ -952,6 +979,19 @@ int tdnnf_net_set_buffers(tdnnf_net *n, float *params, float *grads) {
                 "net_set_buffers: buffers must be non-null and 16-byte aligned");
   n->params = params;
   n->grads = grads;
+  return TDNNF_OK;
+}
+
+int tdnnf_net_num_grad_buckets(const tdnnf_net *n) { return n ? (int)n->buckets.size() : 0; }
+int tdnnf_net_grad_bucket(const tdnnf_net *n, int i, long long *begin, long long *end) {
+  TDNNF_REQUIRE(n && i >= 0 && i < (int)n->buckets.size(), "net_grad_bucket: bad index");
+  if (begin) *begin = n->buckets[i].begin;
+  if (end) *end = n->buckets[i].end;
+  return TDNNF_OK;
+}
+int tdnnf_net_wait_grad_bucket(const tdnnf_net *n, int i, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n && i >= 0 && i < (int)n->buckets.size(), "net_wait_grad_bucket: bad index");
+  TDNNF_HIP(hipStreamWaitEvent((hipStream_t)stream, n->buckets[i].ready, 0));
   return TDNNF_OK;
 }
 
@@ -1201,6 +1241,25 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
+  // A bucket of the flat gradient buffer is final once the last of its components (in backward order) has been enqueued:
+  // grads[range] += this minibatch's gradient (unless the objective failed), then the bucket's event.  With natural gradient
+  // the components' commits run on the side stream, so the bucket's commit follows them there.
+  auto close_bucket = [&](int key) -> int {
+    for (auto &gb : n->buckets) {
+      if (gb.close_key != key) continue;
+      hipStream_t cs = s;
+      if (use_ng) {
+        TDNNF_HIP(hipEventRecord(gb.handoff, s));  // s-side writes of the range (bias sums, architecture parameters) are done
+        TDNNF_HIP(hipStreamWaitEvent(n->s3, gb.handoff, 0));
+        cs = n->s3;
+      }
+      const long long cnt = gb.end - gb.begin;
+      if (cnt > 0)
+        hipLaunchKernelGGL(commit_grads_kernel, dim3(grid_for(cnt, 256)), dim3(256), 0, cs, n->grads + gb.begin, n->gtmp + gb.begin, cnt, results);
+      TDNNF_HIP(hipEventRecord(gb.ready, cs));
+    }
+    return TDNNF_OK;
+  };
   // Gradient of one component's weights [+ bias] from its input (tap views) and output derivative.
   //   raw:  W += c_i dY^T X_i, bias += colsum(dY)                      (UpdateSimple, :433-455)
   //   NG :  X~ = [c_i X_i ..., 1], (X~', a) = NG_in(X~), (dY', b) = NG_out(dY), W += a b dY'^T X~'[:, :K Di],
@@ -1303,6 +1362,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   CK(capture("prefinal-l.deriv", d_pl));
   CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0, false));
+  CK(close_bucket(-2));
   float *d_cur = n->dA, *d_next = n->dB;  // d_cur: deriv w.r.t. the current layer's output (noop)
   {
     tdnnf_mat d_top = M(d_cur, No, Hd);
@@ -1378,6 +1438,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat in = M(in_act, ni, Hd);
     // (the never-added bias of a DARTS .linear is still updated by the reference, :614 -- Bg() is null for plain layers)
     CK(tdnn_wgrad(L.lin, &in, &d_lin, lin_eff, false));
+    CK(close_bucket(l));
     // deriv w.r.t. the layer input = linear backprop (overwrites) + bypass_scale * d_out on the output-grid rows
     tdnnf_mat d_in = M(d_next, ni, Hd);
     tdnnf_mat d_byp = sub_grid_view(d_next, L.gin, L.gout, B, Hd);
@@ -1397,11 +1458,11 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }
-  if (use_ng) {  // join the side stream: every component's preconditioned gradient is in gtmp
+  CK(close_bucket(-1));
+  if (use_ng) {  // join the side stream: every bucket has been committed into grads
     TDNNF_HIP(hipEventRecord(n->ev_s3, n->s3));
     TDNNF_HIP(hipStreamWaitEvent(s, n->ev_s3, 0));
   }
-  hipLaunchKernelGGL(commit_grads_kernel, dim3(grid_for(n->num_params, 256)), dim3(256), 0, s, n->grads, n->gtmp, n->num_params, results);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }

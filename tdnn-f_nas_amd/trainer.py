@@ -254,16 +254,56 @@ class ChainNet:
         """Sum the raw parameter gradients over ranks (RCCL all-reduce over xGMI: backend "nccl" on ROCm)."""
         allreduce_flat(self.grads, group)
 
+    def grad_buckets(self):
+        """[(begin, end)] element ranges of the flat gradient buffer in the order the backward pass finishes them
+        (tdnnf_net_grad_bucket): the heads and prefinal-l first, then groups of tdnnf layers from the top down."""
+        out = []
+        for i in range(self.lib.tdnnf_net_num_grad_buckets(self.h)):
+            b, e = C.c_longlong(), C.c_longlong()
+            hipabi.check(self.lib.tdnnf_net_grad_bucket(self.h, i, C.byref(b), C.byref(e)))
+            out.append((b.value, e.value))
+        return out
+
+    def allreduce_grads_overlapped(self, comm_stream, group=None):
+        """The same sum, one collective per bucket, each enqueued on `comm_stream` behind the event the library recorded when
+        that bucket's gradients became final -- so the reductions of the upper layers run while the backward pass (already
+        enqueued: the host is far ahead of the GPU) is still working on the lower ones.  Call right after forward_backward;
+        the current stream waits for the reductions before anything else touches the gradients."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        works = []
+        for i, (b, e) in enumerate(self.grad_buckets()):
+            hipabi.check(self.lib.tdnnf_net_wait_grad_bucket(self.h, i, C.c_void_p(comm_stream.cuda_stream)))
+            with torch.cuda.stream(comm_stream):
+                if dist.get_backend(group) == "gloo":  # rehearsal on one GPU: host-staged, blocking
+                    allreduce_flat(self.grads[b:e], group)
+                else:
+                    works.append(dist.all_reduce(self.grads[b:e], op=dist.ReduceOp.SUM, group=group, async_op=True))
+        for w in works:
+            w.wait()  # the current stream waits for the collective's stream
+        torch.cuda.current_stream().wait_stream(comm_stream)
+
 
 def allreduce_flat(flat, group=None):
     """The one exchange step of the data-parallel path: sequences (chunks) of a minibatch are sharded over
     ranks (they are independent through every component except BatchNorm statistics, which stay per-shard
     like Kaldi's per-job statistics), every rank accumulates the raw gradient of its shard, and the flat
-    gradient buffer is summed over ranks -- 74.8 MB of fp32 for the 7q net, one collective per step.
-    The reference has no counterpart (single process).  No-op for world size 1."""
+    gradient buffer is SUMMED over ranks -- 74.8 MB of fp32 for the 7q net.
+    Step size: to first order this is Kaldi's num_jobs jobs at learning rate lr_eff x num_jobs followed by model
+    averaging (steps/libs/nnet3/train/common.py:618), mean_j(lr_eff J g_j) = lr_eff sum_j g_j -- so the summed gradient
+    is applied with the EFFECTIVE learning rate, not lr_eff x num_jobs (tests/test_data_parallel_gloo.py).
+    The reference has no counterpart (single process).  No-op for world size 1.
+    gloo (CPU rehearsals, also with both ranks on one GPU) reduces host memory: device tensors are staged."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if flat.is_cuda and dist.get_backend(group) == "gloo":
+            host = flat.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            flat.copy_(host)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
 
 
@@ -272,6 +312,25 @@ def shard_sequences(num_sequences, rank, world_size):
     base, rem = divmod(num_sequences, world_size)
     begin = rank * base + min(rank, rem)
     return begin, begin + base + (1 if rank < rem else 0)
+
+
+def shard_supervision(sup, begin, end):
+    """The numerator graphs of sequences [begin, end) of a merged minibatch (the dict of synth.make_supervision /
+    egs.merge): what rank g of a strong-scaling step hands to tdnnf_supervision_create."""
+    sb, ab = np.asarray(sup["seq_state_begin"]), np.asarray(sup["seq_arc_begin"])
+    s0, s1, a0, a1 = int(sb[begin]), int(sb[end]), int(ab[begin]), int(ab[end])
+    out = dict(sup)
+    out.update(B=end - begin, seq_state_begin=(sb[begin:end + 1] - s0).astype(np.int32), seq_arc_begin=(ab[begin:end + 1] - a0).astype(np.int32),
+               state_time=np.asarray(sup["state_time"])[s0:s1], final_logprob=np.asarray(sup["final_logprob"])[s0:s1],
+               arc_src=(np.asarray(sup["arc_src"])[a0:a1] - s0).astype(np.int32), arc_dst=(np.asarray(sup["arc_dst"])[a0:a1] - s0).astype(np.int32),
+               arc_pdf=np.asarray(sup["arc_pdf"])[a0:a1], arc_logprob=np.asarray(sup["arc_logprob"])[a0:a1])
+    return out
+
+
+def shard_rows(mat, num_sequences, begin, end):
+    """Rows of sequences [begin, end) of a t-major matrix (row = t * num_sequences + b), t-major again."""
+    m = np.asarray(mat)
+    return np.ascontiguousarray(m.reshape(-1, num_sequences, m.shape[1])[:, begin:end]).reshape(-1, m.shape[1])
 
 
 def learning_rate(iteration, num_jobs, num_iters, num_archives_processed, num_archives_to_process,

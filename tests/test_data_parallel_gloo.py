@@ -49,8 +49,9 @@ def _worker(rank, world, port, out_dir):
         dist.all_gather(gathered, torch.from_numpy(local))
         expect = sum(g.numpy().astype(np.float64) for g in gathered)
         assert np.allclose(flat.numpy(), expect, rtol=1e-5, atol=1e-6)
-        # identical update everywhere: learning rate x num_jobs (common.py:618), l2 scale = local sequences
-        lr = pkg.trainer.learning_rate(0, world, 10, 0, 10)
+        # identical update everywhere: the SUMMED gradient takes the effective learning rate (see
+        # test_summed_gradient_step_is_kaldis_job_average), l2 scale = local sequences
+        lr = pkg.trainer.learning_rate(0, 1, 10, 0, 10)
         p2 = net.update(params, flat.numpy(), lr, float(b1 - b0), step=0)
         ps = [torch.zeros(len(p2)) for _ in range(world)]
         dist.all_gather(ps, torch.from_numpy(p2))
@@ -80,3 +81,33 @@ def test_learning_rate_schedule(pkg):
     assert abs(lr(99, 1, 100, 99, 100) - 2.5e-5) < 1e-12          # last iteration: final rate
     assert abs(lr(50, 1, 100, 50, 100) - 2.5e-4 * np.sqrt(0.1)) < 1e-9
     assert lr(10, 8, 100, 10, 100) == 8 * lr(10, 1, 100, 10, 100)  # x num_jobs
+
+
+def test_summed_gradient_step_is_kaldis_job_average(pkg):
+    """Kaldi trains num_jobs jobs from the same model, each at learning rate lr_eff x num_jobs on its own minibatch with
+    l2_regularize_factor = 1 / num_jobs, and averages the models (train.py / common.py:618).  The data-parallel step here sums
+    the jobs' raw gradients and applies lr_eff once with the local sequence count as l2 scale: the same model, exactly, as long
+    as max-change does not bind and no orthonormal step is scheduled (both are nonlinear in the step)."""
+    from tests.oracle_net import decision
+    from tests.test_oracle_net import tiny_setup
+    J, T = 2, 12
+    cfg, comps, params, net, feats, iv, den, sup = tiny_setup(pkg, T=T, B=2, seed=7)
+    step = next(s for s in range(1000) if all(c["orthonormal"] == 0.0 or decision(s, 2 * i + 1) % 4 != 0 for i, c in enumerate(comps)))
+    rng = np.random.default_rng(5)
+    lr_eff = 1e-4  # small: max-change stays out of it
+    job_models, grads = [], []
+    for j in range(J):
+        f = rng.standard_normal(feats.shape).astype(np.float32)
+        v = rng.standard_normal(iv.shape).astype(np.float32)
+        sp = pkg.synth.make_supervision(2, T // 3, 24, seed=60 + j)
+        _, g, _ = net.forward_backward(params, f, v, den, sp, step=step)
+        grads.append(g.copy())
+        job_models.append(net.update(params, g, lr_eff * J, 2.0 / J, step))  # the job's own step: lr x J, l2 factor 1/J
+    averaged = np.mean(job_models, axis=0)
+    summed = net.update(params, np.sum(grads, axis=0), lr_eff, 2.0, step)  # what every rank does after allreduce_flat
+    assert np.abs(averaged - params).max() > 0
+    d1, d2 = (summed - params).astype(np.float64), (averaged - params).astype(np.float64)
+    assert np.linalg.norm(d1 - d2) < 1e-4 * np.linalg.norm(d2)  # float32 rounding of the parameters only
+    # ... and NOT the step the previous round took (sum applied with lr_eff x num_jobs): that one is num_jobs times too long
+    too_long = net.update(params, np.sum(grads, axis=0), lr_eff * J, 2.0, step)
+    assert np.linalg.norm(too_long - params) > 1.9 * np.linalg.norm(averaged - params)

@@ -1,0 +1,120 @@
+"""-m gpu: the data-parallel step on the HIP trainer itself, two processes on this one GPU (gloo, as bench.py's rehearsal
+mode): SURVEY.md 8(e) "N-rank raw-gradient step == 1-rank step with the same global batch".
+
+Sequences are independent through everything except train-mode BatchNorm statistics and the natural-gradient state, so the
+exact check uses a net whose BatchNorm runs in test mode and that still forms gradients: the offset supernet in cv-update
+mode (BatchNormTest from stored statistics, TdnnDARTSV3 components at learning-rate factor 1e-4, Gumbel coefficients from
+shared draws).  Rank g takes sequences [4g, 4g + 4) of an 8-sequence minibatch (trainer.shard_rows / shard_supervision);
+the summed gradient -- reduced per bucket behind the library's "bucket final" events, and as one flat buffer -- must be the
+single process's gradient of all 8, and the update the same parameters."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from tests.gpu_util import dev, host, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(frames_per_chunk=24, num_sequences=8, strides=[1, 1, 1], bottleneck=16, feat_dim=40, ivector_dim=100, num_pdfs=96, hidden_dim=64,
+          small_dim=32, darts_num_offsets=3, darts_flags=1 | 16, darts_temp_proportion=0.8, cv_update=1,
+          relu_self_repair_scale=0.0)  # (self-repair looks at ReLU statistics that include the shard just seen)
+
+
+def _problem(pkg, B):
+    T = pkg.trainer
+    cfg = T.make_config(**dict(KW, num_sequences=B))
+    net = T.ChainNet(cfg)
+    full = T.ChainNet(T.make_config(**KW)) if B != KW["num_sequences"] else net
+    rng = np.random.default_rng(3)
+    params = full.init_params_numpy(seed=1, output_stddev=0.3)
+    for c in full.components:  # trained-looking architecture logits
+        n = c["rows"] * c["cols"]
+        params[c["begin"] + n:c["begin"] + n + c["num_alpha"]] = rng.standard_normal(c["num_alpha"]).astype(np.float32) * 0.5
+    stats = np.abs(rng.standard_normal(int(full.lib.tdnnf_net_stats_size(full.h)))) + 0.5
+    # valid BatchNorm / ReLU statistics: [count, sum[D], sumsq[D]] with sumsq/count > (sum/count)^2
+    o = 0
+    Hd, S = cfg.hidden_dim, cfg.prefinal_small_dim
+    dims = [Hd, Hd] + [Hd, Hd] * cfg.num_layers + [Hd, Hd, S] * 2
+    for D in dims:
+        stats[o] = 100.0
+        mean = rng.standard_normal(D) * 0.3
+        var = rng.uniform(0.5, 1.5, D)
+        stats[o + 1:o + 1 + D] = 100.0 * mean
+        stats[o + 1 + D:o + 1 + 2 * D] = 100.0 * (var + mean * mean)
+        o += 1 + 2 * D
+    feats, iv = T.synthetic_egs(full, seed=4)
+    den = pkg.synth.make_den_graph(40, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+    sup = pkg.synth.make_supervision(KW["num_sequences"], cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)
+    draws = np.random.default_rng(9).uniform(0.05, 0.95, full.num_draws).astype(np.float32)
+    if full is not net:
+        full.close()
+    net.set_params(params)
+    net.set_stats(stats)
+    net.set_random_draws(draws)  # every rank: the same architecture sample
+    return net, feats, iv, den, sup
+
+
+def _rank_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    T = pkg.trainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        Bg = KW["num_sequences"]
+        b0, b1 = T.shard_sequences(Bg, rank, world)
+        net, feats, iv, den, sup = _problem(pkg, b1 - b0)
+        fd, ivd = dev(T.shard_rows(feats, Bg, b0, b1)), dev(np.ascontiguousarray(iv[b0:b1]))
+        dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(T.shard_supervision(sup, b0, b1))
+        # (a) per bucket, behind the bucket events, on a communication stream
+        comm = torch.cuda.Stream()
+        r = host(net.forward_backward(fd, ivd, dg, ds, step=0)).copy()
+        net.allreduce_grads_overlapped(comm)
+        g_bucketed = host(net.grads).copy()
+        buckets = net.grad_buckets()
+        # (b) one flat all-reduce
+        net.grads.zero_()
+        net.forward_backward(fd, ivd, dg, ds, step=0)
+        local = host(net.grads).copy()
+        net.allreduce_grads()
+        g_flat = host(net.grads).copy()
+        # strong scaling: ONE minibatch of Bg sequences -> l2 scale = global count; effective learning rate (the sum is not x num_jobs)
+        net.update(1e-3, l2_regularize_scale=float(Bg), step=0)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), g_bucketed=g_bucketed, g_flat=g_flat, local=local, params=host(net.params), res=r,
+                 buckets=np.asarray(buckets))
+        net.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_on_the_hip_trainer_match_one_process(pkg, tmp_path):
+    import torch.multiprocessing as mp
+    net, feats, iv, den, sup = _problem(pkg, KW["num_sequences"])
+    r1 = host(net.forward_backward(dev(feats), dev(iv), pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup), step=0)).copy()
+    g1 = host(net.grads).copy()
+    assert r1[5] == 1.0 and np.linalg.norm(g1) > 0
+    net.update(1e-3, l2_regularize_scale=float(KW["num_sequences"]), step=0)
+    p1 = host(net.params).copy()
+    buckets1 = net.grad_buckets()
+    net.close()
+    # buckets: contiguous, cover the buffer, highest addresses (the heads) first
+    assert buckets1[0][1] == len(g1) and buckets1[-1][0] == 0 and all(a[0] == b[1] for a, b in zip(buckets1, buckets1[1:]))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(2)]
+    for o in out:
+        assert [tuple(b) for b in o["buckets"]] == buckets1
+        assert np.array_equal(o["g_bucketed"], o["g_flat"])  # same sums either way, bit for bit (two addends)
+        assert rel_l2(o["g_flat"], g1) < 1e-5, rel_l2(o["g_flat"], g1)  # == the single process's gradient of the whole minibatch
+        assert rel_l2(o["params"], p1) < 1e-6
+    assert np.array_equal(out[0]["g_flat"], out[1]["g_flat"]) and np.array_equal(out[0]["params"], out[1]["params"])
+    assert not np.array_equal(out[0]["local"], out[1]["local"])  # the shards did differ
+    # objective: the shards' sums add up
+    assert abs(out[0]["res"][0] + out[1]["res"][0] - r1[0]) < 1e-5 * abs(r1[0]) and out[0]["res"][2] + out[1]["res"][2] == r1[2]
