@@ -4,6 +4,8 @@
 // Reference: /root/reference/src/nnet3/nnet-tdnn-component.cc (Propagate :214-333, Backprop
 // :335-431, UpdateSimple :433-455, GetInputPart :806-820), nnet-simple-component.cc
 // (AffineComponent :1235-1279).
+#include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -26,6 +28,34 @@ void set_error(const char *fmt, ...) {
 int hip_status(hipError_t e, const char *what) {
   set_error("HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   return TDNNF_EHIP;
+}
+
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)();
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+bool roctx_ready() {
+  static const bool ok = [] {
+    const char *e = getenv("TDNNF_ROCTX");
+    if (e && atoi(e) == 0) return false;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+      g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+      if (g_roctx_push && g_roctx_pop) return true;
+    }
+    return false;
+  }();
+  return ok;
+}
+}  // namespace
+TraceRange::TraceRange(const char *name) : on(roctx_ready()) {
+  if (on) g_roctx_push(name);
+}
+TraceRange::~TraceRange() {
+  if (on) g_roctx_pop();
 }
 
 // rows of `in` needed by tap views: GetInputPart's assert, nnet-tdnn-component.cc:811-813

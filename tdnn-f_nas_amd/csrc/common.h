@@ -42,6 +42,15 @@ inline bool vec4_ok(const MatView &m) {
 
 #define TDNNF_LAUNCH_CHECK(name) TDNNF_HIP(hipGetLastError())
 
+// Named ranges for profilers (rocprofv3 --marker-trace; the reference's NVTX_RANGE at nnet-normalize-component.cc:185,476 is
+// the same idea): roctxRangePush / Pop from librocprofiler-sdk-roctx.so (or libroctx64.so), resolved with dlopen on first use so
+// that the library has no link-time dependency on a profiler; without the library (or with TDNNF_ROCTX=0) a range is a no-op.
+struct TraceRange {
+  explicit TraceRange(const char *name);
+  ~TraceRange();
+  bool on;
+};
+
 // CuMatrix::ApplyFloor semantics: `if (x < floor) x = floor`, so a NaN stays a NaN (fmaxf would swallow it and a
 // diverged minibatch would no longer be detected by the objective's finiteness check).
 __host__ __device__ inline float floor_keep_nan(float x, float f) { return x < f ? f : x; }

@@ -69,7 +69,7 @@ TransposedWeightsScope::~TransposedWeightsScope() {
   g_tw_n = prev_n;
 }
 const float *transposed_weights(const float *W) {
-  if ((g_gemm_prec != 1 && g_gemm_prec != 3) || !g_tw_w || !g_tw_wt || W < g_tw_w || W >= g_tw_w + g_tw_n) return nullptr;
+  if (!g_tw_w || !g_tw_wt || W < g_tw_w || W >= g_tw_w + g_tw_n) return nullptr;
   return g_tw_wt + (W - g_tw_w);
 }
 SplitKScratchOverride::~SplitKScratchOverride() {
@@ -1716,6 +1716,11 @@ int wgrad_slots(int variant) {
                                                                                                    : wgrad_slots_of<2, 2, 2, 2>();
 }
 
+inline int wgrad_min_rounds() {
+  static const int r = getenv("TDNNF_WGRAD_ROUNDS") ? std::min(8, std::max(1, atoi(getenv("TDNNF_WGRAD_ROUNDS")))) : 2;
+  return r;
+}
+
 // Split the row (reduction) range so that tiles * splits fills whole rounds of resident blocks: every block
 // runs equally long, so a grid of q*slots + r blocks costs q+1 rounds; we want r == 0 (just under a multiple).
 WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0, bool x3 = false) {
@@ -1725,7 +1730,11 @@ WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0, boo
   const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
   const int max_splits = std::max(1, (N + 255) / 256);  // at least 256 rows per split
   int splits = 1;
-  for (int rounds = 1; rounds <= 4; rounds++) {
+  // at least two rounds of resident blocks: a launch sized for exactly one round runs two as soon as a few slots are taken by
+  // another stream's kernels (the denominator, the natural-gradient side stream); with shorter blocks the stragglers cost half
+  // (weight-gradient class 30.7 -> 29.1 ms per step; TDNNF_WGRAD_ROUNDS for experiments)
+  const int min_rounds = wgrad_min_rounds();
+  for (int rounds = min_rounds; rounds <= std::max(4, min_rounds); rounds++) {
     splits = (rounds * slots) / tiles;
     if (splits >= 1 && (rounds * slots) / tiles * tiles >= rounds * slots * 3 / 4) break;  // >= 75 % of the round used
   }
@@ -1752,7 +1761,8 @@ size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
                              ((Do + wt1.BM - 1) / wt1.BM) * ((Di + wt1.BN - 1) / wt1.BN));  // worst case: one active tap, either arithmetic
   // wgrad_plan picks one round when tiles <= slots/4 (splits = slots/tiles) and at most 4 rounds otherwise (< 16 splits);
   // slots <= 1024 on any gfx950 part
-  size_t max_splits = std::max<size_t>(1, std::min<size_t>((N + 255) / 256, std::max<size_t>(1024 / tiles + 1, 16)));
+  // (with r = wgrad_min_rounds(): r rounds when tiles <= r slots / 4, i.e. splits = r slots / tiles, else < 16 splits)
+  size_t max_splits = std::max<size_t>(1, std::min<size_t>((N + 255) / 256, std::max<size_t>((size_t)std::max(wgrad_min_rounds(), 4) * 1024 / tiles + 1, 16)));
   return sizeof(float) * (max_splits * Do * K * Di) + colreduce_bytes(N, Do) + 64;
 }
 

@@ -380,7 +380,11 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
   n->dropout_masks = (c.use_dropout && !c.cv_update) ? A.take<float>((size_t)(c.num_layers + 1) * B * Hd) : nullptr;
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
-  n->paramsT = n->cfg.gemm_precision != 0 ? A.take<float>((size_t)n->num_params + 16) : nullptr;
+  // transposed copy of every weight matrix for the split-bf16 backward-data GEMMs (k-contiguous B operand).  Measured for
+  // exact f32 too (TDNNF_WT=1: the k-contiguous kernel variant instead of four 4-byte LDS reads per B fragment): the
+  // backward-data classes did not move (36.8 / 26.2 against 36.4 / 26.1 ms per step), the step got 1-2 ms slower -- not kept
+  static const bool force_wt = getenv("TDNNF_WT") != nullptr;
+  n->paramsT = (n->cfg.gemm_precision != 0 || force_wt) ? A.take<float>((size_t)n->num_params + 16) : nullptr;
   n->ngBias = nullptr;
   n->s3_scratch = nullptr;
   n->s3_scratch_bytes = 0;
@@ -1057,7 +1061,15 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_den, hipEventDisableTiming));
-    TDNNF_HIP(hipStreamCreateWithFlags(&n->s3, hipStreamNonBlocking));
+    {
+      // the natural-gradient side stream carries small latency-bound launches that should fill idle slots, not take slots from
+      // the backward pass (a launch sized for one round of resident blocks runs two when a few slots are taken): lowest priority
+      int lo = 0, hi = 0;
+      static const bool flat_prio = getenv("TDNNF_S3_PRIO") && atoi(getenv("TDNNF_S3_PRIO")) == 0;  // experiments
+      if (!flat_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) TDNNF_HIP(hipStreamCreateWithPriority(&n->s3, hipStreamNonBlocking, lo));
+      else TDNNF_HIP(hipStreamCreateWithFlags(&n->s3, hipStreamNonBlocking));
+      (void)hipGetLastError();
+    }
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_s3, hipEventDisableTiming));
     for (auto &S : n->ngset) {
       TDNNF_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
@@ -1084,6 +1096,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   auto coin = [&]() { return (int)(::tdnnf::tdnnf_decision((unsigned long long)step, 2 * coin_k++) & 1); };
 
   // ================================================================= forward
+  TraceRange trace_step("tdnnf_net_forward_backward");
   const int N0 = N_of(n->g_lda, B);
   tdnnf_mat lda_in = M(n->lda_in, N0, lda_dim), lda_out = M(n->lda_out, N0, lda_dim);
   CK(tdnnf_splice_input(feats, ivectors, B, 3, &lda_in, s));
@@ -1109,6 +1122,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   int layer_no = 0;
   for (auto &L : n->layers) {
     layer_no++;
+    TraceRange trace_layer(("forward tdnnf" + std::to_string(layer_no + 1)).c_str());
     tdnnf_mat in = M(prev, N_of(L.gin, B), Hd);
     tdnnf_mat lin = M(L.lin_out, L.lin.rows_out, L.bn);
     const float *lin_eff = nullptr, *aff_eff = nullptr;
@@ -1169,6 +1183,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       // ====================================================== objective, part 1 (second stream)
       // The denominator forward-backward (one workgroup per sequence) only needs the chain head's output: it
       // runs on n->s2 while this stream does the xent head forward, the numerator and the xent head backward.
+      TraceRange trace_den("chain denominator forward-backward (second stream)");
       TDNNF_HIP(hipEventRecord(n->ev_fork, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
       CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2));
@@ -1330,6 +1345,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
+    TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");
     if (h == 0) {
       // objective, part 3: join the denominator stream, d_y += posteriors, objf / failure handling
       TDNNF_HIP(hipStreamWaitEvent(s, n->ev_den, 0));
@@ -1375,6 +1391,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // d_cur is needed again for the bypass term, so the derivative w.r.t. the affine output goes to dC
     tdnnf_mat d_out = M(d_cur, no, Hd), d_aff = M(n->dC, no, Hd);
     const std::string lname = "tdnnf" + std::to_string(l + 2);
+    TraceRange trace_layer(("backward " + lname).c_str());
     CK(capture(lname + ".noop.deriv", d_out));
     {
       const bool store = coin() || step == 0;
@@ -1470,6 +1487,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
 int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdnnf_stream stream) {
   TDNNF_REQUIRE(n && n->params && n->grads, "net_update: call net_set_buffers first");
   TDNNF_REQUIRE(lr >= 0.f && l2_scale >= 0.f, "net_update: learning rate and l2 scale must be >= 0 (nnet-utils.cc:2240)");
+  TraceRange trace_update("tdnnf_net_update");
   hipStream_t s = (hipStream_t)stream;
   const int nc = (int)n->comps.size();
   UpdTable tb;
