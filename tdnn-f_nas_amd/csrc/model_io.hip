@@ -477,7 +477,7 @@ void write_linear(Ctx &x, const CompDesc &cd) {  // :3161-3188
     o.f32(cd.orthonormal);
   }
   o.token("<UseNaturalGradient>");
-  o.boolean(true);
+  o.boolean(x.n->cfg.use_natural_gradient != 0);  // what this net trains with (the reference's components default to true)
   int ri, ro;
   ng_ranks(cd, &ri, &ro);
   o.token("<RankInOut>");
@@ -522,7 +522,7 @@ void write_tdnn(Ctx &x, const CompDesc &cd, const Tdnn &t) {  // nnet-tdnn-compo
   o.token("<OrthonormalConstraint>");
   o.f32(cd.orthonormal);
   o.token("<UseNaturalGradient>");
-  o.boolean(true);
+  o.boolean(x.n->cfg.use_natural_gradient != 0);  // what this net trains with (the reference's components default to true)
   int ri, ro;
   ng_ranks(cd, &ri, &ro);
   o.token("<NumSamplesHistory>");

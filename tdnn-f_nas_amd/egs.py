@@ -148,18 +148,25 @@ def minibatches(path, net, frame_shift=0, discard_partial=True, prefetch=0):
 
     def host_batches():
         group = []
-        for eg in Reader(path):
-            group.append(eg)
-            if len(group) == B:
-                f, iv, sup = merge(group, first_t, num_t, frame_shift, with_ivectors=with_iv)
-                for e in group:
-                    e.close()
-                group = []
-                if sup["T"] * sub != chunk:
-                    raise ValueError("examples of %d output frames, the net was built for %d" % (sup["T"], chunk // sub))
-                yield f, iv, sup
-        if group and not discard_partial:
-            raise ValueError("the last %d examples do not fill a minibatch of %d" % (len(group), B))
+        reader = Reader(path)
+        try:
+            for eg in reader:
+                group.append(eg)
+                if len(group) == B:
+                    f, iv, sup = merge(group, first_t, num_t, frame_shift, with_ivectors=with_iv)
+                    for e in group:
+                        e.close()
+                    group = []
+                    if sup["T"] * sub != chunk:
+                        raise ValueError("examples of %d output frames, the net was built for %d" % (sup["T"], chunk // sub))
+                    yield f, iv, sup
+            if group and not discard_partial:
+                raise ValueError("the last %d examples do not fill a minibatch of %d" % (len(group), B))
+        finally:  # also when the consumer stops early: no example handle or open archive is left behind
+            for e in group:
+                e.close()
+            if hasattr(reader, "close"):
+                reader.close()
 
     def to_device(f, iv, sup):
         return torch.from_numpy(f).cuda(), torch.from_numpy(iv).cuda() if iv is not None else None, hipabi.Supervision(sup)
@@ -173,20 +180,27 @@ def minibatches(path, net, frame_shift=0, discard_partial=True, prefetch=0):
     q = queue.Queue(maxsize=prefetch)
     stop = threading.Event()
 
+    def put(item):
+        """hand `item` to the consumer unless it has stopped listening (generator closed, exception in to_device)"""
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
     def worker():
+        gen = host_batches()
         try:
-            for item in host_batches():
-                while not stop.is_set():
-                    try:
-                        q.put(item, timeout=0.1)
-                        break
-                    except queue.Full:
-                        pass
-                if stop.is_set():
+            for item in gen:
+                if not put(item):
                     return
-            q.put(None)
+            put(None)
         except BaseException as e:  # handed to the consumer
-            q.put(e)
+            put(e)
+        finally:
+            gen.close()  # closes the Reader and the examples of an unfinished group (host_batches' own finally)
 
     th = threading.Thread(target=worker, daemon=True)
     th.start()

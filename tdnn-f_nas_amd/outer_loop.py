@@ -7,7 +7,7 @@ the per-minibatch work is ChainNet.forward_backward + update.
 Kaldi, not shipped with the reference; restated here from the command lines train.py passes them:
  * every job of an iteration starts from <iter>.mdl, trains on its own archive with the iteration's learning rate
    (nnet3-chain-train; a fresh process, so the natural-gradient state starts from scratch), writes <iter+1>.<job>.raw;
- * the jobs' models are averaged (nnet3-average) into <iter+1>.mdl, scaled by the shrinkage value;
+ * every job starts from <iter>.mdl scaled by the shrinkage value; the jobs' models are averaged (nnet3-average) into <iter+1>.mdl;
  * final.mdl = combination of the models of `model_combine_iters`: with combine egs given, nnet3-chain-combine's search
    (combine_models below: running average over the models, latest first, the average with the best objective on the
    combine egs wins, its BatchNorm statistics are recomputed); without, their plain average.  Restated from the upstream
@@ -174,6 +174,11 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
         diagnostic_egs=None):
     """Runs the whole schedule.  net_factory() -> a ChainNet with initial parameters set (called once per job: a fresh process in
     the reference, so fresh natural-gradient state; BatchNorm / ReLU statistics and parameters come from <iter>.mdl).
+    As upstream's train_one_iteration (absent from the reference, restated from what train.py passes): every job starts from
+    <iter>.mdl scaled by the iteration's shrink value (nnet3-am-copy --scale), trains at learning rate lr_eff x num_jobs with
+    l2_regularize_factor = 1 / num_jobs, and the jobs' models are averaged.  NOT restated: upstream's special case for
+    iteration 0 (minibatch halved, max-param-change / sqrt(2), the best job's model instead of the average) -- a ChainNet is
+    built for one minibatch shape; the reference recipes run one job, where only the halved minibatch would differ.
     egs_for_archive(archive_index, minibatch_index) -> (feats, ivectors, den_graph, supervision) device objects for
     ChainNet.forward_backward.  Writes <work_dir>/<iter>.mdl for every iteration and final.mdl; returns the plan with the
     per-iteration mean objective added.  combine_egs: minibatches [(feats, ivectors, den_graph, supervision)] for the final
@@ -215,6 +220,8 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
                 net.close()
                 net = net_factory()
             net.read_model(path(i))
+            if it["shrink"] != 1.0:  # the job's input model: "nnet3-am-copy --scale=<shrink>" (parameters only)
+                net.params.mul_(float(it["shrink"]))
             if it["temperature_proportion"] is not None:
                 net.set_temperature_proportion(it["temperature_proportion"])
             if it["dropout_proportion"] is not None:
@@ -226,7 +233,8 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
                 if net.num_draws:
                     net.set_random_draws(generator=g)
                 r = net.forward_backward(feats, iv, den, sup, step=step + m)
-                net.update(lr, step=step + m)
+                # l2 scale = GetNumNvalues x l2_regularize_factor, the factor being 1 / num_jobs (train.py -> train_one_iteration)
+                net.update(lr, l2_regularize_scale=float(net.cfg.num_sequences) / jobs, step=step + m)
                 r = r.cpu().numpy()
                 objf += float(r[0])
                 weight += float(r[2])
@@ -241,7 +249,7 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
             buf = buf.cpu().numpy()
             acc_p, acc_s, objf, weight = buf[:acc_p.size], buf[acc_p.size:acc_p.size + acc_s.size], buf[-2], buf[-1]
         it["objf_per_frame"] = objf / weight if weight else float("nan")
-        net.set_params((it["shrink"] * acc_p / jobs).astype(np.float32))  # nnet3-average ... | nnet3-copy --scale=shrink
+        net.set_params((acc_p / jobs).astype(np.float32))  # nnet3-average
         net.set_stats(acc_s / jobs)
         if rank == 0:
             net.write_model(path(i + 1), binary=binary, learning_rate=lr)

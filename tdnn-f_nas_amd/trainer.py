@@ -405,41 +405,43 @@ def temperature(temperature_init, temperature_final, data_fraction):
     return temperature_init * (temperature_final / temperature_init) ** data_fraction
 
 
+def parse_dropout_schedule(schedule):
+    """[(data_fraction, proportion)] in ascending data_fraction of a --trainer.dropout-schedule function such as
+    '0,0@0.20,0.5@0.50,0' (run_tdnn_fbk_40_iv_sp_7q.sh:48): the parser the reference keeps (commented out) in
+    steps/libs/nnet3/train/temperature_schedule.py:122-182 (_parse_dropout_string): at least two values; the first sits at
+    data fraction 0, the last at 1; a middle value 'v@x' at x, a middle value WITHOUT '@x' at 0.5; data fractions must not
+    decrease and must lie in [0, 1], proportions in [0, 1]."""
+    parts = str(schedule).strip().split(",")
+    if len(parts) < 2:
+        raise ValueError("dropout schedule %r: at least the start and end proportions are needed" % (schedule,))
+    pts = [(0.0, float(parts[0]))]
+    for tok in parts[1:-1]:
+        v, at, x = tok.strip().partition("@")
+        frac = float(x) if at else 0.5
+        if frac < pts[-1][0] or frac > 1.0:
+            raise ValueError("dropout schedule %r: data fractions must be in increasing order and <= 1 (%r)" % (schedule, tok))
+        pts.append((frac, float(v)))
+    pts.append((1.0, float(parts[-1])))
+    if not all(0.0 <= f <= 1.0 and 0.0 <= v <= 1.0 for f, v in pts):
+        raise ValueError("dropout schedule %r: fractions and proportions must lie in [0, 1]" % (schedule,))
+    return pts
+
+
 def dropout_proportion(schedule, data_fraction):
-    """Value at data_fraction of a --trainer.dropout-schedule function such as '0,0@0.20,0.5@0.50,0'
-    (run_tdnn_fbk_40_iv_sp_7q.sh:48; semantics in the option's help text, steps/libs/nnet3/train/common.py:883-905; the parser
-    itself, dropout_schedule.py, is upstream): comma-separated values, optionally value@x; the first and last sit at x = 0 and
-    x = 1, unspecified x are spread evenly between their specified neighbours, linear in between.  One function for every
-    component (the recipes give no per-pattern rules)."""
+    """Dropout proportion at data_fraction: piecewise linear on parse_dropout_schedule(), as _get_component_dropout
+    (temperature_schedule.py:185-239): at a repeated data fraction the later point wins from there on.  One function for every
+    component (the recipes give no per-pattern rules); None = no dropout."""
     if schedule is None:
         return 0.0
-    pts = []
-    for tok in str(schedule).split(","):
-        v, _, x = tok.strip().partition("@")
-        pts.append([float(v), float(x) if x else None])
-    if len(pts) == 1:
-        return pts[0][0]
-    if pts[0][1] is None:
-        pts[0][1] = 0.0
-    if pts[-1][1] is None:
-        pts[-1][1] = 1.0
-    i = 0
-    while i < len(pts):  # fill runs of unspecified x between known ones
-        if pts[i][1] is None:
-            j = i
-            while pts[j][1] is None:
-                j += 1
-            x0, x1, n = pts[i - 1][1], pts[j][1], j - i + 1
-            for k in range(i, j):
-                pts[k][1] = x0 + (x1 - x0) * (k - i + 1) / n
-            i = j
-        i += 1
-    assert all(a[1] <= b[1] for a, b in zip(pts, pts[1:])) and pts[0][1] == 0.0 and pts[-1][1] == 1.0, "x values must rise from 0 to 1"
+    pts = parse_dropout_schedule(schedule)
     f = min(max(float(data_fraction), 0.0), 1.0)
-    for (v0, x0), (v1, x1) in zip(pts, pts[1:]):
-        if f <= x1:
-            return v0 if x1 == x0 else v0 + (v1 - v0) * (f - x0) / (x1 - x0)
-    return pts[-1][0]
+    if f == 0.0:
+        return pts[0][1]
+    lo = max(i for i, (x, _) in enumerate(pts) if x <= f)  # the last point at or below f (the reference searches from the top)
+    if lo == len(pts) - 1:
+        return pts[-1][1]
+    (x0, v0), (x1, v1) = pts[lo], pts[lo + 1]
+    return v0 if x1 == x0 else v0 + (v1 - v0) * (f - x0) / (x1 - x0)
 
 
 def temperature_edit_string(data_fraction):

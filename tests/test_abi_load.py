@@ -87,6 +87,13 @@ def test_outer_loop_plan(pkg):
     assert t.dropout_proportion('0,0.2,0', 0.5) == pytest.approx(0.2) and t.dropout_proportion('0,0.2,0', 0.25) == pytest.approx(0.1)
     assert t.dropout_proportion('0,0.2@0.25,0', 0.25) == pytest.approx(0.2) and t.dropout_proportion('0,0.2@0.25,0', 0.625) == pytest.approx(0.1)
     assert t.dropout_proportion('0,0@0.20,0.5@0.50,0', 0.35) == pytest.approx(0.25) and t.dropout_proportion(None, 0.3) == 0.0
+    # the upstream parser the reference keeps (temperature_schedule.py:122-182): an unspecified middle x is 0.5, not "evenly spread"
+    assert t.parse_dropout_schedule('0,0.1,0.3,0') == [(0.0, 0.0), (0.5, 0.1), (0.5, 0.3), (1.0, 0.0)]
+    assert t.dropout_proportion('0,0.1,0.3,0', 0.25) == pytest.approx(0.05) and t.dropout_proportion('0,0.1,0.3,0', 0.5) == pytest.approx(0.3)
+    assert t.dropout_proportion('0,0.1,0.3,0', 0.75) == pytest.approx(0.15) and t.dropout_proportion('0.2,0.5', 1.0) == pytest.approx(0.5)
+    for bad in ('0.3', '0,0.2@0.6,0.1@0.4,0', '0,0.2@1.5,0', '0,1.2,0'):
+        with pytest.raises(ValueError):
+            t.parse_dropout_schedule(bad)
     assert len(plan) == 30 and plan[0]["num_jobs"] == 2 and plan[-1]["num_jobs"] == 6
     assert [p["num_jobs"] for p in plan] == sorted(p["num_jobs"] for p in plan)
     assert abs(sum(p["num_jobs"] for p in plan) - to_process) <= 6
