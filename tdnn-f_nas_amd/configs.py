@@ -269,3 +269,193 @@ def bottleneck_top5_model_sizes(model_lines, child_type, dims=derive.BOTTLENECK_
 def node_lines(lines):
     """The graph part of a config (what Nnet::Write keeps in a model file): input / component / dim-range / output nodes."""
     return [l for l in lines if l.split(' ')[0] in ('input-node', 'component-node', 'dim-range-node', 'output-node')]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# final.config IN: the front-end of SURVEY.md 8(f) rank 2.  The recipes write network.xconfig, xconfig_to_configs.py turns it
+# into configs/final.config (steps/libs/nnet3/xconfig/composite_layers.py:135-215,706-792,1283-1331), the NAS scripts rewrite
+# that text (generate_config.py, generate_bottleneckCB8share_onehottrain_config.py, add_flopsconstraint.py) and nnet3-init
+# (UPSTREAM) builds the initial model from it: Nnet::ReadConfig parses `component name=.. type=.. key=value ..`,
+# `component-node`, `dim-range-node`, `input-node`, `output-node` lines and calls every component's InitFromConfig
+# (TdnnDARTSV3Component::InitFromConfig nnet-tdnn-component.cc:109-212).  parse_config() / net_config_from_final_config() /
+# init_params_from_final_config() are that step for the graphs of SURVEY.md 3.4, the ones the trainer runs.
+def parse_config(lines):
+    """The lines of a final.config as {'inputs': {name: dim}, 'components': {name: {'type': .., key: value, ..}} (in file order),
+    'nodes': [node lines, whitespace-normalised, in file order], 'outputs': [names]}.  Values stay strings (a ConfigLine's
+    GetValue converts on demand).  Raises ValueError for a line that is none of the five kinds."""
+    out = {"inputs": {}, "components": {}, "nodes": [], "outputs": []}
+    for raw in lines:
+        line = raw.split("#")[0].strip()
+        if not line:
+            continue
+        kind, _, rest = line.partition(" ")
+        if kind not in ("input-node", "component", "component-node", "dim-range-node", "output-node"):
+            raise ValueError("final.config: unknown line type %r in %r" % (kind, raw))
+        # key=value pairs; a value runs to the next ' key=' (descriptors contain spaces and commas)
+        import re
+        pairs = re.findall(r"([A-Za-z][\w\-]*)=(.*?)(?=\s+[A-Za-z][\w\-]*=|\s*$)", rest)
+        kv = {k: v.strip() for k, v in pairs}
+        if "name" not in kv:
+            raise ValueError("final.config: line without name=: %r" % raw)
+        if kind == "input-node":
+            out["inputs"][kv["name"]] = int(kv["dim"])
+        elif kind == "component":
+            if "type" not in kv:
+                raise ValueError("final.config: component without type=: %r" % raw)
+            if kv["name"] in out["components"]:
+                raise ValueError("final.config: component %s defined twice" % kv["name"])
+            out["components"][kv["name"]] = {k: v for k, v in kv.items() if k != "name"}
+        else:
+            if kind == "output-node":
+                out["outputs"].append(kv["name"])
+            out["nodes"].append(" ".join(line.split()))
+    out["nodes"] = ["input-node name=%s dim=%d" % (k, v) for k, v in out["inputs"].items()] + out["nodes"]
+    return out
+
+
+def _b(v, default):
+    return default if v is None else {"true": True, "t": True, "1": True, "false": False, "f": False, "0": False}[str(v).strip().lower()]
+
+
+def net_config_kwargs_from_final_config(lines):
+    """trainer.make_config keyword arguments for the network a final.config describes: dimensions and hyper-parameters from
+    the component lines, the layer structure (time strides / per-layer offsets of a derived child / the K taps and flags of
+    the offset supernet / the choice blocks and mode of the bottleneck supernet / BatchNormTestComponent = cv-update) from
+    their types and time-offsets, the bypass scale from the tdnnfN.noop descriptor.  The graph WIRING is not taken on trust:
+    net_config_from_final_config() checks it line by line."""
+    import re
+    cfg = parse_config(lines)
+    comp = cfg["components"]
+
+    def need(name):
+        if name not in comp:
+            raise ValueError("final.config: no component %s -- not one of the TDNN-F graphs the trainer runs" % name)
+        return comp[name]
+
+    kw = dict(feat_dim=cfg["inputs"].get("input"), ivector_dim=cfg["inputs"].get("ivector"))
+    if kw["feat_dim"] is None or kw["ivector_dim"] is None:
+        raise ValueError("final.config: needs input-node name=input and name=ivector")
+    t1 = need("tdnn1.affine")
+    kw["hidden_dim"] = int(t1["output-dim"])
+    kw["l2_hidden"] = float(t1.get("l2-regularize", 0.0))
+    layers = sorted({int(m.group(1)) for n in comp for m in [re.match(r"tdnnf(\d+)\.linear$", n)] if m})
+    if not layers or layers != list(range(2, 2 + len(layers))):
+        raise ValueError("final.config: tdnnf layers must be tdnnf2 .. tdnnfN, found %s" % layers)
+    offs, bns, darts_K, flags, temp = [], [], 0, None, 1.0
+    for n in layers:
+        lin, aff = need("tdnnf%d.linear" % n), need("tdnnf%d.affine" % n)
+        if lin["type"] != aff["type"] or lin["type"] not in ("TdnnComponent", "TdnnDARTSV3Component"):
+            raise ValueError("final.config: tdnnf%d: unsupported component types %s / %s" % (n, lin["type"], aff["type"]))
+        lo, ao = [int(v) for v in lin["time-offsets"].split(",")], [int(v) for v in aff["time-offsets"].split(",")]
+        bns.append(int(lin["output-dim"]))
+        if lin["type"] == "TdnnDARTSV3Component" and len(lo) > 2:  # the K-tap search space of generate_config.py
+            K = len(lo)
+            if lo != list(range(-(K - 1), 1)) or ao != list(range(0, K)):
+                raise ValueError("final.config: tdnnf%d: offset supernet taps must be -(K-1)..0 / 0..K-1" % n)
+            # InitFromConfig :150-163: every flag defaults to TRUE when the line does not give it
+            f = ((1 if _b(lin.get("use-gumbel"), True) else 0) | (2 if _b(lin.get("free-select"), True) else 0) | (4 if _b(lin.get("uniform-sample"), True) else 0) |
+                 (8 if _b(lin.get("use-entropy"), True) else 0) | (16 if _b(lin.get("update-alpha"), True) else 0))
+            if darts_K not in (0, K) or flags not in (None, f):
+                raise ValueError("final.config: the trainer runs one K and one set of flags for every layer")
+            darts_K, flags, temp = K, f, float(lin.get("Temp-Proportion", 1.0))
+            offs.append((0, 0))
+            continue
+        if not ((lo == [0] or (len(lo) == 2 and lo[1] == 0 and lo[0] < 0)) and (ao == [0] or (len(ao) == 2 and ao[0] == 0 and ao[1] > 0))):
+            raise ValueError("final.config: tdnnf%d: time-offsets %s / %s are not {-a,0} / {0,b}" % (n, lo, ao))
+        offs.append((-lo[0] if len(lo) == 2 else 0, ao[1] if len(ao) == 2 else 0))
+    if darts_K:
+        kw.update(darts_num_offsets=darts_K, darts_flags=flags, darts_temp_proportion=temp, strides=[1] * len(layers))
+    elif all(a == b for a, b in offs):
+        kw["strides"] = [a for a, _ in offs]
+    else:
+        kw["layer_offsets"] = offs
+    kw["bottleneck"] = bns
+    # bottleneck supernet: CopyN blocks tdnnf<N><k>.copyn, the C-vector component tdnnfN.softmax / tdnnfN.alpha
+    first = "tdnnf%d" % layers[0]
+    blocks = sorted(int(m.group(1)) for n in comp for m in [re.match(re.escape(first) + r"(\d)\.copyn$", n)] if m)
+    if blocks:
+        kw["bn_choice_dims"] = [int(comp["%s%d.copyn" % (first, k)]["output-dim"]) for k in blocks]
+        sm = need(first + ".softmax")["type"]
+        kw["bn_mode"] = {"OnehotFunctionComponent": 0, "SoftmaxFlopsComponent": 1, "GumbelSoftmaxFlopsComponent": 2}.get(sm)
+        if kw["bn_mode"] is None:
+            raise ValueError("final.config: %s.softmax of type %s" % (first, sm))
+        if kw["bn_mode"]:
+            kw["bn_flops_scale"] = float(comp[first + ".softmax"].get("scale", comp[first + ".softmax"].get("flops-scale", 0.0)))
+            kw["bn_temp_proportion"] = float(comp[first + ".softmax"].get("Temp-Proportion", 1.0))
+    relu = need("tdnn1.relu")
+    kw["relu_self_repair_scale"] = float(relu.get("self-repair-scale", 1.0e-5))
+    kw["use_dropout"] = int(any(c["type"] == "GeneralDropoutComponent" for c in comp.values()))
+    kw["cv_update"] = int(need("tdnn1.batchnorm")["type"] == "BatchNormTestComponent")
+    kw["small_dim"] = int(need("prefinal-l")["output-dim"])
+    out, xent = need("output.affine"), need("output-xent.affine")
+    kw["num_pdfs"] = int(out["output-dim"])
+    kw["l2_output"] = float(out.get("l2-regularize", 0.0))
+    lrf = float(xent.get("learning-rate-factor", 1.0))
+    kw["xent_regularize"] = 0.5 / lrf if lrf != 1.0 else 0.1
+    kw["use_natural_gradient"] = int(_b(t1.get("use-natural-gradient"), True))  # (the reference's components default to true)
+    noop = [n for n in cfg["nodes"] if n.startswith("component-node name=%s.noop " % first)]
+    m = re.search(r"Scale\(([0-9.eE+\-]+),", noop[0]) if noop else None
+    kw["bypass_scale"] = float(m.group(1)) if m else 0.66
+    return kw
+
+
+def net_config_from_final_config(lines, frames_per_chunk=150, num_sequences=64, **overrides):
+    """trainer.NetConfig for a final.config (what nnet3-init + the trainer's own option parsing would arrive at), verified: the
+    node lines the library writes for that configuration (tdnnf_net_config_text -- themselves pinned by the reference scripts'
+    outputs, tests/test_configs.py) must be the file's node lines, name for name and descriptor for descriptor.  A graph the
+    trainer does not run (another wiring, extra nodes) is refused with the first differing line."""
+    from . import trainer
+    kw = net_config_kwargs_from_final_config(lines)
+    kw.update(overrides)
+    cfg = trainer.make_config(frames_per_chunk=frames_per_chunk, num_sequences=num_sequences, **kw)
+    norm = lambda s: "".join(s.split())  # noqa: E731
+    want = [norm(n) for n in parse_config(lines)["nodes"]]
+    have = [norm(n) for n in trainer.config_text(cfg).split("\n") if n.strip()]
+    if sorted(want) != sorted(have):
+        extra = [n for n in want if n not in have][:1] + [n for n in have if n not in want][:1]
+        raise ValueError("final.config: not a graph the trainer runs; first difference: %s" % extra)
+    return cfg
+
+
+def init_params_from_final_config(lines, net, seed=0, lda_matrix=None):
+    """nnet3-init for `net` (a trainer.ChainNet of net_config_from_final_config): every component's InitFromConfig with the
+    keys of its config line -- TdnnDARTSV3Component / TdnnComponent: linear_params ~ N(0, param-stddev^2), param-stddev
+    default 1 / sqrt(input-dim x num-offsets); bias ~ N(bias-mean, bias-stddev^2), bias-stddev default 1, architecture logits 0
+    (nnet-tdnn-component.cc:139-176); NaturalGradientAffineComponent: param-stddev default 1 / sqrt(input-dim), bias-stddev 1;
+    LinearComponent: param-stddev default 1 / sqrt(input-dim); OnehotFunction / ConstantFunction output_: zeros.  The lda
+    matrix comes from its file (`lda_matrix`: the D x (D + 1) array of configs/lda.mat; trainer.read_kaldi_matrix) or, without
+    one, a random orthonormal transform.  Returns the flat float32 parameter vector (numpy's generator stands in for Kaldi's
+    RandGauss: the distribution is restated, not the random stream)."""
+    import numpy as np
+    from . import trainer
+    comp = parse_config(lines)["components"]
+    rng = np.random.default_rng(seed)
+    p = np.zeros(net.num_params, np.float32)
+    for c in net.components:
+        name, rows, cols = c["name"], c["rows"], c["cols"]
+        if name == "lda":
+            if lda_matrix is not None:
+                trainer.set_lda(p, net.components, lda_matrix)
+            else:
+                q = np.linalg.qr(rng.standard_normal((rows, cols)))[0]
+                p[c["begin"]:c["begin"] + rows * cols] = q.astype(np.float32).ravel()
+            continue
+        line = comp.get(name)
+        if line is None:
+            raise ValueError("final.config has no component %s" % name)
+        if line["type"] in ("OnehotFunctionComponent", "ConstantFunctionComponent"):
+            continue  # output_ starts at zero
+        taps = len(line["time-offsets"].split(",")) if "time-offsets" in line else 1
+        in_dim = int(line["input-dim"])
+        if cols != in_dim * taps or rows != int(line["output-dim"]):
+            raise ValueError("final.config: %s is %s x %s x %d taps, the net has %d x %d" % (name, line["output-dim"], line["input-dim"], taps, rows, cols))
+        sd = float(line.get("param-stddev", -1.0))
+        if sd < 0:
+            sd = 1.0 / np.sqrt(in_dim * taps)
+        n = rows * cols
+        p[c["begin"]:c["begin"] + n] = (rng.standard_normal(n) * sd).astype(np.float32)
+        if c["has_bias"]:
+            bsd, bmean = float(line.get("bias-stddev", 1.0)), float(line.get("bias-mean", 0.0))
+            o = c["begin"] + n + c["num_alpha"]  # the num_alpha logits in front stay 0 (:176)
+            p[o:o + rows] = (rng.standard_normal(rows) * bsd + bmean).astype(np.float32)
+    return p
