@@ -474,7 +474,8 @@ int tdnnf_net_set_dropout_proportion(tdnnf_net *, float proportion);
 int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
 /* Model state outside the parameter vector, as doubles in network order (tdnn1, tdnnf2.., prefinal-chain, prefinal-xent):
    per BatchNorm [count, stats_sum[D], stats_sumsq[D]] (BatchNormComponent::StoreStats, nnet-normalize-component.cc:551-589)
-   and per ReLU [count, value_sum[D], deriv_sum[D]] (NonlinearComponent::StoreStatsInternal, nnet-component-itf.cc:433);
+   and per ReLU [count, value_sum[D], deriv_sum[D], oderiv_count, oderiv_sumsq[D]] (NonlinearComponent::StoreStatsInternal and
+   StoreBackpropStats, nnet-component-itf.cc:433-480: the latter on three minibatches in four, always on the first);
    block order per unit: batchnorm, relu (heads: batchnorm1, relu, batchnorm2).  Host buffers; both calls synchronise. */
 long long tdnnf_net_stats_size(const tdnnf_net *);
 int tdnnf_net_get_stats(const tdnnf_net *, double *stats_host, tdnnf_stream);

@@ -29,6 +29,10 @@ size_t bn_relu_bwd_workspace_bytes(int rows, int cols);
 hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
                        void *ws, size_t ws_bytes, hipStream_t s, const float *mask = nullptr, int B = 1,  // mask: dz is multiplied by it first
-                       const NgFuse *ng = nullptr);
+                       const NgFuse *ng = nullptr,
+                       // NonlinearComponent::StoreBackpropStats (nnet-component-itf.cc:461-480) for the ReLU: [oderiv_count,
+                       // oderiv_sumsq[D]] doubles to add this minibatch's count and column sums of squares of the ReLU's
+                       // out_deriv to; null = not this minibatch
+                       double *oderiv_stats = nullptr);
 
 }  // namespace tdnnf

@@ -58,11 +58,11 @@ __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const f
 template <int VEC, bool RELU_STATS>
 __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatView dz, const float *mean, const float *scale,
                                                                  int rows_per_chunk, int chunks, float *partial, const float *mask, int B) {
-  __shared__ float red[4][4][64 * 4 + 4];
+  __shared__ float red[5][4][64 * 4 + 4];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + tc) * VEC;
   const int r0 = blockIdx.y * rows_per_chunk, r1 = min(x.rows, r0 + rows_per_chunk);
-  float s[4][4] = {};
+  float s[5][4] = {};  // sum z dz, sum dz, sum dz^2 (StoreBackpropStats), [sum x, count x > 0]
   if (col < x.cols) {
     float mu[4], sc[4];
 #pragma unroll
@@ -84,14 +84,15 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
         const float z = (xv[j] - mu[j]) * sc[j];
         s[0][j] += z * dv[j];
         s[1][j] += dv[j];
+        s[2][j] += dv[j] * dv[j];
         if (RELU_STATS) {
-          s[2][j] += xv[j];
-          s[3][j] += xv[j] > 0.f ? 1.f : 0.f;
+          s[3][j] += xv[j];
+          s[4][j] += xv[j] > 0.f ? 1.f : 0.f;
         }
       }
     }
   }
-  constexpr int NQ = RELU_STATS ? 4 : 2;
+  constexpr int NQ = RELU_STATS ? 5 : 3;
 #pragma unroll
   for (int q = 0; q < NQ; q++)
 #pragma unroll
@@ -109,22 +110,38 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
 }
 
 // memo rows 3 (var_deriv_mod) and 4 (temp) from the partials (nnet-normalize-component.cc:520-526);
-// optionally the ReLU statistics [count, value_sum[D], deriv_sum[D]] (StoreStatsInternal).
+// optionally the ReLU statistics [count, value_sum[D], deriv_sum[D]] (StoreStatsInternal) and, into oderiv =
+// [oderiv_count, oderiv_sumsq[D]], NonlinearComponent::StoreBackpropStats (nnet-component-itf.cc:461-480): the column sums of
+// squares of the ReLU's out_deriv dr = (dz + temp) scale + z vdm.  They need no pass of their own:
+//   sum_r dr^2 = scale^2 (sum dz^2 - (sum dz)^2 / N) + 2 vdm scale sum z dz + vdm^2 sum z^2,   sum z^2 = N var scale^2
+// (train mode: sum z = 0; test mode: temp = vdm = 0) from the quantities this reduction already forms, plus sum dz^2.
 __global__ __launch_bounds__(kFinThreads) void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms,
-                                                                           float *memo, double *relu_stats, int test_mode) {
-  __shared__ double red[4 * kFinLanes * (kFinCols + 1)];
+                                                                           float *memo, double *relu_stats, int test_mode, double *oderiv) {
+  __shared__ double red[5 * kFinLanes * (kFinCols + 1)];
   const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
   if (relu_stats && blockIdx.x == 0 && threadIdx.x == 0) relu_stats[0] += (double)N;
-  double q[4];
-  finalize_sums<4, double>(partial, chunks, chunks, D, relu_stats ? 4 : 2, q, red);
+  if (oderiv && blockIdx.x == 0 && threadIdx.x == 0) oderiv[0] += (double)N;
+  double q[5];
+  finalize_sums<5, double>(partial, chunks, chunks, D, relu_stats ? 5 : 3, q, red);
   if (threadIdx.x >= kFinCols || d >= D) return;
   const float coeff = -1.0f / (target_rms * target_rms * N);
   // test mode (BatchNormTestComponent::Backprop, nnet-normalize-component.cc:879-922): in_deriv = out_deriv * scale
-  memo[3 * D + d] = test_mode ? 0.f : (float)(coeff * q[0]) * memo[2 * D + d];
+  const float sc = memo[2 * D + d];
+  const float vdm = test_mode ? 0.f : (float)(coeff * q[0]) * sc;
+  memo[3 * D + d] = vdm;
   memo[4 * D + d] = test_mode ? 0.f : (float)(-q[1] / N);
   if (relu_stats) {
-    relu_stats[1 + d] += q[2];
-    relu_stats[1 + D + d] += q[3];
+    relu_stats[1 + d] += q[3];
+    relu_stats[1 + D + d] += q[4];
+  }
+  if (oderiv) {
+    const double sc2 = (double)sc * sc;
+    double v = sc2 * (test_mode ? q[2] : q[2] - q[1] * q[1] / N);
+    if (!test_mode) {
+      const double var = (double)memo[D + d] - (double)memo[d] * memo[d];  // uvar - mean^2 (memo rows 1, 0 of the forward pass)
+      v += 2.0 * vdm * sc * q[0] + (double)vdm * vdm * (double)N * (var > 0 ? var : 0.0) * sc2;
+    }
+    oderiv[1 + d] += v > 0 ? v : 0.0;
   }
 }
 
@@ -372,14 +389,14 @@ bool bn_relu_bwd_ng_pays(int rows) {
 size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
   ColReducePlan p = colreduce_plan(rows, cols);
   const size_t blocks128 = ((size_t)rows + 127) / 128;  // column-sum partials of the natural-gradient form: one row per 128-row block
-  return sizeof(float) * (4 * (size_t)p.chunks + std::max((size_t)p.chunks, blocks128)) * cols + 64;
+  return sizeof(float) * (5 * (size_t)p.chunks + std::max((size_t)p.chunks, blocks128)) * cols + 64;
 }
 
 // x: ReLU output (= BatchNorm input), dz: derivative w.r.t. the BatchNorm output, memo: forward memo (rows 0-2
 // valid).  Writes d_aff (may alias dz) and adds lr_scale * colsum(d_aff) into bias_acc (may be null).
 hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
-                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask, int B, const NgFuse *ng) {
+                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask, int B, const NgFuse *ng, double *oderiv_stats) {
   if (x.rows == 0) return hipSuccess;
   if (ws_bytes < bn_relu_bwd_workspace_bytes(x.rows, x.cols)) return hipErrorInvalidValue;
   if (ng && (!bn_relu_bwd_ng_ok(x, dz, d_aff, ng->Rp) || (reinterpret_cast<uintptr_t>(memo) & 15) || (reinterpret_cast<uintptr_t>(ng->W) & 15) || ng->ldw % 4))
@@ -389,8 +406,8 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
   const bool vec = vec4_ok(x) && vec4_ok(dz) && vec4_ok(d_aff);
   const int per = vec ? 256 : 64;
   dim3 grid((D + per - 1) / per, pl.chunks), block(256);
-  float *partial = (float *)ws;                                  // quantities 0..3 of the reduction
-  float *bias_partial = partial + 4 * (size_t)pl.chunks * D;     // column sums of d_aff
+  float *partial = (float *)ws;                                  // quantities 0..4 of the reduction
+  float *bias_partial = partial + 5 * (size_t)pl.chunks * D;     // column sums of d_aff
   // Order as in the reference: StoreStats runs with the forward pass, RepairGradients in Backprop sees the
   // statistics including this minibatch (when it was stored).
   if (store_relu_stats) {
@@ -401,7 +418,7 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
   }
   hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
-                     store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0);
+                     store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0, oderiv_stats);
   const double *rep = self_repair ? relu_stats : nullptr;
   if (ng) {
     const int blocks = (x.rows + 127) / 128;

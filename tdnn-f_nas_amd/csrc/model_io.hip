@@ -309,23 +309,23 @@ struct HostNet {
 void stat_layout(const tdnnf_net *n, HostNet *h) {  // the order of tdnnf_net_get_stats (net.hip: stat_blocks)
   const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
   size_t off = 0;
-  auto add = [&](const std::string &name, int D) {
+  auto add = [&](const std::string &name, int D, bool relu = false) {  // relu: [count, value_sum, deriv_sum, oderiv_count, oderiv_sumsq]
     h->stat_off[name] = off;
     h->stat_dim[name] = D;
-    off += 1 + 2 * (size_t)D;
+    off += relu ? 2 + 3 * (size_t)D : 1 + 2 * (size_t)D;
   };
   add("tdnn1.batchnorm", Hd);
-  add("tdnn1.relu", Hd);
+  add("tdnn1.relu", Hd, true);
   for (size_t l = 0; l < n->layers.size(); l++) {
     const std::string p = "tdnnf" + std::to_string(l + 2);
     add(p + ".batchnorm", Hd);
-    add(p + ".relu", Hd);
+    add(p + ".relu", Hd, true);
   }
   const char *hn[2] = {"chain", "xent"};
   for (int k = 0; k < 2; k++) {
     const std::string p = std::string("prefinal-") + hn[k];
     add(p + ".batchnorm1", Hd);
-    add(p + ".relu", Hd);
+    add(p + ".relu", Hd, true);
     add(p + ".batchnorm2", S);
   }
 }
@@ -578,16 +578,20 @@ void write_nonlinear(Ctx &x, const char *type, int D, const std::string &stat_na
   o.token(std::string("<") + type + ">");
   o.token("<Dim>");
   o.i32(D);
-  std::vector<float> va, da;
-  double count = 0;
+  std::vector<float> va, da, orms;
+  double count = 0, ocount = 0;
   if (!stat_name.empty()) {
     const double *st = x.h->stats.data() + x.h->stat_off.at(stat_name);
     count = st[0];
+    ocount = st[1 + 2 * D];
     va.resize(D);
     da.resize(D);
+    orms.resize(D);
     for (int d = 0; d < D; d++) {
       va[d] = (float)(count != 0 ? st[1 + d] / count : st[1 + d]);
       da[d] = (float)(count != 0 ? st[1 + D + d] / count : st[1 + D + d]);
+      const double v = ocount != 0 ? st[2 + 2 * D + d] / ocount : st[2 + 2 * D + d];  // :658-664: scale, ApplyFloor(0), ApplyPow(0.5)
+      orms[d] = (float)sqrt(v > 0 ? v : 0.0);
     }
   }
   o.token("<ValueAvg>");
@@ -597,9 +601,9 @@ void write_nonlinear(Ctx &x, const char *type, int D, const std::string &stat_na
   o.token("<Count>");
   o.f64(count);
   o.token("<OderivRms>");
-  o.vec(nullptr, 0);
+  o.vec(orms.data(), (int)orms.size());
   o.token("<OderivCount>");
-  o.f64(0.0);
+  o.f64(ocount);
   o.token("<NumDimsSelfRepaired>");
   o.f64(0.0);
   o.token("<NumDimsProcessed>");
@@ -800,7 +804,7 @@ int write_components(Ctx &x, bool count_only) {
 // --------------------------------------------------------------------------------------------- component readers
 struct Parsed {  // what one component block contributed
   std::string type;
-  std::vector<float> W, b, out_vec, mean, var, value_avg, deriv_avg;
+  std::vector<float> W, b, out_vec, mean, var, value_avg, deriv_avg, oderiv_rms;
   int rows = 0, cols = 0;
   double count = 0;
   std::vector<int> offsets;
@@ -878,6 +882,7 @@ bool read_block(In &in, const std::string &type, Parsed *p) {
         else if (t == "<StatsVar>") p->var = v;
         else if (t == "<ValueAvg>") { p->value_avg = v; p->have_stats = true; }
         else if (t == "<DerivAvg>") p->deriv_avg = v;
+        else if (t == "<OderivRms>") p->oderiv_rms = v;
         break;
     }
   }
@@ -1049,6 +1054,11 @@ int tdnnf_net_read_model(tdnnf_net *n, const char *path, tdnnf_stream stream) {
           dstat[1 + d] = (double)p.value_avg[d] * p.count;
           dstat[1 + D + d] = (double)p.deriv_avg[d] * p.count;
         }
+        // NonlinearComponent::Read itf.cc:584-590: oderiv_sumsq_ = rms^2 * oderiv_count_ (an empty vector: nothing stored yet)
+        const auto oc = p.num.find("<OderivCount>");
+        const double ocount = oc != p.num.end() ? oc->second : 0.0;
+        dstat[1 + 2 * D] = (int)p.oderiv_rms.size() == D ? ocount : 0.0;
+        for (int d = 0; d < D; d++) dstat[2 + 2 * D + d] = (int)p.oderiv_rms.size() == D ? (double)p.oderiv_rms[d] * p.oderiv_rms[d] * ocount : 0.0;
       }
     }
   }

@@ -326,7 +326,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->t1_bn = A.mat(N0, Hd);
   n->t1_bn_memo = A.take<float>(5 * Hd);
   n->t1_bn_stats = A.take<double>(1 + 2 * Hd);
-  n->t1_relu_stats = A.take<double>(1 + 2 * Hd);
+  n->t1_relu_stats = A.take<double>(2 + 3 * Hd);  // [count, value_sum, deriv_sum, oderiv_count, oderiv_sumsq]
   int max_rows = N0, max_lin_rows = 0;
   for (auto &L : n->layers) {
     const int nl = N_of(L.lin.out, B), no = N_of(L.gout, B);
@@ -346,7 +346,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     L.lin.active = L.lin.darts ? A.take<int>(TDNNF_MAX_OFFSETS + 1) : nullptr;
     L.aff.active = L.aff.darts ? A.take<int>(TDNNF_MAX_OFFSETS + 1) : nullptr;
     L.bn_stats = A.take<double>(1 + 2 * Hd);
-    L.relu_stats = A.take<double>(1 + 2 * Hd);
+    L.relu_stats = A.take<double>(2 + 3 * Hd);
     max_rows = std::max(max_rows, std::max(no, N_of(L.gin, B)));
     max_lin_rows = std::max(max_lin_rows, nl);
   }
@@ -363,7 +363,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     H.bn2_memo = A.take<float>(5 * S);
     H.bn1_stats = A.take<double>(1 + 2 * Hd);
     H.bn2_stats = A.take<double>(1 + 2 * S);
-    H.relu_stats = A.take<double>(1 + 2 * Hd);
+    H.relu_stats = A.take<double>(2 + 3 * Hd);
   }
   n->xent_logsoftmax = A.mat(No, P);
   n->d_y = A.mat(No, P);
@@ -902,18 +902,20 @@ int tdnnf_net_component_info(const tdnnf_net *n, int i, char *name_out, long lon
 
 // model statistics outside the parameter vector: [count, sum[D], sumsq[D]] of every BatchNorm and
 // [count, value_sum[D], deriv_sum[D]] of every ReLU, in network order
-static void stat_blocks(const tdnnf_net *n, std::vector<std::pair<double *, int>> &out) {
+static void stat_blocks(const tdnnf_net *n, std::vector<std::pair<double *, int>> &out) {  // (pointer, number of doubles)
   const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
-  out.push_back({n->t1_bn_stats, Hd});
-  out.push_back({n->t1_relu_stats, Hd});
+  auto bn = [&](double *p, int D) { out.push_back({p, 1 + 2 * D}); };
+  auto relu = [&](double *p, int D) { out.push_back({p, 2 + 3 * D}); };
+  bn(n->t1_bn_stats, Hd);
+  relu(n->t1_relu_stats, Hd);
   for (auto &L : n->layers) {
-    out.push_back({L.bn_stats, Hd});
-    out.push_back({L.relu_stats, Hd});
+    bn(L.bn_stats, Hd);
+    relu(L.relu_stats, Hd);
   }
   for (int h = 0; h < 2; h++) {
-    out.push_back({n->head[h].bn1_stats, Hd});
-    out.push_back({n->head[h].relu_stats, Hd});
-    out.push_back({n->head[h].bn2_stats, S});
+    bn(n->head[h].bn1_stats, Hd);
+    relu(n->head[h].relu_stats, Hd);
+    bn(n->head[h].bn2_stats, S);
   }
 }
 long long tdnnf_net_stats_size(const tdnnf_net *n) {
@@ -921,7 +923,7 @@ long long tdnnf_net_stats_size(const tdnnf_net *n) {
   std::vector<std::pair<double *, int>> b;
   stat_blocks(n, b);
   long long t = 0;
-  for (auto &x : b) t += 1 + 2 * x.second;
+  for (auto &x : b) t += x.second;
   return t;
 }
 int tdnnf_net_get_stats(const tdnnf_net *n, double *host_out, tdnnf_stream stream) {
@@ -930,8 +932,8 @@ int tdnnf_net_get_stats(const tdnnf_net *n, double *host_out, tdnnf_stream strea
   stat_blocks(n, b);
   TDNNF_HIP(hipStreamSynchronize((hipStream_t)stream));
   for (auto &x : b) {
-    TDNNF_HIP(hipMemcpy(host_out, x.first, sizeof(double) * (1 + 2 * x.second), hipMemcpyDeviceToHost));
-    host_out += 1 + 2 * x.second;
+    TDNNF_HIP(hipMemcpy(host_out, x.first, sizeof(double) * x.second, hipMemcpyDeviceToHost));
+    host_out += x.second;
   }
   return TDNNF_OK;
 }
@@ -941,8 +943,8 @@ int tdnnf_net_set_stats(tdnnf_net *n, const double *host_in, tdnnf_stream stream
   stat_blocks(n, b);
   TDNNF_HIP(hipStreamSynchronize((hipStream_t)stream));
   for (auto &x : b) {
-    TDNNF_HIP(hipMemcpy(x.first, host_in, sizeof(double) * (1 + 2 * x.second), hipMemcpyHostToDevice));
-    host_in += 1 + 2 * x.second;
+    TDNNF_HIP(hipMemcpy(x.first, host_in, sizeof(double) * x.second, hipMemcpyHostToDevice));
+    host_in += x.second;
   }
   return TDNNF_OK;
 }
@@ -1243,6 +1245,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     fused_set = &S;
     return 1;
   };
+  // NonlinearComponent::StoreBackpropStats (nnet-component-itf.cc:461-480): "if (RandInt(0, 3) == 0 && oderiv_count_ != 0) return"
+  // -- three minibatches in four, always the first; a decision stream of its own (the k-th ReLU of the backward pass)
+  unsigned long long relu_k = 0;
+  auto oderiv_of = [&](double *relu_stats) -> double * {
+    const bool skip = step != 0 && ::tdnnf::tdnnf_decision((unsigned long long)step, 2 * (4096 + relu_k)) % 4 == 0;
+    relu_k++;
+    return skip ? nullptr : relu_stats + 1 + 2 * Hd;
+  };
   auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc, int comp,
                               const float *mask = nullptr) -> int {
     const bool store = coin() || step == 0;
@@ -1252,7 +1262,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const int fuse = out_stats_fuse(comp, view(&x), view(&d), view(&d), f);
     if (fuse < 0) return TDNNF_EINVAL;
     TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, cv, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
-                          n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr));
+                          n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr, oderiv_of(relu_stats)));
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
@@ -1401,7 +1411,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const int fuse = out_stats_fuse(L.aff.comp, view(&x), view(&d_out), view(&d_aff), f);
       if (fuse < 0) return TDNNF_EINVAL;
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
-                            view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr));
+                            view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr,
+                            oderiv_of(L.relu_stats)));
     }
     CK(capture(lname + ".affine.deriv", d_aff));
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);

@@ -335,9 +335,9 @@ class OracleNet:
             if kind == "bn":
                 st = self.bn_stats.get(key, dict(count=0.0, sum=np.zeros(D), sumsq=np.zeros(D)))
                 out += [[st["count"]], st["sum"], st["sumsq"]]
-            else:
+            else:  # [count, value_sum, deriv_sum, oderiv_count, oderiv_sumsq] (NonlinearComponent, nnet-component-itf.cc:433-480)
                 st = self.relu_stats.get(key, dict(count=0.0, vs=np.zeros(D), ds=np.zeros(D)))
-                out += [[st["count"]], st["vs"], st["ds"]]
+                out += [[st["count"]], st["vs"], st["ds"], [st.get("oc", 0.0)], st.get("os", np.zeros(D))]
         return np.concatenate([np.asarray(a, np.float64) for a in out])
 
     def set_stats(self, flat):
@@ -349,7 +349,8 @@ class OracleNet:
             if kind == "bn":
                 self.bn_stats[key] = dict(count=cnt, sum=a, sumsq=b)
             else:
-                self.relu_stats[key] = dict(count=cnt, vs=a, ds=b)
+                self.relu_stats[key] = dict(count=cnt, vs=a, ds=b, oc=float(flat[o]), os=np.array(flat[o + 1:o + 1 + D], np.float64))
+                o += 1 + D
         assert o == len(flat)
 
     def _to_rho(self, x, rho, inverse=False):
@@ -535,9 +536,18 @@ class OracleNet:
             Lb.oracle_affine_backprop(ora.omat(dyy), ora.fptr(W), W.shape[1], W.shape[1], ora.omat(dx))
             return dx
 
+        relu_k = [0]
+
         def relu_bwd(key, relu_out, d):
             dd = ((relu_out > 0) * d).astype(F)
             st = self.relu_stats.setdefault(key, dict(count=0.0, vs=np.zeros(relu_out.shape[1]), ds=np.zeros(relu_out.shape[1])))
+            # StoreBackpropStats (nnet-component-itf.cc:461-480) on the ReLU's out_deriv d: skipped when "RandInt(0, 3) == 0" except
+            # on the first minibatch -- the trainer's k-th ReLU of the backward pass takes decision(step, 2 (4096 + k)) for it
+            skip = step != 0 and decision(step, 2 * (4096 + relu_k[0])) % 4 == 0
+            relu_k[0] += 1
+            if not skip:
+                st["os"] = st.get("os", np.zeros(d.shape[1])) + (d.astype(np.float64) ** 2).sum(0)
+                st["oc"] = st.get("oc", 0.0) + d.shape[0]
             # reference order: StoreStats runs with the forward pass (w.p. 1/2, always on the first minibatch,
             # nnet-simple-component.cc:1084), RepairGradients in Backprop (w.p. 1/2, :1017) sees the updated stats
             if coin() or step == 0:

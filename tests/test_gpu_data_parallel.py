@@ -37,14 +37,15 @@ def _problem(pkg, B):
     # valid BatchNorm / ReLU statistics: [count, sum[D], sumsq[D]] with sumsq/count > (sum/count)^2
     o = 0
     Hd, S = cfg.hidden_dim, cfg.prefinal_small_dim
-    dims = [Hd, Hd] + [Hd, Hd] * cfg.num_layers + [Hd, Hd, S] * 2
-    for D in dims:
+    dims = [(Hd, 0), (Hd, 1)] + [(Hd, 0), (Hd, 1)] * cfg.num_layers + [(Hd, 0), (Hd, 1), (S, 0)] * 2  # (dimension, is a ReLU block)
+    for D, relu in dims:
         stats[o] = 100.0
         mean = rng.standard_normal(D) * 0.3
         var = rng.uniform(0.5, 1.5, D)
         stats[o + 1:o + 1 + D] = 100.0 * mean
         stats[o + 1 + D:o + 1 + 2 * D] = 100.0 * (var + mean * mean)
-        o += 1 + 2 * D
+        o += 1 + 2 * D + ((1 + D) if relu else 0)  # a ReLU block also carries [oderiv_count, oderiv_sumsq[D]]
+    assert o == len(stats)
     feats, iv = T.synthetic_egs(full, seed=4)
     den = pkg.synth.make_den_graph(40, cfg.num_pdfs, mean_out_degree=4.0, seed=5)
     sup = pkg.synth.make_supervision(KW["num_sequences"], cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=6)

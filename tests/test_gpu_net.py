@@ -232,7 +232,12 @@ def test_net_cv_update_after_pretrain_matches_oracle(pkg, name, pre_kw, cv_kw):
         params = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
     st_gpu, st_ref = net.get_stats(), ref.get_stats()
     assert st_gpu.shape == st_ref.shape and st_ref[0] > 0
-    assert rel_l2(st_gpu, st_ref) < 1e-5, rel_l2(st_gpu, st_ref)
+    # (the ReLU blocks' oderiv_sumsq entries come out of the reduction pass in closed form, in float: fused.hip, bn_relu_bwd_finalize_kernel)
+    assert rel_l2(st_gpu, st_ref) < 5e-5, rel_l2(st_gpu, st_ref)
+    D = cfg.hidden_dim  # second block = tdnn1.relu: [count, value_sum, deriv_sum, oderiv_count, oderiv_sumsq]
+    relu_blk = slice(1 + 2 * D, 1 + 2 * D + 2 + 3 * D)
+    assert st_ref[relu_blk][1 + 2 * D] > 0 and st_gpu[relu_blk][1 + 2 * D] == st_ref[relu_blk][1 + 2 * D]  # oderiv_count: always stored on the first minibatch
+    assert rel_l2(st_gpu[relu_blk][2 + 2 * D:], st_ref[relu_blk][2 + 2 * D:]) < 1e-4 and st_ref[relu_blk][2 + 2 * D:].min() >= 0
     net.close()
 
     cfg2 = pkg.trainer.make_config(**cv_kw)
