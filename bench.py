@@ -37,8 +37,8 @@ HBM_PEAK_GBS = 8000.0
 TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")  # tools/make_profiles.py: separate --pmc passes of this command
 
 # parity bars of BASELINE.json's north_star: objective 1e-4 relative, parameter-gradient L2 1e-3; with natural gradient the
-# preconditioners' eigen-decompositions feed rounding differences back (tests hold 5e-3 there)
-OBJF_TOL, GRAD_TOL, GRAD_TOL_NG = 1e-4, 1e-3, 5e-3
+# first step also held to 1e-3 (measured 1e-5 once ReLU ties are agreed; later steps feed the eigen-decompositions back)
+OBJF_TOL, GRAD_TOL = 1e-4, 1e-3
 
 
 def workload_kwargs(args):
@@ -51,46 +51,65 @@ def workload_kwargs(args):
     return {}
 
 
-def parity_and_cpu_baseline(pkg, args, want_baseline=True):
-    """A bounded sample of the SAME workload (same net at full width, chunk 150, --cpu-sequences sequences, same denominator
-    graph family): (1) one training step on the GPU through the C-ABI against the double-accumulating CPU oracle -- objective
-    and parameter gradient, asserted against BASELINE.json's bars; (2) the float/OpenMP build of the oracle timed on this
-    box's host cores (2 warm-ups, median of 5), all usable cores and one thread."""
+def hip_step_against_oracle(pkg, args, gemm_precision, tie_tol, state=None):
+    """One training step of the full-width net on the bounded sample (chunk 150 x --cpu-sequences) on the GPU against the
+    double-accumulating oracle: relative objective and gradient differences, ReLU ties counted (taken over where the oracle's
+    own pre-activation is within tie_tol x rms of zero)."""
     import numpy as np
     import torch
     from tests.oracle_net import OracleNet, component_table
     B, T = args.cpu_sequences, 150
-    cfg = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B, use_natural_gradient=args.natural_gradient, **workload_kwargs(args))
+    cfg = pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B, use_natural_gradient=args.natural_gradient, gemm_precision=gemm_precision,
+                                  **workload_kwargs(args))
     net = pkg.trainer.ChainNet(cfg)
     comps, num_params = component_table(cfg)
     assert num_params == net.num_params and [c["begin"] for c in comps] == [c["begin"] for c in net.components]
-    params = net.init_params_numpy(seed=0, output_stddev=0.05)
-    net.set_params(params)
-    feats, iv = pkg.trainer.synthetic_egs(net, seed=100)
-    den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
-    sup = pkg.synth.make_supervision_from_den(den, B, T // 3, num_paths=2, seed=2)
-    draws = np.random.default_rng(5).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(np.float32)
-    net.set_random_draws(draws)
-    r = net.forward_backward(torch.from_numpy(feats).cuda(), torch.from_numpy(iv).cuda(), pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup), step=0)
+    if state is None:
+        params = net.init_params_numpy(seed=0, output_stddev=0.05)
+        feats, iv = pkg.trainer.synthetic_egs(net, seed=100)
+        den = pkg.synth.make_den_graph(args.den_states, cfg.num_pdfs, mean_out_degree=args.den_degree, seed=1)
+        sup = pkg.synth.make_supervision_from_den(den, B, T // 3, num_paths=2, seed=2)
+        draws = np.random.default_rng(5).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(np.float32)
+        state = dict(params=params, feats=feats, iv=iv, den=den, sup=sup, draws=draws, comps=comps)
+    net.set_params(state["params"])
+    net.set_random_draws(state["draws"])
+    r = net.forward_backward(torch.from_numpy(state["feats"]).cuda(), torch.from_numpy(state["iv"]).cuda(), pkg.hipabi.DenGraph(state["den"]),
+                             pkg.hipabi.Supervision(state["sup"]), step=0)
     torch.cuda.synchronize()
     r, g = r.cpu().numpy(), net.grads.cpu().numpy()
-    # ReLU outputs of the GPU step: a pre-activation within rounding of zero flips its derivative mask between two correct
-    # float implementations (and one flip among ~10^6 elements is ~1e-3 of a layer's derivative norm); the oracle takes those
-    # ties over -- after checking that they ARE ties -- and counts them
     relu_names = ["tdnn1.relu"] + ["tdnnf%d.relu" % (l + 2) for l in range(cfg.num_layers)] + ["prefinal-chain.relu", "prefinal-xent.relu"]
     relus = {k: net.activation(k).cpu().numpy() for k in relu_names}
     net.close()
     ref = OracleNet(pkg, cfg, comps)  # double-accumulating build
-    res_ref, g_ref, _ = ref.forward_backward(params, feats, iv, den, sup, step=0, draws=draws, relu_like=relus)
+    ref.relu_tie_tol = tie_tol
+    res_ref, g_ref, _ = ref.forward_backward(state["params"], state["feats"], state["iv"], state["den"], state["sup"], step=0, draws=state["draws"], relu_like=relus)
     objf_rel = abs(r[0] - res_ref["objf"]) / abs(res_ref["objf"])
     grad_rel = float(np.linalg.norm(g.astype(np.float64) - g_ref) / np.linalg.norm(g_ref.astype(np.float64)))
-    gtol = GRAD_TOL_NG if args.natural_gradient else GRAD_TOL
-    parity = {"objf_rel": float(f"{objf_rel:.3e}"), "grad_rel_l2": float(f"{grad_rel:.3e}"), "objf_tol": OBJF_TOL, "grad_tol": gtol,
-              "ok": bool(r[5] == 1.0 and objf_rel < OBJF_TOL and grad_rel < gtol and np.isfinite(g).all()),
-              "objf_hip": float(r[0]), "objf_oracle": float(res_ref["objf"]),
-              "relu_ties": int(sum(ref.relu_ties.values())), "relu_elements": int(sum(v.size for v in relus.values())),
-              "sample": f"one training step (natural gradient {'on' if args.natural_gradient else 'off'}) of the full-width net on {B} sequences x {T} frames, "
-                        f"{args.den_states}-state denominator graph; HIP through the C-ABI against oracle/ (double-accumulating CPU restatement, parity unpinned vs Kaldi)"}
+    out = {"objf_rel": float(f"{objf_rel:.3e}"), "grad_rel_l2": float(f"{grad_rel:.3e}"), "objf_tol": OBJF_TOL, "grad_tol": GRAD_TOL,
+           "ok": bool(r[5] == 1.0 and objf_rel < OBJF_TOL and grad_rel < GRAD_TOL and np.isfinite(g).all()),
+           "objf_hip": float(r[0]), "objf_oracle": float(res_ref["objf"]),
+           "relu_ties": int(sum(ref.relu_ties.values())), "relu_elements": int(sum(v.size for v in relus.values())), "relu_tie_tolerance_x_rms": tie_tol}
+    return out, state
+
+
+def parity_and_cpu_baseline(pkg, args, want_baseline=True):
+    """A bounded sample of the SAME workload (same net at full width, chunk 150, --cpu-sequences sequences, same denominator
+    graph family): (1) one training step on the GPU through the C-ABI against the double-accumulating CPU oracle -- objective
+    and parameter gradient, asserted against BASELINE.json's bars (objective 1e-4, gradient L2 1e-3), for the arithmetic of
+    this run and, beside it, for the split-bf16 arithmetic of "alt"; (2) the float/OpenMP build of the oracle timed on this
+    box's host cores (2 warm-ups, median of 5), a probed thread count and one thread."""
+    import numpy as np
+    from tests.oracle_net import OracleNet
+    B, T = args.cpu_sequences, 150
+    prec = {"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.gemm]
+    parity, state = hip_step_against_oracle(pkg, args, prec, 2e-3 if prec == 1 else 1e-4)
+    parity["sample"] = (f"one training step (natural gradient {'on' if args.natural_gradient else 'off'}, --gemm {args.gemm}) of the full-width net on {B} sequences x "
+                        f"{T} frames, {args.den_states}-state denominator graph; HIP through the C-ABI against oracle/ (double-accumulating CPU "
+                        f"restatement, parity unpinned vs Kaldi).  ReLU pre-activations within rounding of zero flip their derivative mask between "
+                        f"any two correct implementations: those ties are taken over from the GPU run and counted")
+    if args.gemm == "f32" and not args.no_alt:
+        parity["bf16x3"], _ = hip_step_against_oracle(pkg, args, 1, 2e-3, state)  # the arithmetic of "alt", same sample, same bars
+    params, den, draws, comps = state["params"], state["den"], state["draws"], state["comps"]
     if not want_baseline:
         return parity, None
 
@@ -117,7 +136,7 @@ def parity_and_cpu_baseline(pkg, args, want_baseline=True):
 
     # thread count: the oracle's OpenMP loops stop scaling long before 256 threads on matrices this small, so one step is
     # timed at a few counts and the timed runs use the fastest
-    cands = sorted({c for c in (avail, 128, 64, 32, 16) if c <= avail}, reverse=True)
+    cands = sorted({c for c in (min(avail, 64), 32, 16) if c <= avail}, reverse=True)  # (256 threads: 27 s per step on these matrices)
     probe = {c: timed_steps(B, c, 1, 1, 7)[0] for c in cands} if len(cands) > 1 else {avail: 0.0}
     cores = min(probe, key=probe.get)
     ts = timed_steps(B, cores, 2, 5, 7)
@@ -386,6 +405,8 @@ def main():
             ok = parity["ok"]
             if base is not None:
                 out["cpu_baseline"] = base
+        if "alt" in out and "parity" in out and "bf16x3" in out["parity"]:
+            out["alt"]["parity"] = out["parity"].pop("bf16x3")
         print(json.dumps(out), flush=True)
         if not ok:
             raise SystemExit("bench.py: the HIP step does not match the oracle on the parity sample: " + json.dumps(out["parity"]))

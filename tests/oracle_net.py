@@ -389,7 +389,7 @@ class OracleNet:
                 mism = (r > 0) != (other > 0)
                 n = int(mism.sum())
                 if n:
-                    tol = 1e-4 * float(np.sqrt((a.astype(np.float64) ** 2).mean()))  # forward values agree to ~1e-5 of the rms by the last layers
+                    tol = getattr(self, "relu_tie_tol", 1e-4) * float(np.sqrt((a.astype(np.float64) ** 2).mean()))  # forward values agree to ~1e-5 of the rms by the last layers
                     worst = float(np.abs(a[mism]).max())
                     assert worst <= tol, "%s: ReLU masks differ at %d elements whose pre-activations are NOT ties (|a| up to %.3e, tolerance %.3e)" % (name, n, worst, tol)
                     r[mism] = other[mism]

@@ -7,13 +7,14 @@ pkg = ge.load_package()
 from tests.oracle_net import OracleNet, component_table
 from tests.gpu_util import dev, host, rel_l2
 kw = dict(a.split("=") for a in sys.argv[1:])
-B = int(kw.pop("B", 8)); ng = int(kw.pop("ng", 0)); rep = float(kw.pop("repair", 1e-5)); osd = float(kw.pop("osd", 0.05))
-cfg = pkg.trainer.make_config(frames_per_chunk=150, num_sequences=B, use_natural_gradient=ng, relu_self_repair_scale=rep)
+B = int(kw.pop("B", 8)); ng = int(kw.pop("ng", 0)); rep = float(kw.pop("repair", 1e-5)); osd = float(kw.pop("osd", 0.05)); prec = int(kw.pop("prec", 0)); steps = int(kw.pop("steps", 1))
+cfg = pkg.trainer.make_config(frames_per_chunk=150, num_sequences=B, use_natural_gradient=ng, relu_self_repair_scale=rep, gemm_precision=prec)
 net = pkg.trainer.ChainNet(cfg)
 table, n = component_table(cfg)
 params = net.init_params_numpy(seed=0, output_stddev=osd)
 net.set_params(params)
 ref = OracleNet(pkg, cfg, table)
+ref.relu_tie_tol = float(kw.pop("tietol", 1e-4))
 feats, iv = pkg.trainer.synthetic_egs(net, seed=100)
 den = pkg.synth.make_den_graph(4000, cfg.num_pdfs, mean_out_degree=12.0, seed=1)
 sup = pkg.synth.make_supervision_from_den(den, B, 50, num_paths=2, seed=200)
