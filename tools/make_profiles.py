@@ -71,4 +71,26 @@ for k, t in traffic.items():
                       write_size_kb_per_launch=t["write_kb"] / t["launches"],
                       hbm_bytes_per_launch=(2 * t["fetch_kb"] + t["write_kb"]) * 1024 / t["launches"])
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
+# the bench line of the profiled run (its per-class FLOPs and algorithmic bytes per step come from the launch shapes inside the
+# library), the per-stream busy / alone times and the dispatch count per step
+import os
+for src, dst in ((f"gpurun_out/{stats_dir}_bench_line.json", f"profiles/{tag}_bench_line_of_the_profiled_run.json"),
+                 (f"gpurun_out/{stats_dir}_overlap.txt", f"profiles/{tag}_stream_overlap.txt"),
+                 (f"gpurun_out/{stats_dir}_dispatches.txt", f"profiles/{tag}_dispatches_per_step.txt"),
+                 (f"gpurun_out/{stats_dir}_shapes.txt", f"profiles/{tag}_kernel_shapes_per_step.txt")):
+    if os.path.exists(src):
+        shutil.copy(src, dst)
+bl = f"gpurun_out/{stats_dir}_bench_line.json"
+if os.path.exists(bl):
+    line = json.load(open(bl))
+    steps = line["steps"]
+    with open(f"profiles/{tag}_class_work_per_step.csv", "w") as f:
+        f.write("kernel_class,launches_per_step,event_ms_per_step,tflops_per_step,algorithmic_gb_per_step,tflop_per_s,pmc_hbm_gb_per_step,pmc_over_algorithmic\n")
+        for k in line["roofline"]["all_kernels"]:
+            n = k["launches"] / steps
+            pm = out.get(k["kernel"], {}).get("hbm_bytes_per_launch")
+            pm_step = pm * n / 1e9 if pm else None
+            alg = k["algorithmic_bytes_per_step"] / 1e9
+            f.write("%s,%.1f,%.3f,%.4f,%.3f,%.2f,%s,%s\n" % (k["kernel"], n, k["ms"] / steps, k["flops_per_step"] / 1e12, alg, k["tflops"],
+                                                         "%.3f" % pm_step if pm_step else "", "%.3f" % (pm_step / alg) if pm_step and alg else ""))
 print("wrote profiles for", tag, "classes:", len(by), "pmc kernels:", len(out))
