@@ -317,13 +317,24 @@ __global__ __launch_bounds__(256) void den_wide_fwd_kernel(DenDev g, int B, int 
   }
 }
 
-// out[s] = sum over the nblk partial rows (fixed order: deterministic); 1024 threads = 16 waves stride the rows
+// out[s] = sum over the nblk partial rows (fixed order: deterministic); 1024 threads = 16 waves stride the rows, eight
+// independent requests in flight per lane (the kernel sits between two frames of the recursion and is pure latency: with one
+// request at a time it took 38 us per frame at 1 875 partial rows, half as long as the recursion kernel itself)
 __global__ __launch_bounds__(1024) void den_wide_sum_kernel(const float *part, int nblk, int B, float *out) {
   __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sq = blockIdx.x * 64 + lane;
   float v = 0.f;
-  if (sq < B)
-    for (int i = wave; i < nblk; i += 16) v += part[(size_t)i * B + sq];
+  if (sq < B) {
+    float a[8];
+    int i = wave;
+    for (; i + 7 * 16 < nblk; i += 8 * 16) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) a[u] = part[(size_t)(i + 16 * u) * B + sq];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v += a[u];
+    }
+    for (; i < nblk; i += 16) v += part[(size_t)i * B + sq];
+  }
   red[wave][lane] = v;
   __syncthreads();
   if (wave == 0 && sq < B) {
@@ -333,34 +344,42 @@ __global__ __launch_bounds__(1024) void den_wide_sum_kernel(const float *part, i
   }
 }
 
-// tot(s) = sum_h alpha_dash(T, h, s) = A(T, s) (1 + leaky init_sum); log-prob; beta_dash(T, ., s) = 1 / tot and its init-weighted sum
-__global__ __launch_bounds__(256) void den_wide_total_kernel(DenDev g, int B, int T, float leaky, const float *asum, float *tot, double *logprob,
-                                                             float *bnextT, float *lsum) {
+// tot(s) = sum_h alpha_dash(T, h, s) = A(T, s) (1 + leaky init_sum); log-prob of the sequence
+__global__ __launch_bounds__(256) void den_wide_total_kernel(DenDev g, int B, int T, float leaky, const float *asum, double *logprob) {
   const int sq = blockIdx.x * 256 + threadIdx.x;
   if (sq >= B) return;
   const float tt = asum[(size_t)T * B + sq] * (1.0f + leaky * g.init_sum);
   double lc = 0.0;
   for (int t = 0; t < T; t++) lc += (double)logf(asum[(size_t)t * B + sq]);
   logprob[sq] = (double)logf(tt) + lc;
-  tot[sq] = tt;
-  lsum[sq] = g.init_sum / tt;
-  (void)bnextT;
-}
-__global__ __launch_bounds__(256) void den_wide_beta_init_kernel(DenDev g, int B, const float *tot, float *bnextT) {
-  const long long e = blockIdx.x * 256LL + threadIdx.x;
-  if (e < (long long)g.H * B) bnextT[e] = 1.0f / tot[e % B];  // BetaDashLastFrame
 }
 
-// beta_dash(t, h, s) = 1/A(t, s) sum_arcs p x(t, pdf, s) beta(t+1, dst, s); partials of sum_h init_h beta_dash(t, h, s)
-__global__ __launch_bounds__(256) void den_wide_beta_kernel(DenDev g, int B, int t, float leaky, const float *xT, const float *asum, const float *bnextT,
-                                                            const float *lsum_next, float *bcurT, float *part) {
+// The backward recursion does not wait for the forward one: it runs SELF-NORMALISED on a stream of its own, beside it.
+// beta_dash is linear and homogeneous in its last frame, so with b(T, h) = 1, S(t) = sum_h init_h b(t, h) and
+//   b(t, h, s) = sum_arcs p x(t, pdf, s) (b(t+1, dst, s) / S(t+1, s) + leaky)
+// the true beta_dash(t) is a per-(frame, sequence) multiple of b(t) (the leaky term of the normalised vector is the constant
+// `leaky`: sum_h init_h b/S = 1).  The multiple never has to be formed: the occupancies of a frame sum to one, so
+//   gamma(t, p, s) = x(t, p, s) sum_arcs p alpha_dash(t, src, s) (b(t+1, dst, s) / S(t+1, s) + leaky) / Zd(t, s),
+//   Zd(t, s) = sum_h alpha_dash(t, h, s) b(t, h, s)        (= the sum over p of the numerators, by the recursion above),
+// which needs alpha (kept for every frame anyway) and b for every frame (another (T+1) x H x B floats: 7.7 GB at 30 000 states,
+// 128 x 500 frames -- what 288 GB are for) and leaves the occupancy pass with no dependence between frames: ONE launch over
+// all of them instead of one per frame.
+__global__ __launch_bounds__(256) void den_wide_beta_init_kernel(DenDev g, int B, float *bT, float *S) {
+  const long long e = blockIdx.x * 256LL + threadIdx.x;
+  if (e < (long long)g.H * B) bT[e] = 1.0f;
+  if (e < B) S[e] = g.init_sum;
+}
+
+// b(t) from b(t+1) (bnextT) and S(t+1); partials of S(t) = sum_h init_h b(t, h, s)
+__global__ __launch_bounds__(256) void den_wide_beta_kernel(DenDev g, int B, int t, float leaky, const float *xT, const float *bnextT, const float *Snext,
+                                                            float *bcurT, float *part) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float *x = xT + (size_t)t * g.P * B;
   for (int s0 = 0; s0 < B; s0 += 64) {
     const int sq = s0 + lane;
     const bool on = sq < B;
-    const float inv = on ? 1.0f / asum[(size_t)t * B + sq] : 0.f, lk = on ? leaky * lsum_next[sq] : 0.f;
+    const float inv = on ? 1.0f / Snext[sq] : 0.f;
     float total = 0.f;
     for (int r = 0; r < kWideRows / 4; r++) {
       const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
@@ -375,9 +394,8 @@ __global__ __launch_bounds__(256) void den_wide_beta_kernel(DenDev g, int B, int
         for (int j = 0; j < w; j++) {
           const uint2 a = ap[j * 64];
           const unsigned dst = a.x & 0xffffu, pdf = a.x >> 16;
-          acc += __uint_as_float(a.y) * x[(size_t)pdf * B + sq] * (bnextT[(size_t)dst * B + sq] + lk);
+          acc += __uint_as_float(a.y) * x[(size_t)pdf * B + sq] * (bnextT[(size_t)dst * B + sq] * inv + leaky);
         }
-        acc *= inv;
         bcurT[(size_t)h * B + sq] = acc;
       }
       total += g.init[h] * acc;
@@ -386,16 +404,33 @@ __global__ __launch_bounds__(256) void den_wide_beta_kernel(DenDev g, int B, int
   }
 }
 
-// x(t, p, s) <- deriv_weight gamma_den(t, p, s) = deriv_weight x(t, p, s) sum_arcs p alpha_dash(t, src, s)/A(t, s) beta(t+1, dst, s)  (in place)
-__global__ __launch_bounds__(256) void den_wide_gamma_kernel(DenDev g, int B, int t, float leaky, float *xT, const float *alphaT, const float *asum, int Hs,
-                                                             const float *bnextT, const float *lsum_next, float deriv_weight) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *alpha = alphaT + (size_t)t * Hs * B;
+// Zd(t, s) = sum_h (alpha(t, h, s) + leaky A(t, s) init_h) b(t, h, s) for every frame: block (t, chunk of 64 sequences), the four
+// waves stride the states
+__global__ __launch_bounds__(256) void den_wide_dot_kernel(DenDev g, int B, float leaky, const float *alphaT, const float *asum, int Hs, const float *bT,
+                                                           float *Zd) {
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = blockIdx.x, sq = blockIdx.y * 64 + lane;
+  const float *alpha = alphaT + (size_t)t * Hs * B, *b = bT + (size_t)t * Hs * B;
+  double acc = 0.0;
+  if (sq < B) {
+    const float lka = leaky * asum[(size_t)t * B + sq];
+    for (int h = wave; h < g.H; h += 4) acc += (double)((alpha[(size_t)h * B + sq] + lka * g.init[h]) * b[(size_t)h * B + sq]);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && sq < B) Zd[(size_t)t * B + sq] = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
+// x(t, p, s) <- deriv_weight gamma_den(t, p, s)  (in place), every frame in one launch: blockIdx.y = t
+__global__ __launch_bounds__(256) void den_wide_gamma_kernel(DenDev g, int B, float leaky, float *xT, const float *alphaT, const float *asum, int Hs,
+                                                             const float *bT, const float *S, const float *Zd, float deriv_weight) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = blockIdx.y;
+  const float *alpha = alphaT + (size_t)t * Hs * B, *bnext = bT + (size_t)(t + 1) * Hs * B;
   float *x = xT + (size_t)t * g.P * B;
   for (int s0 = 0; s0 < B; s0 += 64) {
     const int sq = s0 + lane;
     if (sq >= B) continue;
-    const float A = asum[(size_t)t * B + sq], inv = 1.0f / A, lka = leaky * A, lkb = leaky * lsum_next[sq];
+    const float lka = leaky * asum[(size_t)t * B + sq], inv = 1.0f / S[(size_t)(t + 1) * B + sq], scale = deriv_weight / Zd[(size_t)t * B + sq];
     for (int r = 0; r < kWideRows / 4; r++) {
       const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
       if (slot >= g.by_pdf.nslices * 64) break;
@@ -408,9 +443,9 @@ __global__ __launch_bounds__(256) void den_wide_gamma_kernel(DenDev g, int B, in
       for (int j = 0; j < w; j++) {
         const uint2 a = ap[j * 64];
         const unsigned src = a.x & 0xffffu, dst = a.x >> 16;
-        acc += __uint_as_float(a.y) * ((alpha[(size_t)src * B + sq] + lka * g.init[src]) * inv) * (bnextT[(size_t)dst * B + sq] + lkb);
+        acc += __uint_as_float(a.y) * (alpha[(size_t)src * B + sq] + lka * g.init[src]) * (bnext[(size_t)dst * B + sq] * inv + leaky);
       }
-      x[(size_t)p * B + sq] *= deriv_weight * acc;
+      x[(size_t)p * B + sq] *= scale * acc;
     }
   }
 }
@@ -626,9 +661,10 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
   const int rows = std::max(std::max(g->by_dst.nslices, g->by_src.nslices), g->by_pdf.nslices) * 64;
   p.wide_blocks = (rows + kWideRows - 1) / kWideRows;
   p.alpha_floats = (size_t)B * (T + 1) * p.Hs;
-  p.asum_floats = (size_t)B * (T + 4);  // wide: A(0..T), tot, and two rows of init-weighted beta sums
-  // wide: beta_dash double buffer, partial rows, and x = exp(clamp(y)) / the derivative, sequence-minor (T x P x B)
-  p.gstate_floats = p.wide ? (size_t)B * (2 * p.Hs + p.wide_blocks) + (size_t)T * g->P * B : (p.lds_state ? 0 : (size_t)B * 3 * p.Hs);
+  p.asum_floats = (size_t)B * (3 * T + 4);  // wide: A(0..T), S(0..T) of the backward recursion, Zd(0..T-1)
+  // wide: the backward vectors of every frame, two sets of partial rows (the recursions run side by side) and x = exp(clamp(y)) /
+  // the derivative, sequence-minor (T x P x B)
+  p.gstate_floats = p.wide ? (size_t)B * ((size_t)(T + 1) * p.Hs + 2 * p.wide_blocks) + (size_t)T * g->P * B : (p.lds_state ? 0 : (size_t)B * 3 * p.Hs);
   p.la_floats = 4 * (size_t)num_states_sup + 2;  // two arrays of DOUBLES (log alpha, log beta of the numerator), 8-byte aligned
   return p;
 }
@@ -838,25 +874,39 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     const int Hs = b.p.Hs, P = g->P;
     const int nb_dst = (g->by_dst.nslices * 64 + kWideRows - 1) / kWideRows, nb_src = (g->by_src.nslices * 64 + kWideRows - 1) / kWideRows,
               nb_pdf = (g->by_pdf.nslices * 64 + kWideRows - 1) / kWideRows;
-    float *alphaT = b.alpha, *asum = b.asum, *tot = asum + (size_t)(T + 1) * B, *lsA = tot + B, *lsB = lsA + B;
-    float *bufa = b.gstate, *bufb = bufa + (size_t)B * Hs, *part = bufb + (size_t)B * Hs, *xT = part + (size_t)B * b.p.wide_blocks;
+    float *alphaT = b.alpha, *asum = b.asum, *S = asum + (size_t)(T + 1) * B, *Zd = S + (size_t)(T + 1) * B;
+    float *bT = b.gstate, *part = bT + (size_t)B * Hs * (T + 1), *part2 = part + (size_t)B * b.p.wide_blocks, *xT = part2 + (size_t)B * b.p.wide_blocks;
     const dim3 blk(256), tr((P + 63) / 64, (B + 63) / 64, T), nseq((B + 63) / 64);
+    // a second stream for the backward recursion (per device, created on first use) and the fork / join events
+    static hipStream_t aux = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (!aux) {
+      TDNNF_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+      TDNNF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+      TDNNF_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
     hipLaunchKernelGGL(den_wide_prep_kernel, tr, blk, 0, s, yv, B, P, xT);
+    TDNNF_HIP(hipEventRecord(ev_fork, s));
+    TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+    // forward recursion (this stream)
     hipLaunchKernelGGL(den_wide_init_kernel, dim3(grid_for((long long)g->H * B, 256)), blk, 0, s, gd, B, alphaT, asum);
     for (int t = 1; t <= T; t++) {
       hipLaunchKernelGGL(den_wide_fwd_kernel, dim3(nb_dst), blk, 0, s, gd, B, t, leaky, xT, alphaT, asum, Hs, part);
       hipLaunchKernelGGL(den_wide_sum_kernel, nseq, dim3(1024), 0, s, part, nb_dst, B, asum + (size_t)t * B);
     }
-    hipLaunchKernelGGL(den_wide_total_kernel, dim3((B + 255) / 256), blk, 0, s, gd, B, T, leaky, asum, tot, b.den_lp, bufa, lsA);
-    hipLaunchKernelGGL(den_wide_beta_init_kernel, dim3(grid_for((long long)g->H * B, 256)), blk, 0, s, gd, B, tot, bufa);
-    float *bnext = bufa, *bcur = bufb, *ls_next = lsA, *ls_cur = lsB;
+    hipLaunchKernelGGL(den_wide_total_kernel, dim3((B + 255) / 256), blk, 0, s, gd, B, T, leaky, asum, b.den_lp);
+    // backward recursion, self-normalised (the other stream)
+    hipLaunchKernelGGL(den_wide_beta_init_kernel, dim3(grid_for((long long)g->H * B, 256)), blk, 0, aux, gd, B, bT + (size_t)T * Hs * B, S + (size_t)T * B);
     for (int t = T - 1; t >= 0; t--) {
-      hipLaunchKernelGGL(den_wide_beta_kernel, dim3(nb_src), blk, 0, s, gd, B, t, leaky, xT, asum, bnext, ls_next, bcur, part);
-      hipLaunchKernelGGL(den_wide_gamma_kernel, dim3(nb_pdf), blk, 0, s, gd, B, t, leaky, xT, alphaT, asum, Hs, bnext, ls_next, -sp->weight);
-      hipLaunchKernelGGL(den_wide_sum_kernel, nseq, dim3(1024), 0, s, part, nb_src, B, ls_cur);
-      std::swap(bnext, bcur);
-      std::swap(ls_next, ls_cur);
+      hipLaunchKernelGGL(den_wide_beta_kernel, dim3(nb_src), blk, 0, aux, gd, B, t, leaky, xT, bT + (size_t)(t + 1) * Hs * B, S + (size_t)(t + 1) * B,
+                         bT + (size_t)t * Hs * B, part2);
+      hipLaunchKernelGGL(den_wide_sum_kernel, nseq, dim3(1024), 0, aux, part2, nb_src, B, S + (size_t)t * B);
     }
+    TDNNF_HIP(hipEventRecord(ev_join, aux));
+    TDNNF_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    // occupancies of every frame at once
+    hipLaunchKernelGGL(den_wide_dot_kernel, dim3(T, (B + 63) / 64), blk, 0, s, gd, B, leaky, alphaT, asum, Hs, bT, Zd);
+    hipLaunchKernelGGL(den_wide_gamma_kernel, dim3(nb_pdf, T), blk, 0, s, gd, B, leaky, xT, alphaT, asum, Hs, bT, S, Zd, -sp->weight);
     hipLaunchKernelGGL(den_wide_unprep_kernel, tr, blk, 0, s, xT, B, P, dv);
     TDNNF_LAUNCH_CHECK();
     return TDNNF_OK;
