@@ -31,6 +31,7 @@ struct tdnnf_den_graph {
     int *base;       // nslices + 1 (device)
     unsigned *row;   // nslices * 64
     uint2 *arc;      // key: (other-state-or-src | pdf << 16), or (src | dst << 16) for the by-pdf table
+    uint4 *arc4;     // the same arcs as (key, prob, prob * init[key & 0xffff] or 0, 0): what the wide form loads
     long long entries;
   } by_dst, by_src, by_pdf;
   float *init;  // H
@@ -229,119 +230,238 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
 // The persistent kernels above give a sequence one workgroup and keep its state vectors in LDS: right while they fit (up to
 // ~10 000 states), a crawl beyond (30 000 states / 360 000 arcs: every arc is a 4-byte gather from L2, 580 ms per
 // minibatch).  The wide form runs the recursion one frame per launch over ALL sequences with the SEQUENCE as the fastest
-// index of every array (alpha[t][state][seq], x[t][pdf][seq] -- Kaldi's own layout, for the same reason): a wave walks one
-// state's arcs, its lanes are 64 sequences, so every arc costs two coalesced 256-byte reads.  The leaky-HMM terms are
-// applied where the stored alpha / beta_dash are read (alpha_dash = alpha + leaky A init; beta = beta_dash + leaky
-// sum_j init_j beta_dash_j), so a frame is two launches forward (recursion, normaliser) and three backward.
-constexpr int kWideRows = 16;  // rows (states / pdfs) per 256-thread block: 4 per wave
+// index of every array (Kaldi's own choice, for the same reason), in GROUPS of SG sequences (32; 16 for minibatches of <= 16):
+//   alpha[t][group][state][SG],  x[t][group][pdf][SG]          (SG = 32: one whole 128-byte line per state, line-aligned)
+//  * a wave is SG sequences x 64/SG rows (states / pdfs).  The arcs of its rows are not fetched arc by arc: one coalesced
+//    16-byte load per lane brings 64 arcs (4 arc positions of the wave's 16 rows) as (state | pdf << 16, p, p init_src), and
+//    each lane group picks the arc of its row out of the holder's registers with ds_bpermute (the LDS crossbar, no memory).
+//    Per arc step that leaves the two gathers the recursion cannot do without (alpha_src, x_pdf): the leaky-HMM term
+//    alpha_dash = alpha + leaky A init_src costs no third one because p init_src travels in the arc.
+//  * a workgroup serves ONE group: group = blockIdx.x % num_groups.  Workgroups go to the eight XCDs round-robin, so an XCD
+//    only ever touches the frame slices of its own group(s) -- at 128 sequences and SG 32: 30 000 states x 128 bytes = 3.8 MB
+//    of alpha + 0.8 MB of x against a 4 MB L2 (measured hit rate 77 %, 3.4 M L2 requests per launch; SG 16 fits better, 89 %
+//    of 6.3 M, and is slower: L2 requests are per line, and a 64-byte run is half a line).  Runs that straddle a line cost a
+//    second request each: every array of the wide form is 128-byte aligned.  The arc table streams past with non-temporal loads.
+//  * the normaliser A(t-1, s) = sum_h alpha(t-1, h, s) is NOT a launch of its own between two frames: every workgroup of frame
+//    t starts by summing the previous launch's partial sums for its group's sequences (fixed order, float4 loads all in
+//    flight at once), so a frame is ONE launch forward and one backward.
+// Measured (30 000 states / 360 000 arcs, 128 x 500 frames, tools/den_bench.py): 56 ms for the whole objective, from 105 ms with
+// one 256-byte run per state and arc-by-arc loads; a recursion launch takes 48 us alone, 55 us beside the other direction's.
+constexpr int kWideBatch = 8;   // arc steps whose picks and gathers are issued together (a multiple of 4)
+constexpr int kWideSlices = 2;  // SELL slices (of 64 rows) per 256-thread block of the recursions: a wave takes 16 rows of each (TDNNF_WIDE_SLICES: experiments)
 
-// xT[t][p][s] = exp(clamp(y[t*B + s][p])): per frame a B x P -> P x B transpose through LDS
-__global__ __launch_bounds__(256) void den_wide_prep_kernel(MatView y, int B, int P, float *xT) {
+struct WideDims {
+  int B, NG, SG;  // sequences, groups, sequences per group (16 or 32; NG * SG >= B)
+};
+
+typedef unsigned uv4 __attribute__((ext_vector_type(4)));
+
+// xT[t][g][p][sl] = exp(clamp(y[t*B + g*SG + sl][p])): per frame a B x P -> P x B transpose through LDS
+__global__ __launch_bounds__(256) void den_wide_prep_kernel(MatView y, WideDims d, int P, float *xT) {
   __shared__ float tile[64][65];
   const int t = blockIdx.z, p0 = blockIdx.x * 64, s0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int sq = s0 + i, p = p0 + tx;
-    tile[i][tx] = (sq < B && p < P) ? exp_limited(y.data[(size_t)(t * B + sq) * y.stride + p]) : 0.f;
+    tile[i][tx] = (sq < d.B && p < P) ? exp_limited(y.data[(size_t)(t * d.B + sq) * y.stride + p]) : 0.f;
   }
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int p = p0 + i, sq = s0 + tx;
-    if (p < P && sq < B) xT[((size_t)t * P + p) * B + sq] = tile[tx][i];
+    if (p < P && sq < d.NG * d.SG) xT[(((size_t)t * d.NG + sq / d.SG) * P + p) * d.SG + sq % d.SG] = tile[tx][i];
   }
 }
-// deriv[t*B + s][p] = dT[t][p][s]
-__global__ __launch_bounds__(256) void den_wide_unprep_kernel(const float *dT, int B, int P, MatView deriv) {
+// deriv[t*B + s][p] = dT[t][g][p][sl]
+__global__ __launch_bounds__(256) void den_wide_unprep_kernel(const float *dT, WideDims d, int P, MatView deriv) {
   __shared__ float tile[64][65];
   const int t = blockIdx.z, p0 = blockIdx.x * 64, s0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   for (int i = ty; i < 64; i += 4) {
     const int p = p0 + i, sq = s0 + tx;
-    tile[i][tx] = (p < P && sq < B) ? dT[((size_t)t * P + p) * B + sq] : 0.f;
+    tile[i][tx] = (p < P && sq < d.B) ? dT[(((size_t)t * d.NG + sq / d.SG) * P + p) * d.SG + sq % d.SG] : 0.f;
   }
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int sq = s0 + i, p = p0 + tx;
-    if (sq < B && p < P) deriv.data[(size_t)(t * B + sq) * deriv.stride + p] = tile[tx][i];
+    if (sq < d.B && p < P) deriv.data[(size_t)(t * d.B + sq) * deriv.stride + p] = tile[tx][i];
   }
 }
 
-__global__ __launch_bounds__(256) void den_wide_init_kernel(DenDev g, int B, float *alphaT, float *asum) {
+// frame 0 of alpha (before the leaky term) / frame T of b: v[g][h][sl] = init_h or 1; norm[s] = init_sum
+__global__ __launch_bounds__(256) void den_wide_init_kernel(DenDev g, WideDims d, int Hs, bool ones, float *v, float *norm) {
   const long long e = blockIdx.x * 256LL + threadIdx.x;
-  if (e < (long long)g.H * B) alphaT[e] = g.init[e / B];  // alpha(0, h) before the leaky term
-  if (e < B) asum[e] = g.init_sum;
-}
-
-// block-level sum over the 4 waves of per-lane values -> part[blockIdx.x][s]
-__device__ __forceinline__ void wide_store_partial(float v, float (*red)[64], float *part, int B, int sq) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  red[wave][lane] = v;
-  __syncthreads();
-  if (wave == 0 && sq < B) part[(size_t)blockIdx.x * B + sq] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
-}
-
-// alpha(t, h, s) = 1/A(t-1, s) sum_arcs alpha_dash(t-1, src, s) p x(t-1, pdf, s); partials of sum_h alpha(t, h, s)
-__global__ __launch_bounds__(256) void den_wide_fwd_kernel(DenDev g, int B, int t, float leaky, const float *xT, float *alphaT, const float *asum, int Hs,
-                                                           float *part) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *prev = alphaT + (size_t)(t - 1) * Hs * B;
-  float *cur = alphaT + (size_t)t * Hs * B;
-  const float *x = xT + (size_t)(t - 1) * g.P * B;
-  for (int s0 = 0; s0 < B; s0 += 64) {
-    const int sq = s0 + lane;
-    const bool on = sq < B;
-    const float Aprev = on ? asum[(size_t)(t - 1) * B + sq] : 1.f;
-    const float inv = 1.0f / Aprev, lk = leaky * Aprev;
-    float total = 0.f;
-    for (int r = 0; r < kWideRows / 4; r++) {
-      const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
-      if (slot >= g.by_dst.nslices * 64) break;
-      const unsigned h = g.by_dst.row[slot];
-      if (h == 0xffffffffu) continue;
-      const int sl = slot >> 6, b0 = g.by_dst.base[sl], w = (g.by_dst.base[sl + 1] - b0) >> 6;
-      const uint2 *ap = g.by_dst.arc + b0 + (slot & 63);
-      float acc = 0.f;
-      if (on) {
-#pragma unroll 4
-        for (int j = 0; j < w; j++) {
-          const uint2 a = ap[j * 64];
-          const unsigned src = a.x & 0xffffu, pdf = a.x >> 16;
-          acc += (prev[(size_t)src * B + sq] + lk * g.init[src]) * __uint_as_float(a.y) * x[(size_t)pdf * B + sq];
-        }
-        acc *= inv;
-        cur[(size_t)h * B + sq] = acc;
-      }
-      total += acc;
-    }
-    wide_store_partial(total, red, part, B, sq);
+  if (e < (long long)d.NG * Hs * d.SG) {
+    const int h = (int)((e / d.SG) % Hs);
+    v[e] = h < g.H ? (ones ? 1.0f : g.init[h]) : 0.f;
   }
+  if (e < d.B) norm[e] = g.init_sum;
 }
 
-// out[s] = sum over the nblk partial rows (fixed order: deterministic); 1024 threads = 16 waves stride the rows, eight
-// independent requests in flight per lane (the kernel sits between two frames of the recursion and is pure latency: with one
-// request at a time it took 38 us per frame at 1 875 partial rows, half as long as the recursion kernel itself)
-__global__ __launch_bounds__(1024) void den_wide_sum_kernel(const float *part, int nblk, int B, float *out) {
-  __shared__ float red[16][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, sq = blockIdx.x * 64 + lane;
+// where a workgroup of the recursion kernels stands: its group, its block of slices, its lane's sequence and row lane
+template <int SG>
+struct WideLane {
+  static constexpr int RL = 64 / SG;  // rows side by side in a wave
+  static constexpr int IT = 16 / RL;  // passes over a wave's 16 rows
+  int grp, blk, sl, rl, sq, wave, lane;
+  bool on;
+  __device__ WideLane(const WideDims &d, int g, int b) {
+    lane = threadIdx.x & 63;
+    wave = threadIdx.x >> 6;
+    grp = g;
+    blk = b;
+    sl = lane % SG;
+    rl = lane / SG;
+    sq = grp * SG + sl;
+    on = sq < d.B;
+  }
+};
+// Normaliser of the previous launch for this lane's sequence: the sum of the group's `nblk` partial sums, 256/SG threads per
+// sequence and four of them per load, then the threads' sums in fixed order (the same number in every workgroup); stored by
+// the first workgroup of a group.  part[group][sequence][npad], npad = nblk rounded up to 4 with the tail zeroed: the sums of one
+// sequence are contiguous, and every thread has all its loads (<= 8 float4 for up to 1 024 partial sums at SG 32) in flight at
+// once -- the partial sums were written by the previous launch, possibly through another XCD's L2, so each load is a trip to
+// memory, and a chain of them was most of a frame's time.
+__device__ __forceinline__ int wide_npad(int nblk) { return (nblk + 3) & ~3; }
+template <int SG>
+__device__ __forceinline__ float wide_norm(const float *part, int nblk, float *norm_out, float *red, const WideLane<SG> &L) {
+  constexpr int NQ = 256 / SG;
+  const int q = threadIdx.x / SG, nch = wide_npad(nblk) >> 2;
+  const float4 *pp = (const float4 *)(part + ((size_t)L.grp * SG + L.sl) * wide_npad(nblk));
   float v = 0.f;
-  if (sq < B) {
-    float a[8];
-    int i = wave;
-    for (; i + 7 * 16 < nblk; i += 8 * 16) {
+  for (int c0 = q; c0 < nch; c0 += 8 * NQ) {
+    float4 f[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) a[u] = part[(size_t)(i + 16 * u) * B + sq];
+    for (int u = 0; u < 8; u++) f[u] = c0 + u * NQ < nch ? pp[c0 + u * NQ] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int u = 0; u < 8; u++) v += a[u];
-    }
-    for (; i < nblk; i += 16) v += part[(size_t)i * B + sq];
+    for (int u = 0; u < 8; u++) v += (f[u].x + f[u].y) + (f[u].z + f[u].w);
   }
-  red[wave][lane] = v;
+  red[q * SG + L.sl] = v;
   __syncthreads();
-  if (wave == 0 && sq < B) {
-    float tot = 0.f;
-    for (int q = 0; q < 16; q++) tot += red[q][lane];
-    out[sq] = tot;
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NQ; i++) tot += red[i * SG + L.sl];
+  __syncthreads();  // red is used again for the block's own partial
+  if (L.blk == 0 && q == 0 && L.on) norm_out[L.sq] = tot;
+  return L.on ? tot : 1.0f;
+}
+// sum of `v` over the block's rows for each sequence of the group -> part[grp][sl][blk] (padding sequences: 0)
+template <int SG>
+__device__ __forceinline__ void wide_store_partial(float v, float *red, float *part, int nblk, const WideLane<SG> &L) {
+#pragma unroll
+  for (int o = SG; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  if (L.rl == 0) red[L.wave * SG + L.sl] = v;
+  __syncthreads();
+  if (threadIdx.x < SG) {
+    float *row = part + ((size_t)L.grp * SG + L.sl) * wide_npad(nblk);
+    row[L.blk] = (red[L.sl] + red[SG + L.sl]) + (red[2 * SG + L.sl] + red[3 * SG + L.sl]);
+    if (L.blk == nblk - 1)
+      for (int k = nblk; k < wide_npad(nblk); k++) row[k] = 0.f;
   }
+}
+// One load for 4 consecutive arc positions of a wave's 16 rows: lane l holds arc (position jb + l/16, row l%16 of the 16)
+__device__ __forceinline__ uv4 wide_load_arcs(const uv4 *ap, int jb, int w, int lane) {
+  const int j = jb + (lane >> 4);
+  uv4 a = {0u, 0u, 0u, 0u};
+  if (j < w) a = __builtin_nontemporal_load(ap + (size_t)j * 64);
+  return a;
+}
+
+// The arcs of one SELL slice for this wave's 16 rows.  Every arc step needs the arc's (key, p, p init_src) and two gathered
+// values: t1[(key & 0xffff) * SG + sl] and t2[(key >> 16) * SG + sl].  kWideBatch steps at a time: all their picks and gathers are
+// issued before the first product is formed, and the load of the next four arc positions goes out BEHIND the gathers -- loads
+// complete in order, so an arc load (a trip to memory) issued ahead of them would hold every gather's data back.
+// MODE 0 forward:  acc += t2 p t1,  acl += t2 p init_src           (t1 = alpha(t-1), t2 = x(t-1))
+// MODE 1 backward: acc += p t2 t1,  acl += p t2                    (t1 = b(t+1),     t2 = x(t))
+// MODE 2 occupancy: acc += (t1 p + c0 p init_src) (t2 c1 + c2)      (t1 = alpha(t),   t2 = b(t+1); c0 = leaky A, c1 = 1/S, c2 = leaky)
+template <int SG, int MODE>
+__device__ __forceinline__ void wide_slice(const tdnnf_den_graph::Sell &T, int slice, const float *t1, const float *t2, const WideLane<SG> &L, float c0, float c1,
+                                           float c2, float *acc, float *acl) {
+  using WL = WideLane<SG>;
+  const int b0 = T.base[slice], w = (T.base[slice + 1] - b0) >> 6;
+  const uv4 *ap = (const uv4 *)T.arc4 + b0 + L.wave * 16 + (L.lane & 15);
+  uv4 a = wide_load_arcs(ap, 0, w, L.lane);
+  constexpr int BS = kWideBatch, NB = WL::IT * 4 / BS;  // arc steps per batch, batches per four arc positions
+  for (int jb = 0; jb < w; jb += 4) {
+    uv4 an = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int h = 0; h < NB; h++) {
+      float g1[BS], g2[BS], pr[BS], iq[BS];
+#pragma unroll
+      for (int k = 0; k < BS; k++) {
+        const int e = h * BS + k, row4 = ((e / 4) * WL::RL + L.rl) * 4 + (e % 4) * 64;  // step e: row pass e/4, arc position e%4
+        const unsigned key = (unsigned)__builtin_amdgcn_ds_bpermute(row4, (int)a.x);
+        pr[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(row4, (int)a.y));
+        iq[k] = MODE != 1 ? __int_as_float(__builtin_amdgcn_ds_bpermute(row4, (int)a.z)) : 0.f;
+        g1[k] = t1[(key & 0xffffu) * SG + L.sl];
+        g2[k] = t2[(key >> 16) * SG + L.sl];
+      }
+      if (h == NB - 1) an = wide_load_arcs(ap, jb + 4, w, L.lane);  // zeros past the end
+#pragma unroll
+      for (int k = 0; k < BS; k++) {
+        const int it = (h * BS + k) / 4;
+        if (MODE == 0) {
+          acc[it] += g2[k] * pr[k] * g1[k];
+          acl[it] += g2[k] * iq[k];
+        } else if (MODE == 1) {
+          const float px = pr[k] * g2[k];
+          acc[it] += px * g1[k];
+          acl[it] += px;
+        } else {
+          acc[it] += (g1[k] * pr[k] + c0 * iq[k]) * (g2[k] * c1 + c2);
+        }
+      }
+      // keep the next batch's picks and loads behind this batch's arithmetic (4 BS live values each): the arc registers are
+      // "redefined" here and the batch's sums "used"
+      asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z)::"memory");
+#pragma unroll
+      for (int it = h * BS / 4; it < (h + 1) * BS / 4; it++) {
+        asm volatile("" : "+v"(acc[it]));
+        if (MODE != 2) asm volatile("" : "+v"(acl[it]));
+      }
+    }
+    a = an;
+  }
+}
+
+// alpha(t, h, s) = 1/A(t-1, s) sum_arcs alpha_dash(t-1, src, s) p x(t-1, pdf, s)
+//               = (1/A) sum_arcs alpha(t-1, src, s) p x + leaky sum_arcs p init_src x        (alpha_dash = alpha + leaky A init).
+// part_prev: launch t-1's partial sums of A(t-1) (null at t = 1: A(0) is in asum[0] already); nsl: slices per block
+template <int SG>
+__global__ __launch_bounds__(256) void den_wide_fwd_kernel(DenDev g, WideDims d, int t, float leaky, const float *xT, float *alphaT, float *asum, int Hs,
+                                                           const float *part_prev, int nblk, int nsl, float *part) {
+  using WL = WideLane<SG>;
+  __shared__ float red[256];
+  const WL L(d, blockIdx.x % d.NG, blockIdx.x / d.NG);
+  const size_t frame = (size_t)d.NG * Hs * SG;
+  const float *prev = alphaT + (size_t)(t - 1) * frame + (size_t)L.grp * Hs * SG;  // uniform; lanes add (state * SG + sl)
+  float *cur = alphaT + (size_t)t * frame + (size_t)L.grp * Hs * SG;
+  const float *x = xT + ((size_t)(t - 1) * d.NG + L.grp) * g.P * SG;
+  const int s0 = L.blk * nsl, s1 = min(s0 + nsl, g.by_dst.nslices);
+  const float Aprev = part_prev ? wide_norm<SG>(part_prev, nblk, asum + (size_t)(t - 1) * d.B, red, L) : (L.on ? asum[(size_t)(t - 1) * d.B + L.sq] : 1.f);
+  const float inv = 1.0f / Aprev;
+  float total = 0.f;
+  for (int slice = s0; slice < s1; slice++) {
+    float acc[WL::IT], acl[WL::IT];
+#pragma unroll
+    for (int it = 0; it < WL::IT; it++) acc[it] = acl[it] = 0.f;
+    wide_slice<SG, 0>(g.by_dst, slice, prev, x, L, 0.f, 0.f, 0.f, acc, acl);
+#pragma unroll
+    for (int it = 0; it < WL::IT; it++) {
+      const unsigned h = g.by_dst.row[slice * 64 + L.wave * 16 + it * WL::RL + L.rl];
+      if (h != 0xffffffffu && L.on) {
+        const float v = acc[it] * inv + leaky * acl[it];
+        cur[h * SG + L.sl] = v;
+        total += v;
+      }
+    }
+  }
+  wide_store_partial<SG>(total, red, part, nblk, L);
+}
+
+// out[s] = sum over the nblk partial rows, in the order wide_norm takes them (after the last frame of a recursion)
+template <int SG>
+__global__ __launch_bounds__(256) void den_wide_sum_kernel(const float *part, int nblk, WideDims d, float *out) {
+  __shared__ float red[256];
+  const WideLane<SG> L(d, blockIdx.x, 0);
+  wide_norm<SG>(part, nblk, out, red, L);
 }
 
 // tot(s) = sum_h alpha_dash(T, h, s) = A(T, s) (1 + leaky init_sum); log-prob of the sequence
@@ -364,89 +484,88 @@ __global__ __launch_bounds__(256) void den_wide_total_kernel(DenDev g, int B, in
 // which needs alpha (kept for every frame anyway) and b for every frame (another (T+1) x H x B floats: 7.7 GB at 30 000 states,
 // 128 x 500 frames -- what 288 GB are for) and leaves the occupancy pass with no dependence between frames: ONE launch over
 // all of them instead of one per frame.
-__global__ __launch_bounds__(256) void den_wide_beta_init_kernel(DenDev g, int B, float *bT, float *S) {
-  const long long e = blockIdx.x * 256LL + threadIdx.x;
-  if (e < (long long)g.H * B) bT[e] = 1.0f;
-  if (e < B) S[e] = g.init_sum;
-}
 
-// b(t) from b(t+1) (bnextT) and S(t+1); partials of S(t) = sum_h init_h b(t, h, s)
-__global__ __launch_bounds__(256) void den_wide_beta_kernel(DenDev g, int B, int t, float leaky, const float *xT, const float *bnextT, const float *Snext,
-                                                            float *bcurT, float *part) {
-  __shared__ float red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *x = xT + (size_t)t * g.P * B;
-  for (int s0 = 0; s0 < B; s0 += 64) {
-    const int sq = s0 + lane;
-    const bool on = sq < B;
-    const float inv = on ? 1.0f / Snext[sq] : 0.f;
-    float total = 0.f;
-    for (int r = 0; r < kWideRows / 4; r++) {
-      const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
-      if (slot >= g.by_src.nslices * 64) break;
-      const unsigned h = g.by_src.row[slot];
-      if (h == 0xffffffffu) continue;
-      const int sl = slot >> 6, b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
-      const uint2 *ap = g.by_src.arc + b0 + (slot & 63);
-      float acc = 0.f;
-      if (on) {
-#pragma unroll 4
-        for (int j = 0; j < w; j++) {
-          const uint2 a = ap[j * 64];
-          const unsigned dst = a.x & 0xffffu, pdf = a.x >> 16;
-          acc += __uint_as_float(a.y) * x[(size_t)pdf * B + sq] * (bnextT[(size_t)dst * B + sq] * inv + leaky);
-        }
-        bcurT[(size_t)h * B + sq] = acc;
+// b(t) from b(t+1) (bnextT) and S(t+1) = (1/S) sum_arcs p x b(t+1, dst) + leaky sum_arcs p x; partials of S(t) = sum_h init_h b(t, h, s).
+// part_prev: the partial sums of launch t+1 (null at t = T-1: S(T) is in S already)
+template <int SG>
+__global__ __launch_bounds__(256) void den_wide_beta_kernel(DenDev g, WideDims d, int t, float leaky, const float *xT, const float *bnextT, float *S, int Hs,
+                                                            float *bcurT, const float *part_prev, int nblk, int nsl, float *part) {
+  using WL = WideLane<SG>;
+  __shared__ float red[256];
+  const WL L(d, blockIdx.x % d.NG, blockIdx.x / d.NG);
+  const float *bnext = bnextT + (size_t)L.grp * Hs * SG;
+  float *bcur = bcurT + (size_t)L.grp * Hs * SG;
+  const float *x = xT + ((size_t)t * d.NG + L.grp) * g.P * SG;
+  const int s0 = L.blk * nsl, s1 = min(s0 + nsl, g.by_src.nslices);
+  const float Snext = part_prev ? wide_norm<SG>(part_prev, nblk, S + (size_t)(t + 1) * d.B, red, L) : (L.on ? S[(size_t)(t + 1) * d.B + L.sq] : 1.f);
+  const float inv = 1.0f / Snext;
+  float total = 0.f;
+  for (int slice = s0; slice < s1; slice++) {
+    float acc[WL::IT], acl[WL::IT];
+#pragma unroll
+    for (int it = 0; it < WL::IT; it++) acc[it] = acl[it] = 0.f;
+    wide_slice<SG, 1>(g.by_src, slice, bnext, x, L, 0.f, 0.f, 0.f, acc, acl);
+#pragma unroll
+    for (int it = 0; it < WL::IT; it++) {
+      const unsigned h = g.by_src.row[slice * 64 + L.wave * 16 + it * WL::RL + L.rl];
+      if (h != 0xffffffffu && L.on) {
+        const float v = acc[it] * inv + leaky * acl[it];
+        bcur[h * SG + L.sl] = v;
+        total += g.init[h] * v;
       }
-      total += g.init[h] * acc;
     }
-    wide_store_partial(total, red, part, B, sq);
   }
+  wide_store_partial<SG>(total, red, part, nblk, L);
 }
 
-// Zd(t, s) = sum_h (alpha(t, h, s) + leaky A(t, s) init_h) b(t, h, s) for every frame: block (t, chunk of 64 sequences), the four
-// waves stride the states
-__global__ __launch_bounds__(256) void den_wide_dot_kernel(DenDev g, int B, float leaky, const float *alphaT, const float *asum, int Hs, const float *bT,
+// Zd(t, s) = sum_h (alpha(t, h, s) + leaky A(t, s) init_h) b(t, h, s) for every frame: block (t, group), 256/SG threads per
+// sequence stride the states
+template <int SG>
+__global__ __launch_bounds__(256) void den_wide_dot_kernel(DenDev g, WideDims d, float leaky, const float *alphaT, const float *asum, int Hs, const float *bT,
                                                            float *Zd) {
-  __shared__ double red[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = blockIdx.x, sq = blockIdx.y * 64 + lane;
-  const float *alpha = alphaT + (size_t)t * Hs * B, *b = bT + (size_t)t * Hs * B;
+  __shared__ double red[256];
+  const int t = blockIdx.x, grp = blockIdx.y, sl = threadIdx.x % SG, hl = threadIdx.x / SG, sq = grp * SG + sl;
+  const size_t off = ((size_t)t * d.NG + grp) * Hs * SG + sl;
+  const float *alpha = alphaT + off, *b = bT + off;
   double acc = 0.0;
-  if (sq < B) {
-    const float lka = leaky * asum[(size_t)t * B + sq];
-    for (int h = wave; h < g.H; h += 4) acc += (double)((alpha[(size_t)h * B + sq] + lka * g.init[h]) * b[(size_t)h * B + sq]);
+  if (sq < d.B) {
+    const float lka = leaky * asum[(size_t)t * d.B + sq];
+    for (int h = hl; h < g.H; h += 256 / SG) acc += (double)((alpha[(size_t)h * SG] + lka * g.init[h]) * b[(size_t)h * SG]);
   }
-  red[wave][lane] = acc;
+  red[threadIdx.x] = acc;
   __syncthreads();
-  if (wave == 0 && sq < B) Zd[(size_t)t * B + sq] = (float)((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+  if (hl == 0 && sq < d.B) {
+    double tot = 0.0;
+    for (int q = 0; q < 256 / SG; q++) tot += red[q * SG + sl];
+    Zd[(size_t)t * d.B + sq] = (float)tot;
+  }
 }
 
-// x(t, p, s) <- deriv_weight gamma_den(t, p, s)  (in place), every frame in one launch: blockIdx.y = t
-__global__ __launch_bounds__(256) void den_wide_gamma_kernel(DenDev g, int B, float leaky, float *xT, const float *alphaT, const float *asum, int Hs,
+// x(t, p, s) <- deriv_weight gamma_den(t, p, s)  (in place), every frame in one launch: blockIdx.y = t, one SELL slice per
+// block (x fastest: the resident waves stay within a frame or two, whose alpha and b slices an XCD's L2 can hold)
+template <int SG>
+__global__ __launch_bounds__(256) void den_wide_gamma_kernel(DenDev g, WideDims d, float leaky, float *xT, const float *alphaT, const float *asum, int Hs,
                                                              const float *bT, const float *S, const float *Zd, float deriv_weight) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = blockIdx.y;
-  const float *alpha = alphaT + (size_t)t * Hs * B, *bnext = bT + (size_t)(t + 1) * Hs * B;
-  float *x = xT + (size_t)t * g.P * B;
-  for (int s0 = 0; s0 < B; s0 += 64) {
-    const int sq = s0 + lane;
-    if (sq >= B) continue;
-    const float lka = leaky * asum[(size_t)t * B + sq], inv = 1.0f / S[(size_t)(t + 1) * B + sq], scale = deriv_weight / Zd[(size_t)t * B + sq];
-    for (int r = 0; r < kWideRows / 4; r++) {
-      const int slot = blockIdx.x * kWideRows + wave * (kWideRows / 4) + r;
-      if (slot >= g.by_pdf.nslices * 64) break;
-      const unsigned p = g.by_pdf.row[slot];
-      if (p == 0xffffffffu) continue;
-      const int sl = slot >> 6, b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
-      const uint2 *ap = g.by_pdf.arc + b0 + (slot & 63);
-      float acc = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < w; j++) {
-        const uint2 a = ap[j * 64];
-        const unsigned src = a.x & 0xffffu, dst = a.x >> 16;
-        acc += __uint_as_float(a.y) * (alpha[(size_t)src * B + sq] + lka * g.init[src]) * (bnext[(size_t)dst * B + sq] * inv + leaky);
-      }
-      x[(size_t)p * B + sq] *= scale * acc;
-    }
+  using WL = WideLane<SG>;
+  const WL L(d, blockIdx.x % d.NG, blockIdx.x / d.NG);
+  const int t = blockIdx.y, slice = L.blk;
+  const size_t frame = (size_t)d.NG * Hs * SG;
+  const float *alpha = alphaT + (size_t)t * frame + (size_t)L.grp * Hs * SG, *bnext = bT + (size_t)(t + 1) * frame + (size_t)L.grp * Hs * SG;
+  float *x = xT + ((size_t)t * d.NG + L.grp) * g.P * SG;
+  float lka = 0.f, inv = 0.f, scale = 0.f;
+  if (L.on) {
+    lka = leaky * asum[(size_t)t * d.B + L.sq];
+    inv = 1.0f / S[(size_t)(t + 1) * d.B + L.sq];
+    scale = deriv_weight / Zd[(size_t)t * d.B + L.sq];
+  }
+  float acc[WL::IT];
+#pragma unroll
+  for (int it = 0; it < WL::IT; it++) acc[it] = 0.f;
+  wide_slice<SG, 2>(g.by_pdf, slice, alpha, bnext, L, lka, inv, leaky, acc, nullptr);
+#pragma unroll
+  for (int it = 0; it < WL::IT; it++) {
+    const unsigned p = g.by_pdf.row[slice * 64 + L.wave * 16 + it * WL::RL + L.rl];
+    if (p != 0xffffffffu && L.on) x[p * SG + L.sl] *= scale * acc[it];
   }
 }
 
@@ -610,7 +729,8 @@ int to_device(const std::vector<T> &v, T **out) {
 }
 
 // rows[r] = list of (key, prob); builds SELL-64 over rows sorted by descending degree (stable)
-int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, float>>> &rows, tdnnf_den_graph::Sell *out) {
+// init (may be null): initial probabilities indexed by the low 16 bits of the key (the arc's source state), for arc4.z
+int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, float>>> &rows, const std::vector<float> *init, tdnnf_den_graph::Sell *out) {
   const int ns = (nrows + 63) / 64;
   std::vector<int> order(nrows);
   for (int r = 0; r < nrows; r++) order[r] = r;
@@ -619,6 +739,7 @@ int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, floa
   for (int k = 0; k < ns; k++) base[k + 1] = base[k] + (int)rows[order[64 * k]].size() * 64;
   std::vector<unsigned> rowid((size_t)ns * 64, 0xffffffffu);
   std::vector<uint2> arc(base[ns], make_uint2(0u, 0u));  // padding: state 0 / pdf 0 with prob 0
+  std::vector<uint4> arc4(base[ns], make_uint4(0u, 0u, 0u, 0u));
   for (int s = 0; s < nrows; s++) {
     const int r = order[s];
     rowid[s] = (unsigned)r;
@@ -626,6 +747,10 @@ int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, floa
       unsigned bits;
       memcpy(&bits, &rows[r][j].second, 4);
       arc[base[s / 64] + j * 64 + s % 64] = make_uint2(rows[r][j].first, bits);
+      const float ip = init ? rows[r][j].second * (*init)[rows[r][j].first & 0xffffu] : 0.f;
+      unsigned ibits;
+      memcpy(&ibits, &ip, 4);
+      arc4[base[s / 64] + j * 64 + s % 64] = make_uint4(rows[r][j].first, bits, ibits, 0u);
     }
   }
   out->nrows = nrows;
@@ -634,6 +759,7 @@ int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, floa
   int rc;
   if ((rc = to_device(base, &out->base))) return rc;
   if ((rc = to_device(rowid, &out->row))) return rc;
+  if ((rc = to_device(arc4, &out->arc4))) return rc;
   return to_device(arc, &out->arc);
 }
 
@@ -642,6 +768,7 @@ struct ChainPlan {
   bool lds_state;
   bool wide;          // den_wide_*: one launch per frame over all sequences, sequence-minor arrays
   int wide_blocks;    // partial rows of the widest launch
+  int SG, NG;         // wide: sequences per group, groups
   size_t alpha_floats, asum_floats, gstate_floats, la_floats;
   size_t lds_fwd, lds_bwd;
 };
@@ -659,12 +786,20 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
   }
   p.wide = g_den_mode == 2 || (g_den_mode == 0 && !p.lds_state);
   const int rows = std::max(std::max(g->by_dst.nslices, g->by_src.nslices), g->by_pdf.nslices) * 64;
-  p.wide_blocks = (rows + kWideRows - 1) / kWideRows;
-  p.alpha_floats = (size_t)B * (T + 1) * p.Hs;
-  p.asum_floats = (size_t)B * (3 * T + 4);  // wide: A(0..T), S(0..T) of the backward recursion, Zd(0..T-1)
-  // wide: the backward vectors of every frame, two sets of partial rows (the recursions run side by side) and x = exp(clamp(y)) /
+  p.wide_blocks = (rows / 64 + 3) & ~3;  // partial sums per sequence (at most one per slice), padded to float4
+  // 32 sequences per group (a whole 128-byte line per state) unless the minibatch has no more than 16; TDNNF_WIDE_SG=16|32 forces one
+  static const int sg_env = [] {
+    const char *e = getenv("TDNNF_WIDE_SG");
+    return e && atoi(e) == 32 ? 32 : 16;
+  }();
+  p.SG = getenv("TDNNF_WIDE_SG") ? sg_env : (B > 16 ? 32 : 16);
+  p.NG = (B + p.SG - 1) / p.SG;
+  const size_t Bw = p.wide ? (size_t)p.NG * p.SG : (size_t)B;  // the wide arrays hold whole groups
+  p.alpha_floats = Bw * (T + 1) * p.Hs;
+  p.asum_floats = ((size_t)B * (3 * T + 4) + 31) & ~(size_t)31;  // wide: A(0..T), S(0..T) of the backward recursion, Zd(0..T-1)
+  // wide: the backward vectors of every frame, two double-buffered sets of partial rows (the recursions run side by side) and x = exp(clamp(y)) /
   // the derivative, sequence-minor (T x P x B)
-  p.gstate_floats = p.wide ? (size_t)B * ((size_t)(T + 1) * p.Hs + 2 * p.wide_blocks) + (size_t)T * g->P * B : (p.lds_state ? 0 : (size_t)B * 3 * p.Hs);
+  p.gstate_floats = p.wide ? Bw * (size_t)(T + 1) * p.Hs + 4 * Bw * p.wide_blocks + (size_t)T * g->P * Bw : (p.lds_state ? 0 : (size_t)B * 3 * p.Hs);
   p.la_floats = 4 * (size_t)num_states_sup + 2;  // two arrays of DOUBLES (log alpha, log beta of the numerator), 8-byte aligned
   return p;
 }
@@ -712,7 +847,7 @@ int tdnnf_den_graph_create(int H, int A, int P, const int *src, const int *dst, 
     bp[pdf[a]].push_back({(unsigned)src[a] | ((unsigned)dst[a] << 16), prob[a]});
   }
   int rc;
-  if ((rc = build_sell(H, bd, &g->by_dst)) || (rc = build_sell(H, bs, &g->by_src)) || (rc = build_sell(P, bp, &g->by_pdf)) ||
+  if ((rc = build_sell(H, bd, &init, &g->by_dst)) || (rc = build_sell(H, bs, nullptr, &g->by_src)) || (rc = build_sell(P, bp, &init, &g->by_pdf)) ||
       (rc = to_device(init, &g->init))) {
     tdnnf_den_graph_destroy(g);
     return rc;
@@ -733,6 +868,7 @@ void tdnnf_den_graph_destroy(tdnnf_den_graph *g) {
     hipFree(x->base);
     hipFree(x->row);
     hipFree(x->arc);
+    hipFree(x->arc4);
   }
   hipFree(g->init);
   delete g;
@@ -828,7 +964,7 @@ int tdnnf_chain_set_denominator_mode(int mode) {
 size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *g, int B, int T) {
   if (!g || B <= 0 || T <= 0) return 0;
   ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
-  return sizeof(double) * (3 * (size_t)B + 2) + sizeof(float) * (p.alpha_floats + p.asum_floats + p.gstate_floats + p.la_floats) + 256;
+  return sizeof(double) * (3 * (size_t)B + 2) + sizeof(float) * (p.alpha_floats + p.asum_floats + p.gstate_floats + p.la_floats) + 512;
 }
 
 }  // extern "C"
@@ -848,7 +984,7 @@ ChainBufs chain_bufs(const tdnnf_den_graph *g, int B, int T, void *ws) {
   b.num_lp = b.den_lp + B;
   b.xent = b.num_lp + B;
   b.l2sum = b.xent + B;
-  b.alpha = (float *)(b.l2sum + 2);
+  b.alpha = (float *)(((uintptr_t)(b.l2sum + 2) + 127) & ~(uintptr_t)127);  // the wide form gathers 64- / 128-byte runs: keep them in one line
   b.asum = b.alpha + b.p.alpha_floats;
   b.gstate = b.asum + b.p.asum_floats;
   b.la = (double *)(((uintptr_t)(b.gstate + b.p.gstate_floats) + 7) & ~(uintptr_t)7);
@@ -872,42 +1008,55 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
   MatView yv = view(y), dv = view(deriv);
   if (b.p.wide) {
     const int Hs = b.p.Hs, P = g->P;
-    const int nb_dst = (g->by_dst.nslices * 64 + kWideRows - 1) / kWideRows, nb_src = (g->by_src.nslices * 64 + kWideRows - 1) / kWideRows,
-              nb_pdf = (g->by_pdf.nslices * 64 + kWideRows - 1) / kWideRows;
+    const WideDims d{B, b.p.NG, b.p.SG};
+    const size_t Bw = (size_t)d.NG * d.SG, frame = Bw * Hs, prow = Bw * b.p.wide_blocks;
+    static const int nsl = [] {
+      const char *e = getenv("TDNNF_WIDE_SLICES");
+      return e && atoi(e) >= 1 && atoi(e) <= 16 ? atoi(e) : kWideSlices;
+    }();
+    static const bool serial = getenv("TDNNF_WIDE_SERIAL") != nullptr;  // experiments: the backward recursion behind the forward one
+    auto blocks = [&](const tdnnf_den_graph::Sell &t) { return (t.nslices + nsl - 1) / nsl; };
+    const int nb_dst = blocks(g->by_dst), nb_src = blocks(g->by_src);
     float *alphaT = b.alpha, *asum = b.asum, *S = asum + (size_t)(T + 1) * B, *Zd = S + (size_t)(T + 1) * B;
-    float *bT = b.gstate, *part = bT + (size_t)B * Hs * (T + 1), *part2 = part + (size_t)B * b.p.wide_blocks, *xT = part2 + (size_t)B * b.p.wide_blocks;
-    const dim3 blk(256), tr((P + 63) / 64, (B + 63) / 64, T), nseq((B + 63) / 64);
+    float *bT = b.gstate, *part = bT + frame * (T + 1), *part2 = part + 2 * prow, *xT = part2 + 2 * prow;
+    const dim3 blk(256), tr((P + 63) / 64, (B + 63) / 64, T), ini(grid_for((long long)frame, 256));
     // a second stream for the backward recursion (per device, created on first use) and the fork / join events
-    static hipStream_t aux = nullptr;
+    static hipStream_t aux_stream = nullptr;
     static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (!aux) {
-      TDNNF_HIP(hipStreamCreateWithFlags(&aux, hipStreamNonBlocking));
+    if (!aux_stream) {
+      TDNNF_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
       TDNNF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
       TDNNF_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     }
-    hipLaunchKernelGGL(den_wide_prep_kernel, tr, blk, 0, s, yv, B, P, xT);
+    hipStream_t aux = serial ? s : aux_stream;
+    hipLaunchKernelGGL(den_wide_prep_kernel, tr, blk, 0, s, yv, d, P, xT);
     TDNNF_HIP(hipEventRecord(ev_fork, s));
     TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-    // forward recursion (this stream)
-    hipLaunchKernelGGL(den_wide_init_kernel, dim3(grid_for((long long)g->H * B, 256)), blk, 0, s, gd, B, alphaT, asum);
-    for (int t = 1; t <= T; t++) {
-      hipLaunchKernelGGL(den_wide_fwd_kernel, dim3(nb_dst), blk, 0, s, gd, B, t, leaky, xT, alphaT, asum, Hs, part);
-      hipLaunchKernelGGL(den_wide_sum_kernel, nseq, dim3(1024), 0, s, part, nb_dst, B, asum + (size_t)t * B);
-    }
+#define WIDE_LAUNCH(kernel, ...)                                      \
+  do {                                                                \
+    if (d.SG == 16) hipLaunchKernelGGL(kernel<16>, __VA_ARGS__);      \
+    else hipLaunchKernelGGL(kernel<32>, __VA_ARGS__);                 \
+  } while (0)
+    // forward recursion (this stream): launch t sums launch t-1's partial rows itself
+    hipLaunchKernelGGL(den_wide_init_kernel, ini, blk, 0, s, gd, d, Hs, false, alphaT, asum);
+    for (int t = 1; t <= T; t++)
+      WIDE_LAUNCH(den_wide_fwd_kernel, dim3(nb_dst * d.NG), blk, 0, s, gd, d, t, leaky, xT, alphaT, asum, Hs,
+                  t > 1 ? part + (size_t)((t - 1) & 1) * prow : (const float *)nullptr, nb_dst, nsl, part + (size_t)(t & 1) * prow);
+    WIDE_LAUNCH(den_wide_sum_kernel, dim3(d.NG), blk, 0, s, part + (size_t)(T & 1) * prow, nb_dst, d, asum + (size_t)T * B);
     hipLaunchKernelGGL(den_wide_total_kernel, dim3((B + 255) / 256), blk, 0, s, gd, B, T, leaky, asum, b.den_lp);
     // backward recursion, self-normalised (the other stream)
-    hipLaunchKernelGGL(den_wide_beta_init_kernel, dim3(grid_for((long long)g->H * B, 256)), blk, 0, aux, gd, B, bT + (size_t)T * Hs * B, S + (size_t)T * B);
-    for (int t = T - 1; t >= 0; t--) {
-      hipLaunchKernelGGL(den_wide_beta_kernel, dim3(nb_src), blk, 0, aux, gd, B, t, leaky, xT, bT + (size_t)(t + 1) * Hs * B, S + (size_t)(t + 1) * B,
-                         bT + (size_t)t * Hs * B, part2);
-      hipLaunchKernelGGL(den_wide_sum_kernel, nseq, dim3(1024), 0, aux, part2, nb_src, B, S + (size_t)t * B);
-    }
+    hipLaunchKernelGGL(den_wide_init_kernel, ini, blk, 0, aux, gd, d, Hs, true, bT + (size_t)T * frame, S + (size_t)T * B);
+    for (int t = T - 1; t >= 0; t--)
+      WIDE_LAUNCH(den_wide_beta_kernel, dim3(nb_src * d.NG), blk, 0, aux, gd, d, t, leaky, xT, bT + (size_t)(t + 1) * frame, S, Hs, bT + (size_t)t * frame,
+                  t < T - 1 ? part2 + (size_t)((t + 1) & 1) * prow : (const float *)nullptr, nb_src, nsl, part2 + (size_t)(t & 1) * prow);
+    WIDE_LAUNCH(den_wide_sum_kernel, dim3(d.NG), blk, 0, aux, part2, nb_src, d, S);
     TDNNF_HIP(hipEventRecord(ev_join, aux));
     TDNNF_HIP(hipStreamWaitEvent(s, ev_join, 0));
     // occupancies of every frame at once
-    hipLaunchKernelGGL(den_wide_dot_kernel, dim3(T, (B + 63) / 64), blk, 0, s, gd, B, leaky, alphaT, asum, Hs, bT, Zd);
-    hipLaunchKernelGGL(den_wide_gamma_kernel, dim3(nb_pdf, T), blk, 0, s, gd, B, leaky, xT, alphaT, asum, Hs, bT, S, Zd, -sp->weight);
-    hipLaunchKernelGGL(den_wide_unprep_kernel, tr, blk, 0, s, xT, B, P, dv);
+    WIDE_LAUNCH(den_wide_dot_kernel, dim3(T, d.NG), blk, 0, s, gd, d, leaky, alphaT, asum, Hs, bT, Zd);
+    WIDE_LAUNCH(den_wide_gamma_kernel, dim3(g->by_pdf.nslices * d.NG, T), blk, 0, s, gd, d, leaky, xT, alphaT, asum, Hs, bT, S, Zd, -sp->weight);
+#undef WIDE_LAUNCH
+    hipLaunchKernelGGL(den_wide_unprep_kernel, tr, blk, 0, s, xT, d, P, dv);
     TDNNF_LAUNCH_CHECK();
     return TDNNF_OK;
   }
