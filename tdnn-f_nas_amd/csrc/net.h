@@ -109,6 +109,19 @@ struct tdnnf_net {
   hipEvent_t ev_s3;
   float *s3_scratch;   // split-K scratch of the GEMMs launched on s3
   size_t s3_scratch_bytes;
+  // Weight-gradient stream: a component's parameter gradient (and, with natural gradient, the N-sized statistics passes) is
+  // independent of the backward-data GEMM that follows it.  At the recipes' minibatch (3 200 rows) neither fills the chip, so
+  // they run side by side: param_grad() goes to s4 with a workspace of its own, the caller's stream waits for the one before
+  // the last (the buffers a gradient reads are rewritten two components later at the earliest).  Off for minibatches whose
+  // GEMMs fill the chip by themselves (TDNNF_WGRAD_STREAM=0|1 forces it).
+  bool wg_on;
+  hipStream_t s4;
+  hipEvent_t ev_pg[2], ev_pg_in;
+  unsigned pg_count;
+  void *ws4;
+  float *s4_scratch;   // split-K scratch of the GEMMs launched on s4
+  size_t s4_scratch_bytes;
+  float *ngBias2;      // raw bias gradient formed on s4 (components whose bias sums do not come with the ReLU backward pass)
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den;

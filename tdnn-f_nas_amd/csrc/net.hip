@@ -433,6 +433,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     }
     n->s3_scratch_bytes = 16u << 20;
     n->s3_scratch = A.take<float>(n->s3_scratch_bytes / sizeof(float));
+
     n->ngBias = A.take<float>(mb + 16);
   }
   // shared workspace: wgrad slabs, column reductions, orthonormal
@@ -458,6 +459,14 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   if (n->cfg.bn_num_choices > 0) upd(sizeof(float) * (size_t)((max_lin_rows + 511) / 512 + 1) * 512);
   n->ws_bytes = ws + 256;
   n->ws = A.take<char>(n->ws_bytes);
+  {
+    const char *e = getenv("TDNNF_WGRAD_STREAM");
+    n->wg_on = e ? atoi(e) != 0 : std::max(max_rows, N0) <= 32768;
+  }
+  n->ws4 = n->wg_on ? A.take<char>(n->ws_bytes) : nullptr;
+  n->s4_scratch_bytes = n->wg_on ? (32u << 20) : 0;
+  n->s4_scratch = n->wg_on ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
+  n->ngBias2 = (n->wg_on && n->cfg.use_natural_gradient) ? A.take<float>((size_t)std::max(std::max(Hd, P), S) + 16) : nullptr;
 }
 
 #define CK(expr)             \
@@ -803,6 +812,9 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   n->ev_fork = n->ev_den = nullptr;
   n->s3 = nullptr;
   n->ev_s3 = nullptr;
+  n->s4 = nullptr;
+  n->ev_pg[0] = n->ev_pg[1] = n->ev_pg_in = nullptr;
+  n->pg_count = 0;
   n->ng_next = 0;
   for (auto &S : n->ngset) {
     S.ready = S.done = nullptr;
@@ -857,6 +869,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
 void tdnnf_net_destroy(tdnnf_net *n) {
   if (!n) return;
   if (n->s3) hipStreamSynchronize(n->s3);  // its kernels use the preconditioners' buffers
+  if (n->s4) hipStreamSynchronize(n->s4);
   if (n->s2) hipStreamSynchronize(n->s2);
   if (n->owns_ng) {
     for (auto *g : n->ng_in) tdnnf_ng_destroy(g);
@@ -878,6 +891,9 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   }
   if (n->ev_s3) hipEventDestroy(n->ev_s3);
   if (n->s3) hipStreamDestroy(n->s3);
+  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg_in})
+    if (e) hipEventDestroy(e);
+  if (n->s4) hipStreamDestroy(n->s4);
   delete n;
 }
 
@@ -1073,12 +1089,21 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       (void)hipGetLastError();
     }
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_s3, hipEventDisableTiming));
+    if (n->wg_on) {
+      TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
+      TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[0], hipEventDisableTiming));
+      TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[1], hipEventDisableTiming));
+      TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg_in, hipEventDisableTiming));
+    }
+    // (one side stream: giving each of the four buffer sets a stream of its own, so that the components' ~14-launch chains
+    // run side by side, made the step 1.6x (150 x 64) to 1.14x (1500 x 128) SLOWER, with 4, 8 or 12 hardware queues alike)
     for (auto &S : n->ngset) {
       TDNNF_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
       TDNNF_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
     }
   }
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
+  n->pg_count = 0;
   GemmPrecisionScope gemm_arith(c.gemm_precision == 2 ? 3 : c.gemm_precision);  // scope values: 1 two planes, 3 three planes
   TransposedWeightsScope gemm_wt(n->params, n->paramsT, n->paramsT ? n->num_params : 0);
   if (n->paramsT) {  // split-bf16 backward-data GEMMs read W^T (k-contiguous B operand)
@@ -1273,6 +1298,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     for (auto &gb : n->buckets) {
       if (gb.close_key != key) continue;
       hipStream_t cs = s;
+      if (!use_ng && n->wg_on && n->pg_count > 0)  // the components' gradients were formed on s4
+        TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
       if (use_ng) {
         TDNNF_HIP(hipEventRecord(gb.handoff, s));  // s-side writes of the range (bias sums, architecture parameters) are done
         TDNNF_HIP(hipStreamWaitEvent(n->s3, gb.handoff, 0));
@@ -1303,42 +1330,64 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const int ldw = K * Di;
     float *bias_acc = Bg(n, comp);
     if (n->comps[comp].lr_factor == 0.f) return TDNNF_OK;  // frozen component (cv-update): the reference skips its update
-    if (!use_ng)
-      return tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, Wg(n, comp), ldw, bias_done ? nullptr : bias_acc, n->ws, n->ws_bytes,
-                                     active, max_active, s);
+    // sw: where the gradient is formed -- the weight-gradient stream (its inputs are final on s now), or s itself
+    hipStream_t sw = s;
+    void *wsw = n->ws;
+    if (n->wg_on) {
+      sw = n->s4;
+      wsw = n->ws4;
+      TDNNF_HIP(hipEventRecord(n->ev_pg_in, s));
+      TDNNF_HIP(hipStreamWaitEvent(sw, n->ev_pg_in, 0));
+    }
+    SplitKScratchOverride sw_scratch(n->wg_on ? n->s4_scratch : nullptr, n->wg_on ? n->s4_scratch_bytes : 0);
+    // after this component is enqueued the caller's stream may only run ahead of it, not of the one before: what that one reads
+    // (derivative scratch, the bias sums) is rewritten from here on
+    auto handed_off = [&]() -> int {
+      if (!n->wg_on) return TDNNF_OK;
+      TDNNF_HIP(hipEventRecord(n->ev_pg[n->pg_count & 1], sw));
+      if (n->pg_count > 0) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
+      n->pg_count++;
+      return TDNNF_OK;
+    };
+    if (!use_ng) {
+      CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, Wg(n, comp), ldw, bias_done ? nullptr : bias_acc, wsw, n->ws_bytes, active, max_active, sw));
+      return handed_off();
+    }
     const int N = dyv->rows, ones = bias_acc ? 1 : 0, Dx = ldw + ones, ldT = (Dx + 3) & ~3;
     auto &S = n->ngset[n->ng_next++ % 4];
-    if (S.used) TDNNF_HIP(hipStreamWaitEvent(s, S.done, 0));  // the side stream still owned this set four components ago
+    if (S.used) TDNNF_HIP(hipStreamWaitEvent(sw, S.done, 0));  // the side stream still owned this set four components ago
     float *T = S.T;
-    TDNNF_HIP(hipMemsetAsync(T, 0, sizeof(float) * (size_t)Do * ldT, s));
+    TDNNF_HIP(hipMemsetAsync(T, 0, sizeof(float) * (size_t)Do * ldT, sw));
     if (from_tapgrad)
-      hipLaunchKernelGGL(scaled_taps_to_kernel, dim3(grid_for((long long)Do * ldw, 256)), dim3(256), 0, s, n->tapgrad, eff, Do, ldw, Di, T, ldT);
+      hipLaunchKernelGGL(scaled_taps_to_kernel, dim3(grid_for((long long)Do * ldw, 256)), dim3(256), 0, sw, n->tapgrad, eff, Do, ldw, Di, T, ldT);
     else
-      CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, T, ldT, nullptr, n->ws, n->ws_bytes, active, max_active, s));
+      CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, T, ldT, nullptr, wsw, n->ws_bytes, active, max_active, sw));
     if (ones) {
+      float *bsum = n->ngBias;  // filled by the fused ReLU backward pass on s
       if (!bias_done) {
-        TDNNF_HIP(hipMemsetAsync(n->ngBias, 0, sizeof(float) * Do, s));
-        TDNNF_HIP(colsum_add(view(dyv), 1.0f, n->ngBias, n->ws, s));
+        if (n->wg_on) bsum = n->ngBias2;
+        TDNNF_HIP(hipMemsetAsync(bsum, 0, sizeof(float) * Do, sw));
+        TDNNF_HIP(colsum_add(view(dyv), 1.0f, bsum, wsw, sw));
       }
-      hipLaunchKernelGGL(set_column_kernel, dim3((Do + 255) / 256), dim3(256), 0, s, n->ngBias, Do, T, ldT, ldw);
+      hipLaunchKernelGGL(set_column_kernel, dim3((Do + 255) / 256), dim3(256), 0, sw, bsum, Do, T, ldT, ldw);
     }
-    // ---- the passes over the N-sized operands, on this stream
+    // ---- the passes over the N-sized operands
     NgInput xin;
     memset(&xin, 0, sizeof(xin));
     xin.x = view(x); xin.ix = ix; xin.Di = Di; xin.ones = ones; xin.N = N; xin.eff = eff; xin.active = active; xin.max_active = max_active;
-    CK(ng_stats_main(n->ng_in[comp], xin, S.H_in, S.part_in, n->ws, n->ws_bytes, s));
+    CK(ng_stats_main(n->ng_in[comp], xin, S.H_in, S.part_in, wsw, n->ws_bytes, sw));
     NgInput yin;
     memset(&yin, 0, sizeof(yin));
     yin.x = view(dyv); yin.ix.row_stride = 1; yin.ix.num_offsets = 1; yin.Di = Do; yin.N = N;
     if (fused_comp == comp) {  // H_out and its partials came with the BatchNorm/ReLU backward sweep
       TDNNF_REQUIRE(fused_set == &S, "net_forward_backward: the fused statistics went to another buffer set");
       fused_comp = -1;
-      CK(ng_external_end(n->ng_out[comp], yin, S.H_out, n->ws, n->ws_bytes, s));
+      CK(ng_external_end(n->ng_out[comp], yin, S.H_out, wsw, n->ws_bytes, sw));
     } else {
-      CK(ng_stats_main(n->ng_out[comp], yin, S.H_out, S.part_out, n->ws, n->ws_bytes, s));
+      CK(ng_stats_main(n->ng_out[comp], yin, S.H_out, S.part_out, wsw, n->ws_bytes, sw));
     }
     // ---- the R x R work, the projections of the raw gradient and the commit, on the side stream
-    TDNNF_HIP(hipEventRecord(S.ready, s));
+    TDNNF_HIP(hipEventRecord(S.ready, sw));
     TDNNF_HIP(hipStreamWaitEvent(n->s3, S.ready, 0));
     {
       SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
@@ -1350,6 +1399,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                        ng_scale_dev(n->ng_out[comp]), Wg(n, comp), bias_acc);
     TDNNF_HIP(hipEventRecord(S.done, n->s3));
     S.used = true;
+    CK(handed_off());
+    // (the unscaled tap gradients this one reads are rebuilt by the next DARTS component on the caller's stream)
+    if (from_tapgrad && n->wg_on) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
     return TDNNF_OK;
   };
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
@@ -1487,6 +1539,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }
   CK(close_bucket(-1));
+  if (n->wg_on && n->pg_count > 0) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));  // join the weight-gradient stream
   if (use_ng) {  // join the side stream: every bucket has been committed into grads
     TDNNF_HIP(hipEventRecord(n->ev_s3, n->s3));
     TDNNF_HIP(hipStreamWaitEvent(s, n->ev_s3, 0));
