@@ -44,6 +44,8 @@ struct tdnnf_ng {
   size_t scratch_floats;
   // deferred refresh
   int pending, job_done, job_N;
+  hipEvent_t ev_job;  // the refresh's K, L and tr(XX^T) have reached the pinned buffers: the pool thread waits for it
+  int device;
   bool cur_upd;  // the call in flight between ng_stats_main and ng_stats_side
   int cur_N, cur_ones;
   std::vector<float> d_next;
@@ -139,6 +141,10 @@ struct NgPool {
         ng = q.front();
         q.pop_front();
       }
+      // the job was queued when its copies were enqueued, not when they finished (a stream callback for that stalls the
+      // stream for ~0.1 ms per refresh, 72 of them in a refresh step): wait for them here
+      (void)hipSetDevice(ng->device);
+      (void)hipEventSynchronize(ng->ev_job);
       host_update(ng);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -156,7 +162,6 @@ NgPool &pool() {
   static NgPool *p = new NgPool();  // never destroyed: worker threads outlive static destruction
   return *p;
 }
-void enqueue_cb(void *p) { pool().push((tdnnf_ng *)p); }
 
 void compute_et(const std::vector<float> &d, double beta, std::vector<double> &sqrt_e, std::vector<double> &inv_sqrt_e) {
   const int R = (int)d.size();
@@ -255,6 +260,10 @@ int alloc_state(tdnnf_ng *ng, int D) {
   ng->scal = (double *)p;
   const size_t pin_floats = 3 * fRR + Rp + 4 + 4;
   TDNNF_HIP(hipHostMalloc((void **)&ng->pin, sizeof(float) * pin_floats, hipHostMallocDefault));
+  if (!ng->ev_job) {
+    TDNNF_HIP(hipGetDevice(&ng->device));
+    TDNNF_HIP(hipEventCreateWithFlags(&ng->ev_job, hipEventDisableTiming | hipEventBlockingSync));
+  }
   memset(ng->pin, 0, sizeof(float) * pin_floats);
   float *h = ng->pin;
   ng->h_K = h; h += fRR;
@@ -457,12 +466,8 @@ int stats_side(tdnnf_ng *ng, const float *H, const double *part, void *wg_ws, si
   ng->job_N = N;
   ng->job_done = 0;
   ng->pending = 1;
-  if (hipLaunchHostFunc(s, enqueue_cb, ng) != hipSuccess) {  // no stream callbacks: do the host part here
-    (void)hipGetLastError();
-    TDNNF_HIP(hipStreamSynchronize(s));
-    host_update(ng);
-    ng->job_done = 1;
-  }
+  TDNNF_HIP(hipEventRecord(ng->ev_job, s));
+  pool().push(ng);
   return TDNNF_OK;
 }
 
@@ -653,6 +658,7 @@ void tdnnf_ng_destroy(tdnnf_ng *ng) {
   hipFree(ng->dev);
   hipHostFree(ng->pin);
   hipFree(ng->scratch);
+  if (ng->ev_job) hipEventDestroy(ng->ev_job);
   delete ng;
 }
 

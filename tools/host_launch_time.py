@@ -35,4 +35,6 @@ for i in range(14, 30):
     t2 = time.perf_counter()
     host.append(t1 - t0)
     total.append(t2 - t0)
+print("per-step synchronised ms:", " ".join("%.1f" % (1e3 * t) for t in total))
+print("per-step host enqueue ms:", " ".join("%.1f" % (1e3 * t) for t in host))
 print("chunk %d x %d: host enqueue %.2f ms / step (median), synchronised step %.2f ms" % (chunk, mb, 1e3 * np.median(host), 1e3 * np.median(total)))
