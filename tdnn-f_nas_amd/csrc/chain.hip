@@ -287,12 +287,12 @@ __global__ __launch_bounds__(256) void den_wide_unprep_kernel(const float *dT, W
 
 // frame 0 of alpha (before the leaky term) / frame T of b: v[g][h][sl] = init_h or 1; norm[s] = init_sum
 __global__ __launch_bounds__(256) void den_wide_init_kernel(DenDev g, WideDims d, int Hs, bool ones, float *v, float *norm) {
-  const long long e = blockIdx.x * 256LL + threadIdx.x;
-  if (e < (long long)d.NG * Hs * d.SG) {
+  const long long total = (long long)d.NG * Hs * d.SG;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {  // (grid_for caps the grid)
     const int h = (int)((e / d.SG) % Hs);
     v[e] = h < g.H ? (ones ? 1.0f : g.init[h]) : 0.f;
   }
-  if (e < d.B) norm[e] = g.init_sum;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < d.B; e += gridDim.x * 256LL) norm[e] = g.init_sum;
 }
 
 // where a workgroup of the recursion kernels stands: its group, its block of slices, its lane's sequence and row lane
