@@ -392,6 +392,7 @@ def _chain_case(hip, ora, pkg, H, P, B, T, leaky, l2):
     dg, ds = pkg.hipabi.DenGraph(g), pkg.hipabi.Supervision(sup)
     nb = hip.chain_workspace_bytes(dg.h, B, T)
     ws = hip.ws(nb)
+    ws.fill_(float("nan"))  # nothing may depend on what the workspace held
     res = torch.zeros(8, dtype=torch.float64, device="cuda")
     yd, _ = padded(y)
     dd, _ = padded(np.full_like(y, 5.0))
