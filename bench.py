@@ -172,11 +172,12 @@ def workload_text(args):
 class Job:
     """One replica of the trainer on this rank's GPU with its own synthetic egs resident in HBM."""
 
-    def __init__(self, pkg, args, chunk, sequences, den_states, rank, world, gemm=None, first_sequence=0):
+    def __init__(self, pkg, args, chunk, sequences, den_states, rank, world, gemm=None, first_sequence=0, natural_gradient=None):
         import torch
         self.pkg, self.args, self.world = pkg, args, world
         gemm = args.gemm if gemm is None else gemm
-        self.cfg = pkg.trainer.make_config(frames_per_chunk=chunk, num_sequences=sequences, use_natural_gradient=args.natural_gradient,
+        ng = args.natural_gradient if natural_gradient is None else natural_gradient
+        self.cfg = pkg.trainer.make_config(frames_per_chunk=chunk, num_sequences=sequences, use_natural_gradient=ng,
                                            gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[gemm], use_dropout=int(args.dropout > 0),
                                            **workload_kwargs(args))
         self.net = pkg.trainer.ChainNet(self.cfg)
@@ -376,8 +377,8 @@ def main():
                                          for c in classes]},
         }
 
-        def line_item(name, chunk, sequences, den_states, gemm=None, steps=None):
-            j = Job(pkg, args, chunk, sequences, den_states, rank, world, gemm=gemm)
+        def line_item(name, chunk, sequences, den_states, gemm=None, steps=None, natural_gradient=None):
+            j = Job(pkg, args, chunk, sequences, den_states, rank, world, gemm=gemm, natural_gradient=natural_gradient)
             k = args.steps if steps is None else steps
             d = j.run(burn, args.warmup, k, lambda: torch.cuda.synchronize())
             arcs = int(len(j.den["src"]))
@@ -395,9 +396,13 @@ def main():
         if world == 1 and not args.no_also:
             # further line items, same net and step: the reference's own egs shape (chunk 150 x 64, ...pretrain.sh:46,197) and
             # SWBD-scale denominator graphs (10 000 and 30 000 states)
-            out["also"] = [line_item("the recipes' egs shape (--chunk 150 --minibatch 64)", 150, 64, args.den_states),
+            out["also"] = [line_item("the recipes' egs shape (--chunk 150 --minibatch 64)", 150, 64, args.den_states, steps=40),
                            line_item("10 000-state denominator graph (--den-states 10000)", args.chunk, seqs, 10000, steps=4),
                            line_item("30 000-state denominator graph (--den-states 30000)", args.chunk, seqs, 30000, steps=4)]
+            if args.natural_gradient:  # what the preconditioning costs: the same step with raw gradients
+                it = line_item("natural gradient off (--natural-gradient 0)", args.chunk, seqs, args.den_states, natural_gradient=0)
+                it["natural_gradient_cost_ms_per_step"] = round(1e3 * dt / args.steps - it["ms_per_step"], 3)
+                out["also"].append(it)
         ok = True
         if world == 1 and not args.no_parity:
             parity, base = parity_and_cpu_baseline(pkg, args, want_baseline=not args.no_cpu_baseline)

@@ -226,6 +226,100 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
 }
 
 
+// The backward half in two kernels that do not wait for the forward one (persistent form, state vectors in LDS).  As in the wide
+// form below, the backward recursion is linear and homogeneous in its last frame, so it can run SELF-NORMALISED beside the
+// forward recursion:  b(T, h) = 1,  S(t) = sum_h init_h b(t, h),
+//   b(t, h) = sum_arcs p x(t, pdf) (b(t+1, dst) / S(t+1) + leaky),
+// every b(t) and S(t) kept (another (T+1) x Hs floats per sequence); the occupancies then need no dependence between frames:
+//   gamma(t, p) = x(t, p) sum_arcs p alpha_dash(t, src) (b(t+1, dst) / S(t+1) + leaky) / Zd(t),   Zd(t) = sum_h alpha_dash(t, h) b(t, h)
+// -- one workgroup per (frame, sequence).  128 x 500 frames, 4 000 states: 17.8 -> 11.6 ms stand-alone (10 000 states: 34.5 -> 27.9),
+// which is what the component-level entry point gets.  The trainer, which runs the denominator beside the xent head on a stream
+// of its own, keeps the one-kernel backward pass: there the further stream bought nothing at 1500 x 128 (133.8 -> 134.6 ms) and
+// cost 7 ms at 150 x 64 (18.5 -> 25.7: with the weight-gradient stream that is a fifth stream in flight, and beyond four they
+// share hardware queues -- the same cliff as one side stream per natural-gradient buffer set).
+__global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView y, int B, int T, float leaky, float *b_all, float *S_all, int Hs) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[kDenThreads / 64];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const int H = g.H, P = g.P, P4 = (P + 3) & ~3;
+  float *x = smem;       // P: exp of the frame's output row
+  float *bn = smem + P4;  // H: b(t+1, .) / S(t+1) + leaky
+  float *brow = b_all + (size_t)s * (T + 1) * Hs;
+  float *S = S_all + (size_t)s * (T + 1);
+  for (int h = tid; h < H; h += kDenThreads) {
+    brow[(size_t)T * Hs + h] = 1.0f;
+    bn[h] = 1.0f / g.init_sum + leaky;
+  }
+  if (tid == 0) S[T] = g.init_sum;
+  __syncthreads();
+  for (int t = T - 1; t >= 0; t--) {
+    const float *yr = y.data + (size_t)(t * B + s) * y.stride;
+    for (int p = tid; p < P; p += kDenThreads) x[p] = exp_limited(yr[p]);
+    __syncthreads();
+    float *bcur = brow + (size_t)t * Hs;
+    float local = 0.f;
+    for (int slot = tid; slot < g.by_src.nslices * 64; slot += kDenThreads) {
+      const int sl = slot >> 6, ln = slot & 63;
+      const int b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
+      const uint2 *ap = g.by_src.arc + b0 + ln;
+      float acc = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < w; j++) {
+        const uint2 a = ap[j * 64];
+        acc += __uint_as_float(a.y) * x[a.x >> 16] * bn[a.x & 0xffffu];
+      }
+      const unsigned h = g.by_src.row[slot];
+      if (h != 0xffffffffu) {
+        bcur[h] = acc;
+        local += g.init[h] * acc;
+      }
+    }
+    const float St = block_sum(local, red, kDenThreads / 64);  // (its barriers also order the reads of bn above)
+    if (tid == 0) S[t] = St;
+    const float inv = 1.0f / St;
+    for (int h = tid; h < H; h += kDenThreads) bn[h] = bcur[h] * inv + leaky;  // (other threads' rows: visible after block_sum's barriers)
+    __syncthreads();
+  }
+}
+
+// Occupancies of one (frame, sequence): deriv[t*B+s][p] = deriv_weight * gamma_den(t, p) (overwrites the whole row)
+constexpr int kGammaThreads = 512;
+__global__ __launch_bounds__(kGammaThreads) void den_gamma_kernel(DenDev g, MatView y, int B, int T, float leaky, const float *alpha_all, const float *b_all,
+                                                                  const float *S_all, int Hs, float deriv_weight, MatView deriv) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[kGammaThreads / 64];
+  const int t = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
+  const int H = g.H, P = g.P, P4 = (P + 3) & ~3, H4 = (H + 3) & ~3;
+  float *x = smem, *ad = smem + P4, *bn = ad + H4;
+  const float *alpha = alpha_all + ((size_t)s * (T + 1) + t) * Hs;     // alpha_dash(t, .)
+  const float *bt = b_all + ((size_t)s * (T + 1) + t) * Hs, *bt1 = bt + Hs;
+  const float inv = 1.0f / S_all[(size_t)s * (T + 1) + t + 1];
+  const float *yr = y.data + (size_t)(t * B + s) * y.stride;
+  for (int p = tid; p < P; p += kGammaThreads) x[p] = exp_limited(yr[p]);
+  float local = 0.f;
+  for (int h = tid; h < H; h += kGammaThreads) {
+    const float a = alpha[h];
+    ad[h] = a;
+    bn[h] = bt1[h] * inv + leaky;
+    local += a * bt[h];
+  }
+  const float Zd = block_sum(local, red, kGammaThreads / 64);  // (also the barrier before ad / bn / x are read)
+  const float scale = deriv_weight / Zd;
+  float *dr = deriv.data + (size_t)(t * B + s) * deriv.stride;
+  for (int slot = tid; slot < g.by_pdf.nslices * 64; slot += kGammaThreads) {
+    const int sl = slot >> 6, ln = slot & 63;
+    const int b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
+    const uint2 *ap = g.by_pdf.arc + b0 + ln;
+    float acc = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < w; j++) {
+      const uint2 a = ap[j * 64];
+      acc += __uint_as_float(a.y) * ad[a.x & 0xffffu] * bn[a.x >> 16];
+    }
+    const unsigned p = g.by_pdf.row[slot];
+    if (p != 0xffffffffu) dr[p] = scale * acc * x[p];
+  }
+}
 // ---------------------------------------------------------------------------------------------- denominator, wide form
 // The persistent kernels above give a sequence one workgroup and keep its state vectors in LDS: right while they fit (up to
 // ~10 000 states), a crawl beyond (30 000 states / 360 000 arcs: every arc is a 4-byte gather from L2, 580 ms per
@@ -766,6 +860,7 @@ int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, floa
 struct ChainPlan {
   int Hs;
   bool lds_state;
+  bool split;         // persistent form with the backward recursion beside the forward one (den_beta_kernel + den_gamma_kernel)
   bool wide;          // den_wide_*: one launch per frame over all sequences, sequence-minor arrays
   int wide_blocks;    // partial rows of the widest launch
   int SG, NG;         // wide: sequences per group, groups
@@ -785,6 +880,8 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
     p.lds_bwd = sizeof(float) * P4;
   }
   p.wide = g_den_mode == 2 || (g_den_mode == 0 && !p.lds_state);
+  static const bool no_split = getenv("TDNNF_DEN_SPLIT") && atoi(getenv("TDNNF_DEN_SPLIT")) == 0;  // experiments: the one-kernel backward pass
+  p.split = !p.wide && p.lds_state && !no_split;
   const int rows = std::max(std::max(g->by_dst.nslices, g->by_src.nslices), g->by_pdf.nslices) * 64;
   p.wide_blocks = (rows / 64 + 3) & ~3;  // partial sums per sequence (at most one per slice), padded to float4
   // 32 sequences per group (a whole 128-byte line per state) unless the minibatch has no more than 16; TDNNF_WIDE_SG=16|32 forces one
@@ -799,7 +896,7 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
   p.asum_floats = ((size_t)B * (3 * T + 4) + 31) & ~(size_t)31;  // wide: A(0..T), S(0..T) of the backward recursion, Zd(0..T-1)
   // wide: the backward vectors of every frame, two double-buffered sets of partial rows (the recursions run side by side) and x = exp(clamp(y)) /
   // the derivative, sequence-minor (T x P x B)
-  p.gstate_floats = p.wide ? Bw * (size_t)(T + 1) * p.Hs + 4 * Bw * p.wide_blocks + (size_t)T * g->P * Bw : (p.lds_state ? 0 : (size_t)B * 3 * p.Hs);
+  p.gstate_floats = p.wide ? Bw * (size_t)(T + 1) * p.Hs + 4 * Bw * p.wide_blocks + (size_t)T * g->P * Bw : (p.lds_state ? (p.split ? (size_t)B * (T + 1) * (p.Hs + 1) + 32 : 0) : (size_t)B * 3 * p.Hs);
   p.la_floats = 4 * (size_t)num_states_sup + 2;  // two arrays of DOUBLES (log alpha, log beta of the numerator), 8-byte aligned
   return p;
 }
@@ -997,11 +1094,26 @@ SupDev sup_dev(const tdnnf_supervision *sp) {
 }
 }  // namespace
 
+// a second stream for the backward recursion (created on first use) and the fork / join events
+int den_aux_stream(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join) {
+  static hipStream_t st = nullptr;
+  static hipEvent_t ef = nullptr, ej = nullptr;
+  if (!st) {
+    TDNNF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    TDNNF_HIP(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
+    TDNNF_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  }
+  *aux = st;
+  *ev_fork = ef;
+  *ev_join = ej;
+  return TDNNF_OK;
+}
+
 // The three parts of ComputeChainObjfAndDeriv, separately launchable so that the trainer can run the
 // denominator (one workgroup per sequence: half the CUs at 128 sequences) on a second stream beside the xent head.
 // (1) denominator forward + backward: deriv = -weight * gamma_den (whole matrix overwritten), den log-probs -> workspace
 int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws,
-              hipStream_t s) {
+              hipStream_t s, bool beside_other_work) {
   const int B = sp->B, T = sp->T;
   ChainBufs b = chain_bufs(g, B, T, ws);
   DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
@@ -1020,13 +1132,11 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     float *alphaT = b.alpha, *asum = b.asum, *S = asum + (size_t)(T + 1) * B, *Zd = S + (size_t)(T + 1) * B;
     float *bT = b.gstate, *part = bT + frame * (T + 1), *part2 = part + 2 * prow, *xT = part2 + 2 * prow;
     const dim3 blk(256), tr((P + 63) / 64, (B + 63) / 64, T), ini(grid_for((long long)frame, 256));
-    // a second stream for the backward recursion (per device, created on first use) and the fork / join events
-    static hipStream_t aux_stream = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (!aux_stream) {
-      TDNNF_HIP(hipStreamCreateWithFlags(&aux_stream, hipStreamNonBlocking));
-      TDNNF_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-      TDNNF_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    hipStream_t aux_stream;
+    hipEvent_t ev_fork, ev_join;
+    {
+      int rc = den_aux_stream(&aux_stream, &ev_fork, &ev_join);
+      if (rc) return rc;
     }
     hipStream_t aux = serial ? s : aux_stream;
     hipLaunchKernelGGL(den_wide_prep_kernel, tr, blk, 0, s, yv, d, P, xT);
@@ -1060,7 +1170,25 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     TDNNF_LAUNCH_CHECK();
     return TDNNF_OK;
   }
-  if (b.p.lds_state) {
+  if (b.p.split && !beside_other_work) {
+    const int P4 = (g->P + 3) & ~3, H4 = (g->H + 3) & ~3;
+    const size_t lds_beta = sizeof(float) * (P4 + H4), lds_gamma = sizeof(float) * (P4 + 2 * H4);
+    float *b_all = b.gstate, *S_all = b_all + (size_t)B * (T + 1) * b.p.Hs;
+    hipStream_t aux;
+    hipEvent_t ev_fork, ev_join;
+    int rc = den_aux_stream(&aux, &ev_fork, &ev_join);
+    if (rc) return rc;
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_beta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beta));
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gamma));
+    TDNNF_HIP(hipEventRecord(ev_fork, s));
+    TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
+    hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs);
+    TDNNF_HIP(hipEventRecord(ev_join, aux));
+    TDNNF_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    hipLaunchKernelGGL(den_gamma_kernel, dim3(T, B), dim3(kGammaThreads), lds_gamma, s, gd, yv, B, T, leaky, b.alpha, b_all, S_all, b.p.Hs, -sp->weight, dv);
+  } else if (b.p.lds_state) {
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_bwd));
     hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);

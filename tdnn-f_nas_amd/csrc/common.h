@@ -132,7 +132,10 @@ hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t 
 // the three separately launchable parts of the chain objective (chain.hip)
 bool log_softmax_propagate_with_aux(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_mat *aux, float aux_scale, hipStream_t s);  // elementwise.hip
 float chain_supervision_weight(const tdnnf_supervision *sp);
-int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws, hipStream_t s);
+// beside_other_work: the caller runs other kernels next to the denominator (the trainer: the xent head), so the persistent form keeps
+// its one-kernel backward pass instead of running the two recursions side by side on a further stream
+int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws, hipStream_t s,
+              bool beside_other_work = false);
 int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output,
               float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised = false);
 int chain_finish(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float l2_regularize, double *results,

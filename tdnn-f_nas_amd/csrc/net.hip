@@ -1213,7 +1213,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TraceRange trace_den("chain denominator forward-backward (second stream)");
       TDNNF_HIP(hipEventRecord(n->ev_fork, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
-      CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2));
+      CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, true));
       TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));
     }
   }
