@@ -879,7 +879,9 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
     p.lds_fwd = sizeof(float) * P4;
     p.lds_bwd = sizeof(float) * P4;
   }
-  p.wide = g_den_mode == 2 || (g_den_mode == 0 && !p.lds_state);
+  static const int env_mode = getenv("TDNNF_DEN_MODE") ? atoi(getenv("TDNNF_DEN_MODE")) : 0;  // experiments: 1 persistent, 2 wide
+  const int mode = g_den_mode ? g_den_mode : env_mode;
+  p.wide = mode == 2 || (mode == 0 && !p.lds_state);
   static const bool no_split = getenv("TDNNF_DEN_SPLIT") && atoi(getenv("TDNNF_DEN_SPLIT")) == 0;  // experiments: the one-kernel backward pass
   p.split = !p.wide && p.lds_state && !no_split;
   const int rows = std::max(std::max(g->by_dst.nslices, g->by_src.nslices), g->by_pdf.nslices) * 64;
