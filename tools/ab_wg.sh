@@ -1,9 +1,11 @@
 set -e
 B="python bench.py --no-parity --no-cpu-baseline --no-also --no-alt"
-P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"])'
+P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], [round(c["tflops"],1) for c in d["roofline"]["all_kernels"]])'
 run() { echo "$1"; shift; env "$@" 2>/dev/null | python -c "$P"; }
-for cfg in "TDNNF_DEN_MODE=1" "TDNNF_DEN_MODE=2"; do
-  run "$cfg 1500x128 10k states" $cfg $B --steps 6 --warmup 3 --den-states 10000
-  run "$cfg 1500x128 7k states" $cfg $B --steps 6 --warmup 3 --den-states 7000
-  run "$cfg 1500x128 4k states" $cfg $B --steps 6 --warmup 3 --den-states 4000
+for cfg in "TDNNF_GEMM_NOINTERLEAVE=1" "X=1" "TDNNF_GEMM_NOINTERLEAVE=1" "X=1"; do
+  run "$cfg 1500x128" $cfg $B --steps 8 --warmup 4
+done
+for cfg in "TDNNF_GEMM_NOINTERLEAVE=1" "X=1"; do
+  echo $cfg; env $cfg python tools/gemm_bench.py 8 tdnnf 2>/dev/null | grep -E "fwd|bwd" | cut -c1-100
+  env $cfg python tools/gemm_bench.py 8 "in linear" 2>/dev/null | grep -E "fwd" | cut -c1-100
 done
