@@ -393,6 +393,49 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
             Cs[row * LDCS + (wn * TN + j) * 32 + li] = acc[i][j][r];
           }
     }
+    // Interior tiles (the whole tile inside M x N, 16-byte accesses): the values this pass adds to the accumulators -- the old C of an
+    // accumulating launch, the fused addend -- are requested for several row segments at a time (eight for the 128-wide tile) before anything waits for them, and the
+    // stores are not waited for either.  (The general loop below asks for one segment, waits -- also for the previous segment's store,
+    // which shares the counter --, stores, and so on: sixteen trips to memory in a row per tile, most of what a K = 320 tile spent
+    // outside its MFMAs when it carried an addend.)
+    constexpr int kSeg = HALF * (BN / 4) / 256;  // row segments per thread and pass
+    constexpr int kGrp = kSeg % 8 == 0 ? 8 : (kSeg % 5 == 0 ? 5 : (kSeg % 4 == 0 ? 4 : (kSeg % 2 == 0 ? 2 : 1)));  // requested together
+    constexpr bool kFastShape = (HALF * (BN / 4)) % 256 == 0;
+    const bool fast_tile = kFastShape && cvec && p.ksplit <= 1 && !p.serial_epilogue && m0 + BM <= p.M && n0 + BN <= p.N;
+    if (fast_tile) {
+      __syncthreads();
+#pragma unroll
+      for (int g = 0; g < kSeg; g += kGrp) {
+        float4 pre[kGrp], addv[kGrp];  // bias or old C; the fused addend
+#pragma unroll
+        for (int u = 0; u < kGrp; u++) {
+          const int idx = t + 256 * (g + u), m = m0 + pass * HALF + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+          pre[u] = p.init_mode == 0   ? *reinterpret_cast<const float4 *>(p.C + (long long)m * p.ldc + n)
+                   : p.init_mode == 1 ? *reinterpret_cast<const float4 *>(p.bias + n)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+          addv[u] = (p.add && m >= p.add_lo && m < p.add_hi) ? *reinterpret_cast<const float4 *>(p.add + (long long)(m - p.add_lo) * p.ldadd + n)
+                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kGrp; u++) {
+          const int idx = t + 256 * (g + u), row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+          const int m = m0 + pass * HALF + row, n = n0 + c4;
+          float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDCS + c4);
+          v.x += pre[u].x + p.add_scale * addv[u].x;
+          v.y += pre[u].y + p.add_scale * addv[u].y;
+          v.z += pre[u].z + p.add_scale * addv[u].z;
+          v.w += pre[u].w + p.add_scale * addv[u].w;
+          if (p.relu) { v.x = floor_keep_nan(v.x, 0.f); v.y = floor_keep_nan(v.y, 0.f); v.z = floor_keep_nan(v.z, 0.f); v.w = floor_keep_nan(v.w, 0.f); }
+          *reinterpret_cast<float4 *>(p.C + (long long)m * p.ldc + n) = v;
+          if (kColStats && colstats) {  // (kColStats: the thread's column group is the same in every segment)
+            cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w;
+            cq[0] += v.x * v.x; cq[1] += v.y * v.y; cq[2] += v.z * v.z; cq[3] += v.w * v.w;
+          }
+        }
+      }
+      if (pass + 1 < BM / HALF) __syncthreads();
+      continue;
+    }
     __syncthreads();
     for (int idx = t; idx < HALF * (BN / 4); idx += 256) {
       const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
@@ -784,6 +827,41 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(const RowsGemmArgs
             Cs[row * LDCS + (wn * TN + j) * 32 + li] = acc[i][j][r];
           }
     }
+    {  // interior tiles: as in rows_gemm_kernel, the old C / bias / addend of several row segments requested together
+      constexpr int kSeg = HALF * (BN / 4) / 256;
+      constexpr int kGrp = kSeg % 8 == 0 ? 8 : (kSeg % 5 == 0 ? 5 : (kSeg % 4 == 0 ? 4 : (kSeg % 2 == 0 ? 2 : 1)));
+      constexpr bool kFastShape = (HALF * (BN / 4)) % 256 == 0;
+      if (kFastShape && cvec && p.ksplit <= 1 && !p.serial_epilogue && m0 + BM <= p.M && n0 + BN <= p.N) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < kSeg; g += kGrp) {
+          float4 pre[kGrp], addv[kGrp];
+#pragma unroll
+          for (int u = 0; u < kGrp; u++) {
+            const int idx = t + 256 * (g + u), m = m0 + pass * HALF + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
+            pre[u] = p.init_mode == 0   ? *reinterpret_cast<const float4 *>(p.C + (long long)m * p.ldc + n)
+                     : p.init_mode == 1 ? *reinterpret_cast<const float4 *>(p.bias + n)
+                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            addv[u] = (p.add && m >= p.add_lo && m < p.add_hi) ? *reinterpret_cast<const float4 *>(p.add + (long long)(m - p.add_lo) * p.ldadd + n)
+                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int u = 0; u < kGrp; u++) {
+            const int idx = t + 256 * (g + u), row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
+            const int m = m0 + pass * HALF + row, n = n0 + c4;
+            float4 v = *reinterpret_cast<const float4 *>(Cs + row * LDCS + c4);
+            v.x += pre[u].x + p.add_scale * addv[u].x;
+            v.y += pre[u].y + p.add_scale * addv[u].y;
+            v.z += pre[u].z + p.add_scale * addv[u].z;
+            v.w += pre[u].w + p.add_scale * addv[u].w;
+            if (p.relu) { v.x = floor_keep_nan(v.x, 0.f); v.y = floor_keep_nan(v.y, 0.f); v.z = floor_keep_nan(v.z, 0.f); v.w = floor_keep_nan(v.w, 0.f); }
+            *reinterpret_cast<float4 *>(p.C + (long long)m * p.ldc + n) = v;
+          }
+        }
+        if (pass + 1 < BM / HALF) __syncthreads();
+        continue;
+      }
+    }
     __syncthreads();
     for (int idx = t; idx < HALF * (BN / 4); idx += 256) {
       const int row = idx / (BN / 4), c4 = (idx % (BN / 4)) * 4;
@@ -1155,6 +1233,10 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     if (a.add) c_elems += (double)(std::min(a.add_hi, a.M) - std::max(a.add_lo, 0)) * a.N;
     g_prof_next_bytes = 4.0 * (a_elems + b_elems + c_elems);
     g_prof_next_flops = flops;
+  }
+  {
+    static const int serial = getenv("TDNNF_GEMM_SERIAL_EPILOGUE") ? 1 : 0;
+    a.serial_epilogue = serial;
   }
   if (a.prec == 0) a.prec = g_gemm_prec;
   if (a.prec == 2) a.prec = 0;  // 2 = exact f32 regardless of the default
