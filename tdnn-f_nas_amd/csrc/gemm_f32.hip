@@ -406,15 +406,18 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       __syncthreads();
 #pragma unroll
       for (int g = 0; g < kSeg; g += kGrp) {
-        float4 pre[kGrp], addv[kGrp];  // bias or old C; the fused addend
+        // bias or old C; the fused addend.  Branch-free (a segment with nothing to add reads 16 zero bytes), so that the requests
+        // of a group leave back to back.  (Requested before the accumulators go to LDS, the first group's trip to memory would run
+        // under the transposition -- but the extra live registers take the BK 16 kernel from three resident blocks per CU to two.)
+        float4 pre[kGrp], addv[kGrp];
+        const float *zero = reinterpret_cast<const float *>(&g_zero4);
 #pragma unroll
         for (int u = 0; u < kGrp; u++) {
           const int idx = t + 256 * (g + u), m = m0 + pass * HALF + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
-          pre[u] = p.init_mode == 0   ? *reinterpret_cast<const float4 *>(p.C + (long long)m * p.ldc + n)
-                   : p.init_mode == 1 ? *reinterpret_cast<const float4 *>(p.bias + n)
-                                      : make_float4(0.f, 0.f, 0.f, 0.f);
-          addv[u] = (p.add && m >= p.add_lo && m < p.add_hi) ? *reinterpret_cast<const float4 *>(p.add + (long long)(m - p.add_lo) * p.ldadd + n)
-                                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float *pp = p.init_mode == 0 ? p.C + (long long)m * p.ldc + n : (p.init_mode == 1 ? p.bias + n : zero);
+          const float *pa = (p.add && m >= p.add_lo && m < p.add_hi) ? p.add + (long long)(m - p.add_lo) * p.ldadd + n : zero;
+          pre[u] = *reinterpret_cast<const float4 *>(pp);
+          addv[u] = *reinterpret_cast<const float4 *>(pa);
         }
 #pragma unroll
         for (int u = 0; u < kGrp; u++) {
@@ -836,14 +839,14 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(const RowsGemmArgs
 #pragma unroll
         for (int g = 0; g < kSeg; g += kGrp) {
           float4 pre[kGrp], addv[kGrp];
+          const float *zero = reinterpret_cast<const float *>(&g_zero4);
 #pragma unroll
           for (int u = 0; u < kGrp; u++) {
             const int idx = t + 256 * (g + u), m = m0 + pass * HALF + idx / (BN / 4), n = n0 + (idx % (BN / 4)) * 4;
-            pre[u] = p.init_mode == 0   ? *reinterpret_cast<const float4 *>(p.C + (long long)m * p.ldc + n)
-                     : p.init_mode == 1 ? *reinterpret_cast<const float4 *>(p.bias + n)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-            addv[u] = (p.add && m >= p.add_lo && m < p.add_hi) ? *reinterpret_cast<const float4 *>(p.add + (long long)(m - p.add_lo) * p.ldadd + n)
-                                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float *pp = p.init_mode == 0 ? p.C + (long long)m * p.ldc + n : (p.init_mode == 1 ? p.bias + n : zero);
+            const float *pa = (p.add && m >= p.add_lo && m < p.add_hi) ? p.add + (long long)(m - p.add_lo) * p.ldadd + n : zero;
+            pre[u] = *reinterpret_cast<const float4 *>(pp);
+            addv[u] = *reinterpret_cast<const float4 *>(pa);
           }
 #pragma unroll
           for (int u = 0; u < kGrp; u++) {
