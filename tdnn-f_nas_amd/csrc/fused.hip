@@ -212,8 +212,13 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
 // H[128 x Rp] += d_aff[128 x 32] W[Rp x 32]^T on the f32 matrix cores (v_mfma_f32_32x32x2_f32, wave w owns rows 32w..32w+31).
 // The sweep is HBM-bound (x, dz in, d_aff out), the 2 N D Rp flops of H hide behind it: separately the two passes cost
 // an elementwise pass plus a GEMM that re-reads d_aff.  partial[block][col] = column sums of d_aff, part[block] = sum of squares.
-template <int NT>
-__global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
+// MASK (a compile-time switch, not `if (mask)`): behind a run-time branch around the mask load the compiler has to wait for
+// "every outstanding memory operation" where the branches join -- which includes the d_aff store of the previous row, so every
+// step made four trips to HBM in a row (11 us per step of a kernel whose step has 1.3 us of MFMAs; found in the ISA).
+// FULL: every row of the block exists (the per-row `if (r < rows)` around the loads made the compiler wait for ALL outstanding memory
+// operations -- the previous row's store among them -- at each of them: four trips to HBM in a row per step)
+template <int NT, bool MASK, bool FULL>
+__device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
                                                                    float self_repair_scale, MatView d_aff, float *partial, const float *mask, int B,
                                                                    NgFuse ng) {
   constexpr int BM = 128, BK = 32, LD = BK + 4;
@@ -236,12 +241,24 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, Ma
   // L2 (W) run under them
   float xv[4][4], dv[4][4];
   float4 wv[NT];
+  float4 mu_n, sc_n, vdm_n, tmp_n;  // the per-column constants of the requested tile
+  double stv_n[4] = {0.0, 0.0, 0.0, 0.0};
+  const bool repairing = repair_stats && self_repair_scale != 0.f && count != 0.f;
   auto request = [&](int k0) {
     const int col = k0 + c4 * 4;
+    // (the constants first: they are what the next step touches first, and a wait for them is a wait for everything requested before)
+    mu_n = *reinterpret_cast<const float4 *>(memo + col);
+    sc_n = *reinterpret_cast<const float4 *>(memo + 2 * D + col);
+    vdm_n = *reinterpret_cast<const float4 *>(memo + 3 * D + col);
+    tmp_n = *reinterpret_cast<const float4 *>(memo + 4 * D + col);
+    if (repairing) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) stv_n[j] = repair_stats[1 + D + col + j];
+    }
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = r0 + rr + 32 * i;
-      if (r < x.rows) {
+      if (FULL || r < x.rows) {
         ld(x.data + (long long)r * x.stride + col, xv[i], true);
         ld(dz.data + (long long)r * dz.stride + col, dv[i], true);
       }
@@ -256,13 +273,12 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, Ma
   request(0);
   for (int k0 = 0; k0 < D; k0 += BK) {
     const int col = k0 + c4 * 4;
-    const float4 mu = *reinterpret_cast<const float4 *>(memo + col), sc = *reinterpret_cast<const float4 *>(memo + 2 * D + col),
-                 vdm = *reinterpret_cast<const float4 *>(memo + 3 * D + col), tmp = *reinterpret_cast<const float4 *>(memo + 4 * D + col);
+    const float4 mu = mu_n, sc = sc_n, vdm = vdm_n, tmp = tmp_n;
     float rep[4] = {0.f, 0.f, 0.f, 0.f};
-    if (repair_stats && self_repair_scale != 0.f && count != 0.f) {
+    if (repairing) {
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        const float stv = (float)repair_stats[1 + D + col + j];
+        const float stv = (float)stv_n[j];
         const float v = (stv - 0.05f * count > 0.f ? 1.f : 0.f) + (stv - 0.95f * count > 0.f ? 1.f : 0.f) - 1.f;
         rep[j] = v * (-self_repair_scale / 0.5f);
       }
@@ -270,12 +286,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, Ma
     const float mu_[4] = {mu.x, mu.y, mu.z, mu.w}, sc_[4] = {sc.x, sc.y, sc.z, sc.w}, vdm_[4] = {vdm.x, vdm.y, vdm.z, vdm.w},
                 tmp_[4] = {tmp.x, tmp.y, tmp.z, tmp.w};
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    float o[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = r0 + rr + 32 * i;
-      float o[4] = {0.f, 0.f, 0.f, 0.f};
-      if (r < x.rows) {
-        if (mask) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) o[i][j] = 0.f;
+      if (FULL || r < x.rows) {
+        if (MASK) {
           const float *mk = mask + (long long)(r % B) * x.cols + col;
 #pragma unroll
           for (int j = 0; j < 4; j++) dv[i][j] *= mk[j];
@@ -286,18 +304,25 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, Ma
           const float dr = (dv[i][j] + tmp_[j]) * sc_[j] + z * vdm_[j];
           float v = (xv[i][j] > 0.f ? 1.f : 0.f) * dr;
           if (rep[j] != 0.f) v += rep[j];
-          o[j] = v;
+          o[i][j] = v;
           cs[j] += v;
           ssq += v * v;
         }
-        st(d_aff.data + (long long)r * d_aff.stride + col, o, true);
       }
-      *reinterpret_cast<float4 *>(As + (rr + 32 * i) * LD + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<float4 *>(As + (rr + 32 * i) * LD + c4 * 4) = make_float4(o[i][0], o[i][1], o[i][2], o[i][3]);
     }
 #pragma unroll
     for (int j = 0; j < NT; j++) {
       const int idx = t + 256 * j, n = idx >> 3, kk = (idx & 7) * 4;
       *reinterpret_cast<float4 *>(Bs + n * LD + kk) = wv[j];
+    }
+    // the next tile is requested BEFORE this tile's d_aff goes out: memory operations retire in order, so a store issued ahead
+    // of the loads would have to reach HBM before the next step could touch what it loaded
+    if (k0 + BK < D) request(k0 + BK);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r = r0 + rr + 32 * i;
+      if (FULL || r < x.rows) st(d_aff.data + (long long)r * d_aff.stride + col, o[i], true);
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {  // column sums over the wave's 8 row groups (lanes 8 apart hold the same columns)
@@ -307,7 +332,6 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, Ma
       v += __shfl_xor(v, 32, 64);
       if (lane < 8) colred[wave][lane * 4 + j] = v;
     }
-    if (k0 + BK < D) request(k0 + BK);
     __syncthreads();
     {
       const float *as = As + (wave * 32 + li) * LD + lh * 4;
@@ -345,6 +369,14 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, Ma
   if (t == 0) ng.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   if (blockIdx.x == 0)
     for (int i = gridDim.x + t; i < ng.part_cap; i += 256) ng.part[i] = 0.0;
+}
+
+template <int NT, bool MASK>
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
+                                                                   float self_repair_scale, MatView d_aff, float *partial, const float *mask, int B,
+                                                                   NgFuse ng) {
+  if ((int)blockIdx.x * 128 + 128 <= x.rows) bn_relu_bwd_apply_ng_body<NT, MASK, true>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng);
+  else bn_relu_bwd_apply_ng_body<NT, MASK, false>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng);
 }
 
 __global__ __launch_bounds__(kFinThreads) void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
@@ -422,9 +454,15 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
   const double *rep = self_repair ? relu_stats : nullptr;
   if (ng) {
     const int blocks = (x.rows + 127) / 128;
-    if (ng->Rp <= 32) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<1>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
-    else if (ng->Rp <= 64) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<2>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
-    else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<3>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);
+#define APPLY_NG(NT)                                                                                                                                     \
+  do {                                                                                                                                               \
+    if (mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng); \
+    else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);    \
+  } while (0)
+    if (ng->Rp <= 32) APPLY_NG(1);
+    else if (ng->Rp <= 64) APPLY_NG(2);
+    else APPLY_NG(3);
+#undef APPLY_NG
     if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, bias_partial, blocks, D, bias_scale, bias_acc);
     return hipGetLastError();
   }

@@ -1,11 +1,6 @@
-set -e
-B="python bench.py --no-parity --no-cpu-baseline --no-also --no-alt"
-P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"], [round(c["tflops"],1) for c in d["roofline"]["all_kernels"]])'
-run() { echo "$1"; shift; env "$@" 2>/dev/null | python -c "$P"; }
-for cfg in "TDNNF_GEMM_SERIAL_EPILOGUE=1" "X=1" "TDNNF_GEMM_SERIAL_EPILOGUE=1" "X=1"; do
-  run "$cfg 1500x128" $cfg $B --steps 8 --warmup 4
-done
-
-
-
-
+cd /tmp; export TMPDIR=/tmp
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-parity --no-cpu-baseline --no-also --no-alt --steps 6 --warmup 3"
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ap1 -o r -- $B > $GRAFT_REPO_ROOT/gpurun_out/ap1.log 2>&1
+rm -f $GRAFT_REPO_ROOT/gpurun_out/ap1/r_kernel_trace.csv $GRAFT_REPO_ROOT/gpurun_out/ap1/*/r_kernel_trace.csv
+cd $GRAFT_REPO_ROOT
+python -m pytest tests/test_gpu_net.py tests/test_gpu_parity.py -m gpu -q -x -k "ng or natural or batchnorm or relu" > gpurun_out/ap_t.log 2>&1; tail -2 gpurun_out/ap_t.log
