@@ -993,7 +993,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RowsGemmArgs p
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
     const int m = (int)(e / p.N), n = (int)(e % p.N);
     float v = 0.f;
-    for (int sp = 0; sp < p.ksplit; sp++) v += p.partial[((long long)sp * p.M + m) * ldp + n];
+#pragma unroll 4
+    for (int sp = 0; sp < p.ksplit; sp++) v += p.partial[((long long)sp * p.M + m) * ldp + n];  // (unrolled: four requests in flight)
     float *c = p.C + (long long)m * p.ldc + n;
     if (p.init_mode == 1) v += p.bias[n];
     else if (p.init_mode == 0) v += *c;
@@ -1708,6 +1709,7 @@ __global__ void wgrad_reduce_kernel(const float *partial, int splits, int Do, in
        e += (long long)gridDim.x * blockDim.x) {
     const int o = (int)(e / KDi), c = (int)(e % KDi);
     float s = 0.f;
+#pragma unroll 4
     for (int sp = 0; sp < splits; sp++) s += partial[(long long)sp * total + e];
     const float cf = coef ? coef[c / Di] : 1.f;
     if (cf == 0.f) continue;  // skipped tap: its slab may not have been written
