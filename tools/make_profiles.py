@@ -46,10 +46,11 @@ for r in rows:
     by[k][0] += int(r["Calls"])
     by[k][1] += int(r["TotalDurationNs"])
 tot = sum(v[1] for v in by.values())
-with open(f"profiles/{tag}_bench_7q_T1500_B128_kernel_classes.csv", "w") as f:
-    f.write("kernel_class,calls,total_ms,avg_us,percent\n")
+with open(f"profiles/{tag}_bench_7q_T1500_B128_kernel_classes.csv", "w", newline="") as f:
+    w = csv.writer(f)  # (kernel names carry commas: quoted)
+    w.writerow(["kernel_class", "calls", "total_ms", "avg_us", "percent"])
     for k, (n, ns) in sorted(by.items(), key=lambda kv: -kv[1][1]):
-        f.write(f"{k},{n},{ns / 1e6:.3f},{ns / n / 1e3:.1f},{100.0 * ns / tot:.2f}\n")
+        w.writerow([k, n, f"{ns / 1e6:.3f}", f"{ns / n / 1e3:.1f}", f"{100.0 * ns / tot:.2f}"])
 
 
 def load(d):
