@@ -47,8 +47,13 @@ __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const f
     if (prev.data) ld(prev.data + (long long)r * prev.stride + c, pv, VEC == 4);
     // GeneralDropoutComponent between the BatchNorm and the bypass sum: one mask row per sequence, shared over time
     const float *mk = mask ? mask + (long long)(x.cols > D ? c / period : r % B) * D + cd : nullptr;
+    // the column parameters as whole float4s (cd is a multiple of 4 here): 5 memory instructions per output float4 instead of 11
+    float mu[4], sc[4], mv[4] = {1.f, 1.f, 1.f, 1.f};
+    ld(mean + cd, mu, VEC == 4);
+    ld(scale + cd, sc, VEC == 4);
+    if (mk) ld(mk, mv, VEC == 4);
 #pragma unroll
-    for (int j = 0; j < VEC; j++) o[j] = (xv[j] - mean[cd + j]) * scale[cd + j] * (mk ? mk[j] : 1.f) + bypass * pv[j];
+    for (int j = 0; j < VEC; j++) o[j] = (xv[j] - mu[j]) * sc[j] * mv[j] + bypass * pv[j];
     st(out.data + (long long)r * out.stride + c, o, VEC == 4);
   }
 }
@@ -174,10 +179,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
         }
       }
     }
-    for (int r = r0 + tr; r < r1; r += 4) {
-      float xv[4], dv[4], o[4];
-      ld(x.data + (long long)r * x.stride + col, xv, VEC == 4);
-      ld(dz.data + (long long)r * dz.stride + col, dv, VEC == 4);
+    auto apply = [&](const float (&xv)[4], float (&dv)[4], int r) {
+      float o[4];
       if (mask) {
         const float *mk = mask + (long long)(r % B) * x.cols + col;
 #pragma unroll
@@ -193,6 +196,23 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
         s[j] += v;
       }
       st(d_aff.data + (long long)r * d_aff.stride + col, o, VEC == 4);
+    };
+    int r = r0 + tr;
+    for (; r + 12 < r1; r += 16) {  // four rows requested together (d_aff may be dz itself: a row is read before it is written)
+      float xv[4][4], dv[4][4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        ld(x.data + (long long)(r + 4 * u) * x.stride + col, xv[u], VEC == 4);
+        ld(dz.data + (long long)(r + 4 * u) * dz.stride + col, dv[u], VEC == 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) apply(xv[u], dv[u], r + 4 * u);
+    }
+    for (; r < r1; r += 4) {
+      float xv[4], dv[4];
+      ld(x.data + (long long)r * x.stride + col, xv, VEC == 4);
+      ld(dz.data + (long long)r * dz.stride + col, dv, VEC == 4);
+      apply(xv, dv, r);
     }
   }
 #pragma unroll
@@ -392,7 +412,8 @@ __global__ __launch_bounds__(kFinThreads) void colsum_add_kernel(const float *pa
 hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s, const float *mask, int B) {
   if (x.rows == 0) return hipSuccess;
   // period: a super row (cols > D) is a run of rows of D values, each padded to `period` (the plain rows' stride)
-  const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0;
+  const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0 &&
+                   (!mask || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
   const long long work = (long long)x.rows * (vec ? x.cols / 4 : x.cols);
   if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
   else hipLaunchKernelGGL((bn_apply_bypass_kernel<1>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
