@@ -689,8 +689,9 @@ struct SupDev {
 __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, MatView xent_out, double *la, double *lb,
                                                        double *num_logprob, double *xent_objf, MatView deriv,
                                                        MatView xent_deriv, float xent_scale, int phases) {
-  // phases bit 0: forward-backward recursion (la, lb, total) + xent posteriors / objective;
-  //        bit 1: deriv += weight * gamma_num (needs the recursion's la/lb/total, possibly from an earlier launch)
+  // phases bit 0: forward-backward recursion (la, lb, total -> num_logprob): needs the chain output y only;
+  //        bit 2: xent posteriors / objective; bit 1: deriv += weight * gamma_num  (both need the recursion's la / lb / total,
+  //        possibly from an earlier launch)
   const int s = blockIdx.x, lane = threadIdx.x, B = sp.B, T = sp.T;
   const int *fsb = sp.frame_state_begin + (size_t)s * (T + 2);
   const int s0 = sp.seq_state_begin[s], s1 = sp.seq_state_begin[s + 1];
@@ -726,7 +727,8 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
   } else {
     tot = num_logprob[s];
   }
-  const bool do_xent = (phases & 1) != 0, do_deriv = (phases & 2) != 0;
+  const bool do_xent = (phases & 4) != 0, do_deriv = (phases & 2) != 0;
+  if ((phases & 1) && lane == 0) num_logprob[s] = tot;
   // posteriors: lane = frame (distinct output rows per lane, fixed arc order -> deterministic)
   double xo = 0.0;
   for (int t = lane; t < T; t += 64) {
@@ -743,10 +745,7 @@ __global__ __launch_bounds__(64) void numerator_kernel(SupDev sp, MatView y, Mat
   }
   if (do_xent) {
     for (int o = 32; o > 0; o >>= 1) xo += __shfl_xor(xo, o, 64);
-    if (lane == 0) {
-      num_logprob[s] = tot;
-      xent_objf[s] = xo;
-    }
+    if (lane == 0) xent_objf[s] = xo;
   }
 }
 
@@ -1204,8 +1203,19 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
 }
 float chain_supervision_weight(const tdnnf_supervision *sp) { return sp->weight; }
 // (2) numerator recursion; xent_deriv = xent_regularize * gamma_num, xent objective -> workspace.  Does not touch deriv.
-int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output,
-              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised) {
+// In two launchable halves: the recursion needs the chain output only (the trainer starts it beside the denominator, under the
+// xent head's forward pass: 1.35 ms of one wave per sequence walking 2 x 500 dependent frames that the step otherwise waited for),
+// the xent posteriors need the recursion and the xent head's log-softmax.
+int chain_num_recursion(const tdnnf_supervision *sp, const tdnnf_den_graph *g, const tdnnf_mat *y, void *ws, hipStream_t s) {
+  const int B = sp->B, T = sp->T;
+  ChainBufs b = chain_bufs(g, B, T, ws);
+  const MatView none{nullptr, 0, 0, 0};
+  hipLaunchKernelGGL(numerator_kernel, dim3(B), dim3(64), 0, s, sup_dev(sp), view(y), none, b.la, b.lb, b.num_lp, b.xent, none, none, 0.f, 1);
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+int chain_num_xent(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output, float xent_regularize,
+                   tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised) {
   const int B = sp->B, T = sp->T;
   ChainBufs b = chain_bufs(g, B, T, ws);
   MatView yv = view(y);
@@ -1216,9 +1226,15 @@ int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     else hipLaunchKernelGGL(zero_rows_kernel, dim3(grid_for((long long)xdv.rows * xdv.cols, 256)), dim3(256), 0, s, xdv);
   }
   hipLaunchKernelGGL(numerator_kernel, dim3(B), dim3(64), 0, s, sup_dev(sp), yv, xov, b.la, b.lb, b.num_lp, b.xent, MatView{nullptr, 0, 0, 0},
-                     xdv, xent_regularize, 1);
+                     xdv, xent_regularize, 4);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
+}
+int chain_num(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output,
+              float xent_regularize, tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised) {
+  int rc = chain_num_recursion(sp, g, y, ws, s);
+  if (rc) return rc;
+  return chain_num_xent(g, sp, y, xent_output, xent_regularize, xent_deriv, ws, s, xent_deriv_initialised);
 }
 // (3) after (1) and (2): deriv += weight * gamma_num; objective, l2 term, failure handling
 int chain_finish(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float l2_regularize, double *results,

@@ -124,7 +124,7 @@ struct tdnnf_net {
   float *ngBias2;      // raw bias gradient formed on s4 (components whose bias sums do not come with the ReLU backward pass)
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
-  hipEvent_t ev_fork, ev_den;
+  hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done
   int num_draws;
   bool owns_ng = true;    // false: created by tdnnf_net_create_shared, the preconditioners belong to the primary net
   int dropout_draw0;      // first of the (num_layers + 1) * B * hidden_dim dropout draws (cfg.use_dropout)

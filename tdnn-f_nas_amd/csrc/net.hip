@@ -809,7 +809,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   n->chain_ws = nullptr;
   n->chain_ws_bytes = 0;
   n->s2 = nullptr;
-  n->ev_fork = n->ev_den = nullptr;
+  n->ev_fork = n->ev_den = n->ev_num = nullptr;
   n->s3 = nullptr;
   n->ev_s3 = nullptr;
   n->s4 = nullptr;
@@ -885,6 +885,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->s2) hipStreamDestroy(n->s2);
   if (n->ev_fork) hipEventDestroy(n->ev_fork);
   if (n->ev_den) hipEventDestroy(n->ev_den);
+  if (n->ev_num) hipEventDestroy(n->ev_num);
   for (auto &S : n->ngset) {
     if (S.ready) hipEventDestroy(S.ready);
     if (S.done) hipEventDestroy(S.done);
@@ -1079,6 +1080,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_den, hipEventDisableTiming));
+    TDNNF_HIP(hipEventCreateWithFlags(&n->ev_num, hipEventDisableTiming));
     {
       // the natural-gradient side stream carries small latency-bound launches that should fill idle slots, not take slots from
       // the backward pass (a launch sized for one round of resident blocks runs two when a few slots are taken): lowest priority
@@ -1215,6 +1217,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
       CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, true));
       TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));
+      // ... and so does the numerator's forward-backward recursion: on the (idle until the backward pass) side stream
+      TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fork, 0));
+      CK(chain_num_recursion(sup, den, &y, n->chain_ws, n->s3));
+      TDNNF_HIP(hipEventRecord(n->ev_num, n->s3));
     }
   }
   tdnnf_mat yx = M(n->head[1].y, No, P);
@@ -1224,7 +1230,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   const bool dense_first = log_softmax_propagate_with_aux(&yx, &lsm, &dx, -c.xent_regularize * chain_supervision_weight(sup), s);
   if (!dense_first) CK(tdnnf_log_softmax_propagate(&yx, &lsm, s));
   // objective, part 2: numerator recursion -> xent_deriv (+)= xent_regularize * posteriors, xent objective
-  CK(chain_num(den, sup, &y, &lsm, c.xent_regularize, &dx, n->chain_ws, s, dense_first));
+  TDNNF_HIP(hipStreamWaitEvent(s, n->ev_num, 0));
+  CK(chain_num_xent(den, sup, &y, &lsm, c.xent_regularize, &dx, n->chain_ws, s, dense_first));
   if (!dense_first) CK(tdnnf_log_softmax_backprop(&lsm, &dx, &dx, s));  // in place into d_xent
 
   // ================================================================= backward

@@ -1,6 +1,6 @@
-cd /tmp; export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-parity --no-cpu-baseline --no-also --no-alt --steps 6 --warmup 3"
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/ap1 -o r -- $B > $GRAFT_REPO_ROOT/gpurun_out/ap1.log 2>&1
-rm -f $GRAFT_REPO_ROOT/gpurun_out/ap1/r_kernel_trace.csv $GRAFT_REPO_ROOT/gpurun_out/ap1/*/r_kernel_trace.csv
-cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_net.py tests/test_gpu_parity.py -m gpu -q -x -k "batchnorm or dropout or net_matches" > gpurun_out/ap_t.log 2>&1; tail -2 gpurun_out/ap_t.log
+set -e
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_net.py -m gpu -q -x -k "chain or net" > gpurun_out/ap_t.log 2>&1; tail -2 gpurun_out/ap_t.log
+B="python bench.py --no-parity --no-cpu-baseline --no-also --no-alt"
+P='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["value"], d["ms_per_step"], d["roofline"]["frac"])'
+for i in 1 2; do $B --steps 8 --warmup 4 2>/dev/null | python -c "$P"; done
+$B --chunk 150 --minibatch 64 --steps 40 --warmup 8 2>/dev/null | python -c "$P"
