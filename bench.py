@@ -217,16 +217,23 @@ class Job:
             self.step()
         sync()
         lib = self.pkg.hipabi.load()
+        # Live roofline: HIP events around every GEMM launch of the first `event_steps` timed steps (on the launch streams).  Each
+        # event is a marker packet between two launches -- about 1 000 per step, ~3 ms of a 130 ms step -- so the remaining timed
+        # steps run without them (--roofline-steps 0: events on every timed step).
+        event_steps = steps if (profile and self.args.roofline_steps <= 0) else min(steps, self.args.roofline_steps)
         if profile:
             self.pkg.hipabi.check(lib.tdnnf_profile_enable(1))
             sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            if profile and i == event_steps:
+                self.pkg.hipabi.check(lib.tdnnf_profile_enable(0))  # (host side only: stops recording, nothing is synchronised)
             self.step()
         sync()
         dt = time.perf_counter() - t0
         if profile:
             self.pkg.hipabi.check(lib.tdnnf_profile_enable(0))
+            self.event_steps = event_steps
         return dt
 
     def close(self):
@@ -242,6 +249,9 @@ def main():
                     help="setup, with natural gradient on: minibatches run before the warmup so that the preconditioners are past their "
                          "first 10 calls, which refresh on EVERY call (OnlineNaturalGradient's num_initial_updates); afterwards every 4th "
                          "does, and that steady state -- refresh steps included -- is what is timed.  0: time a fresh process's first steps")
+    ap.add_argument("--roofline-steps", type=int, default=4,
+                    help="timed steps whose GEMM launches carry HIP events for the live roofline: the first 4 = one whole refresh cycle of the "
+                         "preconditioners (1 refresh step + 3), so the sample has the timed region's own mix (0: all of them)")
     ap.add_argument("--chunk", type=int, default=1500, help="frames per chunk (north_star: 1500-frame chunks)")
     ap.add_argument("--minibatch", type=int, default=128, help="sequences per GPU (--scaling weak) or per node (--scaling strong)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -373,8 +383,11 @@ def main():
                          "all_kernels": [{"kernel": c["name"], "launches": int(c["launches"]), "ms": round(c["ms"], 3),
                                           "tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2) if c["ms"] > 0 else 0.0,
                                           "algorithmic_gb_per_s": round(c["bytes"] / (c["ms"] * 1e-3) / 1e9, 1) if c["ms"] > 0 else 0.0,
-                                          "flops_per_step": round(c["flops"] / args.steps, 1), "algorithmic_bytes_per_step": round(c["bytes"] / args.steps, 1)}
-                                         for c in classes]},
+                                          "flops_per_step": round(c["flops"] / job.event_steps, 1), "algorithmic_bytes_per_step": round(c["bytes"] / job.event_steps, 1)}
+                                         for c in classes],
+                         "event_steps": job.event_steps,
+                         "event_steps_note": "HIP events bracket every GEMM launch of the first event_steps of the timed steps (the launch "
+                                             "durations above are theirs); the other timed steps run without the ~1 000 marker packets per step"},
         }
 
         def line_item(name, chunk, sequences, den_states, gemm=None, steps=None, natural_gradient=None):
