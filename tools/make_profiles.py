@@ -84,7 +84,7 @@ for src, dst in ((f"gpurun_out/{stats_dir}_bench_line.json", f"profiles/{tag}_be
 bl = f"gpurun_out/{stats_dir}_bench_line.json"
 if os.path.exists(bl):
     line = json.load(open(bl))
-    steps = line["steps"]
+    steps = line["roofline"].get("event_steps") or line["steps"]  # the steps whose launches carried events
     with open(f"profiles/{tag}_class_work_per_step.csv", "w") as f:
         f.write("kernel_class,launches_per_step,event_ms_per_step,tflops_per_step,algorithmic_gb_per_step,tflop_per_s,pmc_hbm_gb_per_step,pmc_over_algorithmic\n")
         for k in line["roofline"]["all_kernels"]:
