@@ -9,7 +9,7 @@
 //                L = H^T H,  tr(X^ X^^T) = tr(XX^T) - 2 tr(L) + <L, W W^T>      (R x R, no second pass over X)
 //   refresh call J = H^T X, K = J J^T              second pass (first 10 calls, then every update_period-th)
 // The R x R symmetric eigen-problem of the refresh is solved on the host in double, where the reference solves it,
-// but off the critical path: K, L and tr(XX^T) are copied to pinned memory, a stream callback hands them to a
+// but off the critical path: K, L and tr(XX^T) are copied to pinned memory, an event behind the copies hands them to a
 // worker thread, and W_{t+1} = A_t (J + diag(c) W_t) is formed on the device the next time this object is used
 // (W_{t+1} is not needed earlier).  X itself is only rewritten by tdnnf_ng_precondition (the component-level entry
 // point); the trainer never materialises X^ (ng.h).
