@@ -80,6 +80,10 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise HipAbiError(f"{LIB_PATH} is not built: run `python __graft_entry__.py` (hipcc --offload-arch=gfx950)")
+    # torch first: its wheel carries a libamdhip64 of its own (soname libamdhip64.so.7), which the library's NEEDED entry
+    # then resolves to.  The other order maps /opt/rocm's runtime as well, and the second HIP runtime of a process finds no
+    # device (hipErrorNoDevice in the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     missing = []
     for s in declared_symbols():
