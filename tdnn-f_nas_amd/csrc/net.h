@@ -99,8 +99,8 @@ struct tdnnf_net {
   struct NgSet {
     float *H_in, *H_out, *T, *Tmp;
     double *part_in, *part_out;
-    void *ws;
-    hipEvent_t ready, done;
+    void *ws, *ws2;
+    hipEvent_t ready, done, out_done;
     bool used;
   } ngset[4];
   size_t ngset_ws_bytes;
@@ -109,6 +109,8 @@ struct tdnnf_net {
   hipEvent_t ev_s3;
   float *s3_scratch;   // split-K scratch of the GEMMs launched on s3
   size_t s3_scratch_bytes;
+  bool ng_out_on_s2;   // small minibatches: the output side's R x R work runs on s2 (idle once the denominator is joined)
+  float *s2_scratch;
   // Weight-gradient stream: a component's parameter gradient (and, with natural gradient, the N-sized statistics passes) is
   // independent of the backward-data GEMM that follows it.  At the recipes' minibatch (3 200 rows) neither fills the chip, so
   // they run side by side: param_grad() goes to s4 with a workspace of its own, the caller's stream waits for the one before
