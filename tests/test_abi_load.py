@@ -17,6 +17,19 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.tdnnf_abi_version() == 1
 
 
+def test_one_hip_runtime_per_process():
+    """build() then smoke() in ONE fresh process (what a driver may do): the library must come up on the HIP runtime torch
+    brought, whichever is asked for first -- a second runtime in the process sees no device (hipErrorNoDevice at the first
+    launch).  Checked without a GPU through the mapped files: exactly one libamdhip64 after load()."""
+    import subprocess
+    import sys
+    code = ("import __graft_entry__ as g; p = g.load_package(); p.hipabi.load(); import torch; "
+            "m = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); print(len(m), m)")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[0] == "1", out.stdout
+
+
 def test_code_object_is_gfx950_only(pkg):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", pkg.hipabi.LIB_PATH], capture_output=True,
                          text=True)
