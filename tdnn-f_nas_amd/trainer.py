@@ -250,9 +250,9 @@ class ChainNet:
         return out
 
     # ------------------------------------------------------------ data-parallel step
-    def allreduce_grads(self, group=None):
+    def allreduce_grads(self, group=None, min_world=2):
         """Sum the raw parameter gradients over ranks (RCCL all-reduce over xGMI: backend "nccl" on ROCm)."""
-        allreduce_flat(self.grads, group)
+        allreduce_flat(self.grads, group, min_world)
 
     def grad_buckets(self):
         """[(begin, end)] element ranges of the flat gradient buffer in the order the backward pass finishes them
@@ -264,14 +264,15 @@ class ChainNet:
             out.append((b.value, e.value))
         return out
 
-    def allreduce_grads_overlapped(self, comm_stream, group=None):
+    def allreduce_grads_overlapped(self, comm_stream, group=None, min_world=2):
         """The same sum, one collective per bucket, each enqueued on `comm_stream` behind the event the library recorded when
         that bucket's gradients became final -- so the reductions of the upper layers run while the backward pass (already
         enqueued: the host is far ahead of the GPU) is still working on the lower ones.  Call right after forward_backward;
-        the current stream waits for the reductions before anything else touches the gradients."""
+        the current stream waits for the reductions before anything else touches the gradients.
+        min_world=1 issues the collectives in a one-rank group too (the RCCL rehearsal on a one-GPU box)."""
         import torch
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= min_world):
             return
         works = []
         for i, (b, e) in enumerate(self.grad_buckets()):
@@ -286,7 +287,7 @@ class ChainNet:
         torch.cuda.current_stream().wait_stream(comm_stream)
 
 
-def allreduce_flat(flat, group=None):
+def allreduce_flat(flat, group=None, min_world=2):
     """The one exchange step of the data-parallel path: sequences (chunks) of a minibatch are sharded over
     ranks (they are independent through every component except BatchNorm statistics, which stay per-shard
     like Kaldi's per-job statistics), every rank accumulates the raw gradient of its shard, and the flat
@@ -297,7 +298,7 @@ def allreduce_flat(flat, group=None):
     The reference has no counterpart (single process).  No-op for world size 1.
     gloo (CPU rehearsals, also with both ranks on one GPU) reduces host memory: device tensors are staged."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= min_world:
         if flat.is_cuda and dist.get_backend(group) == "gloo":
             host = flat.detach().cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

@@ -119,3 +119,43 @@ def test_two_ranks_on_the_hip_trainer_match_one_process(pkg, tmp_path):
     assert not np.array_equal(out[0]["local"], out[1]["local"])  # the shards did differ
     # objective: the shards' sums add up
     assert abs(out[0]["res"][0] + out[1]["res"][0] - r1[0]) < 1e-5 * abs(r1[0]) and out[0]["res"][2] + out[1]["res"][2] == r1[2]
+
+
+def _rccl_one_rank_main(rank, port, out_dir):
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        net, feats, iv, den, sup = _problem(pkg, KW["num_sequences"])
+        fd, ivd, dg, ds = dev(feats), dev(iv), pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+        net.forward_backward(fd, ivd, dg, ds, step=0)
+        torch.cuda.synchronize()
+        before = host(net.grads).copy()
+        net.grads.zero_()
+        comm = torch.cuda.Stream()
+        net.forward_backward(fd, ivd, dg, ds, step=0)
+        net.allreduce_grads_overlapped(comm, min_world=1)  # one RCCL all-reduce per bucket behind the bucket events
+        net.allreduce_grads(min_world=1)                   # and the flat one
+        dist.barrier()
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "rccl.npz"), before=before, after=host(net.grads).copy())
+        net.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_collectives_accept_the_gradient_buffer(pkg, tmp_path):
+    """bench.py --gpus N > 1 uses backend "nccl" (RCCL), which a one-GPU box cannot run with two ranks.  What it can run is the
+    same call sequence in a ONE-rank RCCL group: init_process_group(device_id=...), an async all_reduce per bucket on slices of the
+    library-owned gradient buffer behind the bucket events on a communication stream, the flat all_reduce, a barrier.  The sums of
+    one rank leave the gradient as it was."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_one_rank_main, args=(port, str(tmp_path)), nprocs=1, join=True)
+    o = np.load(tmp_path / "rccl.npz")
+    assert np.linalg.norm(o["before"]) > 0 and np.array_equal(o["before"], o["after"])
