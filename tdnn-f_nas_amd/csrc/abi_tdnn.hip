@@ -234,7 +234,7 @@ namespace tdnnf {
 // active_dev / max_active: optional compacted list of the taps with a non-zero coefficient (gemm_f32.h)
 int tdnn_update_simple_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int Do,
                             int Di, const float *eff_coef, float lr, float *W_acc, int ldw, float *bias_acc, void *ws,
-                            size_t ws_bytes, const int *active_dev, int max_active, tdnnf_stream stream) {
+                            size_t ws_bytes, const int *active_dev, int max_active, tdnnf_stream stream, bool overwrite) {
   TDNNF_REQUIRE(mat_ok(in_value) && mat_ok(out_deriv) && W_acc, "tdnn_update_simple: bad matrices");
   TDNNF_REQUIRE(Do > 0 && Di > 0 && in_value->cols == Di && out_deriv->cols == Do, "tdnn_update_simple: bad dims");
   TDNNF_REQUIRE(tdnn_rows_ok(ix, in_value->rows, out_deriv->rows), "tdnn_update_simple: in_value has too few rows for the time offsets");
@@ -257,7 +257,7 @@ int tdnn_update_simple_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_va
   a.scale = lr;
   a.G = W_acc;
   a.ldg = ldw;
-  a.accumulate = 1;
+  a.accumulate = overwrite ? 0 : 1;  // overwrite: W_acc[:, :K Di] = the gradient (every tap computed: no compacted launch)
   a.bias_acc = bias_acc;
   a.active = active_dev;
   a.max_active = max_active;

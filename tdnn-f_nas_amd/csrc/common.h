@@ -150,7 +150,7 @@ int tdnn_propagate_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in, const
                         float *colstats = nullptr, int *colstats_rows = nullptr);
 int tdnn_update_simple_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *in_value, const tdnnf_mat *out_deriv, int Do, int Di,
                             const float *eff_coef, float lr, float *W_acc, int ldw, float *bias_acc, void *ws, size_t ws_bytes,
-                            const int *active_dev, int max_active, tdnnf_stream stream);
+                            const int *active_dev, int max_active, tdnnf_stream stream, bool overwrite = false);
 int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_deriv, const float *W, int ldw, int Do, int Di,
                             const float *eff_coef, int overwrite, const tdnnf_mat *add, float add_scale, int add_lo,
                             tdnnf_mat *in_deriv, tdnnf_stream stream);

@@ -54,9 +54,12 @@ __global__ void scaled_taps_to_kernel(const float *G, const float *coef, int Do,
     T[(size_t)o * ldT + c] = (coef ? coef[c / Di] : 1.0f) * G[e];
   }
 }
-__global__ void set_column_kernel(const float *v, int rows, float *T, int ldT, int col) {
+__global__ void set_column_kernel(const float *v, int rows, float *T, int ldT, int col) {  // (and zeros in the row's padding)
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < rows) T[(size_t)r * ldT + col] = v[r];
+  if (r < rows) {
+    T[(size_t)r * ldT + col] = v[r];
+    for (int c = col + 1; c < ldT; c++) T[(size_t)r * ldT + c] = 0.f;
+  }
 }
 // W_acc[o][c] += a b T[o][c] (c < ldw), bias_acc[o] += a b T[o][ldw]: "local_lrate = scale * learning_rate_"
 // (nnet-tdnn-component.cc:604-624); a, b are the two preconditioners' scales, still on the device
@@ -1374,11 +1377,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     auto &S = n->ngset[n->ng_next++ % 4];
     if (S.used) TDNNF_HIP(hipStreamWaitEvent(sw, S.done, 0));  // the side stream still owned this set four components ago
     float *T = S.T;
-    TDNNF_HIP(hipMemsetAsync(T, 0, sizeof(float) * (size_t)Do * ldT, sw));
+    // the gradient GEMM writes T[:, :K Di] itself when it computes every tap; the bias column and the row padding come with
+    // set_column_kernel -- no zero fill of the 2-20 MB block first
+    const bool overwrite = !from_tapgrad && !active && (ones || ldT == ldw);
+    if (!overwrite) TDNNF_HIP(hipMemsetAsync(T, 0, sizeof(float) * (size_t)Do * ldT, sw));
     if (from_tapgrad)
       hipLaunchKernelGGL(scaled_taps_to_kernel, dim3(grid_for((long long)Do * ldw, 256)), dim3(256), 0, sw, n->tapgrad, eff, Do, ldw, Di, T, ldT);
     else
-      CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, T, ldT, nullptr, wsw, n->ws_bytes, active, max_active, sw));
+      CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, T, ldT, nullptr, wsw, n->ws_bytes, active, max_active, sw, overwrite));
     if (ones) {
       float *bsum = n->ngBias;  // filled by the fused ReLU backward pass on s
       if (!bias_done) {
