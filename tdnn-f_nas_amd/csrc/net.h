@@ -107,6 +107,7 @@ struct tdnnf_net {
   unsigned ng_next;
   hipStream_t s3;
   hipEvent_t ev_s3;
+  hipEvent_t ev_fin0, ev_fin;  // step start -> s3, and s3's early refresh uploads -> the backward pass
   float *s3_scratch;   // split-K scratch of the GEMMs launched on s3
   size_t s3_scratch_bytes;
   bool ng_out_on_s2;   // small minibatches: the output side's R x R work runs on s2 (idle once the denominator is joined)

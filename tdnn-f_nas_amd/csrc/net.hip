@@ -822,6 +822,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   n->ev_fork = n->ev_den = n->ev_num = nullptr;
   n->s3 = nullptr;
   n->ev_s3 = nullptr;
+  n->ev_fin0 = n->ev_fin = nullptr;
   n->s4 = nullptr;
   n->ev_pg[0] = n->ev_pg[1] = n->ev_pg_in = nullptr;
   n->pg_count = 0;
@@ -902,6 +903,8 @@ void tdnnf_net_destroy(tdnnf_net *n) {
     if (S.out_done) hipEventDestroy(S.out_done);
   }
   if (n->ev_s3) hipEventDestroy(n->ev_s3);
+  if (n->ev_fin0) hipEventDestroy(n->ev_fin0);
+  if (n->ev_fin) hipEventDestroy(n->ev_fin);
   if (n->s3) hipStreamDestroy(n->s3);
   for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg_in})
     if (e) hipEventDestroy(e);
@@ -1102,6 +1105,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       (void)hipGetLastError();
     }
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_s3, hipEventDisableTiming));
+    TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fin0, hipEventDisableTiming));
+    TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fin, hipEventDisableTiming));
     if (n->wg_on) {
       TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
       TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[0], hipEventDisableTiming));
@@ -1118,6 +1123,25 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
   n->pg_count = 0;
+  // Refreshes whose host part has finished: upload W_{t+1} now, on the side stream, which is idle during the forward pass --
+  // otherwise the ~9 small launches of each (18 refreshes per step) sit in front of the component's statistics passes in the
+  // backward pass.  Whatever is not ready yet stays with its next use.
+  bool early_refresh = false;
+  if (c.use_natural_gradient && n->s3) {
+    static const bool off = getenv("TDNNF_NG_EARLY_REFRESH") && atoi(getenv("TDNNF_NG_EARLY_REFRESH")) == 0;
+    if (!off) {
+      TDNNF_HIP(hipEventRecord(n->ev_fin0, s));
+      TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fin0, 0));
+      SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
+      for (auto *list : {&n->ng_in, &n->ng_out})
+        for (tdnnf_ng *g : *list) {
+          int did = 0;
+          CK(ng_finalize_if_ready(g, n->s3, &did));
+          early_refresh = early_refresh || did;
+        }
+      if (early_refresh) TDNNF_HIP(hipEventRecord(n->ev_fin, n->s3));
+    }
+  }
   GemmPrecisionScope gemm_arith(c.gemm_precision == 2 ? 3 : c.gemm_precision);  // scope values: 1 two planes, 3 three planes
   TransposedWeightsScope gemm_wt(n->params, n->paramsT, n->paramsT ? n->num_params : 0);
   if (n->paramsT) {  // split-bf16 backward-data GEMMs read W^T (k-contiguous B operand)
@@ -1439,6 +1463,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     return TDNNF_OK;
   };
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
+  if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_fin, 0));  // the preconditioners refreshed on s3 at the start of the step
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
     TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");

@@ -42,6 +42,9 @@ int ng_stats_side(tdnnf_ng *ng, const float *H, const double *part, void *ws, si
 // >= rank are zero); *W == nullptr means "use ng_stats_main" (first minibatch, W_0 is initialised from the data).  After
 // the producer is enqueued on s (H with leading dimension rank_padded, `part` as for ng_stats_main), ng_external_end does
 // the bookkeeping and, on refresh steps, J.
+// The second half of a refresh (W_{t+1} on the device) is otherwise enqueued by the next call on the object, on that call's stream.
+// If the host part has finished already, enqueue it on `s` now (*did = 1); the caller orders `s` before the object's next use.
+int ng_finalize_if_ready(tdnnf_ng *ng, hipStream_t s, int *did);
 int ng_external_begin(tdnnf_ng *ng, int D, const float **W, int *Rp, int *ldw, hipStream_t s);
 int ng_external_end(tdnnf_ng *ng, const NgInput &in, const float *H, void *ws, size_t ws_bytes, hipStream_t s);
 int ng_h_ld(const tdnnf_ng *ng);        // leading dimension (padded rank) of H, W W^T, ...

@@ -157,6 +157,10 @@ struct NgPool {
     std::unique_lock<std::mutex> lk(mu);
     cv_done.wait(lk, [ng]() { return ng->job_done != 0; });
   }
+  bool done(tdnnf_ng *ng) {
+    std::lock_guard<std::mutex> lk(mu);
+    return ng->job_done != 0;
+  }
 };
 NgPool &pool() {
   static NgPool *p = new NgPool();  // never destroyed: worker threads outlive static destruction
@@ -544,6 +548,15 @@ int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void 
   int rc = finalize(ng, s);  // a refresh started by the previous call on this object
   if (rc) return rc;
   return stats_main(ng, in, H, part, ws, ws_bytes, updating(ng), s);
+}
+
+int ng_finalize_if_ready(tdnnf_ng *ng, hipStream_t s, int *did) {
+  *did = 0;
+  if (!ng || ng->rank == 0 || !ng->pending || !pool().done(ng)) return TDNNF_OK;
+  ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
+  *did = 1;
+  return finalize(ng, s);
 }
 
 int ng_external_begin(tdnnf_ng *ng, int D, const float **W, int *Rp, int *ldw, hipStream_t s) {

@@ -37,4 +37,5 @@ for i in range(14, 30):
     total.append(t2 - t0)
 print("per-step synchronised ms:", " ".join("%.1f" % (1e3 * t) for t in total))
 print("per-step host enqueue ms:", " ".join("%.1f" % (1e3 * t) for t in host))
-print("chunk %d x %d: host enqueue %.2f ms / step (median), synchronised step %.2f ms" % (chunk, mb, 1e3 * np.median(host), 1e3 * np.median(total)))
+print("chunk %d x %d: host enqueue %.2f ms / step (median), synchronised step %.2f ms (median; mean over the refresh cycle %.2f)"
+      % (chunk, mb, 1e3 * np.median(host), 1e3 * np.median(total), 1e3 * np.mean(total)))
