@@ -11,6 +11,9 @@
 
 namespace tdnnf {
 
+struct NgGroup;
+struct NgFin;
+
 struct Grid {
   int t0, step, n;
   int last() const { return t0 + step * (n - 1); }
@@ -23,6 +26,7 @@ struct CompDesc {
   float lr_factor, l2, max_change, orthonormal;
   int num_alpha;  // DARTS: K architecture logits between the weights and the bias
   bool plain = false;  // updated without natural gradient (OnehotFunction / ConstantFunction output_ vectors)
+  bool updatable = true;  // false: the fixed lda layer (FixedAffineComponent: no learning-rate factor, never a gradient)
   long long size() const { return (long long)rows * cols + num_alpha + (has_bias ? rows : 0); }
 };
 
@@ -92,26 +96,35 @@ struct tdnnf_net {
   const float *draws;  // DARTS: uniform draws of this step (caller-owned device buffer)
   std::vector<tdnnf_ng *> ng_in, ng_out;  // per component (natural gradient)
   float *orthoT;       // transpose of a constrained matrix with more rows than columns (null when there is none)
-  float *ngBias;       // natural gradient: raw bias gradient of the component being processed
-  // Natural gradient, per component: the N-sized passes (raw gradient, H = X W^T, J) run on the caller's stream, the
-  // latency-bound rest (L, traces, the rank-R projections of the raw gradient, commit; K and the host hand-off on a
-  // refresh) on stream s3, fed through a ring of buffer sets so that it trails the backward pass instead of stalling it.
-  struct NgSet {
-    float *H_in, *H_out, *T, *Tmp;
-    double *part_in, *part_out;
-    void *ws, *ws2;
-    hipEvent_t ready, done, out_done;
-    bool used;
-  } ngset[4];
-  size_t ngset_ws_bytes;
-  unsigned ng_next;
+  // Natural gradient.  Per component the N-sized passes (raw gradient into T, H = X W^T either side, J on a refresh) run on the
+  // caller's stream (or the weight-gradient stream) into buffers the component keeps for the step; everything latency-bound that
+  // follows (L, traces, the rank-R projections of T, commit; K and the host hand-off on a refresh) runs ONCE PER GRADIENT BUCKET
+  // as grouped launches on stream s3 (ng.h, ng_group.hip).  The per-object form of that chain remains for the first minibatch
+  // (the preconditioners initialise themselves from it) and for TDNNF_NG_GROUPED=0.
+  struct NgComp {
+    float *H_in = nullptr, *H_out = nullptr, *T = nullptr, *bsum = nullptr;
+    double *part_in = nullptr, *part_out = nullptr;
+    int N = 0;
+  };
+  std::vector<NgComp> ngc;         // by component
+  float *ngTmp = nullptr;          // per-object chain: projection scratch
+  void *ng_side_ws = nullptr;      // per-object chain: workspace of L = H^T H
+  size_t ngset_ws_bytes = 0;
+  struct NgBucket {
+    int key;
+    std::vector<int> comps;
+    tdnnf::NgGroup *group;
+  };
+  std::vector<NgBucket> ng_buckets;  // created the first time a bucket closes with every preconditioner initialised
+  std::vector<int> ng_cur;           // components enqueued since the last bucket closed
+  tdnnf::NgFin *ngfin = nullptr;
+  bool ng_grouped = true;
+  hipEvent_t ev_ngc = nullptr;       // the components' N-sized passes of a bucket are enqueued
   hipStream_t s3;
   hipEvent_t ev_s3;
-  hipEvent_t ev_fin0, ev_fin;  // step start -> s3, and s3's early refresh uploads -> the backward pass
+  hipEvent_t ev_fin0, ev_fin;  // step start -> s3, and s3's refresh uploads -> the backward pass
   float *s3_scratch;   // split-K scratch of the GEMMs launched on s3
   size_t s3_scratch_bytes;
-  bool ng_out_on_s2;   // small minibatches: the output side's R x R work runs on s2 (idle once the denominator is joined)
-  float *s2_scratch;
   // Weight-gradient stream: a component's parameter gradient (and, with natural gradient, the N-sized statistics passes) is
   // independent of the backward-data GEMM that follows it.  At the recipes' minibatch (3 200 rows) neither fills the chip, so
   // they run side by side: param_grad() goes to s4 with a workspace of its own, the caller's stream waits for the one before
@@ -124,7 +137,6 @@ struct tdnnf_net {
   void *ws4;
   float *s4_scratch;   // split-K scratch of the GEMMs launched on s4
   size_t s4_scratch_bytes;
-  float *ngBias2;      // raw bias gradient formed on s4 (components whose bias sums do not come with the ReLU backward pass)
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done

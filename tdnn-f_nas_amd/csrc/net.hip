@@ -15,6 +15,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -388,15 +389,12 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   // backward-data classes did not move (36.8 / 26.2 against 36.4 / 26.1 ms per step), the step got 1-2 ms slower -- not kept
   static const bool force_wt = getenv("TDNNF_WT") != nullptr;
   n->paramsT = (n->cfg.gemm_precision != 0 || force_wt) ? A.take<float>((size_t)n->num_params + 16) : nullptr;
-  n->ngBias = nullptr;
   n->s3_scratch = nullptr;
   n->s3_scratch_bytes = 0;
-  n->s2_scratch = nullptr;
-  {  // measured: 150 x 64 (3 200 rows) 15.4 -> 14.95 ms, 150 x 128 (6 400 rows) 22.0 -> 22.4 ms; TDNNF_NG_OUT_S2=0|1 forces it
-    const char *e = getenv("TDNNF_NG_OUT_S2");
-    n->ng_out_on_s2 = n->cfg.use_natural_gradient && (e ? atoi(e) != 0 : std::max(max_rows, N0) <= 4096);
+  {
+    const char *e = getenv("TDNNF_NG_GROUPED");  // 0: the per-object side chain for every component (A/B runs)
+    n->ng_grouped = e ? atoi(e) != 0 : true;
   }
-  for (auto &S : n->ngset) S.H_in = S.H_out = S.T = S.Tmp = nullptr, S.ws = S.ws2 = nullptr;
   size_t tall = 0, tall_ws = 0;
   for (auto &cd : n->comps)
     if (cd.orthonormal != 0.f && cd.rows > cd.cols) {
@@ -405,46 +403,44 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     }
   n->orthoT = tall ? A.take<float>(tall + 16) : nullptr;
   size_t ng_ws = 0;
+  n->ngc.assign(n->comps.size(), tdnnf_net::NgComp());
   if (n->cfg.use_natural_gradient) {
-    size_t mt = 0, mtmp = 0, mb = 0;
+    size_t mtmp = 0;
     auto comp_ng = [&](int comp, int K, int rows) {  // rows = N of the component's output grid
       const CompDesc &cd = n->comps[comp];
-      if (cd.lr_factor == 0.f || cd.plain) return;
+      if (!cd.updatable || cd.plain) return;  // (sized whatever the learning-rate factor is: an edit may unfreeze a component)
       const int Dx = cd.cols + (cd.has_bias ? 1 : 0), ldT = (Dx + 3) & ~3;
       const int rank_in = std::min(20, (Dx + 1) / 2), rank_out = std::min(80, (cd.rows + 1) / 2);
-      mt = std::max(mt, (size_t)cd.rows * ldT);
-      mtmp = std::max(mtmp, std::max((size_t)cd.rows * ((rank_in + 3) & ~3), (size_t)((rank_out + 3) & ~3) * ldT));
-      mb = std::max(mb, (size_t)cd.rows);
+      const int Rpi = (rank_in + 3) & ~3, Rpo = (rank_out + 3) & ~3;
+      mtmp = std::max(mtmp, std::max((size_t)cd.rows * Rpi, (size_t)Rpo * ldT));
       ng_ws = std::max(ng_ws, std::max(ng_stats_workspace_bytes(rank_in, Dx, K, rows), ng_stats_workspace_bytes(rank_out, cd.rows, 1, rows)));
+      auto &S = n->ngc[comp];
+      S.N = rows;
+      S.H_in = A.take<float>((size_t)rows * Rpi + 64);
+      S.H_out = A.take<float>((size_t)rows * Rpo + 64);
+      S.T = A.take<float>((size_t)cd.rows * ldT + 16);
+      S.bsum = A.take<float>((size_t)cd.rows + 16);
+      S.part_in = A.take<double>((size_t)rows_gemm_sumsq_blocks(rows) + 8);
+      S.part_out = A.take<double>((size_t)rows_gemm_sumsq_blocks(rows) + 8);
     };
+    const int No_ = n->Tout * B;
     comp_ng(n->tdnn1.comp, 1, N0);
     for (auto &L : n->layers) {
       comp_ng(L.lin.comp, L.lin.K, L.lin.rows_out);
       comp_ng(L.aff.comp, L.aff.K, L.aff.rows_out);
     }
-    comp_ng(n->c_prefinal_l, 1, No);
+    comp_ng(n->c_prefinal_l, 1, No_);
     for (int h = 0; h < 2; h++) {
-      comp_ng(n->head[h].c_affine, 1, No);
-      comp_ng(n->head[h].c_linear, 1, No);
-      comp_ng(n->head[h].c_output, 1, No);
+      comp_ng(n->head[h].c_affine, 1, No_);
+      comp_ng(n->head[h].c_linear, 1, No_);
+      comp_ng(n->head[h].c_output, 1, No_);
     }
-    const size_t maxN = (size_t)std::max(std::max(max_rows, N0), No);
+    const size_t maxN = (size_t)std::max(std::max(max_rows, N0), No_);
     n->ngset_ws_bytes = wgrad_workspace_bytes(80, 80, 1, (int)maxN) + 256;
-    for (auto &S : n->ngset) {
-      S.H_in = A.take<float>(maxN * 80 + 64);
-      S.H_out = A.take<float>(maxN * 80 + 64);
-      S.T = A.take<float>(mt + 16);
-      S.Tmp = A.take<float>(mtmp + 64);
-      S.part_in = A.take<double>((size_t)rows_gemm_sumsq_blocks(maxN) + 8);
-      S.part_out = A.take<double>((size_t)rows_gemm_sumsq_blocks(maxN) + 8);
-      S.ws = A.take<char>(n->ngset_ws_bytes);
-      S.ws2 = n->ng_out_on_s2 ? A.take<char>(n->ngset_ws_bytes) : nullptr;
-    }
+    n->ngTmp = A.take<float>(mtmp + 64);
+    n->ng_side_ws = A.take<char>(n->ngset_ws_bytes);
     n->s3_scratch_bytes = 16u << 20;
     n->s3_scratch = A.take<float>(n->s3_scratch_bytes / sizeof(float));
-    n->s2_scratch = n->ng_out_on_s2 ? A.take<float>(n->s3_scratch_bytes / sizeof(float)) : nullptr;
-
-    n->ngBias = A.take<float>(mb + 16);
   }
   // shared workspace: wgrad slabs, column reductions, orthonormal
   size_t ws = 0;
@@ -476,7 +472,6 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->ws4 = n->wg_on ? A.take<char>(n->ws_bytes) : nullptr;
   n->s4_scratch_bytes = n->wg_on ? (32u << 20) : 0;
   n->s4_scratch = n->wg_on ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
-  n->ngBias2 = (n->wg_on && n->cfg.use_natural_gradient) ? A.take<float>((size_t)std::max(std::max(Hd, P), S) + 16) : nullptr;
 }
 
 #define CK(expr)             \
@@ -686,6 +681,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   TDNNF_REQUIRE(g.step == 1, "net_create: the first tdnnf layers must run at the input frame rate");
   // ---- components, in nnet3 config order
   n->c_lda = add_comp(n, "lda", lda_dim, lda_dim, 1, 0.f, 0.f, 0.f, 0.f);
+  n->comps[n->c_lda].updatable = false;
   const int c_t1 = add_comp(n, "tdnn1.affine", Hd, lda_dim, 1, 1.f, c.l2_hidden, c.max_change_hidden, 0.f);
   make_tdnn(&n->tdnn1, c_t1, lda_dim, Hd, std::vector<int>{0}, n->g_lda, n->g_lda, B);
   n->num_draws = 0;
@@ -780,7 +776,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
     n->ng_out.assign(n->comps.size(), nullptr);
     for (size_t i = 0; i < n->comps.size(); i++) {
       const CompDesc &cd = n->comps[i];
-      if (cd.lr_factor == 0.f || cd.plain) continue;  // fixed lda layer; vectors updated without natural gradient
+      if (!cd.updatable || cd.plain) continue;  // fixed lda layer; vectors updated without natural gradient
       const int spliced = cd.cols + (cd.has_bias ? 1 : 0);
       const int rank_in = std::min(20, (spliced + 1) / 2), rank_out = std::min(80, (cd.rows + 1) / 2);
       if (tdnnf_ng_create(rank_in, 4, 2000.0f, 4.0f, &n->ng_in[i]) || tdnnf_ng_create(rank_out, 4, 2000.0f, 4.0f, &n->ng_out[i])) {
@@ -826,11 +822,6 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   n->s4 = nullptr;
   n->ev_pg[0] = n->ev_pg[1] = n->ev_pg_in = nullptr;
   n->pg_count = 0;
-  n->ng_next = 0;
-  for (auto &S : n->ngset) {
-    S.ready = S.done = S.out_done = nullptr;
-    S.used = false;
-  }
   if (hipMalloc((void **)&n->arena, n->arena_bytes) != hipSuccess) {
     set_error("net_create: cannot allocate %zu bytes of activations", n->arena_bytes);
     delete n;
@@ -882,6 +873,9 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->s3) hipStreamSynchronize(n->s3);  // its kernels use the preconditioners' buffers
   if (n->s4) hipStreamSynchronize(n->s4);
   if (n->s2) hipStreamSynchronize(n->s2);
+  for (auto &nb : n->ng_buckets) ng_group_destroy(nb.group);
+  ng_fin_destroy(n->ngfin);
+  if (n->ev_ngc) hipEventDestroy(n->ev_ngc);
   if (n->owns_ng) {
     for (auto *g : n->ng_in) tdnnf_ng_destroy(g);
     for (auto *g : n->ng_out) tdnnf_ng_destroy(g);
@@ -897,11 +891,6 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->ev_fork) hipEventDestroy(n->ev_fork);
   if (n->ev_den) hipEventDestroy(n->ev_den);
   if (n->ev_num) hipEventDestroy(n->ev_num);
-  for (auto &S : n->ngset) {
-    if (S.ready) hipEventDestroy(S.ready);
-    if (S.done) hipEventDestroy(S.done);
-    if (S.out_done) hipEventDestroy(S.out_done);
-  }
   if (n->ev_s3) hipEventDestroy(n->ev_s3);
   if (n->ev_fin0) hipEventDestroy(n->ev_fin0);
   if (n->ev_fin) hipEventDestroy(n->ev_fin);
@@ -1113,13 +1102,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[1], hipEventDisableTiming));
       TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg_in, hipEventDisableTiming));
     }
-    // (one side stream: giving each of the four buffer sets a stream of its own, so that the components' ~14-launch chains
-    // run side by side, made the step 1.6x (150 x 64) to 1.14x (1500 x 128) SLOWER, with 4, 8 or 12 hardware queues alike)
-    for (auto &S : n->ngset) {
-      TDNNF_HIP(hipEventCreateWithFlags(&S.ready, hipEventDisableTiming));
-      TDNNF_HIP(hipEventCreateWithFlags(&S.done, hipEventDisableTiming));
-      TDNNF_HIP(hipEventCreateWithFlags(&S.out_done, hipEventDisableTiming));
-    }
+    TDNNF_HIP(hipEventCreateWithFlags(&n->ev_ngc, hipEventDisableTiming));
   }
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
   n->pg_count = 0;
@@ -1127,18 +1110,30 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // otherwise the ~9 small launches of each (18 refreshes per step) sit in front of the component's statistics passes in the
   // backward pass.  Whatever is not ready yet stays with its next use.
   bool early_refresh = false;
+  auto all_ng = [&]() {
+    std::vector<tdnnf_ng *> v;
+    for (auto *list : {&n->ng_in, &n->ng_out})
+      for (tdnnf_ng *g : *list)
+        if (g) v.push_back(g);
+    return v;
+  };
   if (c.use_natural_gradient && n->s3) {
     static const bool off = getenv("TDNNF_NG_EARLY_REFRESH") && atoi(getenv("TDNNF_NG_EARLY_REFRESH")) == 0;
     if (!off) {
       TDNNF_HIP(hipEventRecord(n->ev_fin0, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fin0, 0));
       SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
-      for (auto *list : {&n->ng_in, &n->ng_out})
-        for (tdnnf_ng *g : *list) {
+      if (n->ngfin) {  // all of them in five grouped launches, if every host part has finished
+        int did = 0;
+        CK(ng_fin_run(n->ngfin, n->s3, false, &did));
+        early_refresh = did != 0;
+      } else {
+        for (tdnnf_ng *g : all_ng()) {
           int did = 0;
           CK(ng_finalize_if_ready(g, n->s3, &did));
           early_refresh = early_refresh || did;
         }
+      }
       if (early_refresh) TDNNF_HIP(hipEventRecord(n->ev_fin, n->s3));
     }
   }
@@ -1293,7 +1288,6 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     return tdnnf_sum_scaled(&m, 1.0f, nullptr, 0.f, dst, s);
   };
   int fused_comp = -1;
-  tdnnf_net::NgSet *fused_set = nullptr;
   auto out_stats_fuse = [&](int comp, MatView xv, MatView dzv, MatView dv, NgFuse &f) -> int {  // 1: f is to be passed on
     fused_comp = -1;
     if (!c.use_natural_gradient || n->ng_out.empty() || !n->ng_out[comp] || n->comps[comp].lr_factor == 0.f) return 0;
@@ -1302,15 +1296,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       if (atoi(e) == 0) return 0;
       fuse_always = atoi(e) == 2;
     }
-    auto &S = n->ngset[n->ng_next % 4];
-    if (S.used) TDNNF_HIP(hipStreamWaitEvent(s, S.done, 0));
+    auto &S = n->ngc[comp];
     const float *W = nullptr;
     int Rp = 0, ldw = 0;
     CK(ng_external_begin(n->ng_out[comp], dv.cols, &W, &Rp, &ldw, s));
     if (!W || !bn_relu_bwd_ng_ok(xv, dzv, dv, Rp) || !(fuse_always || bn_relu_bwd_ng_pays(dv.rows))) return 0;
     f.W = W; f.Rp = Rp; f.ldw = ldw; f.H = S.H_out; f.part = S.part_out; f.part_cap = rows_gemm_sumsq_blocks(dv.rows);
     fused_comp = comp;
-    fused_set = &S;
     return 1;
   };
   // NonlinearComponent::StoreBackpropStats (nnet-component-itf.cc:461-480): "if (RandInt(0, 3) == 0 && oderiv_count_ != 0) return"
@@ -1337,7 +1329,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // A bucket of the flat gradient buffer is final once the last of its components (in backward order) has been enqueued:
   // grads[range] += this minibatch's gradient (unless the objective failed), then the bucket's event.  With natural gradient
   // the components' commits run on the side stream, so the bucket's commit follows them there.
+  // (forward declaration of the natural-gradient group chain of the components enqueued since the last bucket closed)
+  std::function<int(int)> ng_close;
   auto close_bucket = [&](int key) -> int {
+    if (use_ng) CK(ng_close(key));
     for (auto &gb : n->buckets) {
       if (gb.close_key != key) continue;
       hipStream_t cs = s;
@@ -1365,10 +1360,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   auto bias_target = [&](int comp) -> float * {  // where a fused backward pass should accumulate the raw bias gradient
     if (n->comps[comp].lr_factor == 0.f) return nullptr;  // "if (to_update && learning_rate != 0)": no model derivative
     if (!use_ng) return Bg(n, comp);
-    (void)hipMemsetAsync(n->ngBias, 0, sizeof(float) * n->comps[comp].rows, s);
-    return n->ngBias;
+    (void)hipMemsetAsync(n->ngc[comp].bsum, 0, sizeof(float) * n->comps[comp].rows, s);
+    return n->ngc[comp].bsum;
   };
-  bool den_joined = false;  // the caller's stream has waited for the denominator: n->s2 is idle from here on
   auto param_grad = [&](int comp, const tdnnf_tdnn_indexes &ix, int K, int Di, int Do, tdnnf_mat *x, tdnnf_mat *dyv, const float *eff,
                         bool bias_done, const int *active, int max_active, bool from_tapgrad) -> int {
     const int ldw = K * Di;
@@ -1398,25 +1392,26 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       return handed_off();
     }
     const int N = dyv->rows, ones = bias_acc ? 1 : 0, Dx = ldw + ones, ldT = (Dx + 3) & ~3;
-    auto &S = n->ngset[n->ng_next++ % 4];
-    if (S.used) TDNNF_HIP(hipStreamWaitEvent(sw, S.done, 0));  // the side stream still owned this set four components ago
+    auto &S = n->ngc[comp];
+    TDNNF_REQUIRE(S.T && S.N == N, "net_forward_backward: component %s has no natural-gradient buffers for %d rows", n->comps[comp].name.c_str(), N);
     float *T = S.T;
+    // grouped chain: once both preconditioners exist (from the second minibatch on)
+    const bool grouped = n->ng_grouped && ng_dim(n->ng_in[comp]) != 0 && ng_dim(n->ng_out[comp]) != 0;
     // the gradient GEMM writes T[:, :K Di] itself when it computes every tap; the bias column and the row padding come with
-    // set_column_kernel -- no zero fill of the 2-20 MB block first
-    const bool overwrite = !from_tapgrad && !active && (ones || ldT == ldw);
+    // set_column_kernel (the group's first launch) -- no zero fill of the 2-20 MB block first.  (With tap coefficients a zero one
+    // makes the reduce kernel skip its columns: those launches start from zeros.)
+    const bool overwrite = !from_tapgrad && !active && eff == nullptr && (ones || ldT == ldw);
     if (!overwrite) TDNNF_HIP(hipMemsetAsync(T, 0, sizeof(float) * (size_t)Do * ldT, sw));
     if (from_tapgrad)
       hipLaunchKernelGGL(scaled_taps_to_kernel, dim3(grid_for((long long)Do * ldw, 256)), dim3(256), 0, sw, n->tapgrad, eff, Do, ldw, Di, T, ldT);
     else
       CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, T, ldT, nullptr, wsw, n->ws_bytes, active, max_active, sw, overwrite));
     if (ones) {
-      float *bsum = n->ngBias;  // filled by the fused ReLU backward pass on s
-      if (!bias_done) {
-        if (n->wg_on) bsum = n->ngBias2;
-        TDNNF_HIP(hipMemsetAsync(bsum, 0, sizeof(float) * Do, sw));
-        TDNNF_HIP(colsum_add(view(dyv), 1.0f, bsum, wsw, sw));
+      if (!bias_done) {  // (otherwise S.bsum was filled by the fused ReLU backward pass on s)
+        TDNNF_HIP(hipMemsetAsync(S.bsum, 0, sizeof(float) * Do, sw));
+        TDNNF_HIP(colsum_add(view(dyv), 1.0f, S.bsum, wsw, sw));
       }
-      hipLaunchKernelGGL(set_column_kernel, dim3((Do + 255) / 256), dim3(256), 0, sw, bsum, Do, T, ldT, ldw);
+      if (!grouped) hipLaunchKernelGGL(set_column_kernel, dim3((Do + 255) / 256), dim3(256), 0, sw, S.bsum, Do, T, ldT, ldw);
     }
     // ---- the passes over the N-sized operands
     NgInput xin;
@@ -1427,50 +1422,98 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     memset(&yin, 0, sizeof(yin));
     yin.x = view(dyv); yin.ix.row_stride = 1; yin.ix.num_offsets = 1; yin.Di = Do; yin.N = N;
     if (fused_comp == comp) {  // H_out and its partials came with the BatchNorm/ReLU backward sweep
-      TDNNF_REQUIRE(fused_set == &S, "net_forward_backward: the fused statistics went to another buffer set");
       fused_comp = -1;
       CK(ng_external_end(n->ng_out[comp], yin, S.H_out, wsw, n->ws_bytes, sw));
     } else {
       CK(ng_stats_main(n->ng_out[comp], yin, S.H_out, S.part_out, wsw, n->ws_bytes, sw));
     }
-    // ---- the R x R work, the projections of the raw gradient and the commit, on the side stream
-    TDNNF_HIP(hipEventRecord(S.ready, sw));
-    TDNNF_HIP(hipStreamWaitEvent(n->s3, S.ready, 0));
-    // The three parts of the chain -- either side's L = H^T H with its traces, and the projections -- do not depend on each other,
-    // only the commit needs all of them.  Once the denominator is joined its stream is idle for the rest of the backward pass:
-    // the output side's part goes there (small minibatches, where the side chain is what the backward pass waits for).
-    const bool out_on_s2 = n->ng_out_on_s2 && den_joined;
-    if (out_on_s2) {
-      TDNNF_HIP(hipStreamWaitEvent(n->s2, S.ready, 0));
-      SplitKScratchOverride den_stream_scratch(n->s2_scratch, n->s3_scratch_bytes);
-      CK(ng_stats_side(n->ng_out[comp], S.H_out, S.part_out, S.ws2, n->ngset_ws_bytes, n->s2));
-      TDNNF_HIP(hipEventRecord(S.out_done, n->s2));
+    if (grouped) {  // the rest comes with the bucket (ng_close)
+      n->ng_cur.push_back(comp);
+      CK(handed_off());
+      if (from_tapgrad && n->wg_on) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
+      return TDNNF_OK;
     }
+    // ---- per-object chain (first minibatch): the R x R work, the projections of the raw gradient and the commit, on the side stream
+    TDNNF_HIP(hipEventRecord(n->ev_ngc, sw));
+    TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_ngc, 0));
     {
       SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
-      CK(ng_stats_side(n->ng_in[comp], S.H_in, S.part_in, S.ws, n->ngset_ws_bytes, n->s3));
-      if (!out_on_s2) CK(ng_stats_side(n->ng_out[comp], S.H_out, S.part_out, S.ws, n->ngset_ws_bytes, n->s3));
-      CK(ng_project(n->ng_in[comp], n->ng_out[comp], T, Do, Dx, ldT, S.Tmp, n->s3));
+      CK(ng_stats_side(n->ng_in[comp], S.H_in, S.part_in, n->ng_side_ws, n->ngset_ws_bytes, n->s3));
+      CK(ng_stats_side(n->ng_out[comp], S.H_out, S.part_out, n->ng_side_ws, n->ngset_ws_bytes, n->s3));
+      CK(ng_project(n->ng_in[comp], n->ng_out[comp], T, Do, Dx, ldT, n->ngTmp, n->s3));
     }
-    if (out_on_s2) TDNNF_HIP(hipStreamWaitEvent(n->s3, S.out_done, 0));
     hipLaunchKernelGGL(ng_commit_kernel, dim3(grid_for((long long)Do * Dx, 256)), dim3(256), 0, n->s3, T, ldT, Do, ldw, ng_scale_dev(n->ng_in[comp]),
                        ng_scale_dev(n->ng_out[comp]), Wg(n, comp), bias_acc);
-    TDNNF_HIP(hipEventRecord(S.done, n->s3));
-    S.used = true;
     CK(handed_off());
     // (the unscaled tap gradients this one reads are rebuilt by the next DARTS component on the caller's stream)
     if (from_tapgrad && n->wg_on) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
     return TDNNF_OK;
   };
+  // Natural gradient, grouped: the chains of the components enqueued since the last bucket closed, as one sequence of grouped
+  // launches on the side stream behind their N-sized passes.
+  ng_close = [&](int key) -> int {
+    if (n->ng_cur.empty()) return TDNNF_OK;
+    tdnnf_net::NgBucket *nb = nullptr;
+    for (auto &b : n->ng_buckets)
+      if (b.key == key) nb = &b;
+    if (!nb) {
+      std::vector<NgGroupComp> gc;
+      for (int comp : n->ng_cur) {
+        const CompDesc &cd = n->comps[comp];
+        auto &S = n->ngc[comp];
+        NgGroupComp g;
+        g.in = n->ng_in[comp]; g.out = n->ng_out[comp];
+        g.T = S.T; g.Do = cd.rows; g.ldw = cd.cols; g.Dx = cd.cols + (cd.has_bias ? 1 : 0); g.ldT = (g.Dx + 3) & ~3;
+        g.bsum = cd.has_bias ? S.bsum : nullptr;
+        g.H_in = S.H_in; g.H_out = S.H_out; g.part_in = S.part_in; g.part_out = S.part_out; g.N = S.N;
+        g.W_acc = Wg(n, comp); g.bias_acc = Bg(n, comp);
+        gc.push_back(g);
+      }
+      NgGroup *grp = nullptr;
+      CK(ng_group_create(gc, &grp));
+      n->ng_buckets.push_back(tdnnf_net::NgBucket{key, n->ng_cur, grp});
+      nb = &n->ng_buckets.back();
+    }
+    TDNNF_REQUIRE(nb->comps == n->ng_cur, "net_forward_backward: the components of gradient bucket %d changed between minibatches", key);
+    // behind the last component's passes (on the weight-gradient stream when that is on)
+    if (n->wg_on && n->pg_count > 0) {
+      TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - 1) & 1], 0));
+    } else {
+      TDNNF_HIP(hipEventRecord(n->ev_ngc, s));
+      TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_ngc, 0));
+    }
+    CK(ng_group_run(nb->group, n->s3));
+    n->ng_cur.clear();
+    return TDNNF_OK;
+  };
+  n->ng_cur.clear();
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
-  if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_fin, 0));  // the preconditioners refreshed on s3 at the start of the step
+  if (use_ng && n->ng_grouped) {
+    // refreshes still pending when the step began: W_{t+1} of ALL of them now, as grouped launches on the side stream (the host
+    // waits for the eigen-decompositions here; the GPU has the forward pass and the denominator in its queues meanwhile)
+    static const bool fin_off = getenv("TDNNF_NG_GROUPED_FIN") && atoi(getenv("TDNNF_NG_GROUPED_FIN")) == 0;  // bisecting aid
+    if (!n->ngfin && !fin_off) {
+      bool ready = false;
+      for (tdnnf_ng *g : all_ng()) ready = ready || ng_dim(g) != 0;
+      if (ready) CK(ng_fin_create(all_ng(), &n->ngfin));
+    }
+    if (n->ngfin) {
+      int did = 0;
+      SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
+      CK(ng_fin_run(n->ngfin, n->s3, true, &did));
+      if (did) {
+        TDNNF_HIP(hipEventRecord(n->ev_fin, n->s3));
+        early_refresh = true;
+      }
+    }
+  }
+  if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_fin, 0));  // the preconditioners refreshed on s3 (at the start of the step, or just now)
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
     TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");
     if (h == 0) {
       // objective, part 3: join the denominator stream, d_y += posteriors, objf / failure handling
       TDNNF_HIP(hipStreamWaitEvent(s, n->ev_den, 0));
-      den_joined = true;
       CK(chain_finish(den, sup, &y, c.chain_l2_regularize, results, &dy, nullptr, n->chain_ws, s));
     }
     tdnnf_mat dout = h == 0 ? dy : dx;

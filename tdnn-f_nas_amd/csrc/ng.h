@@ -10,8 +10,39 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "common.h"
 #include "tdnnf_hip.h"
+
+// State of one OnlineNaturalGradient object (ng.hip owns it; ng_group.hip reads the device pointers for its grouped launches).
+struct tdnnf_ng {
+  int rank, Rp, update_period, t, D, Dp, frozen;
+  float num_samples_history, alpha, epsilon, delta, rho;
+  std::vector<float> d;
+  // device state (one allocation)
+  float *dev;
+  float *W, *WT, *WWT, *wlast, *J, *W1, *Kd, *Ld, *Ad, *coeff, *tmpR, *neg_one, *scale_f;
+  double *scal;  // [0] tr(X X^T)  [1] tr(X^ X^^T)
+  // pinned host staging
+  float *pin;
+  float *h_K, *h_L, *h_At, *h_coeff, *h_scale;
+  double *h_tr0;
+  // scratch of the component-level entry point
+  float *scratch;
+  size_t scratch_floats;
+  // deferred refresh
+  int pending, job_done, job_N;
+  hipEvent_t ev_job;   // the refresh's K, L and tr(XX^T) have reached the pinned buffers: the pool thread waits for it
+  hipEvent_t ev_wait;  // what the pool thread waits for: ev_job, or the event of the grouped launch that staged this object's copies
+  int device;
+  bool cur_upd;  // the call in flight between ng_stats_main and ng_stats_side
+  int cur_N, cur_ones;
+  std::vector<float> d_next;
+  float rho_next;
+  bool must_reorth;
+  std::vector<double> sqrt_e1, inv_sqrt_e1;
+};
 
 namespace tdnnf {
 
@@ -57,5 +88,40 @@ int ng_w_ld(const tdnnf_ng *ng);
 // ng_stats_step on each side.  tmp: ng_project_tmp_floats(...) floats.
 size_t ng_project_tmp_floats(const tdnnf_ng *in, const tdnnf_ng *out, int Do, int ldT);
 int ng_project(tdnnf_ng *in, tdnnf_ng *out, float *T, int Do, int Dx, int ldT, float *tmp, hipStream_t s);
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Grouped side chain (ng_group.hip).  What follows the N-sized passes of a component -- L = H^T H and the traces per side, the
+// two rank-R projections of the raw gradient, the commit, on a refresh K = J J^T and the hand-off to the host -- is
+// latency-bound and independent between components: ~17 small launches each, 36 components per step.  A group runs those
+// stages ONCE for all of its components: every stage is one launch over a task table in device memory.
+struct NgGroupComp {
+  tdnnf_ng *in, *out;       // both initialised (D != 0) and of rank > 0
+  float *T;                 // Do x ldT raw gradient of the spliced input [+ bias column at ldw], projected in place
+  int Do, Dx, ldT, ldw;     // Dx = ldw + (bsum ? 1 : 0)
+  const float *bsum;        // raw bias gradient (Do floats), copied into column ldw of T first; null: no bias
+  const float *H_in, *H_out;
+  const double *part_in, *part_out;
+  int N;                    // rows of H_in / H_out
+  float *W_acc, *bias_acc;  // this minibatch's gradient: W_acc (Do x ldw) += a b T[:, :ldw], bias_acc += a b T[:, ldw]
+};
+struct NgGroup;
+int ng_group_create(const std::vector<NgGroupComp> &comps, NgGroup **out);
+void ng_group_destroy(NgGroup *g);
+// the whole chain for the group's components on stream s (ordered after their ng_stats_main / ng_external_end calls)
+int ng_group_run(NgGroup *g, hipStream_t s);
+// Second half of the refreshes pending on a fixed set of (initialised) objects -- W_{t+1} = A_t (J + diag(c) W_t), W^T, the last
+// column and W W^T on the device -- as five grouped launches on s.  wait = false: only if every host part has finished (*did = 0
+// otherwise); wait = true: blocks the host until they have.
+struct NgFin;
+int ng_fin_create(const std::vector<tdnnf_ng *> &objs, NgFin **out);
+void ng_fin_destroy(NgFin *f);
+int ng_fin_run(NgFin *f, hipStream_t s, bool wait, int *did);
+// hooks into ng.hip for the grouped path
+bool ng_updating(const tdnnf_ng *ng);
+void ng_pool_push(tdnnf_ng *ng);
+void ng_pool_wait(tdnnf_ng *ng);
+bool ng_pool_done(tdnnf_ng *ng);
+int ng_finalize_one(tdnnf_ng *ng, hipStream_t s);  // the per-object form (also does a rare re-orthogonalisation)
 
 }  // namespace tdnnf

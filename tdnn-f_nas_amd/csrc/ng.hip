@@ -27,32 +27,6 @@
 #include "gemm_f32.h"
 #include "host_linalg.h"
 
-struct tdnnf_ng {
-  int rank, Rp, update_period, t, D, Dp, frozen;
-  float num_samples_history, alpha, epsilon, delta, rho;
-  std::vector<float> d;
-  // device state (one allocation)
-  float *dev;
-  float *W, *WT, *WWT, *wlast, *J, *W1, *Kd, *Ld, *Ad, *coeff, *tmpR, *neg_one, *scale_f;
-  double *scal;  // [0] tr(X X^T)  [1] tr(X^ X^^T)
-  // pinned host staging
-  float *pin;
-  float *h_K, *h_L, *h_At, *h_coeff, *h_scale;
-  double *h_tr0;
-  // scratch of the component-level entry point
-  float *scratch;
-  size_t scratch_floats;
-  // deferred refresh
-  int pending, job_done, job_N;
-  hipEvent_t ev_job;  // the refresh's K, L and tr(XX^T) have reached the pinned buffers: the pool thread waits for it
-  int device;
-  bool cur_upd;  // the call in flight between ng_stats_main and ng_stats_side
-  int cur_N, cur_ones;
-  std::vector<float> d_next;
-  float rho_next;
-  bool must_reorth;
-  std::vector<double> sqrt_e1, inv_sqrt_e1;
-};
 
 namespace tdnnf {
 namespace {
@@ -144,7 +118,7 @@ struct NgPool {
       // the job was queued when its copies were enqueued, not when they finished (a stream callback for that stalls the
       // stream for ~0.1 ms per refresh, 72 of them in a refresh step): wait for them here
       (void)hipSetDevice(ng->device);
-      (void)hipEventSynchronize(ng->ev_job);
+      (void)hipEventSynchronize(ng->ev_wait ? ng->ev_wait : ng->ev_job);
       host_update(ng);
       {
         std::lock_guard<std::mutex> lk(mu);
@@ -471,6 +445,7 @@ int stats_side(tdnnf_ng *ng, const float *H, const double *part, void *wg_ws, si
   ng->job_done = 0;
   ng->pending = 1;
   TDNNF_HIP(hipEventRecord(ng->ev_job, s));
+  ng->ev_wait = ng->ev_job;
   pool().push(ng);
   return TDNNF_OK;
 }
@@ -508,6 +483,15 @@ size_t ng_stats_workspace_bytes(int rank, int D, int K, int N) {
   const int Rp = pad4(std::max(1, std::min(rank, D - 1)));
   const int Di = K > 0 ? D / K : D;
   return stats_ws_bytes(Rp, Di, std::max(K, 1), N) + 64;
+}
+bool ng_updating(const tdnnf_ng *ng) { return updating(ng); }
+void ng_pool_push(tdnnf_ng *ng) { pool().push(ng); }
+void ng_pool_wait(tdnnf_ng *ng) { pool().wait(ng); }
+bool ng_pool_done(tdnnf_ng *ng) { return pool().done(ng); }
+int ng_finalize_one(tdnnf_ng *ng, hipStream_t s) {
+  ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
+  return finalize(ng, s);
 }
 int ng_h_ld(const tdnnf_ng *ng) { return ng->Rp; }
 int ng_dim(const tdnnf_ng *ng) { return ng->D; }
@@ -660,6 +644,8 @@ int tdnnf_ng_create(int rank, int update_period, float num_samples_history, floa
   ng->scratch_floats = 0;
   ng->pending = 0;
   ng->job_done = 0;
+  ng->ev_job = nullptr;
+  ng->ev_wait = nullptr;
   ng->must_reorth = false;
   *out = ng;
   return TDNNF_OK;
