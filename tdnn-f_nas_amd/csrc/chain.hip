@@ -1114,7 +1114,7 @@ int den_aux_stream(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join) {
 // denominator (one workgroup per sequence: half the CUs at 128 sequences) on a second stream beside the xent head.
 // (1) denominator forward + backward: deriv = -weight * gamma_den (whole matrix overwritten), den log-probs -> workspace
 int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws,
-              hipStream_t s, bool beside_other_work) {
+              hipStream_t s, bool beside_other_work, hipStream_t caller_aux) {
   const int B = sp->B, T = sp->T;
   ChainBufs b = chain_bufs(g, B, T, ws);
   DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
@@ -1179,6 +1179,7 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     hipEvent_t ev_fork, ev_join;
     int rc = den_aux_stream(&aux, &ev_fork, &ev_join);
     if (rc) return rc;
+    if (caller_aux) aux = caller_aux;  // a stream the caller has idle (beyond four streams in flight they share hardware queues)
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_beta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beta));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gamma));

@@ -135,7 +135,7 @@ float chain_supervision_weight(const tdnnf_supervision *sp);
 // beside_other_work: the caller runs other kernels next to the denominator (the trainer: the xent head), so the persistent form keeps
 // its one-kernel backward pass instead of running the two recursions side by side on a further stream
 int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws, hipStream_t s,
-              bool beside_other_work = false);
+              bool beside_other_work = false, hipStream_t caller_aux = nullptr);
 int chain_num_recursion(const tdnnf_supervision *sp, const tdnnf_den_graph *g, const tdnnf_mat *y, void *ws, hipStream_t s);
 int chain_num_xent(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output, float xent_regularize,
                    tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised = false);

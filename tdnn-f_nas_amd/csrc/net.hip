@@ -1246,12 +1246,25 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TraceRange trace_den("chain denominator forward-backward (second stream)");
       TDNNF_HIP(hipEventRecord(n->ev_fork, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
-      CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, true));
-      TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));
-      // ... and so does the numerator's forward-backward recursion: on the (idle until the backward pass) side stream
+      // few sequences leave most CUs idle while one workgroup per sequence walks the frames: there the backward recursion runs
+      // beside the forward one (den_beta_kernel on a further stream) and the occupancies of all frames at once
+      static const int den_split_env = getenv("TDNNF_DEN_TRAINER_SPLIT") ? atoi(getenv("TDNNF_DEN_TRAINER_SPLIT")) : -1;
+      // measured (ms per step, one-kernel backward -> split): 1500 x 16 37.3 -> 28.5, x 32 53.1 -> 45.3, x 64 80.9 -> 75.2, x 128 127.6 -> 128.2;
+      // 150 x 64 14.2 -> 13.8.  The second recursion runs on the natural-gradient side stream, which is idle until the backward pass
+      // (on a stream of its own -- a fifth in flight -- the step at 150 x 64 took 20.0 ms: they then share hardware queues)
+      const bool den_split = den_split_env >= 0 ? den_split_env != 0 : B <= 96;
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fork, 0));
-      CK(chain_num_recursion(sup, den, &y, n->chain_ws, n->s3));
-      TDNNF_HIP(hipEventRecord(n->ev_num, n->s3));
+      CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, !den_split, n->s3));
+      TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));
+      // ... and so does the numerator's forward-backward recursion (one wave per sequence): on a stream that is idle until the
+      // backward pass -- the weight-gradient stream when there is one, else behind the second recursion on the side stream
+      hipStream_t sn = n->s3;
+      if (n->wg_on && den_split) {
+        sn = n->s4;
+        TDNNF_HIP(hipStreamWaitEvent(sn, n->ev_fork, 0));
+      }
+      CK(chain_num_recursion(sup, den, &y, n->chain_ws, sn));
+      TDNNF_HIP(hipEventRecord(n->ev_num, sn));
     }
   }
   tdnnf_mat yx = M(n->head[1].y, No, P);
@@ -1453,6 +1466,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // launches on the side stream behind their N-sized passes.
   ng_close = [&](int key) -> int {
     if (n->ng_cur.empty()) return TDNNF_OK;
+    bool closes = false;  // (called after every layer: only those that end a gradient bucket run the chain)
+    for (auto &gb : n->buckets) closes = closes || gb.close_key == key;
+    if (!closes) return TDNNF_OK;
     tdnnf_net::NgBucket *nb = nullptr;
     for (auto &b : n->ng_buckets)
       if (b.key == key) nb = &b;

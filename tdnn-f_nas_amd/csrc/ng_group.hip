@@ -156,15 +156,23 @@ __global__ __launch_bounds__(256) void ggemm_kernel(const GTask *tasks) {
   }
 }
 
+// (four blocks per tile, 16 rows each: the K slices are added serially per element, so the chain is nsplit loads long)
 __global__ __launch_bounds__(256) void ggemm_reduce_kernel(const RTask *tasks) {
-  const RTask &p = tasks[blockIdx.x];
+  const RTask &p = tasks[blockIdx.x >> 2];
   const int t = threadIdx.x;
-#pragma unroll 4
-  for (int e = t; e < GT * GT; e += 256) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int e = (blockIdx.x & 3) * 1024 + j * 256 + t;
     const int row = e / GT, col = e % GT, m = p.m0 + row, n = p.n0 + col;
     if (m >= p.M || n >= p.N) continue;
+    const float *src = p.part + e;
     float v = 0.f;
-    for (int s = 0; s < p.nsplit; s++) v += p.part[(size_t)s * GT * GT + e];
+    int s = 0;
+    for (; s + 3 < p.nsplit; s += 4) {
+      const float v0 = src[(size_t)s * GT * GT], v1 = src[(size_t)(s + 1) * GT * GT], v2 = src[(size_t)(s + 2) * GT * GT], v3 = src[(size_t)(s + 3) * GT * GT];
+      v += v0; v += v1; v += v2; v += v3;
+    }
+    for (; s < p.nsplit; s++) v += src[(size_t)s * GT * GT];
     float *c = p.C + (long long)m * p.ldc + n;
     *c = p.mode == 1 ? *c + p.alpha * v : p.alpha * v;
   }
@@ -274,38 +282,39 @@ __global__ __launch_bounds__(256) void ng_l_partial_kernel(const PairDesc *pairs
   else l_partial_body<3>(p, slab, partial, lds);
 }
 
-// one block per (component, side): L from the slab partials (slabs added in order), then
+// one block (1024 threads: an accumulator image per pass) per (component, side): L from the slab partials (slabs added in order), then
 //   tr0 = sum ||X||^2 partials + ones_term,  tr1 = tr0 - 2 tr(L) + <L, W W^T>,  scale = sqrt(tr0 / tr1)
-__global__ __launch_bounds__(256) void ng_l_finish_kernel(const PairDesc *pairs, const float *partial) {
-  __shared__ double red[3][4];
+__global__ __launch_bounds__(1024) void ng_l_finish_kernel(const PairDesc *pairs, const float *partial) {
+  __shared__ double red[3][16];
   const PairDesc &p = pairs[blockIdx.x];
   const int t = threadIdx.x, Rp = p.Rp, nt = p.nt;
   double a = 0, b = 0, c = 0;
-  for (int i = t; i < p.npart; i += 256) a += p.part[i];
+  for (int i = t; i < p.npart; i += 1024) a += p.part[i];
   int q = 0;
   for (int ti = 0; ti < nt; ti++)
     for (int tj = ti; tj < nt; tj++, q++) {
-      for (int e = t; e < 1024; e += 256) {
-        const int r = e >> 6, lane = e & 63;
-        const int m = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = tj * 32 + (lane & 31);
-        if (m >= Rp || n >= Rp) continue;
-        const float *src = partial + (size_t)p.slab0 * 6 * 1024 + (size_t)q * 1024 + e;
-        float v = 0.f;
-        int s = 0;
-        for (; s + 3 < p.nslab; s += 4) {
-          const float v0 = src[(size_t)s * 6144], v1 = src[(size_t)(s + 1) * 6144], v2 = src[(size_t)(s + 2) * 6144], v3 = src[(size_t)(s + 3) * 6144];
-          v += v0; v += v1; v += v2; v += v3;
-        }
-        for (; s < p.nslab; s++) v += src[(size_t)s * 6144];
-        p.Ld[m * Rp + n] = v;
-        const double w = (double)v * (double)p.WWT[m * Rp + n];
-        if (ti != tj) {
-          p.Ld[n * Rp + m] = v;
-          c += 2.0 * w;
-        } else {
-          c += w;
-          if (m == n) b += v;
-        }
+      const int e = t, r = e >> 6, lane = e & 63;
+      const int m = ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), n = tj * 32 + (lane & 31);
+      if (m >= Rp || n >= Rp) continue;
+      const float *src = partial + (size_t)p.slab0 * 6 * 1024 + (size_t)q * 1024 + e;
+      float v = 0.f;
+      int s = 0;
+      for (; s + 7 < p.nslab; s += 8) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] = src[(size_t)(s + u) * 6144];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v += w[u];
+      }
+      for (; s < p.nslab; s++) v += src[(size_t)s * 6144];
+      p.Ld[m * Rp + n] = v;
+      const double w = (double)v * (double)p.WWT[m * Rp + n];
+      if (ti != tj) {
+        p.Ld[n * Rp + m] = v;
+        c += 2.0 * w;
+      } else {
+        c += w;
+        if (m == n) b += v;
       }
     }
   for (int o = 32; o > 0; o >>= 1) {
@@ -320,9 +329,12 @@ __global__ __launch_bounds__(256) void ng_l_finish_kernel(const PairDesc *pairs,
   }
   __syncthreads();
   if (t == 0) {
-    const double tr0 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]) + p.ones_term;
-    const double trL = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    const double trLW = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+    double tr0 = p.ones_term, trL = 0, trLW = 0;
+    for (int w = 0; w < 16; w++) {
+      tr0 += red[0][w];
+      trL += red[1][w];
+      trLW += red[2][w];
+    }
     const double tr1 = tr0 - 2.0 * trL + trLW;
     p.scal[0] = tr0;
     p.scal[1] = tr1;
@@ -443,8 +455,9 @@ struct GemmList {
   // C (M x N, ldc) (op)= alpha * A (M x K) * B (K x N); partial slot offsets are relative (fixed up against the buffer later)
   void add(const float *A, long long sam, long long sak, const float *B, long long sbk, long long sbn, float *C, long long ldc, int M, int N, int K,
            float alpha, int mode) {
-    int nsplit = (K + 383) / 384;
-    if (nsplit > 32) nsplit = 32;
+    // a task is latency-bound (one K step of look-ahead, 8 MFMAs per step): short K slices on many CUs, not long ones on few
+    int nsplit = (K + 127) / 128;
+    if (nsplit > 64) nsplit = 64;
     int kchunk = (((K + nsplit - 1) / nsplit) + GK - 1) / GK * GK;
     nsplit = (K + kchunk - 1) / kchunk;
     const int vecA = al16(A) && (sak == 1 ? sam % 4 == 0 : (sam == 1 && sak % 4 == 0));
@@ -495,7 +508,7 @@ namespace {
 
 int launch_list(const DevList &l, hipStream_t s) {
   if (l.nt) hipLaunchKernelGGL(ggemm_kernel, dim3(l.nt), dim3(256), 0, s, l.tasks);
-  if (l.nr) hipLaunchKernelGGL(ggemm_reduce_kernel, dim3(l.nr), dim3(256), 0, s, l.rtasks);
+  if (l.nr) hipLaunchKernelGGL(ggemm_reduce_kernel, dim3(4 * l.nr), dim3(256), 0, s, l.rtasks);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }
@@ -664,7 +677,7 @@ int ng_group_run(NgGroup *g, hipStream_t s) {
     TDNNF_REQUIRE(ng->cur_upd == upd && ng->cur_N > 0 && !ng->pending, "ng_group_run: the group's preconditioners are out of step");
   hipLaunchKernelGGL(ng_set_columns_kernel, dim3(nc), dim3(256), 0, s, g->cdesc);
   hipLaunchKernelGGL(ng_l_partial_kernel, dim3(g->nslabs), dim3(256), g->l_lds, s, g->pairs, g->npairs, g->lpart);
-  hipLaunchKernelGGL(ng_l_finish_kernel, dim3(g->npairs), dim3(256), 0, s, g->pairs, g->lpart);
+  hipLaunchKernelGGL(ng_l_finish_kernel, dim3(g->npairs), dim3(1024), 0, s, g->pairs, g->lpart);
   if (upd) {
     int rc = launch_list(g->kstage, s);
     if (rc) return rc;
