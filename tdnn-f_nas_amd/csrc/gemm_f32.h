@@ -106,7 +106,7 @@ const float *transposed_weights(const float *W);  // null when there is none (or
 // capacity of the p.sumsq array for M rows: one entry per 128-row block, or per (block, K-slice) when rows_gemm() splits K
 // over idle CUs for a launch of few blocks (then blocks x slices <= the chip's resident blocks <= 1024); the kernel zeroes
 // the entries it does not write, consumers sum all of them
-inline int rows_gemm_colstats_cap(int M) { return (M + 127) / 128 + 64; }
+inline int rows_gemm_colstats_cap(int M) { return (M + 63) / 64 + 64; }  // (row tiles of 64 for launches that do not fill the chip with 128)
 inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128 > 1024 ? (M + 127) / 128 : 1024; }
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).

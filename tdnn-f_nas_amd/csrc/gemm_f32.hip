@@ -1024,6 +1024,7 @@ int rows_slots(bool b_kc, int prec) {  // resident blocks on the chip for this t
   }
   int per_cu = (WM * TM == 4 && WN * TN == 4 && BK == 16 && prec == 0) ? 3 : 2;
   if (prec == 3 && WN * TN == 5) per_cu = 1;
+  if (WM * TM == 2 && prec == 0) per_cu = 4;  // 64-row tiles (27 KiB of LDS, 32 accumulator registers)
   return per_cu * cus;
 }
 
@@ -1272,6 +1273,12 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     // three blocks per CU cover each other's prologue / epilogue (+6..13 % measured); long reductions keep BK 32
     long long kt = 0;
     for (int i = 0; i < a.nseg; i++) kt += a.seg[i].klen;
+    // launches that leave most of the chip's block slots empty with 128 x 128 tiles (the recipes' minibatch: 3 200 rows) take
+    // 64 x 128 tiles: twice the blocks, so the busiest CU carries 3 half tiles instead of 2 whole ones
+    static const int small_env = getenv("TDNNF_GEMM_SMALL_TILE") ? atoi(getenv("TDNNF_GEMM_SMALL_TILE")) : -1;
+    const long long tiles128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool small = tiles128 < 768 && small_env != 0;  // measured at 150 x 64: 13.45 -> 13.28 ms per step; 1500 x 16 unchanged
+    if (small && a.prec == 0 && !a.sumsq) return launch_rows_balanced<2, 2, 1, 2, 16>(a, b_kc, vec, 0, flops, s);
     if ((kt <= 512 && a.prec == 0) || a.prec == 3) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
   }
   return launch_rows_balanced<2, 2, 2, 2, 32>(a, b_kc, vec, 0, flops, s);
