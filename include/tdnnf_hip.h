@@ -472,6 +472,13 @@ int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale
 /* "nnet3-copy --edits='set-dropout-proportion name=* proportion=p'" of train.py's dropout schedule */
 int tdnnf_net_set_dropout_proportion(tdnnf_net *, float proportion);
 int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
+/* The nnet edit "set-learning-rate-factor name=<pattern> learning-rate-factor=f" (ReadEditConfig,
+   /root/reference/src/nnet3/nnet-utils.cc:1232-1256): SetLearningRateFactor(f) on every UPDATABLE component whose name matches
+   the pattern ('*' matches any run of characters, as NameMatchesPattern; the fixed lda layer is not updatable).  The cv-update
+   recipes freeze the parent model with it (run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:129).  *num_set (optional): how many
+   components matched ("Set learning rate factors for N components").  A factor of 0 stops the component's model derivative
+   from being formed at all, as UpdatableComponent's "learning_rate_ != 0" guards do. */
+int tdnnf_net_set_learning_rate_factor(tdnnf_net *, const char *name_pattern, float factor, int *num_set);
 /* Model state outside the parameter vector, as doubles in network order (tdnn1, tdnnf2.., prefinal-chain, prefinal-xent):
    per BatchNorm [count, stats_sum[D], stats_sumsq[D]] (BatchNormComponent::StoreStats, nnet-normalize-component.cc:551-589)
    and per ReLU [count, value_sum[D], deriv_sum[D], oderiv_count, oderiv_sumsq[D]] (NonlinearComponent::StoreStatsInternal and

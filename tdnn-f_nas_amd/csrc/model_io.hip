@@ -1017,6 +1017,11 @@ int tdnnf_net_read_model(tdnnf_net *n, const char *path, tdnnf_stream stream) {
     // ---- parameters
     auto it = by_name.find(name);
     if (it != by_name.end()) {
+      {  // ReadUpdatableCommon (nnet-component-itf.cc:347-414): "<LearningRateFactor>" is written only when it is not 1
+        CompDesc &cdw = n->comps[it->second];
+        const auto lf = p.num.find("<LearningRateFactor>");
+        if (cdw.updatable) cdw.lr_factor = lf != p.num.end() ? (float)lf->second : 1.0f;
+      }
       const CompDesc &cd = n->comps[it->second];
       float *dst = h.params.data() + cd.begin;
       if (!p.out_vec.empty()) {  // OnehotFunction / ConstantFunction output_

@@ -983,6 +983,30 @@ int tdnnf_net_set_temperature_proportion(tdnnf_net *n, float proportion) {
   return TDNNF_OK;
 }
 
+// NameMatchesPattern (UPSTREAM, used by every edit directive of nnet-utils.cc:1166-1415): '*' matches any run of characters
+static bool name_matches(const char *name, const char *pat) {
+  if (*pat == 0) return *name == 0;
+  if (*pat == '*') {
+    for (const char *p = name;; p++) {
+      if (name_matches(p, pat + 1)) return true;
+      if (*p == 0) return false;
+    }
+  }
+  return *name == *pat && name_matches(name + 1, pat + 1);
+}
+
+int tdnnf_net_set_learning_rate_factor(tdnnf_net *n, const char *name_pattern, float factor, int *num_set) {
+  TDNNF_REQUIRE(n && name_pattern && factor >= 0.f, "net_set_learning_rate_factor: bad arguments (the factor must be >= 0)");
+  int cnt = 0;
+  for (auto &cd : n->comps)
+    if (cd.updatable && name_matches(cd.name.c_str(), name_pattern)) {
+      cd.lr_factor = factor;
+      cnt++;
+    }
+  if (num_set) *num_set = cnt;
+  return TDNNF_OK;
+}
+
 int tdnnf_net_component_num_alpha(const tdnnf_net *n, int i) {
   return n && i >= 0 && i < (int)n->comps.size() ? n->comps[i].num_alpha : 0;
 }

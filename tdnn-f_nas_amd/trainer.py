@@ -222,6 +222,52 @@ class ChainNet:
         """nnet edit "set-temperature-proportion name=* proportion=p" (temperature_schedule.py:57-60)."""
         hipabi.check(self.lib.tdnnf_net_set_temperature_proportion(self.h, float(proportion)))
 
+    def set_learning_rate_factor(self, factor, name="*"):
+        """nnet edit "set-learning-rate-factor name=<pattern> learning-rate-factor=f" (nnet-utils.cc:1232-1256); returns the number of
+        components set.  self.components is refreshed."""
+        cnt = C.c_int()
+        hipabi.check(self.lib.tdnnf_net_set_learning_rate_factor(self.h, str(name).encode(), float(factor), C.byref(cnt)))
+        for i, c in enumerate(self.components):
+            lrf = C.c_float()
+            hipabi.check(self.lib.tdnnf_net_component_info(self.h, i, None, None, None, None, None, C.byref(lrf), None, None, None))
+            c["lr_factor"] = lrf.value
+        return cnt.value
+
+    def apply_edits(self, edits):
+        """ReadEditConfig (/root/reference/src/nnet3/nnet-utils.cc:1166-1415) for the directives the NAS recipes use, applied to this
+        net as nnet3-copy / nnet3-am-copy --edits would apply them to the model in memory: `edits` is the option's value (directives
+        separated by ';' or newlines) or a whole "nnet3-copy --edits='...' - - |" command as train.py builds them
+        (temperature_edit_string).  Supported: set-learning-rate-factor [name=pattern] learning-rate-factor=f
+        (run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:129), set-temperature-proportion [name=*] proportion=p (the reference's own
+        addition, :1352-1405), set-dropout-proportion [name=*] proportion=p (:1295-1330).  Anything else is an error, as the
+        reference's KALDI_ERR "Directive ... is not currently supported"; so is a key the directive does not read ("Could not
+        interpret ...").  Returns [(directive, number of components set)]."""
+        done = []
+        for directive, kv in parse_edits(edits):
+            if directive == "set-learning-rate-factor":
+                if "learning-rate-factor" not in kv:
+                    raise ValueError("In edits-config, expected learning-rate-factor to be set in line: %s" % directive)
+                name, f = kv.pop("name", "*"), float(kv.pop("learning-rate-factor"))
+                n = self.set_learning_rate_factor(f, name)
+            elif directive in ("set-temperature-proportion", "set-dropout-proportion"):
+                if "proportion" not in kv:
+                    raise ValueError("In edits-config, expected proportion to be set in line: %s" % directive)
+                name, prop = kv.pop("name", "*"), float(kv.pop("proportion"))
+                if name != "*":
+                    raise ValueError("%s: only name=* is supported (one proportion for the whole net), got %r" % (directive, name))
+                if directive == "set-temperature-proportion":
+                    self.set_temperature_proportion(prop)
+                    n = sum(1 for c in self.components if c["num_alpha"] or c["name"].endswith(".alpha"))
+                else:
+                    self.set_dropout_proportion(prop)
+                    n = (self.cfg.num_layers + 1) if self.cfg.use_dropout else 0
+            else:
+                raise ValueError("Directive '%s' is not currently supported (reading edit-config)." % directive)
+            if kv:
+                raise ValueError("Could not interpret '%s' in edit config line %s" % (" ".join("%s=%s" % i for i in kv.items()), directive))
+            done.append((directive, n))
+        return done
+
     def set_params(self, flat):
         import torch
         self.params.copy_(torch.from_numpy(np.ascontiguousarray(flat, dtype=np.float32)))
@@ -306,6 +352,46 @@ def allreduce_flat(flat, group=None, min_world=2):
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return flat
+
+
+def parse_edits(edits):
+    """[(directive, {key: value})] of an --edits value or of a whole "nnet3-copy --edits='...' - - |" command: the option's ';'
+    separate config lines (nnet3-copy.cc replaces them by newlines), a line is "directive key=value ..." (ConfigLine)."""
+    import re
+    text = str(edits)
+    m = re.search(r"--edits=(['\"])(.*?)\1", text, flags=re.S)
+    if m:
+        text = m.group(2)
+    out = []
+    for line in re.split(r"[;\n]", text):
+        line = line.split("#", 1)[0].strip()
+        if not line:
+            continue
+        toks = line.split()
+        kv = {}
+        for t in toks[1:]:
+            if "=" not in t:
+                raise ValueError("edit config line %r: expected key=value, got %r" % (line, t))
+            k, v = t.split("=", 1)
+            kv[k] = v
+        out.append((toks[0], kv))
+    return out
+
+
+def apply_cvupdate_seds(text, use_gumbel=True):
+    """The literal text substitutions of run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-142 on a TEXT model that already went through
+    --edits="set-learning-rate-factor learning-rate-factor=0": the seven `sed "s/a/b/g"` of the pipeline, in its order (with
+    use_gumbel false the first flag substitution is the recipe's no-op `s/<use-gumbel> F/<use-gumbel> F/g`)."""
+    subs = [("<TdnnDARTSV3Component> <LearningRateFactor> 0", "<TdnnDARTSV3Component> <LearningRateFactor> 0.0001"),
+            ("<use-gumbel> F", "<use-gumbel> T" if use_gumbel else "<use-gumbel> F"),
+            ("<update-alpha> F", "<update-alpha> T"),
+            ("<update-theta> T", "<update-theta> F"),
+            ("<uniform-sample> T", "<uniform-sample> F"),
+            ("<TestMode> F", "<TestMode> T"),
+            ("BatchNormComponent", "BatchNormTestComponent")]
+    for a, b in subs:
+        text = text.replace(a, b)
+    return text
 
 
 def shard_sequences(num_sequences, rank, world_size):
