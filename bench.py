@@ -29,24 +29,31 @@ import statistics
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")  # tools/make_profiles.py: separate --pmc passes of this command
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")  # tools/make_profiles.py: separate rocprofv3 --pmc passes of this command
 
 # parity bars of BASELINE.json's north_star: objective 1e-4 relative, parameter-gradient L2 1e-3; with natural gradient the
 # first step also held to 1e-3 (measured 1e-5 once ReLU ties are agreed; later steps feed the eigen-decompositions back)
 OBJF_TOL, GRAD_TOL = 1e-4, 1e-3
 
 
-def workload_kwargs(args):
-    if args.workload == "darts-offset":
+def workload_kwargs(args, workload=None):
+    workload = args.workload if workload is None else workload
+    import __graft_entry__ as ge
+    T = ge.load_package().trainer
+    if workload == "darts-offset":
         return dict(darts_num_offsets=args.darts_offsets)
-    if args.workload == "bn-supernet":
-        import __graft_entry__ as ge
-        T = ge.load_package().trainer
+    if workload == "darts-offset-cvupdate":
+        # run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-142: Gumbel coefficients on ALL K taps, update-alpha, BatchNormTest from the
+        # parent's statistics, every learning-rate factor 0 except 1e-4 on the TdnnDARTSV3 components
+        return dict(darts_num_offsets=args.darts_offsets, darts_flags=T.DARTS_USE_GUMBEL | T.DARTS_UPDATE_ALPHA, darts_temp_proportion=0.5, cv_update=1)
+    if workload == "bn-supernet":
         return dict(bn_choice_dims=T.BN_CHOICE_DIMS if args.bn_choices == "reference" else [80, 80, 80, 80], bn_mode=T.BN_ONEHOT)
     return {}
 
@@ -73,6 +80,17 @@ def hip_step_against_oracle(pkg, args, gemm_precision, tie_tol, state=None):
         state = dict(params=params, feats=feats, iv=iv, den=den, sup=sup, draws=draws, comps=comps)
     net.set_params(state["params"])
     net.set_random_draws(state["draws"])
+    stats = None
+    if cfg.cv_update:  # BatchNormTest needs stored statistics: those of one pretrain step of the same supernet on this sample
+        kw = dict(workload_kwargs(args, "darts-offset"))
+        pre = pkg.trainer.ChainNet(pkg.trainer.make_config(frames_per_chunk=T, num_sequences=B, use_natural_gradient=0, **kw))
+        pre.set_params(state["params"])
+        pre.set_random_draws(np.random.default_rng(6).uniform(1e-3, 1 - 1e-3, max(pre.num_draws, 1)).astype(np.float32))
+        pre.forward_backward(torch.from_numpy(state["feats"]).cuda(), torch.from_numpy(state["iv"]).cuda(), pkg.hipabi.DenGraph(state["den"]),
+                             pkg.hipabi.Supervision(state["sup"]), step=0)
+        stats = pre.get_stats()
+        pre.close()
+        net.set_stats(stats)
     r = net.forward_backward(torch.from_numpy(state["feats"]).cuda(), torch.from_numpy(state["iv"]).cuda(), pkg.hipabi.DenGraph(state["den"]),
                              pkg.hipabi.Supervision(state["sup"]), step=0)
     torch.cuda.synchronize()
@@ -82,6 +100,8 @@ def hip_step_against_oracle(pkg, args, gemm_precision, tie_tol, state=None):
     net.close()
     ref = OracleNet(pkg, cfg, comps)  # double-accumulating build
     ref.relu_tie_tol = tie_tol
+    if stats is not None:
+        ref.set_stats(stats)
     res_ref, g_ref, _ = ref.forward_backward(state["params"], state["feats"], state["iv"], state["den"], state["sup"], step=0, draws=state["draws"], relu_like=relus)
     objf_rel = abs(r[0] - res_ref["objf"]) / abs(res_ref["objf"])
     grad_rel = float(np.linalg.norm(g.astype(np.float64) - g_ref) / np.linalg.norm(g_ref.astype(np.float64)))
@@ -164,6 +184,9 @@ def workload_text(args):
     if args.workload == "darts-offset":
         return (f"BASELINE configs[3]: DARTS offset supernet, {args.darts_offsets} taps per TdnnDARTSV3 component, pretrain mode "
                 "(uniform tap sample per layer and minibatch), otherwise as configs[1]; " + tail)
+    if args.workload == "darts-offset-cvupdate":
+        return (f"BASELINE configs[3], cv-update stage (run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-142): DARTS offset supernet, Gumbel coefficients "
+                f"over all {args.darts_offsets} taps, BatchNormTest, learning-rate factor 0 except 1e-4 on the TdnnDARTSV3 components; " + tail)
     dims = "25..240 in 8 blocks, the recipe's set" if args.bn_choices == "reference" else "80, 160, 240, 320 in 4 blocks"
     return (f"BASELINE configs[4]: bottleneck-dimension supernet (candidate dims {dims}, Onehot sample per layer and "
             "minibatch), otherwise as configs[1]; " + tail)
@@ -172,17 +195,21 @@ def workload_text(args):
 class Job:
     """One replica of the trainer on this rank's GPU with its own synthetic egs resident in HBM."""
 
-    def __init__(self, pkg, args, chunk, sequences, den_states, rank, world, gemm=None, first_sequence=0, natural_gradient=None):
+    def __init__(self, pkg, args, chunk, sequences, den_states, rank, world, gemm=None, first_sequence=0, natural_gradient=None, workload=None,
+                 stats=None, archive_minibatches=0):
         import torch
         self.pkg, self.args, self.world = pkg, args, world
         gemm = args.gemm if gemm is None else gemm
         ng = args.natural_gradient if natural_gradient is None else natural_gradient
+        kw = workload_kwargs(args, workload)
         self.cfg = pkg.trainer.make_config(frames_per_chunk=chunk, num_sequences=sequences, use_natural_gradient=ng,
-                                           gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[gemm], use_dropout=int(args.dropout > 0),
-                                           **workload_kwargs(args))
+                                           gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[gemm], use_dropout=int(args.dropout > 0 and not kw.get("cv_update")),
+                                           **kw)
         self.net = pkg.trainer.ChainNet(self.cfg)
-        if args.dropout > 0:
+        if args.dropout > 0 and not kw.get("cv_update"):
             self.net.set_dropout_proportion(args.dropout)
+        if stats is not None:  # cv-update: the BatchNormTest components normalise with the parent's stored statistics
+            self.net.set_stats(stats)
         # identical initial model on every rank (seed), different egs per rank (data parallel over sequences)
         self.net.set_params(self.net.init_params_numpy(seed=0, output_stddev=0.05))
         feats, iv = pkg.trainer.synthetic_egs(self.net, seed=100 + rank)
@@ -201,10 +228,40 @@ class Job:
         self.gen.manual_seed(1234)  # same architecture sample on every rank (seed-shared draws)
         self.comm = torch.cuda.Stream() if world > 1 and not args.no_overlap else None
         self.i = 0
+        # archive-fed: every step's minibatch comes out of a cegs archive (16-bit compressed features, as the recipes' egs) through
+        # egs.minibatches(prefetch=2) -- read, decompress, merge on a worker thread, then the copy to the device
+        self.archive, self.feed, self.keep = None, None, []
+        if archive_minibatches > 0:
+            import tempfile
+            E = pkg.egs
+            self.archive = os.path.join(tempfile.mkdtemp(prefix="tdnnf_bench_"), "cegs.1.ark")
+            with E.Writer(self.archive) as w:
+                for m in range(archive_minibatches):
+                    f_m, iv_m = pkg.trainer.synthetic_egs(self.net, seed=1000 + m)
+                    sup_m = pkg.synth.make_supervision_from_den(self.den, sequences, chunk // 3, num_paths=2, seed=2000 + m)
+                    for b in range(sequences):
+                        w.write("u%d-%d" % (m, b), f_m[b::sequences], self.net.first_t, E.sequence_of(sup_m, b), self.cfg.num_pdfs, ivector=iv_m[b], compress=True)
+            self.archive_bytes = os.path.getsize(self.archive)
+
+    def next_minibatch(self):
+        while True:
+            if self.feed is None:
+                self.feed = self.pkg.egs.minibatches(self.archive, self.net, prefetch=2)
+            try:
+                item = next(self.feed)
+                break
+            except StopIteration:  # next epoch: the archive again
+                self.feed = None
+        self.keep = (self.keep + [item])[-4:]  # the GPU is up to a step behind the host: keep what it may still read
+        return item
 
     def step(self):
         self.net.set_random_draws(generator=self.gen)
-        self.net.forward_backward(self.fd, self.ivd, self.dg, self.ds, step=self.i)
+        if self.archive is not None:
+            f, v, sp = self.next_minibatch()
+            self.net.forward_backward(f, v, self.dg, sp, step=self.i)
+        else:
+            self.net.forward_backward(self.fd, self.ivd, self.dg, self.ds, step=self.i)
         if self.comm is not None:  # one collective per gradient bucket, each behind its "bucket final" event: overlaps the backward pass
             self.net.allreduce_grads_overlapped(self.comm)
         else:
@@ -237,7 +294,15 @@ class Job:
         return dt
 
     def close(self):
+        import torch
+        torch.cuda.synchronize()
+        if self.feed is not None:
+            self.feed.close()
+        self.keep = []
         self.net.close()
+        if self.archive is not None:
+            import shutil
+            shutil.rmtree(os.path.dirname(self.archive), ignore_errors=True)
 
 
 def main():
@@ -265,7 +330,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the timed CPU oracle leg (the parity check stays)")
     ap.add_argument("--no-parity", action="store_true", help="skip the HIP-against-oracle check of the bounded sample as well")
     ap.add_argument("--no-also", action="store_true", help="skip the further line items (recipe egs shape, 10 000 / 30 000-state denominator graphs)")
-    ap.add_argument("--workload", default="7q", choices=["7q", "darts-offset", "bn-supernet"],
+    ap.add_argument("--workload", default="7q", choices=["7q", "darts-offset", "darts-offset-cvupdate", "bn-supernet"],
                     help="7q = BASELINE configs[1] (default, the metric's config); darts-offset = configs[3], the K-tap offset "
                          "supernet of run_TDNN_DARTSV3_fbk_stride_pretrain.sh in pretrain (uniform-sample) mode; bn-supernet = "
                          "configs[4], the bottleneck-dimension supernet (8 candidate dims up to 240) in Onehot pretrain mode")
@@ -325,7 +390,13 @@ def main():
             torch.cuda.synchronize()
 
     burn = args.ng_burn_in if args.natural_gradient else 0
-    job = Job(pkg, args, args.chunk, seqs, args.den_states, rank, world)
+    stats0 = None
+    if args.workload == "darts-offset-cvupdate":  # the parent's BatchNorm / ReLU statistics: a few pretrain steps of the same supernet
+        pj = Job(pkg, args, args.chunk, seqs, args.den_states, rank, world, workload="darts-offset")
+        pj.run(0, 0, 3, sync)
+        stats0 = pj.net.get_stats()
+        pj.close()
+    job = Job(pkg, args, args.chunk, seqs, args.den_states, rank, world, stats=stats0)
     cfg = job.cfg
     dt = job.run(burn, args.warmup, args.steps, sync, profile=True)
     if world > 1:
@@ -342,7 +413,9 @@ def main():
         pkg.hipabi.check(lib.tdnnf_profile_read(k, C.byref(n), C.byref(ms), C.byref(fl)))
         pkg.hipabi.check(lib.tdnnf_profile_read_bytes(k, C.byref(by)))
         classes.append(dict(name=lib.tdnnf_profile_class_name(k).decode(), launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value))
-    dom = max(classes[:3], key=lambda c: c["ms"])  # the TDNN-F factored GEMMs (class 3 = natural-gradient statistics)
+    # "dominant" = the TDNN-F factored GEMM class with the most time (north_star's kernel); the natural-gradient class (HBM-bound
+    # passes over the layer inputs / output derivatives) is reported beside it as roofline_secondary
+    dom = max(classes[:3], key=lambda c: c["ms"])
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     # HBM traffic per launch from the PMC passes of THIS command (tools/make_profiles.py writes the file; null when the
     # file is not from this round's kernels)
@@ -352,10 +425,13 @@ def main():
         try:
             tj = json.load(open(tpath))
             traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
-            traffic_src = TRAFFIC_FILE
+            traffic_src = ("committed PMC profile of this command (%s: separate rocprofv3 --pmc passes, FETCH_SIZE / WRITE_SIZE as the MI355X "
+                           "guide prescribes), NOT counters of this process" % TRAFFIC_FILE)
         except Exception:
             traffic = None
     alg_per_launch = dom["bytes"] / max(dom["launches"], 1)
+    job.event_steps_ = getattr(job, "event_steps", 1)
+    ngc = classes[3]
     job.close()
 
     if rank == 0:
@@ -375,7 +451,9 @@ def main():
                                                                                  if t <= 10 or (t - 10) % 4 == 0) if args.natural_gradient else 0},
                        "parallelism": f"dp{world}", "allreduce": None if world == 1 else ("one collective after backward" if args.no_overlap else
                                                                                            "per gradient bucket, overlapped with backward"), "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
-            "roofline": {"bound": "mfma", "kernel": dom["name"], "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma", "kernel": dom["name"], "kernel_choice": "the TDNN-F factored-GEMM class with the most time "
+                         "(forward / backward-data 128x128, 128x160, weight gradient); the natural-gradient class is roofline_secondary",
+                         "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": round(alg_per_launch, 1),
                          "traffic_over_algorithmic": round(traffic / alg_per_launch, 3) if traffic and alg_per_launch else None,
@@ -383,22 +461,38 @@ def main():
                          "all_kernels": [{"kernel": c["name"], "launches": int(c["launches"]), "ms": round(c["ms"], 3),
                                           "tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2) if c["ms"] > 0 else 0.0,
                                           "algorithmic_gb_per_s": round(c["bytes"] / (c["ms"] * 1e-3) / 1e9, 1) if c["ms"] > 0 else 0.0,
-                                          "flops_per_step": round(c["flops"] / job.event_steps, 1), "algorithmic_bytes_per_step": round(c["bytes"] / job.event_steps, 1)}
+                                          "flops_per_step": round(c["flops"] / job.event_steps_, 1), "algorithmic_bytes_per_step": round(c["bytes"] / job.event_steps_, 1)}
                                          for c in classes],
-                         "event_steps": job.event_steps,
+                         "event_steps": job.event_steps_,
                          "event_steps_note": "HIP events bracket every GEMM launch of the first event_steps of the timed steps (the launch "
                                              "durations above are theirs); the other timed steps run without the ~1 000 marker packets per step"},
         }
 
-        def line_item(name, chunk, sequences, den_states, gemm=None, steps=None, natural_gradient=None):
-            j = Job(pkg, args, chunk, sequences, den_states, rank, world, gemm=gemm, natural_gradient=natural_gradient)
+        if args.natural_gradient and ngc["ms"] > 0:
+            gbs = ngc["bytes"] / (ngc["ms"] * 1e-3) / 1e9
+            out["roofline_secondary"] = {"bound": "hbm", "kernel": ngc["name"], "what": "natural-gradient statistics passes (H = X W^T either side, J = H^T X on a "
+                                         "refresh, the rank-R products): algorithmic bytes / HIP-event time of the class", "achieved": round(gbs, 1),
+                                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "tflops": round(ngc["flops"] / (ngc["ms"] * 1e-3) / 1e12, 2),
+                                         "launches": int(ngc["launches"]), "ms_per_step": round(ngc["ms"] / job.event_steps_, 3), "traffic": None}
+
+        def line_item(name, chunk, sequences, den_states, gemm=None, steps=None, natural_gradient=None, workload=None, stats=None, archive_minibatches=0,
+                      want_stats=False):
+            j = Job(pkg, args, chunk, sequences, den_states, rank, world, gemm=gemm, natural_gradient=natural_gradient, workload=workload, stats=stats,
+                    archive_minibatches=archive_minibatches)
             k = args.steps if steps is None else steps
             d = j.run(burn, args.warmup, k, lambda: torch.cuda.synchronize())
             arcs = int(len(j.den["src"]))
+            r = j.net.results.cpu().numpy()
+            it = {"what": name, "value": round(sequences * chunk * k / d, 1), "unit": "frames/s", "ms_per_step": round(1e3 * d / k, 3),
+                  "frames_per_chunk": chunk, "sequences": sequences, "den_graph": {"states": den_states, "arcs": arcs},
+                  "objective_finite": bool(r[5] == 1.0 and np.isfinite(r[0]))}
+            if archive_minibatches:
+                it["archive"] = {"minibatches": archive_minibatches, "bytes": j.archive_bytes, "features": "16-bit compressed (CompressedMatrix kTwoByteAuto)"}
+            if want_stats:
+                it["_stats"] = j.net.get_stats()
             j.close()
             torch.cuda.empty_cache()
-            return {"what": name, "value": round(sequences * chunk * k / d, 1), "unit": "frames/s", "ms_per_step": round(1e3 * d / k, 3),
-                    "frames_per_chunk": chunk, "sequences": sequences, "den_graph": {"states": den_states, "arcs": arcs}}
+            return it
 
         if world == 1 and args.gemm == "f32" and not args.no_alt:
             # the same step with the optional split-bf16 GEMM arithmetic (not the headline: its gradient parity sits AT the
@@ -409,12 +503,33 @@ def main():
         if world == 1 and not args.no_also:
             # further line items, same net and step: the reference's own egs shape (chunk 150 x 64, ...pretrain.sh:46,197) and
             # SWBD-scale denominator graphs (10 000 and 30 000 states)
-            out["also"] = [line_item("the recipes' egs shape (--chunk 150 --minibatch 64)", 150, 64, args.den_states, steps=40),
+            recipe = line_item("the recipes' egs shape (--chunk 150 --minibatch 64)", 150, 64, args.den_states, steps=40)
+            shard = line_item("the per-GPU shard of a 128-sequence minibatch at 8 GPUs, --scaling strong (--chunk 1500 --minibatch 16)", args.chunk, 16, args.den_states,
+                              steps=16)
+            shard["vs_one_eighth_of_the_headline_step"] = round(shard["ms_per_step"] / (1e3 * dt / args.steps / 8.0), 3)
+            out["also"] = [recipe, shard,
                            line_item("10 000-state denominator graph (--den-states 10000)", args.chunk, seqs, 10000, steps=4),
                            line_item("30 000-state denominator graph (--den-states 30000)", args.chunk, seqs, 30000, steps=4)]
             if args.natural_gradient:  # what the preconditioning costs: the same step with raw gradients
                 it = line_item("natural gradient off (--natural-gradient 0)", args.chunk, seqs, args.den_states, natural_gradient=0)
                 it["natural_gradient_cost_ms_per_step"] = round(1e3 * dt / args.steps - it["ms_per_step"], 3)
+                out["also"].append(it)
+            if args.workload == "7q":
+                # the supernets north_star's scaling target is quoted on, same shape and step (BASELINE configs[3] / [4]):
+                # offset supernet pretrain (uniform tap sample), its cv-update (Gumbel over all K taps, BatchNormTest from the
+                # pretrain net's statistics, run_TDNN_DARTSV3_fbk_stride_cvupdate.sh:128-142), bottleneck-dimension supernet
+                pre = line_item("DARTS offset supernet, pretrain (--workload darts-offset)", args.chunk, seqs, args.den_states, steps=6, workload="darts-offset", want_stats=True)
+                stats = pre.pop("_stats")
+                out["also"].append(pre)
+                out["also"].append(line_item("DARTS offset supernet, cv-update: Gumbel over all %d taps, BatchNormTest (--workload darts-offset-cvupdate)" % args.darts_offsets,
+                                             args.chunk, seqs, args.den_states, steps=6, workload="darts-offset-cvupdate", stats=stats))
+                out["also"].append(line_item("bottleneck-dimension supernet, Onehot pretrain (--workload bn-supernet)", args.chunk, seqs, args.den_states, steps=6,
+                                             workload="bn-supernet"))
+            # archive-fed: every minibatch read from a cegs archive, decompressed, merged and copied to the device inside the timed loop
+            for (ch, sq, st, resident) in ((args.chunk, seqs, 8, 1e3 * dt / args.steps), (150, 64, 40, recipe["ms_per_step"])):
+                it = line_item("archive-fed (egs.minibatches(prefetch=2): read + decompress + merge on a worker thread, H2D included), --chunk %d --minibatch %d" % (ch, sq),
+                               ch, sq, args.den_states, steps=st, archive_minibatches=4)
+                it["vs_resident_inputs"] = round(resident / it["ms_per_step"], 3)
                 out["also"].append(it)
         ok = True
         if world == 1 and not args.no_parity:

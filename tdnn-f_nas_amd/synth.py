@@ -78,8 +78,10 @@ def make_supervision_from_den(den, B, T, num_paths=2, seed=0, weight=1.0):
     """Numerator graphs whose paths are paths of the denominator graph (as real chain supervisions are, after
     composition with the normalization FST): per sequence `num_paths` independent random walks on the den graph
     from one start state drawn from the initial distribution; arc log-weights are the den transition
-    log-probs.  With such supervision log p_num <= log p_den + const, so the LF-MMI objective per frame is
-    (essentially) negative, as in real training."""
+    log-probs, and a path's first arc also carries the log of the denominator's initial probability of its start state -- the
+    weight the denominator's own recursion gives that start (alpha(0, i) = init(i)).  Every numerator path is then a
+    denominator path with the same weight, so log p_num <= log p_den and the LF-MMI objective stays <= 0 however long a net is
+    trained on it (without the start weight the objective of a long run settled at +log(1 / init) / T per frame)."""
     rng = np.random.default_rng(seed)
     H = den["H"]
     order = np.argsort(den["src"], kind="stable")
@@ -109,7 +111,10 @@ def make_supervision_from_den(den, B, T, num_paths=2, seed=0, weight=1.0):
                 a_src.append(s_from)
                 a_dst.append(s_to)
                 a_pdf.append(int(den["pdf"][a]))
-                a_lp.append(float(np.log(max(float(den["prob"][a]), 1e-30))))
+                lp = float(np.log(max(float(den["prob"][a]), 1e-30)))
+                if t == 0:
+                    lp += float(np.log(max(float(den["init"][h0]), 1e-30)))
+                a_lp.append(lp)
                 cur[pth] = int(den["dst"][a])
         ns += 1 + T * num_paths
         seq_state_begin.append(ns)

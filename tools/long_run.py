@@ -34,6 +34,8 @@ for i in range(steps):
     if i % 4 == 3:
         r = r.cpu().numpy()
         hist.append(r[0] / r[2])
+        # every numerator path is a denominator path of the same weight (synth.make_supervision_from_den): log p_num <= log p_den
+        assert r[0] / r[2] <= 1e-3, ("LF-MMI objective per frame above 0", i, r[0] / r[2])
         if not np.isfinite(r[0]) or r[5] != 1.0:
             print("step", i, "objf", r[0], "ok flag", r[5])
             sys.exit(1)
