@@ -196,7 +196,7 @@ class Job:
     """One replica of the trainer on this rank's GPU with its own synthetic egs resident in HBM."""
 
     def __init__(self, pkg, args, chunk, sequences, den_states, rank, world, gemm=None, first_sequence=0, natural_gradient=None, workload=None,
-                 stats=None, archive_minibatches=0):
+                 stats=None, archive_minibatches=0, scaling=None):
         import torch
         self.pkg, self.args, self.world = pkg, args, world
         gemm = args.gemm if gemm is None else gemm
@@ -223,7 +223,13 @@ class Job:
         self.lr = pkg.trainer.learning_rate(0, 1, 100, 0, 100)
         # l2 scale = GetNumNvalues x l2_regularize_factor (= 1 / num_jobs): weak scaling = every rank is a Kaldi job with its own
         # minibatch -> its sequence count; strong scaling = ONE minibatch sharded over the ranks -> the global sequence count
-        self.l2_scale = float(sequences * (world if args.scaling == "strong" else 1))
+        scaling = args.scaling if scaling is None else scaling
+        self.l2_scale = float(sequences * (world if scaling == "strong" else 1))
+        # strong scaling shards ONE minibatch: train-mode BatchNorm statistics are all-reduced so that it normalises as the whole
+        # minibatch does on one GPU (--sync-batchnorm auto); weak scaling = independent jobs, statistics per job as in Kaldi
+        self.sync_bn = world > 1 and (args.sync_batchnorm == "on" or (args.sync_batchnorm == "auto" and scaling == "strong"))
+        if self.sync_bn:
+            self.net.set_batchnorm_sync(True)
         self.gen = torch.Generator(device="cuda")
         self.gen.manual_seed(1234)  # same architecture sample on every rank (seed-shared draws)
         self.comm = torch.cuda.Stream() if world > 1 and not args.no_overlap else None
@@ -322,6 +328,10 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak (default): every GPU runs --minibatch sequences, the global batch grows with N; strong: ONE minibatch of "
                          "--minibatch sequences is sharded, rank g takes minibatch / N of them (SURVEY.md 8(e))")
+    ap.add_argument("--sync-batchnorm", default="auto", choices=["auto", "on", "off"],
+                    help="N > 1: all-reduce the train-mode BatchNorm column sums over the ranks (ChainNet.set_batchnorm_sync); auto = on for "
+                         "--scaling strong (a sharded minibatch then equals the single-GPU one), off for weak (per-job statistics, as Kaldi)")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1 with --scaling weak: skip the extra strong-scaling measurement reported under \"strong\"")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one all-reduce of the whole gradient buffer after the backward pass instead of "
                                                                "one per bucket overlapped with it")
     ap.add_argument("--den-states", type=int, default=4000)
@@ -405,6 +415,20 @@ def main():
         dt = float(t.item())
     res = job.net.results.cpu().numpy()
     den_arcs = int(len(job.den["src"]))
+    sync_bn_main = job.sync_bn
+    # N > 1, weak scaling (what the driver runs): the same node also timed on ONE minibatch of --minibatch sequences sharded over the
+    # ranks (strong scaling, synchronised BatchNorm) -- the regime north_star's ">= 6x at 8 GPUs" is the harder question in
+    strong = None
+    if world > 1 and args.scaling == "weak" and not args.no_strong and args.minibatch % world == 0:
+        sj = Job(pkg, args, args.chunk, args.minibatch // world, args.den_states, rank, world, scaling="strong")
+        sdt = sj.run(burn, args.warmup, args.steps, sync)
+        t = torch.tensor([sdt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        sdt = float(t.item())
+        strong = {"scaling": "strong", "value": round(args.minibatch * args.chunk * args.steps / sdt, 1), "unit": "frames/s",
+                  "ms_per_step": round(1e3 * sdt / args.steps, 3), "global_batch": args.minibatch, "sequences_per_gpu": args.minibatch // world,
+                  "sync_batchnorm": bool(sj.sync_bn)}
+        sj.close()
 
     # live roofline of the dominant kernel class (HIP events recorded on the launch stream)
     classes = []
@@ -449,7 +473,7 @@ def main():
                                             "setup_minibatches_before_warmup": burn,
                                             "refresh_steps_in_timed_region": sum(1 for t in range(burn + args.warmup, burn + args.warmup + args.steps)
                                                                                  if t <= 10 or (t - 10) % 4 == 0) if args.natural_gradient else 0},
-                       "parallelism": f"dp{world}", "allreduce": None if world == 1 else ("one collective after backward" if args.no_overlap else
+                       "parallelism": f"dp{world}", "sync_batchnorm": bool(sync_bn_main), "allreduce": None if world == 1 else ("one collective after backward" if args.no_overlap else
                                                                                            "per gradient bucket, overlapped with backward"), "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "kernel_choice": "the TDNN-F factored-GEMM class with the most time "
                          "(forward / backward-data 128x128, 128x160, weight gradient); the natural-gradient class is roofline_secondary",
@@ -474,6 +498,9 @@ def main():
                                          "refresh, the rank-R products): algorithmic bytes / HIP-event time of the class", "achieved": round(gbs, 1),
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "tflops": round(ngc["flops"] / (ngc["ms"] * 1e-3) / 1e12, 2),
                                          "launches": int(ngc["launches"]), "ms_per_step": round(ngc["ms"] / job.event_steps_, 3), "traffic": None}
+
+        if strong is not None:
+            out["strong"] = strong
 
         def line_item(name, chunk, sequences, den_states, gemm=None, steps=None, natural_gradient=None, workload=None, stats=None, archive_minibatches=0,
                       want_stats=False):

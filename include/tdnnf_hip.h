@@ -472,6 +472,17 @@ int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale
 /* "nnet3-copy --edits='set-dropout-proportion name=* proportion=p'" of train.py's dropout schedule */
 int tdnnf_net_set_dropout_proportion(tdnnf_net *, float proportion);
 int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
+/* Synchronised BatchNorm for a data-parallel caller ("BN [sum x, sum x^2] (2 D floats per BN) for exact single-GPU
+   equivalence").  The reference's BatchNormComponent takes its statistics over ALL rows of the minibatch
+   (/root/reference/src/nnet3/nnet-normalize-component.cc:433-445); when the minibatch is sharded over world_size ranks, every
+   train-mode BatchNorm of the net then all-reduces its column sums -- forward [sum x, sum x^2], backward [sum z dz, sum dz, sum dz^2],
+   as doubles -- through `allreduce(ctx, buf, count, stream)`: an in-place SUM over the ranks of `count` doubles at device pointer
+   `buf`, enqueued on `stream` (the trainer's compute stream; must not synchronise it), returning 0.  Mean, scale and the backward
+   terms are then formed with the global row count: the sharded step equals the unsharded one.  Every rank must run the same net on
+   the same number of rows.  allreduce == NULL switches it off (the default: statistics per shard, as Kaldi's per-job statistics).
+   The typedef is spelled in capitals on purpose (not an exported symbol). */
+typedef int TDNNF_ALLREDUCE_FN(void *ctx, double *buf, long long count, tdnnf_stream stream);
+int tdnnf_net_set_batchnorm_sync(tdnnf_net *, TDNNF_ALLREDUCE_FN *allreduce, void *ctx, int world_size);
 /* The nnet edit "set-learning-rate-factor name=<pattern> learning-rate-factor=f" (ReadEditConfig,
    /root/reference/src/nnet3/nnet-utils.cc:1232-1256): SetLearningRateFactor(f) on every UPDATABLE component whose name matches
    the pattern ('*' matches any run of characters, as NameMatchesPattern; the fixed lda layer is not updatable).  The cv-update

@@ -114,6 +114,24 @@ __device__ __forceinline__ void finalize_sums(const float *partial, int chunks, 
 }
 #endif
 
+// Synchronised BatchNorm (data-parallel training): while one of these is installed, every train-mode BatchNorm of the calling thread
+// all-reduces its column sums over the ranks -- forward [sum x, sum x^2], backward [sum z dz, sum dz, sum dz^2] (2 D / 3 D doubles
+// in `buf`) -- through the caller's collective `fn(ctx, buf, count, stream)` before it forms mean / scale and the backward terms
+// with the GLOBAL row count, so that a sharded minibatch normalises exactly as the whole one does
+// (/root/reference/src/nnet3/nnet-normalize-component.cc:433-445 takes its statistics over all rows of the minibatch).
+struct BnSync {
+  int (*fn)(void *ctx, double *buf, long long count, tdnnf_stream stream);
+  void *ctx;
+  double *buf;      // device, >= 5 * max D doubles (the fused BatchNorm / ReLU backward stages five column sums, three are reduced)
+  int world;
+};
+BnSync *bn_sync_current();
+struct BnSyncScope {
+  BnSync *prev;
+  explicit BnSyncScope(BnSync *b);
+  ~BnSyncScope();
+};
+
 // two-stage deterministic column reduction (colreduce.hip)
 struct ColReducePlan {
   int chunks, rows_per_chunk;

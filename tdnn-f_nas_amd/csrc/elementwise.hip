@@ -128,13 +128,25 @@ namespace {
 
 // ---------------------------------------------------------------------------- batchnorm
 // finalize forward stats: memo rows 0 mean, 1 uvar, 2 scale  (nnet-normalize-component.cc:433-445)
+// sums_out (synchronised BatchNorm, first half): only the column sums, as doubles [2][D].  sums_in (second half): the sums come
+// from there (all-reduced over the ranks) instead of from the partial rows, and N is the global row count.
 __global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(const float *partial, int chunks, int D, int N, float epsilon,
-                                                                      float target_rms, float *memo) {
+                                                                      float target_rms, float *memo, double *sums_out = nullptr,
+                                                                      const double *sums_in = nullptr) {
   __shared__ double red[2 * kFinLanes * (kFinCols + 1)];
   const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
   double q[2];
-  finalize_sums<2, double>(partial, chunks, chunks, D, 2, q, red);
+  if (!sums_in) finalize_sums<2, double>(partial, chunks, chunks, D, 2, q, red);
   if (threadIdx.x >= kFinCols || d >= D) return;
+  if (sums_out) {
+    sums_out[d] = q[0];
+    sums_out[D + d] = q[1];
+    return;
+  }
+  if (sums_in) {
+    q[0] = sums_in[d];
+    q[1] = sums_in[D + d];
+  }
   const float mean = (float)(q[0] / N), uvar = (float)(q[1] / N);
   const float var_scale = 1.0f / (target_rms * target_rms);
   float v = var_scale * uvar - var_scale * mean * mean;
@@ -144,12 +156,22 @@ __global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(const floa
   memo[2 * D + d] = 1.0f / sqrtf(v);
 }
 // memo rows 3 var_deriv_mod, 4 temp (:520-526)
-__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms, float *memo) {
+__global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms, float *memo,
+                                                                      double *sums_out = nullptr, const double *sums_in = nullptr) {
   __shared__ double red[2 * kFinLanes * (kFinCols + 1)];
   const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
   double q[2];
-  finalize_sums<2, double>(partial, chunks, chunks, D, 2, q, red);
+  if (!sums_in) finalize_sums<2, double>(partial, chunks, chunks, D, 2, q, red);
   if (threadIdx.x >= kFinCols || d >= D) return;
+  if (sums_out) {
+    sums_out[d] = q[0];
+    sums_out[D + d] = q[1];
+    return;
+  }
+  if (sums_in) {
+    q[0] = sums_in[d];
+    q[1] = sums_in[D + d];
+  }
   const float coeff = -1.0f / (target_rms * target_rms * N);
   memo[3 * D + d] = (float)(coeff * q[0]) * memo[2 * D + d];
   memo[4 * D + d] = (float)(-q[1] / N);
@@ -661,18 +683,46 @@ __global__ void axpy_kernel(const float *x, float a, float *y, size_t n) {
 }  // namespace tdnnf
 
 namespace tdnnf {
+static thread_local BnSync *g_bn_sync = nullptr;
+BnSync *bn_sync_current() { return g_bn_sync; }
+BnSyncScope::BnSyncScope(BnSync *b) : prev(g_bn_sync) { g_bn_sync = b; }
+BnSyncScope::~BnSyncScope() { g_bn_sync = prev; }
+
+// memo rows 0-2 from partial column sums; with a BnSync installed the sums are all-reduced over the ranks first
+static hipError_t bn_fwd_finalize(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s) {
+  BnSync *sy = bn_sync_current();
+  if (!sy) {
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo, sy->buf,
+                     (const double *)nullptr);
+  if (sy->fn(sy->ctx, sy->buf, 2LL * cols, (tdnnf_stream)s)) return hipErrorUnknown;
+  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows * sy->world, epsilon, target_rms, memo,
+                     (double *)nullptr, (const double *)sy->buf);
+  return hipGetLastError();
+}
+static hipError_t bn_bwd_finalize(const float *partial, int chunks, int rows, int D, float target_rms, float *memo, hipStream_t s) {
+  BnSync *sy = bn_sync_current();
+  if (!sy) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, chunks, D, rows, target_rms, memo);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, chunks, D, rows, target_rms, memo, sy->buf, (const double *)nullptr);
+  if (sy->fn(sy->ctx, sy->buf, 2LL * D, (tdnnf_stream)s)) return hipErrorUnknown;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, chunks, D, rows * sy->world, target_rms, memo, (double *)nullptr,
+                     (const double *)sy->buf);
+  return hipGetLastError();
+}
 // BatchNorm forward statistics only (memo rows 0-2); the trainer applies them in a fused pass (fused.hip)
 hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s) {
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   hipError_t e = colreduce_partial(1, a, a, (float *)ws, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(a.cols)), dim3(kFinThreads), 0, s, (const float *)ws, pl.chunks, a.cols,
-                     a.rows, epsilon, target_rms, memo);
-  return hipGetLastError();
+  return bn_fwd_finalize((const float *)ws, pl.chunks, a.rows, a.cols, epsilon, target_rms, memo, s);
 }
 hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s) {
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo);
-  return hipGetLastError();
+  return bn_fwd_finalize(partial, chunks, rows, cols, epsilon, target_rms, memo, s);
 }
 // acc[c] += scale * colsum(a)[c]   (two-stage, float4 loads)
 hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s) {
@@ -700,8 +750,7 @@ int tdnnf_batchnorm_propagate(const tdnnf_mat *in, float epsilon, float target_r
   MatView a = view(in), o = view(out);
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   TDNNF_HIP(colreduce_partial(1, a, a, (float *)ws, s));
-  hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(a.cols)), dim3(kFinThreads), 0, s, (const float *)ws, pl.chunks,
-                     a.cols, a.rows, epsilon, target_rms, memo);
+  TDNNF_HIP(bn_fwd_finalize((const float *)ws, pl.chunks, a.rows, a.cols, epsilon, target_rms, memo, s));
   const bool vec = vec4_ok(a) && vec4_ok(o) && (reinterpret_cast<uintptr_t>(memo) & 15) == 0;
   const long long work = (long long)a.rows * (vec ? a.cols / 4 : a.cols);
   if (vec) hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, a, memo, memo + 2 * a.cols, o);
@@ -722,8 +771,7 @@ int tdnnf_batchnorm_backprop(const tdnnf_mat *out_value, const tdnnf_mat *out_de
   const int D = z.cols;
   ColReducePlan pl = colreduce_plan(z.rows, D);
   TDNNF_HIP(colreduce_partial(2, z, dz, (float *)ws, s));
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, (const float *)ws, pl.chunks, D,
-                     z.rows, target_rms, memo);
+  TDNNF_HIP(bn_bwd_finalize((const float *)ws, pl.chunks, z.rows, D, target_rms, memo, s));
   const bool vec = vec4_ok(z) && vec4_ok(dz) && vec4_ok(dx);
   const long long work = (long long)z.rows * (vec ? D / 4 : D);
   // dx = (dz + temp) * scale + z * vdm

@@ -120,15 +120,26 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
 // squares of the ReLU's out_deriv dr = (dz + temp) scale + z vdm.  They need no pass of their own:
 //   sum_r dr^2 = scale^2 (sum dz^2 - (sum dz)^2 / N) + 2 vdm scale sum z dz + vdm^2 sum z^2,   sum z^2 = N var scale^2
 // (train mode: sum z = 0; test mode: temp = vdm = 0) from the quantities this reduction already forms, plus sum dz^2.
+// Synchronised BatchNorm (common.h BnSync): sums_out != null -- only the five column sums, doubles [5][D]; sums_in != null -- the sums
+// come from there (the first three all-reduced over the ranks), N is the GLOBAL row count and N_local this rank's (ReLU statistics).
 __global__ __launch_bounds__(kFinThreads) void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms,
-                                                                           float *memo, double *relu_stats, int test_mode, double *oderiv) {
+                                                                           float *memo, double *relu_stats, int test_mode, double *oderiv,
+                                                                           double *sums_out = nullptr, const double *sums_in = nullptr, int N_local = 0) {
   __shared__ double red[5 * kFinLanes * (kFinCols + 1)];
   const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
-  if (relu_stats && blockIdx.x == 0 && threadIdx.x == 0) relu_stats[0] += (double)N;
-  if (oderiv && blockIdx.x == 0 && threadIdx.x == 0) oderiv[0] += (double)N;
   double q[5];
-  finalize_sums<5, double>(partial, chunks, chunks, D, relu_stats ? 5 : 3, q, red);
+  const int nq = relu_stats ? 5 : 3;
+  if (!sums_in) finalize_sums<5, double>(partial, chunks, chunks, D, nq, q, red);
+  if (sums_out) {
+    if (threadIdx.x < kFinCols && d < D)
+      for (int k = 0; k < nq; k++) sums_out[(size_t)k * D + d] = q[k];
+    return;
+  }
+  if (relu_stats && blockIdx.x == 0 && threadIdx.x == 0) relu_stats[0] += (double)(sums_in ? N_local : N);
+  if (oderiv && blockIdx.x == 0 && threadIdx.x == 0) oderiv[0] += (double)N;
   if (threadIdx.x >= kFinCols || d >= D) return;
+  if (sums_in)
+    for (int k = 0; k < nq; k++) q[k] = sums_in[(size_t)k * D + d];
   const float coeff = -1.0f / (target_rms * target_rms * N);
   // test mode (BatchNormTestComponent::Backprop, nnet-normalize-component.cc:879-922): in_deriv = out_deriv * scale
   const float sc = memo[2 * D + d];
@@ -470,8 +481,17 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
     else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
   }
-  hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
-                     store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0, oderiv_stats);
+  if (BnSync *sy = bn_test_mode ? nullptr : bn_sync_current()) {
+    // [sum z dz, sum dz, sum dz^2] over all ranks' rows; the ReLU's value / derivative sums (rows 3, 4) stay this rank's
+    hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
+                       store_relu_stats ? relu_stats : (double *)nullptr, 0, (double *)nullptr, sy->buf, (const double *)nullptr, 0);
+    if (sy->fn(sy->ctx, sy->buf, 3LL * D, (tdnnf_stream)s)) return hipErrorUnknown;
+    hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows * sy->world, target_rms, memo,
+                       store_relu_stats ? relu_stats : (double *)nullptr, 0, oderiv_stats, (double *)nullptr, (const double *)sy->buf, x.rows);
+  } else {
+    hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
+                       store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0, oderiv_stats);
+  }
   const double *rep = self_repair ? relu_stats : nullptr;
   if (ng) {
     const int blocks = (x.rows + 127) / 128;

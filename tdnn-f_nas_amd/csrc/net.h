@@ -138,6 +138,7 @@ struct tdnnf_net {
   float *s4_scratch;   // split-K scratch of the GEMMs launched on s4
   size_t s4_scratch_bytes;
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
+  tdnnf::BnSync bn_sync{nullptr, nullptr, nullptr, 1};  // tdnnf_net_set_batchnorm_sync; buf lives in the arena
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done
   int num_draws;

@@ -382,6 +382,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     if (L.lin.darts) tg = std::max(tg, (size_t)L.bn * L.lin.K * Hd);
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
   n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
+  n->bn_sync.buf = A.take<double>(5 * (size_t)std::max(std::max(Hd, S), 1) + 8);  // (the ReLU backward sweep stages five column sums)
   n->dropout_masks = (c.use_dropout && !c.cv_update) ? A.take<float>((size_t)(c.num_layers + 1) * B * Hd) : nullptr;
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
   // transposed copy of every weight matrix for the split-bf16 backward-data GEMMs (k-contiguous B operand).  Measured for
@@ -995,6 +996,14 @@ static bool name_matches(const char *name, const char *pat) {
   return *name == *pat && name_matches(name + 1, pat + 1);
 }
 
+int tdnnf_net_set_batchnorm_sync(tdnnf_net *n, TDNNF_ALLREDUCE_FN *allreduce, void *ctx, int world_size) {
+  TDNNF_REQUIRE(n && world_size >= 1, "net_set_batchnorm_sync: bad arguments");
+  n->bn_sync.fn = allreduce;
+  n->bn_sync.ctx = ctx;
+  n->bn_sync.world = world_size;
+  return TDNNF_OK;
+}
+
 int tdnnf_net_set_learning_rate_factor(tdnnf_net *n, const char *name_pattern, float factor, int *num_set) {
   TDNNF_REQUIRE(n && name_pattern && factor >= 0.f, "net_set_learning_rate_factor: bad arguments (the factor must be >= 0)");
   int cnt = 0;
@@ -1161,6 +1170,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       if (early_refresh) TDNNF_HIP(hipEventRecord(n->ev_fin, n->s3));
     }
   }
+  BnSyncScope bn_sync_scope(n->bn_sync.fn && !c.cv_update ? &n->bn_sync : nullptr);  // synchronised BatchNorm (data-parallel callers)
   GemmPrecisionScope gemm_arith(c.gemm_precision == 2 ? 3 : c.gemm_precision);  // scope values: 1 two planes, 3 three planes
   TransposedWeightsScope gemm_wt(n->params, n->paramsT, n->paramsT ? n->num_params : 0);
   if (n->paramsT) {  // split-bf16 backward-data GEMMs read W^T (k-contiguous B operand)

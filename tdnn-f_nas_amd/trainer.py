@@ -296,6 +296,46 @@ class ChainNet:
         return out
 
     # ------------------------------------------------------------ data-parallel step
+    def set_batchnorm_sync(self, on=True, group=None, min_world=2):
+        """Synchronised BatchNorm (tdnnf_net_set_batchnorm_sync): every train-mode BatchNorm all-reduces its column sums over the
+        ranks of `group` on the compute stream, so that a minibatch sharded over the ranks (bench.py --scaling strong) normalises
+        exactly as the whole minibatch does on one GPU (nnet-normalize-component.cc:433-445: statistics over all rows).  Off (the
+        default): statistics per shard, like the per-job statistics of Kaldi's parallel jobs.  RCCL (backend "nccl") reduces the
+        device buffer in place on that stream; gloo (CPU rehearsals, also two ranks on one GPU) stages through the host."""
+        import torch
+        import torch.distributed as dist
+        if not on or not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= min_world):
+            hipabi.check(self.lib.tdnnf_net_set_batchnorm_sync(self.h, None, None, 1))
+            self._bn_sync_cb = None
+            return False
+        world = dist.get_world_size(group)
+
+        class _DevDoubles:  # zero-copy view of `count` doubles at a raw device pointer
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        def allreduce(ctx, buf, count, stream):
+            try:
+                t = torch.as_tensor(_DevDoubles(int(buf), int(count)), device="cuda")
+                cur = torch.cuda.current_stream()
+                st = cur if (stream or 0) == cur.cuda_stream else torch.cuda.ExternalStream(int(stream or 0))
+                with torch.cuda.stream(st):
+                    if dist.get_backend(group) == "gloo":
+                        host = t.cpu()  # (synchronises the stream: rehearsal only)
+                        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                        t.copy_(host)
+                    else:
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except Exception as e:  # never raise through the C frames
+                import sys
+                print("batchnorm sync all-reduce failed: %r" % (e,), file=sys.stderr)
+                return 1
+
+        self._bn_sync_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_void_p)(allreduce)  # kept alive with the net
+        hipabi.check(self.lib.tdnnf_net_set_batchnorm_sync(self.h, C.cast(self._bn_sync_cb, C.c_void_p), None, int(world)))
+        return True
+
     def allreduce_grads(self, group=None, min_world=2):
         """Sum the raw parameter gradients over ranks (RCCL all-reduce over xGMI: backend "nccl" on ROCm)."""
         allreduce_flat(self.grads, group, min_world)

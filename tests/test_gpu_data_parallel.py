@@ -159,3 +159,79 @@ def test_rccl_collectives_accept_the_gradient_buffer(pkg, tmp_path):
     mp.spawn(_rccl_one_rank_main, args=(port, str(tmp_path)), nprocs=1, join=True)
     o = np.load(tmp_path / "rccl.npz")
     assert np.linalg.norm(o["before"]) > 0 and np.array_equal(o["before"], o["after"])
+
+
+# ------------------------------------------------------------------------------------------------ synchronised BatchNorm
+# Train-mode BatchNorm takes its statistics over all rows of the minibatch (nnet-normalize-component.cc:433-445), so a sharded
+# minibatch only equals the whole one when the column sums are all-reduced (ChainNet.set_batchnorm_sync).
+KW_BN = dict(frames_per_chunk=24, num_sequences=8, strides=[1, 0, 3], bottleneck=16, feat_dim=40, ivector_dim=100, num_pdfs=96, hidden_dim=64,
+             small_dim=32, relu_self_repair_scale=0.0)
+
+
+def _bn_problem(pkg, B):
+    T = pkg.trainer
+    net = T.ChainNet(T.make_config(**dict(KW_BN, num_sequences=B)))
+    full = T.ChainNet(T.make_config(**KW_BN)) if B != KW_BN["num_sequences"] else net
+    params = full.init_params_numpy(seed=1, output_stddev=0.3)
+    feats, iv = T.synthetic_egs(full, seed=4)
+    den = pkg.synth.make_den_graph(40, net.cfg.num_pdfs, mean_out_degree=4.0, seed=5)
+    sup = pkg.synth.make_supervision(KW_BN["num_sequences"], net.cfg.frames_per_chunk // 3, net.cfg.num_pdfs, seed=6)
+    if full is not net:
+        full.close()
+    net.set_params(params)
+    return net, feats, iv, den, sup
+
+
+def _bn_rank_main(rank, world, port, out_dir):
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    T = pkg.trainer
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        Bg = KW_BN["num_sequences"]
+        b0, b1 = T.shard_sequences(Bg, rank, world)
+        net, feats, iv, den, sup = _bn_problem(pkg, b1 - b0)
+        fd, ivd = dev(T.shard_rows(feats, Bg, b0, b1)), dev(np.ascontiguousarray(iv[b0:b1]))
+        dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(T.shard_supervision(sup, b0, b1))
+        out = {}
+        for sync in (True, False):
+            assert net.set_batchnorm_sync(sync) == sync
+            net.grads.zero_()
+            r = host(net.forward_backward(fd, ivd, dg, ds, step=0)).copy()
+            net.allreduce_grads()
+            out["g_sync" if sync else "g_local"] = host(net.grads).copy()
+            out["r_sync" if sync else "r_local"] = r
+            out["y_sync" if sync else "y_local"] = host(net.activation("output")).copy()
+        np.savez(os.path.join(out_dir, "bn_rank%d.npz" % rank), **out)
+        net.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_synchronised_batchnorm_makes_two_shards_equal_the_whole_minibatch(pkg, tmp_path):
+    import torch.multiprocessing as mp
+    net, feats, iv, den, sup = _bn_problem(pkg, KW_BN["num_sequences"])
+    r1 = host(net.forward_backward(dev(feats), dev(iv), pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup), step=0)).copy()
+    g1 = host(net.grads).copy()
+    y1 = host(net.activation("output")).copy()
+    net.close()
+    assert r1[5] == 1.0 and np.linalg.norm(g1) > 0
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bn_rank_main, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    out = [np.load(tmp_path / ("bn_rank%d.npz" % r)) for r in range(2)]
+    T = pkg.trainer
+    Bg = KW_BN["num_sequences"]
+    for r, o in enumerate(out):
+        b0, b1 = T.shard_sequences(Bg, r, 2)
+        # train-mode BatchNorm, raw-gradient path: the reduced gradient of two 4-sequence shards is the single process's of all 8
+        assert rel_l2(o["g_sync"], g1) < 1e-5, rel_l2(o["g_sync"], g1)
+        assert rel_l2(o["y_sync"], T.shard_rows(y1, Bg, b0, b1)) < 1e-5
+        # ... which per-shard statistics (the default, Kaldi's per-job behaviour) do not give
+        assert rel_l2(o["g_local"], g1) > 1e-3 and rel_l2(o["y_local"], T.shard_rows(y1, Bg, b0, b1)) > 1e-3
+    assert np.array_equal(out[0]["g_sync"], out[1]["g_sync"])
+    assert abs(out[0]["r_sync"][0] + out[1]["r_sync"][0] - r1[0]) < 1e-5 * abs(r1[0])
