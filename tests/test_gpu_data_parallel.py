@@ -235,3 +235,41 @@ def test_synchronised_batchnorm_makes_two_shards_equal_the_whole_minibatch(pkg, 
         assert rel_l2(o["g_local"], g1) > 1e-3 and rel_l2(o["y_local"], T.shard_rows(y1, Bg, b0, b1)) > 1e-3
     assert np.array_equal(out[0]["g_sync"], out[1]["g_sync"])
     assert abs(out[0]["r_sync"][0] + out[1]["r_sync"][0] - r1[0]) < 1e-5 * abs(r1[0])
+
+
+def _rccl_bn_sync_main(rank, port, out_dir):
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        net, feats, iv, den, sup = _bn_problem(pkg, KW_BN["num_sequences"])
+        fd, ivd, dg, ds = dev(feats), dev(iv), pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+        net.forward_backward(fd, ivd, dg, ds, step=0)
+        before = host(net.grads).copy()
+        net.grads.zero_()
+        assert net.set_batchnorm_sync(True, min_world=1)  # RCCL all-reduces of the BatchNorm sums on the compute stream (one rank: sums unchanged)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):  # ... also when the compute stream is not torch's default stream
+            side.wait_stream(torch.cuda.default_stream())
+            net.forward_backward(fd, ivd, dg, ds, step=0)
+        side.synchronize()
+        dist.barrier()
+        np.savez(os.path.join(out_dir, "rccl_bn.npz"), before=before, after=host(net.grads).copy())
+        net.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_runs_the_batchnorm_sync_collectives(pkg, tmp_path):
+    """The synchronised-BatchNorm callback under backend "nccl" (RCCL) in a one-rank group: in-place all-reduces of 2 D / 3 D doubles
+    at raw device pointers inside the library's arena, enqueued on the trainer's compute stream from inside tdnnf_net_forward_backward."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_bn_sync_main, args=(port, str(tmp_path)), nprocs=1, join=True)
+    o = np.load(tmp_path / "rccl_bn.npz")
+    assert np.linalg.norm(o["before"]) > 0 and rel_l2(o["after"], o["before"]) < 1e-6
