@@ -183,17 +183,23 @@ def bench_egs(pkg):
     return dev(feats), dev(iv), den, sup
 
 
-def run_bench_shape(pkg, egs, steps, seed_params=0, update=True, keep=(), **kw):
+def run_bench_shape(pkg, egs, steps, seed_params=0, update=True, keep=(), stats=None, **kw):
     """`steps` training steps of the bench workload; returns per step (results, gradient) and, of the last step, the output
     derivative's per-frame sums and the activations named in `keep`.  update=False: the parameters stay put (the gradient
     buffer is zeroed instead), so that every step of two variants starts from the same state."""
     fd, ivd, den, sup = egs
     cfg = pkg.trainer.make_config(**dict(BENCH_KW, **kw))
     net = pkg.trainer.ChainNet(cfg)
+    if fd.shape[0] != net.num_t_in * cfg.num_sequences:  # (the offset supernet reads a wider input window than the 7q net)
+        fd = dev(np.random.default_rng(101).standard_normal((net.num_t_in * cfg.num_sequences, cfg.feat_dim)).astype(F))
     net.set_params(net.init_params_numpy(seed=seed_params, output_stddev=0.05))
+    if stats is not None:  # cv-update: BatchNormTest from a parent's statistics
+        net.set_stats(stats)
     dg, ds = pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
     out = []
     for i in range(steps):
+        if net.num_draws:  # supernets: the step's architecture draws (seeded: two runs see the same)
+            net.set_random_draws(np.random.default_rng(700 + i).uniform(1e-3, 1 - 1e-3, net.num_draws).astype(F))
         r = host(net.forward_backward(fd, ivd, dg, ds, step=i)).copy()
         out.append((r, net.grads.clone()))
         if update:
@@ -201,7 +207,7 @@ def run_bench_shape(pkg, egs, steps, seed_params=0, update=True, keep=(), **kw):
         else:
             net.grads.zero_()
     extra = dict(deriv_row_sums=net.activation("output.deriv").double().sum(1), deriv_abs=float(net.activation("output.deriv").abs().max()),
-                 components=net.components)
+                 components=net.components, stats=net.get_stats())
     for k in keep:
         extra[k] = net.activation(k)
     net.close()
@@ -223,6 +229,48 @@ def test_bench_shape_properties_and_reproducibility(pkg, bench_egs):
     rs = ea["deriv_row_sums"]
     assert rs.numel() == 128 * 500 and ea["deriv_abs"] > 1e-3
     assert float(rs.abs().max()) < 1e-4, float(rs.abs().max())  # sum_pdf (gamma_num - gamma_den) = 1 - 1 on every one of the 64 000 frames
+
+
+SUPERNETS = {
+    # BASELINE configs[3]: run_TDNN_DARTSV3_fbk_stride_pretrain.sh:143-156 (uniform tap sample) and its cv-update stage
+    # (...cvupdate.sh:128-142: Gumbel over all 7 taps, update-alpha, BatchNormTest); configs[4]: the bottleneck-dimension supernet
+    # (generate_bottleneckCB8share_onehottrain_config.py:8-102, Onehot pretrain), the recipe's 8 candidate dims
+    "darts-offset-pretrain": dict(darts_num_offsets=7),
+    "darts-offset-cvupdate": dict(darts_num_offsets=7, darts_flags=1 | 16, darts_temp_proportion=0.5, cv_update=1),
+    "bn-supernet": dict(bn_choice_dims=[25, 25, 30, 20, 20, 40, 40, 40], bn_mode=0),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SUPERNETS))
+def test_bench_shape_supernets(pkg, bench_egs, name):
+    """The supernets at the bench shape (T = 1500 x B = 128, natural gradient on): finite, the chain derivative of every frame sums
+    to zero, the architecture parameters receive a gradient, two runs are bit-identical."""
+    kw = dict(SUPERNETS[name], use_natural_gradient=1)
+    stats = None
+    if kw.get("cv_update"):  # the parent: one pretrain step of the same supernet
+        _, parent = run_bench_shape(pkg, bench_egs, 1, **dict(SUPERNETS["darts-offset-pretrain"], use_natural_gradient=1))
+        stats = parent["stats"]
+    a, ea = run_bench_shape(pkg, bench_egs, 2, stats=stats, **kw)
+    b, _ = run_bench_shape(pkg, bench_egs, 2, stats=stats, **kw)
+    for (ra, ga), (rb, gb) in zip(a, b):
+        assert ra[5] == 1.0 and np.isfinite(ra).all() and bool(torch.isfinite(ga).all())
+        assert ra[2] == 128 * 500.0 and -20.0 < ra[0] / ra[2] < 0.0
+        assert np.array_equal(ra, rb) and torch.equal(ga, gb), "two runs of the same steps differ"
+    rs = ea["deriv_row_sums"]
+    assert rs.numel() == 128 * 500 and float(rs.abs().max()) < 1e-4, float(rs.abs().max())
+    g = host(a[0][1])
+    arch = 0.0
+    for c in ea["components"]:
+        n = c["rows"] * c["cols"]
+        if c["num_alpha"]:  # TdnnDARTSV3: K logits between the weights and the bias
+            arch += float(np.abs(g[c["begin"] + n:c["begin"] + n + c["num_alpha"]]).sum())
+        if c["name"].endswith((".softmax", ".alpha")):
+            arch += float(np.abs(g[c["begin"]:c["begin"] + c["rows"]]).sum())
+    if name != "darts-offset-pretrain":  # (uniform-sample pretraining leaves the offset logits alone: nnet-tdnn-component.cc:502-507)
+        assert arch > 0.0
+    if kw.get("cv_update"):  # frozen components form no gradient at all
+        frozen = [c for c in ea["components"] if c["lr_factor"] == 0.0]
+        assert frozen and all(not g[c["begin"]:c["begin"] + c["rows"] * c["cols"]].any() for c in frozen)
 
 
 def test_bench_shape_fused_statistics_against_separate_passes(pkg, bench_egs, monkeypatch):
