@@ -132,6 +132,7 @@ struct WgradArgs {
   const int *active;
   int max_active;
   int prec;  // 0: exact f32 MFMA, 1: split-bf16 (as RowsGemmArgs::prec)
+  int xcd_order;  // set by wgrad(): XCD-aware block order (the taps of a tile side by side on one XCD)
 };
 size_t wgrad_workspace_bytes(int Do, int Di, int K, int N);  // valid for any max_active <= K
 hipError_t wgrad(const WgradArgs &args, void *workspace, size_t workspace_bytes, hipStream_t stream);

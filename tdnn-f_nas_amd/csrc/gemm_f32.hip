@@ -308,6 +308,9 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
     }
   };
   auto compute = [&](int buf) {
+#ifdef TDNNF_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(TDNNF_GEMM_SETPRIO);
+#endif
     const float *as = As + buf * A_TILE + (wm * TM * 32 + li) * LDAS + lh * 4;
     const float *bs = B_KC ? Bs + buf * B_TILE + (wn * TN * 32 + li) * LDBS + lh * 4
                            : Bs + buf * B_TILE + (lh * 4) * LDBS + wn * TN * 32 + li;
@@ -335,6 +338,9 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
+#ifdef TDNNF_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   if (seg < p.nseg) {
@@ -1299,18 +1305,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p, int ntm, 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float *As = smem, *Bs = smem + 2 * A_TILE;
 
-  const int tiles = ntm * p.K * ntn_tap;
-  int bid = blockIdx.x;  // tile id; blockIdx.y = row split
-  (void)tiles;
-  const int tile_m = bid % ntm;
-  int tap = (bid / ntm) / ntn_tap;
-  const int tile_n = (bid / ntm) % ntn_tap;
+  // Block -> (row split, tile, tap).  The taps of a component are row shifts of ONE matrix, so the blocks that differ only in the
+  // tap stream the same slab of the big operand (X for the .linear components, dY for the .affine ones): they are given
+  // neighbouring logical ids, and every XCD (workgroups are dealt to the eight XCDs round-robin) a contiguous run of logical ids,
+  // so that a slab's second reader finds it in the L2 the first one filled instead of fetching it over the fabric again.
+  const int tiles = ntm * (int)gridDim.x / ntm;  // = gridDim.x: ntm * taps launched * ntn_tap
+  int bid = blockIdx.x, split = blockIdx.y;
+  int tile_m, tile_n, tap;
+  if (p.xcd_order) {
+    const int nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+    const int q = nb / 8, r = nb % 8, xcd = b % 8, j = b / 8;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    const int ktaps = (int)gridDim.x / (ntm * ntn_tap);
+    split = L / tiles;
+    const int w = L % tiles;
+    tap = w % ktaps;
+    tile_m = (w / ktaps) % ntm;
+    tile_n = (w / ktaps) / ntm;
+  } else {
+    tile_m = bid % ntm;
+    tap = (bid / ntm) / ntn_tap;
+    tile_n = (bid / ntm) % ntn_tap;
+  }
   if (p.active) {  // compacted tap list: slots beyond the active count have nothing to do
     if (tap >= p.active[0]) return;
     tap = p.active[1 + tap];
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int split = blockIdx.y;
   const int r_begin = split * rows_per_split;
   const int r_end = min(p.N, r_begin + rows_per_split);
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1873,6 +1894,9 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   const bool use_x3 = planes != 0;
   const WgradTile wt = wgrad_tile(a.Do, a.Di, use_x3);
   const int ktaps = a.active && a.max_active > 0 && a.max_active < a.K ? a.max_active : a.K;
+  static const int xcd_env = getenv("TDNNF_WGRAD_XCD") ? atoi(getenv("TDNNF_WGRAD_XCD")) : 1;  // 0: the plain (tile, split) grid order (A/B runs)
+  WgradArgs a_x = a;
+  a_x.xcd_order = xcd_env && ktaps > 1 ? 1 : 0;
   WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant), ktaps == a.K ? 0 : ktaps, use_x3);
   if (sizeof(float) * pl.slab_floats > workspace_bytes) return hipErrorInvalidValue;
   float *partial = reinterpret_cast<float *>(workspace);
@@ -1902,8 +1926,8 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
       hipFuncSetAttribute((const void *)wgrad_kernel<WM, WN, TM, TN, 1, TAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
       attr_done = true;                                                                                                            \
     }                                                                                                                              \
-    if (vec) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 4, TAG>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial); \
-    else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 1, TAG>), grid, block, lds, s, a, ntm, ntn, pl.rows_per_split, partial);     \
+    if (vec) hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 4, TAG>), grid, block, lds, s, a_x, ntm, ntn, pl.rows_per_split, partial); \
+    else hipLaunchKernelGGL((wgrad_kernel<WM, WN, TM, TN, 1, TAG>), grid, block, lds, s, a_x, ntm, ntn, pl.rows_per_split, partial);     \
   }
 #define WG_LAUNCH_X3(WM, WN, TM, TN, NP, TAG)                                                                                  \
   {                                                                                                                             \
