@@ -106,7 +106,9 @@ def hip_step_against_oracle(pkg, args, gemm_precision, tie_tol, state=None):
     objf_rel = abs(r[0] - res_ref["objf"]) / abs(res_ref["objf"])
     grad_rel = float(np.linalg.norm(g.astype(np.float64) - g_ref) / np.linalg.norm(g_ref.astype(np.float64)))
     out = {"objf_rel": float(f"{objf_rel:.3e}"), "grad_rel_l2": float(f"{grad_rel:.3e}"), "objf_tol": OBJF_TOL, "grad_tol": GRAD_TOL,
-           "ok": bool(r[5] == 1.0 and objf_rel < OBJF_TOL and grad_rel < GRAD_TOL and np.isfinite(g).all()),
+           # (the ties taken over from the GPU run must stay a vanishing fraction: 1e-4 of the ReLU elements for f32 arithmetic)
+           "ok": bool(r[5] == 1.0 and objf_rel < OBJF_TOL and grad_rel < GRAD_TOL and np.isfinite(g).all() and
+                      sum(ref.relu_ties.values()) <= (1e-4 if tie_tol <= 1e-4 else 1e-3) * sum(v.size for v in relus.values())),
            "objf_hip": float(r[0]), "objf_oracle": float(res_ref["objf"]),
            "relu_ties": int(sum(ref.relu_ties.values())), "relu_elements": int(sum(v.size for v in relus.values())), "relu_tie_tolerance_x_rms": tie_tol}
     return out, state

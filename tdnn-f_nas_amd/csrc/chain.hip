@@ -1095,18 +1095,28 @@ SupDev sup_dev(const tdnnf_supervision *sp) {
 }
 }  // namespace
 
-// a second stream for the backward recursion (created on first use) and the fork / join events
+// A second stream for the backward recursion and the fork / join events: one set per DEVICE and calling thread (created on first
+// use on that device; a process that drives several devices, or several host threads, gets a set each -- the entry points are
+// still not re-entrant for one thread).  They live as long as the process: HIP tears them down with the context.
 int den_aux_stream(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join) {
-  static hipStream_t st = nullptr;
-  static hipEvent_t ef = nullptr, ej = nullptr;
-  if (!st) {
-    TDNNF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    TDNNF_HIP(hipEventCreateWithFlags(&ef, hipEventDisableTiming));
-    TDNNF_HIP(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+  struct Set {
+    hipStream_t st = nullptr;
+    hipEvent_t ef = nullptr, ej = nullptr;
+  };
+  constexpr int kMaxDev = 64;
+  static thread_local Set sets[kMaxDev];
+  int dev = 0;
+  TDNNF_HIP(hipGetDevice(&dev));
+  TDNNF_REQUIRE(dev >= 0 && dev < kMaxDev, "chain: device index %d out of range", dev);
+  Set &S = sets[dev];
+  if (!S.st) {
+    TDNNF_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+    TDNNF_HIP(hipEventCreateWithFlags(&S.ef, hipEventDisableTiming));
+    TDNNF_HIP(hipEventCreateWithFlags(&S.ej, hipEventDisableTiming));
   }
-  *aux = st;
-  *ev_fork = ef;
-  *ev_join = ej;
+  *aux = S.st;
+  *ev_fork = S.ef;
+  *ev_join = S.ej;
   return TDNNF_OK;
 }
 

@@ -138,6 +138,11 @@ struct tdnnf_net {
   float *s4_scratch;   // split-K scratch of the GEMMs launched on s4
   size_t s4_scratch_bytes;
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
+  // NonlinearComponent::StoreBackpropStats skips a minibatch w.p. 1/4 only "&& oderiv_count_ != 0" (nnet-component-itf.cc:466): whether a
+  // ReLU's oderiv_count is non-zero, in the order of stat_blocks() (host copy: set by set_stats / read_model and by every store);
+  // a net made by tdnnf_net_create_shared looks at the primary's
+  std::vector<char> oderiv_nonzero_own;
+  std::vector<char> *oderiv_nonzero = &oderiv_nonzero_own;
   tdnnf::BnSync bn_sync{nullptr, nullptr, nullptr, 1};  // tdnnf_net_set_batchnorm_sync; buf lives in the arena
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done

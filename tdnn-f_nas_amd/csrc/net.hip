@@ -769,6 +769,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
     }
     n->ng_in = share->ng_in;
     n->ng_out = share->ng_out;
+    n->oderiv_nonzero = share->oderiv_nonzero;
   } else if (c.use_natural_gradient) {
     // one input-side and one output-side preconditioner per updatable component; configuration of
     // TdnnDARTSV3Component::InitFromConfig (nnet-tdnn-component.cc:183-210), the same defaults as
@@ -962,6 +963,23 @@ int tdnnf_net_set_stats(tdnnf_net *n, const double *host_in, tdnnf_stream stream
   TDNNF_REQUIRE(n && host_in, "net_set_stats: null argument");
   std::vector<std::pair<double *, int>> b;
   stat_blocks(n, b);
+  {  // oderiv_count of every ReLU block ([count, value_sum[D], deriv_sum[D], oderiv_count, oderiv_sumsq[D]]); stat_blocks() order:
+     // tdnn1 (bn, relu), every tdnnf layer (bn, relu), both heads (bn1, relu, bn2)
+    std::vector<char> &nz = *n->oderiv_nonzero;
+    nz.assign(n->cfg.num_layers + 3, 0);
+    std::vector<int> is_relu = {0, 1};
+    for (int l = 0; l < n->cfg.num_layers; l++) is_relu.insert(is_relu.end(), {0, 1});
+    for (int h = 0; h < 2; h++) is_relu.insert(is_relu.end(), {0, 1, 0});
+    const double *p = host_in;
+    int k = 0;
+    for (size_t i = 0; i < b.size(); i++) {
+      if (i < is_relu.size() && is_relu[i]) {
+        const int D = (b[i].second - 2) / 3;
+        nz[k++] = p[1 + 2 * D] != 0.0;
+      }
+      p += b[i].second;
+    }
+  }
   TDNNF_HIP(hipStreamSynchronize((hipStream_t)stream));
   for (auto &x : b) {
     TDNNF_HIP(hipMemcpy(x.first, host_in, sizeof(double) * x.second, hipMemcpyHostToDevice));
@@ -1355,12 +1373,15 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // NonlinearComponent::StoreBackpropStats (nnet-component-itf.cc:461-480): "if (RandInt(0, 3) == 0 && oderiv_count_ != 0) return"
   // -- three minibatches in four, always the first; a decision stream of its own (the k-th ReLU of the backward pass)
   unsigned long long relu_k = 0;
-  auto oderiv_of = [&](double *relu_stats) -> double * {
-    const bool skip = step != 0 && ::tdnnf::tdnnf_decision((unsigned long long)step, 2 * (4096 + relu_k)) % 4 == 0;
+  auto oderiv_of = [&](double *relu_stats, int relu_index) -> double * {  // relu_index: 0 tdnn1, 1 + l tdnnf layer l, num_layers + 1 + h head h
+    std::vector<char> &nz = *n->oderiv_nonzero;
+    if ((int)nz.size() < c.num_layers + 3) nz.resize(c.num_layers + 3, 0);
+    const bool skip = nz[relu_index] && ::tdnnf::tdnnf_decision((unsigned long long)step, 2 * (4096 + relu_k)) % 4 == 0;
     relu_k++;
+    if (!skip) nz[relu_index] = 1;
     return skip ? nullptr : relu_stats + 1 + 2 * Hd;
   };
-  auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc, int comp,
+  auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc, int comp, int relu_index,
                               const float *mask = nullptr) -> int {
     const bool store = coin() || step == 0;
     const bool repair = c.relu_self_repair_scale > 0.f && coin();
@@ -1369,7 +1390,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const int fuse = out_stats_fuse(comp, view(&x), view(&d), view(&d), f);
     if (fuse < 0) return TDNNF_EINVAL;
     TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, cv, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
-                          n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr, oderiv_of(relu_stats)));
+                          n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr, oderiv_of(relu_stats, relu_index)));
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
@@ -1580,7 +1601,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0, false));
     CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
     CK(capture(hname + ".batchnorm1.deriv", d_b1));
-    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine));  // dA -> d affine out
+    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h));  // dA -> d affine out
     CK(capture(hname + ".affine.deriv", d_b1));
     CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
     if (h == 1) {
@@ -1617,7 +1638,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       if (fuse < 0) return TDNNF_EINVAL;
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
                             view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr,
-                            oderiv_of(L.relu_stats)));
+                            oderiv_of(L.relu_stats, 1 + l)));
     }
     CK(capture(lname + ".affine.deriv", d_aff));
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
@@ -1687,7 +1708,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     std::swap(d_cur, d_next);
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
-    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, mask_of(0)));
+    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, 0, mask_of(0)));
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }

@@ -541,9 +541,9 @@ class OracleNet:
         def relu_bwd(key, relu_out, d):
             dd = ((relu_out > 0) * d).astype(F)
             st = self.relu_stats.setdefault(key, dict(count=0.0, vs=np.zeros(relu_out.shape[1]), ds=np.zeros(relu_out.shape[1])))
-            # StoreBackpropStats (nnet-component-itf.cc:461-480) on the ReLU's out_deriv d: skipped when "RandInt(0, 3) == 0" except
-            # on the first minibatch -- the trainer's k-th ReLU of the backward pass takes decision(step, 2 (4096 + k)) for it
-            skip = step != 0 and decision(step, 2 * (4096 + relu_k[0])) % 4 == 0
+            # StoreBackpropStats (nnet-component-itf.cc:461-480) on the ReLU's out_deriv d: "if (RandInt(0, 3) == 0 && oderiv_count_ != 0)
+            # return" -- the trainer's k-th ReLU of the backward pass takes decision(step, 2 (4096 + k)) for the draw
+            skip = st.get("oc", 0.0) != 0 and decision(step, 2 * (4096 + relu_k[0])) % 4 == 0
             relu_k[0] += 1
             if not skip:
                 st["os"] = st.get("os", np.zeros(d.shape[1])) + (d.astype(np.float64) ** 2).sum(0)
