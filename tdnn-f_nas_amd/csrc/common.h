@@ -143,8 +143,10 @@ hipError_t colreduce_partial(int kind, MatView a, MatView b, float *partial, hip
 // the same with the chunking given: partial[c * cols + col] and, second quantity, partial[(sq_row_offset + c) * cols + col], c < chunks
 hipError_t colreduce_partial_into(int kind, MatView a, MatView b, int chunks, int rows_per_chunk, int sq_row_offset, float *partial, hipStream_t s);
 // BatchNorm forward: memo rows 0-2 from column partial sums / sums of squares laid out as above with sq_row_offset == chunks
-hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s);
-hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s);
+// store_stats (optional): BatchNormComponent::StoreStats ([count, sum[D], sumsq[D]] doubles += this minibatch) in the same launch
+hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s,
+                                         double *store_stats = nullptr);
+hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s, double *store_stats = nullptr);
 hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s);  // ws: colreduce_bytes(rows, cols)
 
 // the three separately launchable parts of the chain objective (chain.hip)

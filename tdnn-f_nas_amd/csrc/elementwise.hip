@@ -132,7 +132,7 @@ namespace {
 // from there (all-reduced over the ranks) instead of from the partial rows, and N is the global row count.
 __global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(const float *partial, int chunks, int D, int N, float epsilon,
                                                                       float target_rms, float *memo, double *sums_out = nullptr,
-                                                                      const double *sums_in = nullptr) {
+                                                                      const double *sums_in = nullptr, double *store = nullptr, int store_frames = 0) {
   __shared__ double red[2 * kFinLanes * (kFinCols + 1)];
   const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
   double q[2];
@@ -154,6 +154,11 @@ __global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(const floa
   memo[d] = mean;
   memo[D + d] = uvar;
   memo[2 * D + d] = 1.0f / sqrtf(v);
+  if (store) {  // BatchNormComponent::StoreStats (nnet-normalize-component.cc:551-589) in the same launch: count += I, sum += I mean, sumsq += I uvar
+    if (d == 0) store[0] += (double)store_frames;
+    store[1 + d] += (double)store_frames * mean;
+    store[1 + D + d] += (double)store_frames * uvar;
+  }
 }
 // memo rows 3 var_deriv_mod, 4 temp (:520-526)
 __global__ __launch_bounds__(kFinThreads) void bn_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms, float *memo,
@@ -689,17 +694,19 @@ BnSyncScope::BnSyncScope(BnSync *b) : prev(g_bn_sync) { g_bn_sync = b; }
 BnSyncScope::~BnSyncScope() { g_bn_sync = prev; }
 
 // memo rows 0-2 from partial column sums; with a BnSync installed the sums are all-reduced over the ranks first
-static hipError_t bn_fwd_finalize(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s) {
+static hipError_t bn_fwd_finalize(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s,
+                                  double *store = nullptr) {
   BnSync *sy = bn_sync_current();
   if (!sy) {
-    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo);
+    hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo,
+                       (double *)nullptr, (const double *)nullptr, store, rows);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo, sy->buf,
                      (const double *)nullptr);
   if (sy->fn(sy->ctx, sy->buf, 2LL * cols, (tdnnf_stream)s)) return hipErrorUnknown;
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows * sy->world, epsilon, target_rms, memo,
-                     (double *)nullptr, (const double *)sy->buf);
+                     (double *)nullptr, (const double *)sy->buf, store, rows);
   return hipGetLastError();
 }
 static hipError_t bn_bwd_finalize(const float *partial, int chunks, int rows, int D, float target_rms, float *memo, hipStream_t s) {
@@ -715,14 +722,15 @@ static hipError_t bn_bwd_finalize(const float *partial, int chunks, int rows, in
   return hipGetLastError();
 }
 // BatchNorm forward statistics only (memo rows 0-2); the trainer applies them in a fused pass (fused.hip)
-hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s) {
+hipError_t batchnorm_stats(MatView a, float epsilon, float target_rms, float *memo, void *ws, hipStream_t s, double *store_stats) {
   ColReducePlan pl = colreduce_plan(a.rows, a.cols);
   hipError_t e = colreduce_partial(1, a, a, (float *)ws, s);
   if (e != hipSuccess) return e;
-  return bn_fwd_finalize((const float *)ws, pl.chunks, a.rows, a.cols, epsilon, target_rms, memo, s);
+  return bn_fwd_finalize((const float *)ws, pl.chunks, a.rows, a.cols, epsilon, target_rms, memo, s, store_stats);
 }
-hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s) {
-  return bn_fwd_finalize(partial, chunks, rows, cols, epsilon, target_rms, memo, s);
+hipError_t batchnorm_stats_from_partials(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s,
+                                         double *store_stats) {
+  return bn_fwd_finalize(partial, chunks, rows, cols, epsilon, target_rms, memo, s, store_stats);
 }
 // acc[c] += scale * colsum(a)[c]   (two-stage, float4 loads)
 hipError_t colsum_add(MatView a, float scale, float *acc, void *ws, hipStream_t s) {

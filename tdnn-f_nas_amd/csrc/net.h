@@ -107,6 +107,8 @@ struct tdnnf_net {
     int N = 0;
   };
   std::vector<NgComp> ngc;         // by component
+  float *ng_bsum_all = nullptr;    // the components' raw bias gradients (NgComp::bsum), one block: zeroed once per step
+  size_t ng_bsum_floats = 0;
   float *ngTmp = nullptr;          // per-object chain: projection scratch
   void *ng_side_ws = nullptr;      // per-object chain: workspace of L = H^T H
   size_t ngset_ws_bytes = 0;

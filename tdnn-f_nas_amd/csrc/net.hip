@@ -202,9 +202,15 @@ __global__ void transpose_kernel(const float *in, int rows, int cols, float *out
     out[(size_t)c * rows + r] = in[e];
   }
 }
-__global__ void scale_doubles_kernel(double *x, int n, double s) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] *= s;
+// ScaleBatchnormStats: every BatchNorm's [count, sum[D], sumsq[D]] *= s in one launch (block row = one component)
+struct ScaleTable {
+  double *p[48];
+  int n[48];
+};
+__global__ void scale_doubles_kernel(ScaleTable tb, double s) {
+  double *x = tb.p[blockIdx.y];
+  const int n = tb.n[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) x[i] *= s;
 }
 // lda input: [feats(k+j, b), j < S ; ivector(b)]
 __global__ void splice_input_kernel(MatView feats, MatView iv, int B, int S, MatView out) {
@@ -420,7 +426,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
       S.H_in = A.take<float>((size_t)rows * Rpi + 64);
       S.H_out = A.take<float>((size_t)rows * Rpo + 64);
       S.T = A.take<float>((size_t)cd.rows * ldT + 16);
-      S.bsum = A.take<float>((size_t)cd.rows + 16);
+      S.bsum = nullptr;  // (carved below: one block for all components, zeroed once per step)
       S.part_in = A.take<double>((size_t)rows_gemm_sumsq_blocks(rows) + 8);
       S.part_out = A.take<double>((size_t)rows_gemm_sumsq_blocks(rows) + 8);
     };
@@ -435,6 +441,19 @@ void layout_arena(tdnnf_net *n, Arena &A) {
       comp_ng(n->head[h].c_affine, 1, No_);
       comp_ng(n->head[h].c_linear, 1, No_);
       comp_ng(n->head[h].c_output, 1, No_);
+    }
+    {
+      size_t tot = 0;
+      for (size_t i = 0; i < n->comps.size(); i++)
+        if (n->ngc[i].N > 0) tot += ((size_t)n->comps[i].rows + 15) & ~(size_t)15;  // (N, not the pointers: the sizing pass has none)
+      n->ng_bsum_floats = tot;
+      n->ng_bsum_all = A.take<float>(tot + 16);
+      size_t o = 0;
+      for (size_t i = 0; i < n->comps.size(); i++)
+        if (n->ngc[i].N > 0) {
+          n->ngc[i].bsum = n->ng_bsum_all ? n->ng_bsum_all + o : nullptr;
+          o += ((size_t)n->comps[i].rows + 15) & ~(size_t)15;
+        }
     }
     const size_t maxN = (size_t)std::max(std::max(max_rows, N0), No_);
     n->ngset_ws_bytes = wgrad_workspace_bytes(80, 80, 1, (int)maxN) + 256;
@@ -541,16 +560,17 @@ int affine_relu_bn_stats(tdnnf_net *n, const tdnnf_tdnn_indexes *ix, const tdnnf
   int prows = 0;
   const bool room = n->ws_bytes >= sizeof(float) * 2 * (size_t)Do * rows_gemm_colstats_cap(out->rows);
   CK(tdnn_propagate_impl(ix, in, W, ldw, Do, Di, bias, eff, 1, 1, out, s, room ? (float *)n->ws : nullptr, room ? &prows : nullptr));
-  if (prows > 0) TDNNF_HIP(batchnorm_stats_from_partials((const float *)n->ws, prows, out->rows, Do, 1.0e-3f, 1.0f, memo, s));
-  else TDNNF_HIP(batchnorm_stats(view(out), 1.0e-3f, 1.0f, memo, n->ws, s));
-  return tdnnf_batchnorm_store_stats(memo, Do, out->rows, stats, s);
+  // (StoreStats runs on every minibatch: in the finalize launch)
+  if (prows > 0) TDNNF_HIP(batchnorm_stats_from_partials((const float *)n->ws, prows, out->rows, Do, 1.0e-3f, 1.0f, memo, s, stats));
+  else TDNNF_HIP(batchnorm_stats(view(out), 1.0e-3f, 1.0f, memo, n->ws, s, stats));
+  return TDNNF_OK;
 }
 // statistics of BatchNorm(x) only; the normalisation itself is applied by a fused pass
 int bn_stats(tdnnf_net *n, float *x, int rows, int cols, float *memo, double *stats, hipStream_t s) {
   if (n->cfg.cv_update) return bn_test_memo(memo, stats, cols, s);
   tdnnf_mat a = M(x, rows, cols);
-  TDNNF_HIP(batchnorm_stats(view(&a), 1.0e-3f, 1.0f, memo, n->ws, s));
-  return tdnnf_batchnorm_store_stats(memo, cols, rows, stats, s);
+  TDNNF_HIP(batchnorm_stats(view(&a), 1.0e-3f, 1.0f, memo, n->ws, s, stats));
+  return TDNNF_OK;
 }
 
 }  // namespace
@@ -1156,6 +1176,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_ngc, hipEventDisableTiming));
   }
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
+  if (n->ng_bsum_all && n->ng_bsum_floats) TDNNF_HIP(hipMemsetAsync(n->ng_bsum_all, 0, sizeof(float) * n->ng_bsum_floats, s));  // every component's raw bias gradient
   n->pg_count = 0;
   // Refreshes whose host part has finished: upload W_{t+1} now, on the side stream, which is idle during the forward pass --
   // otherwise the ~9 small launches of each (18 refreshes per step) sit in front of the component's statistics passes in the
@@ -1428,8 +1449,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   auto bias_target = [&](int comp) -> float * {  // where a fused backward pass should accumulate the raw bias gradient
     if (n->comps[comp].lr_factor == 0.f) return nullptr;  // "if (to_update && learning_rate != 0)": no model derivative
     if (!use_ng) return Bg(n, comp);
-    (void)hipMemsetAsync(n->ngc[comp].bsum, 0, sizeof(float) * n->comps[comp].rows, s);
-    return n->ngc[comp].bsum;
+    return n->ngc[comp].bsum;  // (zeroed with all the others at the start of the step)
   };
   auto param_grad = [&](int comp, const tdnnf_tdnn_indexes &ix, int K, int Di, int Do, tdnnf_mat *x, tdnnf_mat *dyv, const float *eff,
                         bool bias_done, const int *active, int max_active, bool from_tapgrad) -> int {
@@ -1475,10 +1495,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     else
       CK(tdnn_update_simple_impl(&ix, x, dyv, Do, Di, eff, 1.0f, T, ldT, nullptr, wsw, n->ws_bytes, active, max_active, sw, overwrite));
     if (ones) {
-      if (!bias_done) {  // (otherwise S.bsum was filled by the fused ReLU backward pass on s)
-        TDNNF_HIP(hipMemsetAsync(S.bsum, 0, sizeof(float) * Do, sw));
-        TDNNF_HIP(colsum_add(view(dyv), 1.0f, S.bsum, wsw, sw));
-      }
+      if (!bias_done) TDNNF_HIP(colsum_add(view(dyv), 1.0f, S.bsum, wsw, sw));  // (otherwise the fused ReLU backward pass on s filled it)
       if (!grouped) hipLaunchKernelGGL(set_column_kernel, dim3((Do + 255) / 256), dim3(256), 0, sw, S.bsum, Do, T, ldT, ldw);
     }
     // ---- the passes over the N-sized operands
@@ -1748,9 +1765,16 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
   // ScaleBatchnormStats
   if (n->cfg.batchnorm_stats_scale != 1.0f && !n->cfg.cv_update) {  // (BatchNormTestComponents are not scaled)
     const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
+    ScaleTable tb;
+    memset(&tb, 0, sizeof(tb));
+    int nb = 0, maxn = 0;
     auto sc = [&](double *st, int D) {
-      hipLaunchKernelGGL(scale_doubles_kernel, dim3((1 + 2 * D + 255) / 256), dim3(256), 0, s, st, 1 + 2 * D,
-                         (double)n->cfg.batchnorm_stats_scale);
+      if (nb < 48) {
+        tb.p[nb] = st;
+        tb.n[nb] = 1 + 2 * D;
+        maxn = std::max(maxn, 1 + 2 * D);
+        nb++;
+      }
     };
     sc(n->t1_bn_stats, Hd);
     for (auto &L : n->layers) sc(L.bn_stats, Hd);
@@ -1758,6 +1782,8 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
       sc(n->head[h].bn1_stats, Hd);
       sc(n->head[h].bn2_stats, S);
     }
+    TDNNF_REQUIRE(nb == (int)n->layers.size() + 5, "net_update: too many BatchNorm components for one launch");
+    hipLaunchKernelGGL(scale_doubles_kernel, dim3((maxn + 255) / 256, nb), dim3(256), 0, s, tb, (double)n->cfg.batchnorm_stats_scale);
   }
   // ConstrainOrthonormal: each constrained component with probability 1/4 (nnet-utils.cc:1062)
   for (int i = 0; i < nc; i++) {

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "tdnnf_nnet3_adapter.h"
+#include "tdnnf_nnet3_components.h"
 
 #define HIPCK(e)                                                                      \
   do {                                                                                \
@@ -274,9 +275,176 @@ static void run_mixing(const Blob &in, FILE *out) {
   write_mat(out, "onehot_acc", onehot_acc.Host());
 }
 
+// ---- the same two scenarios through the Component CLASSES of tdnnf_nnet3_components.h, created by factory name and driven
+// through the virtual interface only (Propagate / StoreStats / Backprop with a second instance as the delta-nnet `to_update`),
+// the way NnetComputer drives kaldi::nnet3::Component.  Outputs carry the names of run_stack / run_tdnn: the test holds them equal.
+namespace n3 = tdnnf_nnet3;
+static void *hook_alloc(size_t bytes) {
+  void *p = nullptr;
+  HIPCK(hipMalloc(&p, std::max<size_t>(bytes, 256)));
+  HIPCK(hipMemset(p, 0, std::max<size_t>(bytes, 256)));
+  return p;
+}
+static void hook_free(void *p) { (void)hipFree(p); }
+static std::vector<float> g_draws;  // what the components' RandUniform calls return, in call order
+static size_t g_draw_pos = 0;
+static void hook_uniform(float *dev, int n) {
+  if (g_draw_pos + n > g_draws.size()) { std::fprintf(stderr, "out of draws\n"); std::exit(4); }
+  HIPCK(hipMemcpy(dev, g_draws.data() + g_draw_pos, sizeof(float) * n, hipMemcpyHostToDevice));
+  g_draw_pos += n;
+}
+static void install_hooks() {
+  n3::Hooks().alloc = hook_alloc;
+  n3::Hooks().free = hook_free;
+  n3::Hooks().fill_uniform = hook_uniform;
+  n3::Hooks().stream = nullptr;
+}
+static n3::CuMatrixBase V(CuMatrixStub &m) { return n3::CuMatrixBase(m.Data(), m.NumRows(), m.NumCols(), m.Stride()); }
+struct DenseParams {  // a component's parameter matrix, dense on the device
+  float *d = nullptr;
+  int rows, cols;
+  DenseParams(int r, int c, const HostMat *init) : rows(r), cols(c) {
+    d = (float *)hook_alloc(sizeof(float) * (size_t)std::max(1, r * c));
+    if (init && !init->v.empty()) HIPCK(hipMemcpy(d, init->v.data(), sizeof(float) * init->v.size(), hipMemcpyHostToDevice));
+  }
+  ~DenseParams() { hook_free(d); }
+  void Zero() { HIPCK(hipMemset(d, 0, sizeof(float) * (size_t)std::max(1, rows * cols))); }
+  HostMat Host() const {
+    HostMat m;
+    m.rows = rows;
+    m.cols = cols;
+    m.v.resize((size_t)rows * cols);
+    HIPCK(hipDeviceSynchronize());
+    if (!m.v.empty()) HIPCK(hipMemcpy(m.v.data(), d, sizeof(float) * m.v.size(), hipMemcpyDeviceToHost));
+    return m;
+  }
+};
+template <class T>
+static T *make(const char *type) {
+  n3::Component *c = n3::Component::NewComponentOfType(type);
+  T *t = dynamic_cast<T *>(c);
+  if (!t || c->Type() != type) { std::fprintf(stderr, "factory: %s\n", type); std::exit(5); }
+  return t;
+}
+
+static void run_stack_classes(const Blob &in, FILE *out) {
+  install_hooks();
+  const HostMat &cfg = in.at("cfg");
+  const int steps = (int)cfg.at(0);
+  const float lr = cfg.at(1), repair = cfg.at(2);
+  const HostMat &hWa = in.at("Wa"), &hWl = in.at("Wl"), &hba = in.at("ba");
+  const int Di = hWa.cols, H = hWa.rows, P = hWl.rows;
+  DenseParams Wa(H, Di, &hWa), Wl(P, H, &hWl), ba(1, H, &hba), Wa_acc(H, Di, nullptr), Wl_acc(P, H, nullptr), ba_acc(1, H, nullptr);
+  DevBytes relu_stats(sizeof(double) * (1 + 2 * H)), bn_stats(sizeof(double) * (1 + 2 * H));
+  auto *aff = make<n3::NaturalGradientAffineComponent>("NaturalGradientAffineComponent");
+  auto *aff_upd = make<n3::NaturalGradientAffineComponent>("NaturalGradientAffineComponent");
+  auto *lin = make<n3::LinearComponent>("LinearComponent");
+  auto *lin_upd = make<n3::LinearComponent>("LinearComponent");
+  auto *relu = make<n3::RectifiedLinearComponent>("RectifiedLinearComponent");
+  auto *bn = make<n3::BatchNormComponent>("BatchNormComponent");
+  auto *lsmc = make<n3::LogSoftmaxComponent>("LogSoftmaxComponent");
+  aff->SetParams(Di, H, Wa.d, ba.d);
+  aff_upd->SetParams(Di, H, Wa_acc.d, ba_acc.d);
+  aff_upd->SetUnderlyingLearningRate(lr);
+  lin->SetParams(H, P, Wl.d, nullptr);
+  lin_upd->SetParams(H, P, Wl_acc.d, nullptr);
+  lin_upd->SetUnderlyingLearningRate(lr);
+  relu->Init(H, repair, (double *)relu_stats.p);
+  bn->Init(H, 1.0e-3f, 1.0f, (double *)bn_stats.p);
+  lsmc->Init(P);
+  for (int t = 0; t < steps; t++) {
+    const std::string sfx = std::to_string(t);
+    CuMatrixStub x(in.at("x" + sfx)), dlsm(in.at("d" + sfx));
+    const int N = x.NumRows();
+    CuMatrixStub a(N, H), r(N, H), z(N, H), l(N, P), lsm(N, P);
+    n3::CuMatrixBase vx = V(x), va = V(a), vr = V(r), vz = V(z), vl = V(l), vlsm = V(lsm), vdlsm = V(dlsm);
+    aff->Propagate(nullptr, vx, &va);
+    relu->Propagate(nullptr, va, &vr);
+    relu->StoreStats(va, vr, nullptr);
+    void *memo = bn->Propagate(nullptr, vr, &vz);
+    bn->StoreStats(vr, vz, memo);
+    lin->Propagate(nullptr, vz, &vl);
+    lsmc->Propagate(nullptr, vl, &vlsm);
+    CuMatrixStub dl(N, P), dz(N, H), dr(N, H), da(N, H), dxm(N, Di);
+    n3::CuMatrixBase vdl = V(dl), vdz = V(dz), vdr = V(dr), vda = V(da), vdx = V(dxm);
+    Wa_acc.Zero(); Wl_acc.Zero(); ba_acc.Zero();
+    lsmc->Backprop("", nullptr, vl, vlsm, vdlsm, nullptr, nullptr, &vdl);
+    lin->Backprop("", nullptr, vz, vl, vdl, nullptr, lin_upd, &vdz);
+    bn->Backprop("", nullptr, vr, vz, vdz, memo, nullptr, &vdr);
+    relu->Backprop("", nullptr, va, vr, vdr, nullptr, relu, &vda);
+    aff->Backprop("", nullptr, vx, va, vda, nullptr, aff_upd, &vdx);
+    HIPCK(hipDeviceSynchronize());
+    bn->DeleteMemo(memo);
+    write_mat(out, "lsm" + sfx, lsm.Host());
+    write_mat(out, "z" + sfx, z.Host());
+    write_mat(out, "dx" + sfx, dxm.Host());
+    write_mat(out, "da" + sfx, da.Host());
+    write_mat(out, "Wl_acc" + sfx, Wl_acc.Host());
+    write_mat(out, "Wa_acc" + sfx, Wa_acc.Host());
+    write_mat(out, "ba_acc" + sfx, ba_acc.Host());
+  }
+  write_mat(out, "relu_stats", doubles_to_host((const double *)relu_stats.p, 1 + 2 * H));
+  write_mat(out, "bn_stats", doubles_to_host((const double *)bn_stats.p, 1 + 2 * H));
+  HIPCK(hipDeviceSynchronize());
+  for (n3::Component *c : std::vector<n3::Component *>{aff, aff_upd, lin, lin_upd, relu, bn, lsmc}) delete c;
+}
+
+static void run_tdnn_classes(const Blob &in, FILE *out) {
+  install_hooks();
+  const HostMat &cfg = in.at("cfg");
+  const int K = (int)cfg.at(0), Di = (int)cfg.at(1), Do = (int)cfg.at(2), rho = (int)cfg.at(3), flags = (int)cfg.at(4), steps = (int)cfg.at(7);
+  const float temp = cfg.at(5), lr = cfg.at(6);
+  const bool darts = flags >= 0, off1pos = cfg.at(8) != 0.f;
+  n3::TdnnPrecomputedIndexes ix;
+  ix.row_stride = rho;
+  for (int i = 0; i < K; i++) ix.row_offsets.push_back((int)cfg.at(9 + i));
+  const HostMat &hW = in.at("W"), &hb = in.at("bias");
+  DenseParams W(Do, K * Di, &hW), bias(1, (int)hb.v.size(), &hb), W_acc(Do, K * Di, nullptr), b_acc(1, (int)hb.v.size(), nullptr);
+  n3::TdnnComponentBase *c = darts ? (n3::TdnnComponentBase *)make<n3::TdnnDARTSV3Component>("TdnnDARTSV3Component") : make<n3::TdnnComponent>("TdnnComponent");
+  n3::TdnnComponentBase *upd = darts ? (n3::TdnnComponentBase *)make<n3::TdnnDARTSV3Component>("TdnnDARTSV3Component") : make<n3::TdnnComponent>("TdnnComponent");
+  c->SetParams(K, Di, Do, W.d, bias.d, off1pos);
+  upd->SetParams(K, Di, Do, W_acc.d, b_acc.d, off1pos);
+  upd->SetUnderlyingLearningRate(lr);
+  if (darts) {
+    c->SetDartsFlags(flags, temp);
+    upd->SetDartsFlags(flags, temp);
+  }
+  for (int t = 0; t < steps; t++) {
+    const std::string sfx = std::to_string(t);
+    CuMatrixStub x(in.at("x" + sfx)), dy(in.at("dy" + sfx));
+    const int N = dy.NumRows();
+    CuMatrixStub y(N, Do), dx(x.NumRows(), Di);
+    if (darts) {
+      g_draws = in.at("draws" + sfx).v;
+      g_draw_pos = 0;
+    }
+    W_acc.Zero();
+    b_acc.Zero();
+    n3::CuMatrixBase vx = V(x), vy = V(y), vdy = V(dy), vdx = V(dx);
+    void *memo = c->Propagate(&ix, vx, &vy);
+    c->Backprop("", &ix, vx, vy, vdy, memo, upd, &vdx);
+    HIPCK(hipDeviceSynchronize());
+    if (darts) {  // [coef | effective coef]
+      HostMat m;
+      m.rows = 1;
+      m.cols = 2 * K;
+      m.v.resize(2 * K);
+      HIPCK(hipMemcpy(m.v.data(), memo, sizeof(float) * 2 * K, hipMemcpyDeviceToHost));
+      write_mat(out, "memo" + sfx, m);
+    }
+    c->DeleteMemo(memo);
+    write_mat(out, "y" + sfx, y.Host());
+    write_mat(out, "dx" + sfx, dx.Host());
+    write_mat(out, "W_acc" + sfx, W_acc.Host());
+    write_mat(out, "b_acc" + sfx, b_acc.Host());
+  }
+  delete c;
+  delete upd;
+}
+
 int main(int argc, char **argv) {
   if (argc != 4) {
-    std::fprintf(stderr, "usage: adapter_driver tdnn|stack|mixing in.bin out.bin\n");
+    std::fprintf(stderr, "usage: adapter_driver tdnn|stack|mixing|tdnn_classes|stack_classes in.bin out.bin\n");
     return 2;
   }
   try {
@@ -287,6 +455,8 @@ int main(int argc, char **argv) {
     if (what == "tdnn") run_tdnn(in, out);
     else if (what == "stack") run_stack(in, out);
     else if (what == "mixing") run_mixing(in, out);
+    else if (what == "stack_classes") run_stack_classes(in, out);
+    else if (what == "tdnn_classes") run_tdnn_classes(in, out);
     else return 2;
     std::fclose(out);
   } catch (const std::exception &e) {

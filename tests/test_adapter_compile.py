@@ -59,3 +59,53 @@ def test_adapter_driver_instantiates_every_adapter_function(tmp_path, pkg):
     unused = sorted(f for f in funcs if not re.search(r"\b%s\(" % f, driver))
     # the two that need a denominator graph / an orthonormal matrix are driven from Python tests through the same C entry points
     assert set(unused) <= {"ChainObjfAndDeriv", "ConstrainOrthonormal", "BatchNormTestPropagate", "BatchNormTestBackprop", "BatchNormComputeDerived"}, unused
+
+
+def test_component_classes_register_under_the_factory_names(tmp_path, pkg):
+    """include/tdnnf_nnet3_components.h compiles with plain g++ (no Kaldi, no HIP headers) and serves the reference's factory
+    names (Component::NewComponentOfType, nnet-component-itf.cc:120-281) with the reference's Properties() flags."""
+    src = tmp_path / "components_check.cc"
+    src.write_text(textwrap.dedent('''
+        #include <cstdio>
+        #include "tdnnf_nnet3_components.h"
+        int main() {
+          using namespace tdnnf_nnet3;
+          for (const std::string &t : RegisteredTypes()) {
+            Component *c = Component::NewComponentOfType(t);
+            if (!c || c->Type() != t) return 1;
+            std::printf("%s %d\\n", t.c_str(), c->Properties());
+            delete c;
+          }
+          if (Component::NewComponentOfType("SigmoidComponent") != nullptr) return 2;  // not ours: the caller falls through to Kaldi's own
+          BatchNormComponent bn;
+          CuMatrixBase m(nullptr, 4, 8, 8);
+          try {  // no allocator hook installed: a clear error, not a crash
+            bn.Propagate(nullptr, m, &m);
+          } catch (const std::runtime_error &e) {
+            std::printf("caught: %s\\n", e.what());
+            return 0;
+          }
+          return 3;
+        }
+    '''))
+    exe = tmp_path / "components_check"
+    lib_dir = os.path.dirname(pkg.hipabi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-ltdnnf_hip", f"-Wl,-rpath,{lib_dir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "caught: tdnnf_nnet3: DeviceHooks::alloc is not installed" in out.stdout, out
+    props = dict(line.split() for line in out.stdout.splitlines() if line and not line.startswith("caught"))
+    k = dict(simple=1, updatable=2, prop_in_place=4, prop_adds=8, reorders=0x10, bp_adds=0x20, needs_in=0x40, needs_out=0x80, bp_in_place=0x100,
+             stores=0x200, memo=0x1000, random=0x2000)
+    # nnet-convolutional-component.h:130-134 (no bias set yet -> kPropagateAdds), nnet-normalize-component.h:182-190 / :359-366,
+    # nnet-simple-component.h (LinearComponent, SoftmaxFlops / GumbelSoftmaxFlops, CopyN, ElementwiseProduct, RectifiedLinear, LogSoftmax)
+    assert int(props["TdnnDARTSV3Component"]) == k["updatable"] | k["reorders"] | k["bp_adds"] | k["prop_adds"] | k["needs_in"] | k["memo"]
+    assert int(props["BatchNormComponent"]) == k["simple"] | k["needs_out"] | k["prop_in_place"] | k["bp_in_place"] | k["memo"] | k["stores"]
+    assert int(props["BatchNormTestComponent"]) == k["simple"] | k["needs_out"] | k["prop_in_place"] | k["bp_in_place"]
+    assert int(props["GumbelSoftmaxFlopsComponent"]) == k["bp_in_place"] | k["simple"] | k["needs_in"] | k["needs_out"] | k["random"]
+    assert int(props["LinearComponent"]) == k["simple"] | k["updatable"] | k["needs_in"] | k["prop_adds"] | k["bp_adds"]
+    assert int(props["CopyNComponent"]) == k["simple"] | k["prop_adds"] | k["bp_adds"]
+    assert int(props["ElementwiseProductComponent"]) == k["simple"] | k["needs_in"]
+    assert int(props["RectifiedLinearComponent"]) == k["simple"] | k["needs_out"] | k["prop_in_place"] | k["stores"]
+    assert int(props["LogSoftmaxComponent"]) == k["simple"] | k["needs_out"] | k["stores"]
+    assert len(props) == 14

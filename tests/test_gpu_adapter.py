@@ -131,6 +131,12 @@ def test_tdnn_components_through_the_adapter(driver, ora, pkg, tmp_path, flags):
             assert rel_l2(got[f"b_acc{t}"].ravel()[:K], b_acc[:K]) < 1e-4 or not np.any(b_acc[:K])
     L.oracle_ng_destroy(ngi)
     L.oracle_ng_destroy(ngo)
+    # the same minibatches through the Component CLASS (tdnnf_nnet3_components.h): created by factory name, driven through the
+    # virtual Propagate / Backprop with a second instance as the delta-nnet, its RandUniform hook fed the same draws
+    cls = driver("tdnn_classes", arrays, tmp_path)
+    assert set(cls) == set(got)
+    for k in got:
+        assert rel_l2(cls[k], got[k]) < 1e-6, (k, rel_l2(cls[k], got[k]))
 
 
 def test_affine_relu_batchnorm_linear_logsoftmax_through_the_adapter(driver, ora, tmp_path):
@@ -187,6 +193,11 @@ def test_affine_relu_batchnorm_linear_logsoftmax_through_the_adapter(driver, ora
     assert rel_l2(got["bn_stats"].ravel(), np.concatenate([[bcnt.value], bsum, bsq])) < 1e-5
     for g in nga + ngl:
         L.oracle_ng_destroy(g)
+    # the same stack as Component CLASSES created by factory name and driven through the virtual interface (StoreStats included)
+    cls = driver("stack_classes", arrays, tmp_path)
+    assert set(cls) == set(got)
+    for k in got:
+        assert rel_l2(cls[k], got[k]) < 1e-6, (k, rel_l2(cls[k], got[k]))
 
 
 def test_darts_mixing_components_through_the_adapter(driver, ora, tmp_path):

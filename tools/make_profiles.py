@@ -28,7 +28,9 @@ def klass(nm):
     if (s.startswith("rows_gemm_kernel") or s.startswith("wgrad_kernel")) and (s.endswith(", 1>") or s.startswith("rows_gemm_kernel<4, 1, 1, 1")
                                                                                 or s.startswith("rows_gemm_kernel<4, 1, 1, 3")):
         return "ng_skinny_gemm_f32"
-    if s.startswith("rows_gemm_kernel<2, 2, 2, 2"):
+    if s.startswith(("ggemm_", "ng_l_", "ng_commit", "ng_set_columns", "ng_stage", "ng_fin_")):
+        return "ng_grouped_side_chain"
+    if s.startswith("rows_gemm_kernel<2, 2, 2, 2") or s.startswith("rows_gemm_kernel<2, 2, 1, 2"):
         return "rows_gemm_f32_128x128"
     if s.startswith("rows_gemm_kernel<4, 1, 1, 5"):
         return "rows_gemm_f32_128x160"
@@ -94,4 +96,27 @@ if os.path.exists(bl):
             alg = k["algorithmic_bytes_per_step"] / 1e9
             f.write("%s,%.1f,%.3f,%.4f,%.3f,%.2f,%s,%s\n" % (k["kernel"], n, k["ms"] / steps, k["flops_per_step"] / 1e12, alg, k["tflops"],
                                                          "%.3f" % pm_step if pm_step else "", "%.3f" % (pm_step / alg) if pm_step and alg else ""))
+# kernel-class tables of the other profiled runs (supernets, small shapes): gpurun_out/<stats_dir>_<name>/
+for d in sorted(glob.glob(f"gpurun_out/{stats_dir}_*")):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)[len(stats_dir) + 1:]
+    st = glob.glob(f"{d}/*/*_kernel_stats.csv") + glob.glob(f"{d}/*_kernel_stats.csv")
+    if not st:
+        continue
+    by2 = collections.defaultdict(lambda: [0, 0])
+    for r in csv.DictReader(open(st[0])):
+        k = klass(r["Name"])
+        by2[k][0] += int(r["Calls"])
+        by2[k][1] += int(r["TotalDurationNs"])
+    tot2 = sum(v[1] for v in by2.values())
+    with open(f"profiles/{tag}_{name}_kernel_classes.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel_class", "calls", "total_ms", "avg_us", "percent"])
+        for k, (n, ns) in sorted(by2.items(), key=lambda kv: -kv[1][1]):
+            w.writerow([k, n, f"{ns / 1e6:.3f}", f"{ns / n / 1e3:.1f}", f"{100.0 * ns / tot2:.2f}"])
+    for suffix, dst in (("_bench_line.json", "_bench_line.json"), ("_overlap.txt", "_stream_overlap.txt"), ("_dispatches.txt", "_dispatches_per_step.txt")):
+        src = f"gpurun_out/{stats_dir}_{name}{suffix}"
+        if os.path.exists(src):
+            shutil.copy(src, f"profiles/{tag}_{name}{dst}")
 print("wrote profiles for", tag, "classes:", len(by), "pmc kernels:", len(out))
