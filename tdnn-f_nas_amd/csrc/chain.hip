@@ -1062,10 +1062,20 @@ int tdnnf_chain_set_denominator_mode(int mode) {
 size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *g, int B, int T) {
   if (!g || B <= 0 || T <= 0) return 0;
   ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
-  return sizeof(double) * (3 * (size_t)B + 2) + sizeof(float) * (p.alpha_floats + p.asum_floats + p.gstate_floats + p.la_floats) + 512;
+  return sizeof(double) * (3 * (size_t)B + 2) + sizeof(float) * (p.alpha_floats + p.asum_floats + p.gstate_floats + p.la_floats) + 768;
 }
 
 }  // extern "C"
+
+namespace tdnnf {
+// Bytes at the END of the workspace that only the split persistent form (den_forward beside den_beta, then den_gamma) touches: a caller
+// that always passes beside_other_work = true to chain_den may allocate that much less.
+size_t chain_split_region_bytes(const tdnnf_den_graph *g, int B, int T) {
+  if (!g || B <= 0 || T <= 0) return 0;
+  ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
+  return p.split ? sizeof(float) * p.gstate_floats : 0;
+}
+}  // namespace tdnnf
 
 namespace tdnnf {
 namespace {
@@ -1084,9 +1094,11 @@ ChainBufs chain_bufs(const tdnnf_den_graph *g, int B, int T, void *ws) {
   b.l2sum = b.xent + B;
   b.alpha = (float *)(((uintptr_t)(b.l2sum + 2) + 127) & ~(uintptr_t)127);  // the wide form gathers 64- / 128-byte runs: keep them in one line
   b.asum = b.alpha + b.p.alpha_floats;
-  b.gstate = b.asum + b.p.asum_floats;
-  b.la = (double *)(((uintptr_t)(b.gstate + b.p.gstate_floats) + 7) & ~(uintptr_t)7);
+  // the numerator's arrays before the denominator's state region: that one is the workspace's tail, so a caller that never runs the split form
+  // (chain_split_region_bytes) can leave it out
+  b.la = (double *)(((uintptr_t)(b.asum + b.p.asum_floats) + 7) & ~(uintptr_t)7);
   b.lb = b.la + (b.p.la_floats - 2) / 4;
+  b.gstate = (float *)(((uintptr_t)(b.la + b.p.la_floats / 2) + 127) & ~(uintptr_t)127);
   return b;
 }
 SupDev sup_dev(const tdnnf_supervision *sp) {

@@ -154,6 +154,7 @@ bool log_softmax_propagate_with_aux(const tdnnf_mat *in, tdnnf_mat *out, tdnnf_m
 float chain_supervision_weight(const tdnnf_supervision *sp);
 // beside_other_work: the caller runs other kernels next to the denominator (the trainer: the xent head), so the persistent form keeps
 // its one-kernel backward pass instead of running the two recursions side by side on a further stream
+size_t chain_split_region_bytes(const tdnnf_den_graph *g, int B, int T);
 int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws, hipStream_t s,
               bool beside_other_work = false, hipStream_t caller_aux = nullptr);
 int chain_num_recursion(const tdnnf_supervision *sp, const tdnnf_den_graph *g, const tdnnf_mat *y, void *ws, hipStream_t s);

@@ -1137,6 +1137,18 @@ static BnChoice bn_choice(const tdnnf_net_config &c) {
   return bc;
 }
 
+namespace {
+// Few sequences leave most CUs idle while one workgroup per sequence walks the frames: there the backward recursion of the denominator runs beside
+// the forward one and the occupancies of all frames at once (the split form).  Measured (ms per step, one-kernel backward -> split): 1500 x 16
+// 37.3 -> 28.5, x 32 53.1 -> 45.3, x 64 80.9 -> 75.2, x 128 127.6 -> 128.2; 150 x 64 14.2 -> 13.8.  The second recursion runs on the
+// natural-gradient side stream, which is idle until the backward pass (on a stream of its own -- a fifth in flight -- the step at 150 x 64 took
+// 20.0 ms: they then share hardware queues).  TDNNF_DEN_TRAINER_SPLIT=0|1 forces one.
+bool den_uses_split(int B) {
+  static const int env = getenv("TDNNF_DEN_TRAINER_SPLIT") ? atoi(getenv("TDNNF_DEN_TRAINER_SPLIT")) : -1;
+  return env >= 0 ? env != 0 : B <= 96;
+}
+}  // namespace
+
 int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *den,
                                const tdnnf_supervision *sup, double *results, long long step, tdnnf_stream stream) {
   TDNNF_REQUIRE(n && n->params && n->grads, "net_forward_backward: call net_set_buffers first");
@@ -1149,7 +1161,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   hipStream_t s = (hipStream_t)stream;
   const bool cv = c.cv_update != 0;  // BatchNorm components are BatchNormTestComponents
   if (!n->chain_ws) {
-    n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout);
+    n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B) ? 0 : chain_split_region_bytes(den, B, n->Tout));
     TDNNF_HIP(hipMalloc(&n->chain_ws, n->chain_ws_bytes));
     TDNNF_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
@@ -1223,7 +1235,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
     hipLaunchKernelGGL(transpose_weights_kernel, dim3(256, nc), dim3(256), 0, s, n->params, n->paramsT, tb);
   }
-  TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout), "net_forward_backward: denominator graph changed size");
+  TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B) ? 0 : chain_split_region_bytes(den, B, n->Tout)),
+                "net_forward_backward: denominator graph changed size");
   // the reference's RandInt()/RandUniform() coin flips, made reproducible: k-th decision of this minibatch
   unsigned long long coin_k = 0;
   auto coin = [&]() { return (int)(::tdnnf::tdnnf_decision((unsigned long long)step, 2 * coin_k++) & 1); };
@@ -1321,11 +1334,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
       // few sequences leave most CUs idle while one workgroup per sequence walks the frames: there the backward recursion runs
       // beside the forward one (den_beta_kernel on a further stream) and the occupancies of all frames at once
-      static const int den_split_env = getenv("TDNNF_DEN_TRAINER_SPLIT") ? atoi(getenv("TDNNF_DEN_TRAINER_SPLIT")) : -1;
-      // measured (ms per step, one-kernel backward -> split): 1500 x 16 37.3 -> 28.5, x 32 53.1 -> 45.3, x 64 80.9 -> 75.2, x 128 127.6 -> 128.2;
-      // 150 x 64 14.2 -> 13.8.  The second recursion runs on the natural-gradient side stream, which is idle until the backward pass
-      // (on a stream of its own -- a fifth in flight -- the step at 150 x 64 took 20.0 ms: they then share hardware queues)
-      const bool den_split = den_split_env >= 0 ? den_split_env != 0 : B <= 96;
+      const bool den_split = den_uses_split(B);
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fork, 0));
       CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, !den_split, n->s3));
       TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));

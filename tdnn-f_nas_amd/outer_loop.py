@@ -220,8 +220,13 @@ def run(net_factory, egs_for_archive, work_dir, num_epochs, num_archives, miniba
                 net.close()
                 net = net_factory()
             net.read_model(path(i))
-            if it["shrink"] != 1.0:  # the job's input model: "nnet3-am-copy --scale=<shrink>" (parameters only)
+            if it["shrink"] != 1.0:
+                # the job's input model: "nnet3-am-copy --scale=<shrink>" = ScaleNnet: parameters, and every component's statistics too --
+                # NonlinearComponent::Scale (nnet-component-itf.cc:533-541: value / deriv / oderiv sums and both counts) and
+                # BatchNormComponent::Scale (nnet-normalize-component.cc:644-654: count, sum, sumsq); every entry of the statistics
+                # block is such a sum or count, so the averages they stand for are unchanged and old minibatches weigh less
                 net.params.mul_(float(it["shrink"]))
+                net.set_stats(net.get_stats() * float(it["shrink"]))
             if it["temperature_proportion"] is not None:
                 net.set_temperature_proportion(it["temperature_proportion"])
             if it["dropout_proportion"] is not None:

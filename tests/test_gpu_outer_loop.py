@@ -180,3 +180,33 @@ def test_compute_prob_and_combination_by_objective(pkg, tmp_path):
     np.testing.assert_allclose(probe.get_stats(), comb.get_stats(), rtol=1e-5, atol=1e-7)
     comb.close()
     probe.close()
+
+
+def test_shrink_scales_parameters_and_statistics(pkg, tmp_path):
+    """nnet3-am-copy --scale = ScaleNnet: statistics sums and counts shrink with the parameters (nnet-component-itf.cc:533-541,
+    nnet-normalize-component.cc:644-654).  One iteration of one minibatch at shrink value 0.5 from a model with statistics on board: a count in the
+    written model is (0.5 x old + frames) [x 0.8 for BatchNorm, ScaleBatchnormStats] against (old + frames) [x 0.8] of the unshrunk run."""
+    cfg, factory, egs, probe = _setup(pkg)
+    o = pkg.outer_loop
+    base = dict(num_epochs=1, num_archives=1, minibatches_per_archive=1, frame_subsampling_factor=1, num_jobs_initial=1, num_jobs_final=1,
+                initial_effective_lrate=1e-3, final_effective_lrate=1e-3, max_models_combine=1)
+    o.run(factory, egs, str(tmp_path / "seed"), **base)  # its 1.mdl carries one minibatch of statistics
+
+    def seeded():
+        net = factory()
+        net.read_model(tmp_path / "seed" / "1.mdl")
+        return net
+
+    probe.read_model(tmp_path / "seed" / "1.mdl")
+    old = probe.get_stats().copy()
+    assert old[0] > 0  # the first entry of the block is a count (include/tdnnf_hip.h, tdnnf_net_get_stats)
+    out = {}
+    for name, shrink in (("plain", 0.0), ("shrunk", 500.0)):  # shrink value 1 - 500 x 1e-3 = 0.5
+        plan, _, _ = o.run(seeded, egs, str(tmp_path / name), proportional_shrink=shrink, **base)
+        assert plan[0]["shrink"] == pytest.approx(1.0 if shrink == 0 else 0.5)
+        probe.read_model(tmp_path / name / "1.mdl")
+        out[name] = (probe.params.detach().cpu().numpy().copy(), probe.get_stats().copy())
+    assert not np.array_equal(out["plain"][0], out["shrunk"][0])
+    d = (out["plain"][1][0] - out["shrunk"][1][0]) / old[0]
+    assert d == pytest.approx(0.5, rel=1e-5) or d == pytest.approx(0.4, rel=1e-5), d
+    probe.close()
