@@ -17,6 +17,7 @@
 // K-step); LDS rows are padded by 4 floats so the ds_read_b128 fragment reads are
 // bank-conflict free (stride 36 / 20 dwords).
 #include "gemm_f32.h"
+#include "gemm_ring.h"
 
 #include "common.h"
 
@@ -978,10 +979,19 @@ void launch_rows_kernel(dim3 grid, const RowsGemmArgs &a, int ntm, int ntn, bool
   else launch_rows_kernel_tagged<WM, WN, TM, TN, BK, 0>(grid, a, ntm, ntn, b_kc, vec, s);
 }
 
+template <int WM, int WN, int TM, int TN>
+constexpr bool kRingTile = (WM == 2 && WN == 2 && TM == 2 && TN == 2) || (WM == 4 && WN == 1 && TM == 1 && TN == 5);
+inline bool ring_applies(const RowsGemmArgs &a, bool b_kc, bool vec, int tile_cols) {
+  return g_prof_override != 3 && (tile_cols == 128 || rows_gemm_ring_mode() >= 2) && rows_gemm_ring_ok(a, b_kc, vec);
+}
+
 template <int WM, int WN, int TM, int TN, int BK>
 hipError_t launch_rows(const RowsGemmArgs &a, bool b_kc, bool vec, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+  if constexpr (kRingTile<WM, WN, TM, TN>) {  // the persistent LDS-DMA-ring form (gemm_ring.hip) where it applies
+    if (ring_applies(a, b_kc, vec, BN)) return rows_gemm_ring(a, b_kc, BN, s);
+  }
   launch_rows_kernel<WM, WN, TM, TN, BK>(dim3(ntm * ntn), a, ntm, ntn, b_kc, vec, s);
   return hipGetLastError();
 }
@@ -1063,7 +1073,11 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
     ProfScope ps(cls, flops, s);
     return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
   }
-  const int tiles = ntm * ntn, slots = rows_slots<WM, WN, TM, TN, BK>(b_kc, (b_kc && vec) ? a.prec : 0);
+  int slots = rows_slots<WM, WN, TM, TN, BK>(b_kc, (b_kc && vec) ? a.prec : 0);
+  if constexpr (kRingTile<WM, WN, TM, TN>) {
+    if (ring_applies(a, b_kc, vec, BN)) slots = rows_gemm_ring_slots(BN);
+  }
+  const int tiles = ntm * ntn;
   const int q = tiles / slots, r = tiles % slots;
   const bool stats = a.colstats != nullptr;  // (rows_gemm() leaves it set only for the exact-f32 128 x 128 tile)
   long long ktot = 0;

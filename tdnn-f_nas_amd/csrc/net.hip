@@ -22,6 +22,7 @@
 #include "common.h"
 #include "fused.h"
 #include "gemm_f32.h"
+#include "gemm_ring.h"
 #include "net.h"
 #include "ng.h"
 
@@ -394,8 +395,10 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   // transposed copy of every weight matrix for the split-bf16 backward-data GEMMs (k-contiguous B operand).  Measured for
   // exact f32 too (TDNNF_WT=1: the k-contiguous kernel variant instead of four 4-byte LDS reads per B fragment): the
   // backward-data classes did not move (36.8 / 26.2 against 36.4 / 26.1 ms per step), the step got 1-2 ms slower -- not kept
-  static const bool force_wt = getenv("TDNNF_WT") != nullptr;
-  n->paramsT = (n->cfg.gemm_precision != 0 || force_wt) ? A.take<float>((size_t)n->num_params + 16) : nullptr;
+  // [r3] TDNNF_WT=1 with the persistent ring kernel (gemm_ring.hip takes k-contiguous B operands only) puts the backward-data GEMMs on it as
+  // well: 127.7 against 126.4 ms per step with the ring on the forward GEMMs alone -- their epilogue reads the old C and the bypass addend
+  static const bool use_wt = getenv("TDNNF_WT") ? atoi(getenv("TDNNF_WT")) != 0 : false;
+  n->paramsT = (n->cfg.gemm_precision != 0 || use_wt) ? A.take<float>((size_t)n->num_params + 16) : nullptr;
   n->s3_scratch = nullptr;
   n->s3_scratch_bytes = 0;
   {

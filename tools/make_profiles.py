@@ -30,9 +30,9 @@ def klass(nm):
         return "ng_skinny_gemm_f32"
     if s.startswith(("ggemm_", "ng_l_", "ng_commit", "ng_set_columns", "ng_stage", "ng_fin_")):
         return "ng_grouped_side_chain"
-    if s.startswith("rows_gemm_kernel<2, 2, 2, 2") or s.startswith("rows_gemm_kernel<2, 2, 1, 2"):
+    if s.startswith("rows_gemm_kernel<2, 2, 2, 2") or s.startswith("rows_gemm_kernel<2, 2, 1, 2") or s.startswith("rows_gemm_ring_kernel<2, 2, 2, 2"):
         return "rows_gemm_f32_128x128"
-    if s.startswith("rows_gemm_kernel<4, 1, 1, 5"):
+    if s.startswith("rows_gemm_kernel<4, 1, 1, 5") or s.startswith("rows_gemm_ring_kernel<4, 1, 1, 5"):
         return "rows_gemm_f32_128x160"
     if s.startswith("wgrad_kernel"):
         return "wgrad_f32"
