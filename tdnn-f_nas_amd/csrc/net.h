@@ -138,6 +138,18 @@ struct tdnnf_net {
   unsigned pg_count;
   void *ws4;
   float *s4_scratch;   // split-K scratch of the GEMMs launched on s4
+  // Input-side natural-gradient statistics ahead of the backward pass: H_in = X~ W_x^T (and J = H^T X on refresh steps) of a component
+  // needs its forward input and the preconditioner state only, so from the second grouped minibatch on they are launched on s4 as soon as
+  // the forward pass is enqueued -- beside the denominator and the xent head, HBM-bound work beside MFMA-bound work -- with the
+  // arguments the component's backward call recorded one minibatch earlier (early_rec), checked again when that call comes.
+  struct EarlyIn {
+    unsigned char xin[256];  // a tdnnf::NgInput (net.h does not see ng.h)
+    long long recorded = -1, done = -1;  // fb_count values
+  };
+  std::vector<EarlyIn> early;
+  long long fb_count = 0;
+  bool early_on = false, early_any = false;
+  hipEvent_t ev_early_in = nullptr, ev_early = nullptr;
   size_t s4_scratch_bytes;
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   // NonlinearComponent::StoreBackpropStats skips a minibatch w.p. 1/4 only "&& oderiv_count_ != 0" (nnet-component-itf.cc:466): whether a

@@ -492,9 +492,14 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     const char *e = getenv("TDNNF_WGRAD_STREAM");
     n->wg_on = e ? atoi(e) != 0 : std::max(max_rows, N0) <= 32768;
   }
-  n->ws4 = n->wg_on ? A.take<char>(n->ws_bytes) : nullptr;
-  n->s4_scratch_bytes = n->wg_on ? (32u << 20) : 0;
-  n->s4_scratch = n->wg_on ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
+  {
+    const char *e = getenv("TDNNF_NG_EARLY_IN");  // 0: input-side statistics with the component's backward call, as before (A/B runs)
+    n->early_on = n->cfg.use_natural_gradient && n->ng_grouped && (e ? atoi(e) != 0 : true);
+  }
+  const bool s4_used = n->wg_on || n->early_on;
+  n->ws4 = s4_used ? A.take<char>(n->ws_bytes) : nullptr;
+  n->s4_scratch_bytes = s4_used ? (32u << 20) : 0;
+  n->s4_scratch = s4_used ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
 }
 
 #define CK(expr)             \
@@ -920,7 +925,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->ev_fin0) hipEventDestroy(n->ev_fin0);
   if (n->ev_fin) hipEventDestroy(n->ev_fin);
   if (n->s3) hipStreamDestroy(n->s3);
-  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg_in})
+  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg_in, n->ev_early_in, n->ev_early})
     if (e) hipEventDestroy(e);
   if (n->s4) hipStreamDestroy(n->s4);
   delete n;
@@ -1182,6 +1187,12 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_s3, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fin0, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fin, hipEventDisableTiming));
+    if (n->early_on) {
+      TDNNF_HIP(hipEventCreateWithFlags(&n->ev_early_in, hipEventDisableTiming));
+      TDNNF_HIP(hipEventCreateWithFlags(&n->ev_early, hipEventDisableTiming));
+      n->early.assign(n->comps.size(), tdnnf_net::EarlyIn());
+    }
+    if (n->early_on && !n->wg_on) TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
     if (n->wg_on) {
       TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
       TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[0], hipEventDisableTiming));
@@ -1190,6 +1201,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_ngc, hipEventDisableTiming));
   }
+  n->fb_count++;
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
   if (n->ng_bsum_all && n->ng_bsum_floats) TDNNF_HIP(hipMemsetAsync(n->ng_bsum_all, 0, sizeof(float) * n->ng_bsum_floats, s));  // every component's raw bias gradient
   n->pg_count = 0;
@@ -1514,7 +1526,18 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     NgInput xin;
     memset(&xin, 0, sizeof(xin));
     xin.x = view(x); xin.ix = ix; xin.Di = Di; xin.ones = ones; xin.N = N; xin.eff = eff; xin.active = active; xin.max_active = max_active;
-    CK(ng_stats_main(n->ng_in[comp], xin, S.H_in, S.part_in, wsw, n->ws_bytes, sw));
+    static_assert(sizeof(NgInput) <= sizeof(tdnnf_net::EarlyIn::xin), "EarlyIn::xin too small");
+    if (n->early_on && n->early[comp].done == n->fb_count) {
+      // H_in (and J on a refresh) were formed ahead of the backward pass from the arguments recorded one minibatch ago: they must be these
+      TDNNF_REQUIRE(memcmp(n->early[comp].xin, &xin, sizeof(xin)) == 0, "net_forward_backward: the input of component %s moved between minibatches",
+                    n->comps[comp].name.c_str());
+    } else {
+      CK(ng_stats_main(n->ng_in[comp], xin, S.H_in, S.part_in, wsw, n->ws_bytes, sw));
+    }
+    if (n->early_on) {
+      memcpy(n->early[comp].xin, &xin, sizeof(xin));
+      n->early[comp].recorded = n->fb_count;
+    }
     NgInput yin;
     memset(&yin, 0, sizeof(yin));
     yin.x = view(dyv); yin.ix.row_stride = 1; yin.ix.num_offsets = 1; yin.Di = Do; yin.N = N;
@@ -1582,6 +1605,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(hipEventRecord(n->ev_ngc, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_ngc, 0));
     }
+    if (n->early_any) TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_early, 0));  // the H_in of this step (all of them: one event)
     CK(ng_group_run(nb->group, n->s3));
     n->ng_cur.clear();
     return TDNNF_OK;
@@ -1608,6 +1632,32 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_fin, 0));  // the preconditioners refreshed on s3 (at the start of the step, or just now)
+  n->early_any = false;
+  if (use_ng && n->early_on) {
+    // input-side statistics of every component whose backward call of the previous minibatch recorded its arguments and whose
+    // preconditioners exist (the grouped chain will take them): on s4, behind the forward pass and the refresh uploads
+    bool forked = false;
+    SplitKScratchOverride early_scratch(n->s4_scratch, n->s4_scratch_bytes);
+    for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
+      auto &E = n->early[comp];
+      if (E.recorded != n->fb_count - 1 || !n->ng_in[comp] || !n->ng_out[comp] || ng_dim(n->ng_in[comp]) == 0 || ng_dim(n->ng_out[comp]) == 0) continue;
+      if (n->comps[comp].lr_factor == 0.f || !n->ngc[comp].H_in) continue;
+      if (!forked) {
+        TDNNF_HIP(hipEventRecord(n->ev_early_in, s));
+        TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_early_in, 0));
+        if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_fin, 0));
+        forked = true;
+      }
+      NgInput xin;
+      memcpy(&xin, E.xin, sizeof(xin));
+      CK(ng_stats_main(n->ng_in[comp], xin, n->ngc[comp].H_in, n->ngc[comp].part_in, n->ws4, n->ws_bytes, n->s4));
+      E.done = n->fb_count;
+    }
+    if (forked) {
+      TDNNF_HIP(hipEventRecord(n->ev_early, n->s4));
+      n->early_any = true;
+    }
+  }
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
     TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");
