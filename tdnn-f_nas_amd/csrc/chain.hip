@@ -33,6 +33,7 @@ struct tdnnf_den_graph {
     uint2 *arc;      // key: (other-state-or-src | pdf << 16), or (src | dst << 16) for the by-pdf table
     uint4 *arc4;     // the same arcs as (key, prob, prob * init[key & 0xffff] or 0, 0): what the wide form loads
     long long entries;
+    int mw_max_arcs[9];  // [G]: most arc entries any of G workgroups owns when slice k belongs to workgroup k % G (den_*_mw_kernel); G = 2, 4, 8
   } by_dst, by_src, by_pdf;
   float *init;  // H
   float init_sum;
@@ -59,6 +60,7 @@ namespace tdnnf {
 namespace {
 
 constexpr int kDenThreads = 1024;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float block_sum(float v, float *red, int nwaves) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -280,6 +282,222 @@ __global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView
     for (int h = tid; h < H; h += kDenThreads) bn[h] = bcur[h] * inv + leaky;  // (other threads' rows: visible after block_sum's barriers)
     __syncthreads();
   }
+}
+
+// ---- The two recursions with SEVERAL workgroups per sequence (few sequences: the 8-GPU shard of a minibatch, the recipes' own egs).
+// One workgroup per sequence walks T dependent frames at ~15 us each -- 384 KB of arcs from L2 per frame on one CU, and the fixed work of
+// a frame -- while the other CUs have nothing to do.  Here G workgroups share a sequence: slice k of the SELL table belongs to workgroup
+// k % G (every workgroup gets the same mix of row degrees), its arcs stay in LDS for the whole kernel, and per frame a workgroup
+//   publishes the new values of its rows (exchange buffer in slot order, double-buffered by frame parity: agent-scope stores, every
+//   wave's vmcnt(0), workgroup barrier, one agent-scope add to the sequence's counter),
+//   waits until the counter shows all G slices of the frame (one lane polls; bounded: on a time-out it raises the abort word, which
+//   every poll also reads, and the host reports an error instead of hanging), and
+//   reads the whole vector back (agent-scope loads) into LDS, where the frame's normaliser is summed.
+// MI355X_MICROARCH.md, inter-workgroup visibility: stores and loads of the handed-off bytes all sc1, the signal behind every storing
+// wave's wait and a barrier, the loads behind the poll and a barrier.  A buffer of parity q is rewritten for frame t + 2 only after the
+// counter has reached G (t + 1), i.e. after every workgroup has published frame t + 1, which it does after reading frame t.
+// The workgroups of a sequence sit on one XCD when the sequence count is a multiple of 8 (blocks b and b + 8 share an XCD).
+struct MwCtl {
+  unsigned long long *ctr;  // [2 * B]: forward counters, then backward counters
+  unsigned *abort_flag;
+  float *xf, *xb;           // [B][2][NSp] exchange buffers of the forward / backward recursion
+  int NSp;
+};
+constexpr unsigned kMwSpinLimit = 1u << 22;  // polls of ~0.5 us: seconds -- a launch that cannot make progress ends, it does not hang
+
+__device__ __forceinline__ void mw_block_of(int b, int B, int G, int *s, int *gi) {
+  if (B % 8 == 0) {
+    const int x = b & 7, j = b >> 3;
+    *s = (j / G) * 8 + x;
+    *gi = j % G;
+  } else {
+    *s = b / G;
+    *gi = b % G;
+  }
+}
+// publish: all of this workgroup's stores are issued; wait, barrier, one add.
+__device__ __forceinline__ void mw_publish(unsigned long long *ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// consume: wait for `target` adds (one lane polls, the others wait at the barrier).  Returns false on abort.
+__device__ __forceinline__ bool mw_wait(unsigned long long *ctr, unsigned *abort_flag, unsigned target, unsigned *lds_flag) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0, ab = 0;
+    while (true) {
+      const unsigned long long v = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ab = __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)v >= target || ab) break;
+      if (++spins > kMwSpinLimit) {
+        __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    *lds_flag = ab;
+  }
+  __syncthreads();
+  return *lds_flag == 0;
+}
+
+// dir 0: alpha recursion over by_dst (as den_forward_kernel<true>); dir 1: the self-normalised beta recursion over by_src (den_beta_kernel)
+template <int DIR>
+__global__ __launch_bounds__(kDenThreads) void den_mw_kernel(DenDev g, MwCtl ctl, int G, MatView y, int B, int T, float leaky, float *vec_all, float *sum_all,
+                                                             int Hs, double *logprob) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __shared__ float red[kDenThreads / 64];
+  __shared__ unsigned flag;
+  __shared__ int loff[64 + 1];  // LDS offsets (arc entries) of the slices this workgroup owns
+  const tdnnf_den_graph::Sell &tab = DIR == 0 ? g.by_dst : g.by_src;
+  int s, gi;
+  mw_block_of(blockIdx.x, B, G, &s, &gi);
+  const int tid = threadIdx.x;
+  const int H = g.H, P = g.P, P4 = (P + 3) & ~3, H4 = (H + 3) & ~3, ns = tab.nslices, NSp = ctl.NSp;
+  float *x = smem;            // P: exp of the frame's output row
+  float *cur = smem + P4;     // H: the previous frame's vector, by state (forward: alpha_dash(t-1); backward: b(t+1)/S(t+1) + leaky)
+  uint2 *arcs = reinterpret_cast<uint2 *>(cur + H4);
+  unsigned long long *ctr = ctl.ctr + (DIR == 0 ? s : B + s);
+  float *xch = (DIR == 0 ? ctl.xf : ctl.xb) + (size_t)s * 2 * NSp;
+  float *vec = vec_all + (size_t)s * (T + 1) * Hs;
+  float *sums = sum_all + (size_t)s * (T + 1);
+  const int nown = ns > gi ? (ns - gi + G - 1) / G : 0;  // slices gi, gi + G, ...
+  if (tid == 0) {
+    int o = 0;
+    for (int i = 0; i < nown; i++) {
+      loff[i] = o;
+      const int k = gi + i * G;
+      o += tab.base[k + 1] - tab.base[k];
+    }
+    loff[nown] = o;
+  }
+  __syncthreads();
+  for (int i = 0; i < nown; i++) {
+    const int k = gi + i * G, b0 = tab.base[k], n = tab.base[k + 1] - b0;
+    for (int e = tid; e < n; e += kDenThreads) arcs[loff[i] + e] = tab.arc[b0 + e];
+  }
+  // the share of the final arrays this workgroup writes: states [h0, h1)
+  const int h0 = (int)((long long)H * gi / G), h1 = (int)((long long)H * (gi + 1) / G);
+  float prev_sum = g.init_sum;
+  double logcorr = 0.0;
+  if (DIR == 0) {  // AlphaFirstFrame + AlphaDash(0)
+    for (int h = tid; h < H; h += kDenThreads) {
+      const float a = g.init[h] + leaky * g.init_sum * g.init[h];
+      cur[h] = a;
+      if (h >= h0 && h < h1) vec[h] = a;
+    }
+    if (gi == 0 && tid == 0) sums[0] = g.init_sum;
+  } else {  // b(T, .) = 1, S(T) = sum init
+    for (int h = tid; h < H; h += kDenThreads) {
+      cur[h] = 1.0f / g.init_sum + leaky;
+      if (h >= h0 && h < h1) vec[(size_t)T * Hs + h] = 1.0f;
+    }
+    if (gi == 0 && tid == 0) sums[T] = g.init_sum;
+  }
+  __syncthreads();
+  // the output row of a frame is requested (into registers) before the exchange of the frame before it and turned into x behind it:
+  // its trip to memory runs under the wait for the other workgroups
+  constexpr int kRowRegs = 8, kRowThreads = kDenThreads - 64;  // waves 1-15: P <= 8 * 960 (checked on the host)
+  float yv[kRowRegs];
+  const int rt = tid - 64;
+  auto request_row = [&](int step) {
+    const int yrow = DIR == 0 ? step - 1 : T - step;
+    const float *yr = y.data + (size_t)(yrow * B + s) * y.stride;
+    if (rt >= 0) {
+#pragma unroll
+      for (int i = 0; i < kRowRegs; i++) yv[i] = rt + i * kRowThreads < P ? yr[rt + i * kRowThreads] : 0.f;
+    }
+  };
+  auto row_to_x = [&]() {
+    if (rt >= 0) {
+#pragma unroll
+      for (int i = 0; i < kRowRegs; i++)
+        if (rt + i * kRowThreads < P) x[rt + i * kRowThreads] = exp_limited(yv[i]);
+    }
+  };
+  float *stage = reinterpret_cast<float *>(arcs + loff[nown]);  // nown * 64: this workgroup's new values, for 16-byte stores
+  request_row(1);
+  row_to_x();
+  __syncthreads();
+  for (int step = 1; step <= T; step++) {
+    const int t = DIR == 0 ? step : T - step;  // the frame whose vector is formed
+    const float inv = 1.0f / prev_sum;
+    if (DIR == 0) logcorr += (double)logf(prev_sum);
+    float *xw = xch + (size_t)(step & 1) * NSp;
+    for (int q = tid; q < nown * 64; q += kDenThreads) {
+      const int i = q >> 6, ln = q & 63;
+      const int w = (loff[i + 1] - loff[i]) >> 6;
+      const uint2 *ap = arcs + loff[i] + ln;
+      float acc = 0.f;
+#pragma unroll 4
+      for (int j = 0; j < w; j++) {
+        const uint2 a = ap[j * 64];
+        acc += cur[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16];
+      }
+      if (DIR == 0) acc *= inv;
+      stage[q] = acc;  // (a padding slot: 0)
+    }
+    __syncthreads();
+    for (int q = tid; q < nown * 16; q += kDenThreads) {  // 16 bytes per store, agent scope
+      const int i = q >> 4, c = q & 15, k = gi + i * G;
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(stage + i * 64 + c * 4);
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(xw + k * 64 + c * 4), "v"(v) : "memory");
+    }
+    mw_publish(ctr);
+    if (step < T) request_row(step + 1);  // (behind the signal; not by the polling wave, whose polls would queue behind these loads)
+    if (!mw_wait(ctr, ctl.abort_flag, (unsigned)(G * step), &flag)) return;
+    // the whole vector of this frame, slot order -> by state; its normaliser
+    float local = 0.f;
+    for (int q4 = tid; q4 < ns * 16; q4 += kDenThreads) {
+      f32x4 v;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(xw + q4 * 4) : "memory");
+      const uint4 hh = *reinterpret_cast<const uint4 *>(tab.row + q4 * 4);
+      const unsigned hs[4] = {hh.x, hh.y, hh.z, hh.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (hs[e] != 0xffffffffu) {
+          cur[hs[e]] = v[e];
+          local += DIR == 0 ? v[e] : g.init[hs[e]] * v[e];
+        }
+      }
+    }
+    const float sum = block_sum(local, red, kDenThreads / 64);  // (its barriers order the writes of cur above before the reads below)
+    if (gi == 0 && tid == 0) sums[t] = sum;
+    if (DIR == 0) {
+      for (int h = tid; h < H; h += kDenThreads) {  // AlphaDash(t)
+        const float a = cur[h] + leaky * sum * g.init[h];
+        cur[h] = a;
+        if (h >= h0 && h < h1) vec[(size_t)t * Hs + h] = a;
+      }
+    } else {
+      const float is = 1.0f / sum;
+      for (int h = tid; h < H; h += kDenThreads) {
+        const float v = cur[h];
+        if (h >= h0 && h < h1) vec[(size_t)t * Hs + h] = v;  // b(t, h), as den_beta_kernel keeps it
+        cur[h] = v * is + leaky;
+      }
+    }
+    if (step < T) row_to_x();
+    prev_sum = sum;
+    __syncthreads();
+  }
+  if (DIR == 0) {
+    float local = 0.f;
+    for (int h = tid; h < H; h += kDenThreads) local += cur[h];
+    const float tot = block_sum(local, red, kDenThreads / 64);
+    if (gi == 0 && tid == 0) {
+      logprob[s] = (double)logf(tot) + logcorr;
+      sums[T] = tot;  // (as den_forward_kernel: the total of alpha_dash(T))
+    }
+  }
+}
+
+// a multi-workgroup launch that gave up (mw_exchange's time-out): the denominator log-probs become NaN, which the objective's
+// not-finite path reports (chain_finish: the minibatch is skipped with a failure code, as for any other NaN)
+__global__ void den_mw_check_kernel(const unsigned *abort_flag, double *logprob, int B) {
+  if (*abort_flag == 0) return;
+  for (int s = threadIdx.x; s < B; s += blockDim.x) logprob[s] = __longlong_as_double(0x7ff8000000000000ll);
 }
 
 // Occupancies of one (frame, sequence): deriv[t*B+s][p] = deriv_weight * gamma_den(t, p) (overwrites the whole row)
@@ -849,6 +1067,15 @@ int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, floa
   out->nrows = nrows;
   out->nslices = ns;
   out->entries = base[ns];
+  for (int G = 0; G <= 8; G++) {
+    out->mw_max_arcs[G] = 0;
+    if (G != 2 && G != 4 && G != 8) continue;
+    for (int g = 0; g < G; g++) {
+      int own = 0;
+      for (int k = g; k < ns; k += G) own += base[k + 1] - base[k];
+      out->mw_max_arcs[G] = std::max(out->mw_max_arcs[G], own);
+    }
+  }
   int rc;
   if ((rc = to_device(base, &out->base))) return rc;
   if ((rc = to_device(rowid, &out->row))) return rc;
@@ -867,6 +1094,33 @@ struct ChainPlan {
   size_t lds_fwd, lds_bwd;
 };
 int g_den_mode = 0;  // tdnnf_chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide
+// exchange buffers and counters of the multi-workgroup recursions (den_mw_kernel), behind b_all / S_all in the split region
+size_t mw_slots(const tdnnf_den_graph *g) { return (size_t)std::max(g->by_dst.nslices, g->by_src.nslices) * 64; }
+size_t mw_extra_floats(const tdnnf_den_graph *g, int B) { return 4 * (size_t)B * mw_slots(g) + 4 * (size_t)B + 64; }
+// workgroups per sequence for B sequences (0: one workgroup per sequence, the other kernels): both recursions at once must fit the chip at one
+// workgroup per CU, every workgroup's arcs and state vectors its LDS, and a workgroup owns at most 64 slices.  TDNNF_DEN_MW=0 turns it off.
+int mw_groups(const tdnnf_den_graph *g, int B, int T, bool both = true) {
+  const char *e = getenv("TDNNF_DEN_MW");
+  if ((e && atoi(e) == 0) || T < 8) return 0;
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    (void)hipGetLastError();
+  }
+  for (int G = 8; G >= 2; G /= 2) {
+    if ((both ? 2 : 1) * B * G > cus) continue;
+    const int ns = std::min(g->by_dst.nslices, g->by_src.nslices), nsmax = std::max(g->by_dst.nslices, g->by_src.nslices);
+    if (ns < G || (nsmax + G - 1) / G > 64) continue;
+    const size_t arcs = (size_t)std::max(g->by_dst.mw_max_arcs[G], g->by_src.mw_max_arcs[G]);
+    const size_t lds = sizeof(float) * (((g->P + 3) & ~3) + ((g->H + 3) & ~3)) + 8 * arcs + 256 * (size_t)((nsmax + G - 1) / G);
+    if (lds > 150 * 1024 || g->P > 8 * 960) continue;
+    return G;
+  }
+  return 0;
+}
+
 ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup) {
   ChainPlan p;
   p.Hs = (g->H + 3) & ~3;
@@ -897,7 +1151,7 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
   p.asum_floats = ((size_t)B * (3 * T + 4) + 31) & ~(size_t)31;  // wide: A(0..T), S(0..T) of the backward recursion, Zd(0..T-1)
   // wide: the backward vectors of every frame, two double-buffered sets of partial rows (the recursions run side by side) and x = exp(clamp(y)) /
   // the derivative, sequence-minor (T x P x B)
-  p.gstate_floats = p.wide ? Bw * (size_t)(T + 1) * p.Hs + 4 * Bw * p.wide_blocks + (size_t)T * g->P * Bw : (p.lds_state ? (p.split ? (size_t)B * (T + 1) * (p.Hs + 1) + 32 : 0) : (size_t)B * 3 * p.Hs);
+  p.gstate_floats = p.wide ? Bw * (size_t)(T + 1) * p.Hs + 4 * Bw * p.wide_blocks + (size_t)T * g->P * Bw : (p.lds_state ? (p.split ? (size_t)B * (T + 1) * (p.Hs + 1) + 32 + mw_extra_floats(g, B) : 0) : (size_t)B * 3 * p.Hs);
   p.la_floats = 4 * (size_t)num_states_sup + 2;  // two arrays of DOUBLES (log alpha, log beta of the numerator), 8-byte aligned
   return p;
 }
@@ -1207,10 +1461,40 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gamma));
     TDNNF_HIP(hipEventRecord(ev_fork, s));
     TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
-    hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs);
+    int G = mw_groups(g, B, T);
+    // more sequences than that: the two recursions one after the other, each with the chip to itself (TDNNF_DEN_MW_SEQ=0: one workgroup per
+    // sequence, both at once)
+    bool mw_seq = false;
+    if (G == 0 && !(getenv("TDNNF_DEN_MW_SEQ") && atoi(getenv("TDNNF_DEN_MW_SEQ")) == 0)) {
+      G = mw_groups(g, B, T, false);
+      mw_seq = G > 0;
+    }
+    const unsigned *mw_abort = nullptr;
+    if (G > 0) {  // several workgroups per sequence
+      float *mw = S_all + (size_t)B * (T + 1) + 32;
+      MwCtl ctl;
+      ctl.NSp = (int)mw_slots(g);
+      ctl.ctr = reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(mw) + 15) & ~(uintptr_t)15);
+      ctl.abort_flag = reinterpret_cast<unsigned *>(ctl.ctr + 2 * B);
+      ctl.xf = reinterpret_cast<float *>(ctl.ctr + 2 * B + 2);
+      ctl.xb = ctl.xf + (size_t)B * 2 * ctl.NSp;
+      const size_t stage_b = 256 * (size_t)((std::max(g->by_dst.nslices, g->by_src.nslices) + G - 1) / G);
+      const size_t lds_f = sizeof(float) * (P4 + H4) + 8 * (size_t)g->by_dst.mw_max_arcs[G] + stage_b, lds_b = sizeof(float) * (P4 + H4) + 8 * (size_t)g->by_src.mw_max_arcs[G] + stage_b;
+      TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+      TDNNF_HIP(hipMemsetAsync(ctl.ctr, 0, sizeof(unsigned long long) * (2 * B + 2), s));  // (in front of the fork: both streams see it)
+      TDNNF_HIP(hipEventRecord(ev_fork, s));
+      TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
+      hipLaunchKernelGGL(den_mw_kernel<0>, dim3(B * G), dim3(kDenThreads), lds_f, s, gd, ctl, G, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp);
+      hipLaunchKernelGGL(den_mw_kernel<1>, dim3(B * G), dim3(kDenThreads), lds_b, mw_seq ? s : aux, gd, ctl, G, yv, B, T, leaky, b_all, S_all, b.p.Hs, (double *)nullptr);
+      mw_abort = ctl.abort_flag;
+    } else {
+      hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
+      hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs);
+    }
     TDNNF_HIP(hipEventRecord(ev_join, aux));
     TDNNF_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    if (mw_abort) hipLaunchKernelGGL(den_mw_check_kernel, dim3(1), dim3(64), 0, s, mw_abort, b.den_lp, B);
     hipLaunchKernelGGL(den_gamma_kernel, dim3(T, B), dim3(kGammaThreads), lds_gamma, s, gd, yv, B, T, leaky, b.alpha, b_all, S_all, b.p.Hs, -sp->weight, dv);
   } else if (b.p.lds_state) {
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));

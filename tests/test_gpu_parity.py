@@ -505,3 +505,39 @@ def test_natural_gradient(hip, ora):
         assert abs(sd.value - sr.value) < 2e-3 * sr.value, it
     hip.lib.tdnnf_ng_destroy(ng)
     L.oracle_ng_destroy(ng_ref)
+
+
+# the recursions with several workgroups per sequence (few sequences: chain.hip, den_mw_kernel), against the oracle like the other forms
+# and bit for bit against themselves; B = 16 / 8: eight workgroups per sequence on one XCD; B = 12: the plain block order; B = 24: four
+@pytest.mark.parametrize("H,P,B,T,leaky", [(4000, 6034, 16, 40, 0.1), (1500, 700, 8, 60, 1e-5), (900, 400, 12, 30, 0.05), (2100, 900, 24, 25, 0.1)])
+def test_chain_denominator_several_workgroups_per_sequence(hip, ora, pkg, monkeypatch, H, P, B, T, leaky):
+    monkeypatch.delenv("TDNNF_DEN_MW", raising=False)
+    pkg.hipabi.check(pkg.hipabi.load().tdnnf_chain_set_denominator_mode(1))
+    try:
+        _chain_case(hip, ora, pkg, H, P, B, T, leaky, 0.0)  # (the entry point takes the split form, whose recursions these are)
+        got = _chain_deriv(hip, pkg, H, P, B, T, leaky)
+        monkeypatch.setenv("TDNNF_DEN_MW", "0")
+        one = _chain_deriv(hip, pkg, H, P, B, T, leaky)
+    finally:
+        pkg.hipabi.load().tdnnf_chain_set_denominator_mode(0)
+    assert not np.array_equal(got[1], one[1])  # the switch did switch: other summation orders
+    assert abs(got[0] - one[0]) < 1e-6 * abs(one[0])
+    assert rel_l2(got[1], one[1]) < 1e-5
+
+
+def _chain_deriv(hip, pkg, H, P, B, T, leaky):
+    g = pkg.synth.make_den_graph(H, P, mean_out_degree=6.0, seed=H)
+    sup = pkg.synth.make_supervision(B, T, P, seed=T, weight=1.0)
+    rng = np.random.default_rng(H + T)
+    y = (_rand(rng, T * B, P) * 1.5).astype(F)
+    xo = _rand(rng, T * B, P)
+    dg, ds = pkg.hipabi.DenGraph(g), pkg.hipabi.Supervision(sup)
+    nb = hip.chain_workspace_bytes(dg.h, B, T)
+    ws = hip.ws(nb)
+    ws.fill_(float("nan"))
+    res = torch.zeros(8, dtype=torch.float64, device="cuda")
+    yd, _ = padded(y)
+    dd, _ = padded(np.full_like(y, 5.0))
+    xdd = torch.full((T * B, P), 5.0, device="cuda")
+    hip.chain_objf_and_deriv(dg.h, ds.h, yd, dev(xo), leaky, 0.0, 0.1, hip.vec(res), dd, xdd, hip.vec(ws), nb, hip.stream())
+    return host(res)[0], host(dd)

@@ -12,7 +12,7 @@ for ng in 1 0; do
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [int(r["Start_Timestamp"]) for r in rows if "den_forward" in r["Kernel_Name"] or "den_wide_init" in r["Kernel_Name"]]
+marks = [int(r["Start_Timestamp"]) for r in rows if "den_forward" in r["Kernel_Name"] or "den_wide_init" in r["Kernel_Name"] or "den_mw_kernel<0>" in r["Kernel_Name"]]
 t0 = marks[-5]
 keep = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
 w = csv.DictWriter(open(sys.argv[2], "w", newline=""), fieldnames=["Kernel_Name", "Stream_Id", "Queue_Id", "Start_Timestamp", "End_Timestamp", "Grid_Size", "Workgroup_Size"], extrasaction="ignore")

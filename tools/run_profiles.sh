@@ -16,7 +16,7 @@ python3 - "$F" <<'PY' > gpurun_out/r3_stats_dispatches.txt
 import csv, sys
 rows = [(int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
-marks = [s for s, n in rows if "den_forward" in n or "den_wide_init" in n]
+marks = [s for s, n in rows if "den_forward" in n or "den_wide_init" in n or "den_mw_kernel<0>" in n]
 t0, t1 = marks[-9], marks[-1]
 print("kernel dispatches per step over the last 8 steps: %.1f" % (sum(1 for s, n in rows if t0 <= s < t1) / 8.0))
 PY

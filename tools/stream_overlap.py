@@ -13,7 +13,7 @@ with open(sys.argv[1]) as f:
         q = r.get("Stream_Id") or r.get("Queue_Id")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "%s/%s" % (r.get("Queue_Id"), q), r["Kernel_Name"]))
 rows.sort()
-marks = [s for s, e, q, n in rows if "den_forward" in n or "den_wide_init" in n]
+marks = [s for s, e, q, n in rows if "den_forward" in n or "den_wide_init" in n or "den_mw_kernel<0>" in n]
 t0, t1 = marks[-steps - 1], marks[-1]
 win = [(max(s, t0), min(e, t1), q, n) for s, e, q, n in rows if e > t0 and s < t1]
 ev = []

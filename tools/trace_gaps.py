@@ -14,7 +14,7 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id"), r["Kernel_Name"]))
 rows.sort()
-marks = [s for s, e, q, n in rows if "den_forward" in n or "den_wide_init" in n]
+marks = [s for s, e, q, n in rows if "den_forward" in n or "den_wide_init" in n or "den_mw_kernel<0>" in n]
 t0, t1 = marks[-steps - 1], marks[-1]
 win = [r for r in rows if r[1] > t0 and r[0] < t1]
 
