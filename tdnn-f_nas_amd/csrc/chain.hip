@@ -1099,7 +1099,7 @@ size_t mw_slots(const tdnnf_den_graph *g) { return (size_t)std::max(g->by_dst.ns
 size_t mw_extra_floats(const tdnnf_den_graph *g, int B) { return 4 * (size_t)B * mw_slots(g) + 4 * (size_t)B + 64; }
 // workgroups per sequence for B sequences (0: one workgroup per sequence, the other kernels): both recursions at once must fit the chip at one
 // workgroup per CU, every workgroup's arcs and state vectors its LDS, and a workgroup owns at most 64 slices.  TDNNF_DEN_MW=0 turns it off.
-int mw_groups(const tdnnf_den_graph *g, int B, int T, bool both = true) {
+int mw_groups(const tdnnf_den_graph *g, int B, int T) {
   const char *e = getenv("TDNNF_DEN_MW");
   if ((e && atoi(e) == 0) || T < 8) return 0;
   int cus = 256;
@@ -1109,8 +1109,8 @@ int mw_groups(const tdnnf_den_graph *g, int B, int T, bool both = true) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     (void)hipGetLastError();
   }
-  for (int G = 8; G >= 2; G /= 2) {
-    if ((both ? 2 : 1) * B * G > cus) continue;
+  for (int G = 8; G >= 4; G /= 2) {  // (two per sequence: measured, no faster than one -- 64 sequences x 500 frames 9.6 ms either way)
+    if (2 * B * G > cus) continue;
     const int ns = std::min(g->by_dst.nslices, g->by_src.nslices), nsmax = std::max(g->by_dst.nslices, g->by_src.nslices);
     if (ns < G || (nsmax + G - 1) / G > 64) continue;
     const size_t arcs = (size_t)std::max(g->by_dst.mw_max_arcs[G], g->by_src.mw_max_arcs[G]);
@@ -1461,14 +1461,7 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gamma));
     TDNNF_HIP(hipEventRecord(ev_fork, s));
     TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-    int G = mw_groups(g, B, T);
-    // more sequences than that: the two recursions one after the other, each with the chip to itself (TDNNF_DEN_MW_SEQ=0: one workgroup per
-    // sequence, both at once)
-    bool mw_seq = false;
-    if (G == 0 && !(getenv("TDNNF_DEN_MW_SEQ") && atoi(getenv("TDNNF_DEN_MW_SEQ")) == 0)) {
-      G = mw_groups(g, B, T, false);
-      mw_seq = G > 0;
-    }
+    const int G = mw_groups(g, B, T);
     const unsigned *mw_abort = nullptr;
     if (G > 0) {  // several workgroups per sequence
       float *mw = S_all + (size_t)B * (T + 1) + 32;
@@ -1486,7 +1479,7 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
       TDNNF_HIP(hipEventRecord(ev_fork, s));
       TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
       hipLaunchKernelGGL(den_mw_kernel<0>, dim3(B * G), dim3(kDenThreads), lds_f, s, gd, ctl, G, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp);
-      hipLaunchKernelGGL(den_mw_kernel<1>, dim3(B * G), dim3(kDenThreads), lds_b, mw_seq ? s : aux, gd, ctl, G, yv, B, T, leaky, b_all, S_all, b.p.Hs, (double *)nullptr);
+      hipLaunchKernelGGL(den_mw_kernel<1>, dim3(B * G), dim3(kDenThreads), lds_b, aux, gd, ctl, G, yv, B, T, leaky, b_all, S_all, b.p.Hs, (double *)nullptr);
       mw_abort = ctl.abort_flag;
     } else {
       hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
