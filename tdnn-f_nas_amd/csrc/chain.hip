@@ -1109,7 +1109,12 @@ int mw_groups(const tdnnf_den_graph *g, int B, int T) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     (void)hipGetLastError();
   }
-  for (int G = 8; G >= 4; G /= 2) {  // (two per sequence: measured, no faster than one -- 64 sequences x 500 frames 9.6 ms either way)
+  // Four per sequence.  Measured in the step at 1500 x 16 (ms): one 27.3, two 27.5, four 23.8, eight 25.2 -- eight are faster alone (5.0 against
+  // 5.6 ms for both recursions) but their 256 workgroups hold every CU while the xent head's backward pass wants them; two cost what they gain.
+  // TDNNF_DEN_MW_G=8 (experiments): eight where they fit
+  const int gmax = getenv("TDNNF_DEN_MW_G") ? atoi(getenv("TDNNF_DEN_MW_G")) : 4;
+  for (int G = 8; G >= 4; G /= 2) {
+    if (G > gmax) continue;
     if (2 * B * G > cus) continue;
     const int ns = std::min(g->by_dst.nslices, g->by_src.nslices), nsmax = std::max(g->by_dst.nslices, g->by_src.nslices);
     if (ns < G || (nsmax + G - 1) / G > 64) continue;

@@ -1633,9 +1633,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_fin, 0));  // the preconditioners refreshed on s3 (at the start of the step, or just now)
   n->early_any = false;
-  if (use_ng && n->early_on) {
-    // input-side statistics of every component whose backward call of the previous minibatch recorded its arguments and whose
-    // preconditioners exist (the grouped chain will take them): on s4, behind the forward pass and the refresh uploads
+  auto launch_early_in = [&]() -> int {
+    if (!(use_ng && n->early_on)) return TDNNF_OK;
+    // input-side statistics of every component whose backward call of the previous minibatch recorded its arguments (and has not come yet
+    // in this one) and whose preconditioners exist (the grouped chain will take them): on s4, behind the forward pass and the refresh uploads
     bool forked = false;
     SplitKScratchOverride early_scratch(n->s4_scratch, n->s4_scratch_bytes);
     for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
@@ -1657,7 +1658,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(hipEventRecord(n->ev_early, n->s4));
       n->early_any = true;
     }
-  }
+    return TDNNF_OK;
+  };
+  // Small minibatches (the ones whose weight gradients have a stream of their own) are launch-bound on the host around this point: the ~60
+  // launches of the statistics are enqueued after the xent head's backward pass, which the caller's stream is waiting for, not before it
+  // (150 x 64: 0.8 ms of the caller's stream idle behind the host otherwise)
+  const bool early_after_xent = n->wg_on;
+  if (!early_after_xent) CK(launch_early_in());
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
     TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");
@@ -1685,6 +1692,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
+      if (early_after_xent) CK(launch_early_in());
     } else {
       tdnnf_mat tmp = M(n->d_small2, No, S);
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &tmp, s));
