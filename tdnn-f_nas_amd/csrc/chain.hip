@@ -1102,13 +1102,13 @@ size_t mw_extra_floats(const tdnnf_den_graph *g, int B) { return 4 * (size_t)B *
 int mw_groups(const tdnnf_den_graph *g, int B, int T) {
   const char *e = getenv("TDNNF_DEN_MW");
   if ((e && atoi(e) == 0) || T < 8) return 0;
-  int cus = 256;
-  {
-    int dev = 0;
+  static const int cus = [] {
+    int dev = 0, n = 256;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
     (void)hipGetLastError();
-  }
+    return n;
+  }();
   // Four per sequence.  Measured in the step at 1500 x 16 (ms): one 27.3, two 27.5, four 23.8, eight 25.2 -- eight are faster alone (5.0 against
   // 5.6 ms for both recursions) but their 256 workgroups hold every CU while the xent head's backward pass wants them; two cost what they gain.
   // TDNNF_DEN_MW_G=8 (experiments): eight where they fit

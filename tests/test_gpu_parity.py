@@ -541,3 +541,44 @@ def _chain_deriv(hip, pkg, H, P, B, T, leaky):
     xdd = torch.full((T * B, P), 5.0, device="cuda")
     hip.chain_objf_and_deriv(dg.h, ds.h, yd, dev(xo), leaky, 0.0, 0.1, hip.vec(res), dd, xdd, hip.vec(ws), nb, hip.stream())
     return host(res)[0], host(dd)
+
+
+# the persistent LDS-DMA-ring form of the rows GEMM (csrc/gemm_ring.hip) takes launches without tap coefficients whose taps are whole K
+# steps of 16 and whose output gets the 128-wide tile: every init mode, ragged row and column tiles, row strides, a block that walks
+# several tiles (more tiles than the chip has block slots), against a float64 product of the spliced input
+RING_CASES = [
+    # name, offsets, num_t_out, B, Di, Do, t_step_out
+    ("affine-k2", [0, 1], 37, 16, 160, 1536, 1),          # 592 rows: ragged last row tile
+    ("affine-k2-stride3", [0, 3], 11, 24, 160, 1536, 3),
+    ("ragged-columns", [-1, 0, 1], 9, 13, 48, 200, 1),    # 117 rows, 200 columns: one tile row, a 72-column tile
+    ("output-layer", [0], 5, 31, 256, 6034, 1),
+    ("many-tiles", [0], 400, 128, 32, 4096, 1),           # 51 200 x 4 096: 12 800 tiles on 768 slots
+]
+
+
+@pytest.mark.parametrize("case", RING_CASES, ids=[c[0] for c in RING_CASES])
+def test_rows_gemm_persistent_ring_shapes(hip, pkg, case):
+    name, offs, nt, B, Di, Do, step = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000)
+    rho, ro, rows_in, N = pkg.synth.tdnn_indexes(offs, nt, B, t_step_out=step)
+    K = len(offs)
+    x = _rand(rng, rows_in, Di)
+    W = (_rand(rng, Do, K * Di) / np.sqrt(K * Di)).astype(F)
+    b = _rand(rng, Do)
+    y0 = _rand(rng, N, Do)
+    xt, Wt = torch.from_numpy(x).cuda().double(), torch.from_numpy(W).cuda().double()
+    ref = torch.zeros(N, Do, dtype=torch.float64, device="cuda")
+    out_rows = torch.arange(N, device="cuda")
+    for k in range(K):
+        src = int(ro[k]) + out_rows * rho  # (PrecomputeIndexes: input row = row_offset + row_stride * output row)
+        ref += xt[src] @ Wt[:, k * Di:(k + 1) * Di].T
+    ix = pkg.hipabi.indexes(rho, ro)
+    xd, _ = padded(x)
+    Wd, bd = dev(W), dev(b)
+    for mode in (1, 0, 2):
+        yd, ybuf = padded(y0)
+        hip.tdnn_propagate(C.byref(ix), xd, hip.vec(Wd), K * Di, Do, Di, hip.vec(bd) if mode == 1 else None, None, mode, yd, hip.stream())
+        want = ref + (torch.from_numpy(b).cuda().double() if mode == 1 else 0) + (torch.from_numpy(y0).cuda().double() if mode == 0 else 0)
+        got = yd.double()
+        assert float((got - want).norm() / want.norm()) < TOL, (name, mode)
+        assert (host(ybuf)[:, Do:] == 7.0).all(), "wrote outside the view"
