@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
+BF16_PEAK_TFLOPS = 2500.0       # the same guide: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")  # tools/make_profiles.py: separate rocprofv3 --pmc passes of this command
 
 # parity bars of BASELINE.json's north_star: objective 1e-4 relative, parameter-gradient L2 1e-3; with natural gradient the
@@ -508,11 +509,11 @@ def main():
             out["strong"] = strong
 
         def line_item(name, chunk, sequences, den_states, gemm=None, steps=None, natural_gradient=None, workload=None, stats=None, archive_minibatches=0,
-                      want_stats=False):
+                      want_stats=False, profile=False):
             j = Job(pkg, args, chunk, sequences, den_states, rank, world, gemm=gemm, natural_gradient=natural_gradient, workload=workload, stats=stats,
                     archive_minibatches=archive_minibatches)
             k = args.steps if steps is None else steps
-            d = j.run(burn, args.warmup, k, lambda: torch.cuda.synchronize())
+            d = j.run(burn, args.warmup, k, lambda: torch.cuda.synchronize(), profile=profile)
             arcs = int(len(j.den["src"]))
             r = j.net.results.cpu().numpy()
             it = {"what": name, "value": round(sequences * chunk * k / d, 1), "unit": "frames/s", "ms_per_step": round(1e3 * d / k, 3),
@@ -522,6 +523,12 @@ def main():
                 it["archive"] = {"minibatches": archive_minibatches, "bytes": j.archive_bytes, "features": "16-bit compressed (CompressedMatrix kTwoByteAuto)"}
             if want_stats:
                 it["_stats"] = j.net.get_stats()
+            if profile:  # the event-timed GEMM classes of this job (as the headline's "roofline")
+                it["_classes"], it["_event_steps"] = [], j.event_steps
+                for kc in range(4):
+                    n_, ms_, fl_ = C.c_double(), C.c_double(), C.c_double()
+                    pkg.hipabi.check(lib.tdnnf_profile_read(kc, C.byref(n_), C.byref(ms_), C.byref(fl_)))
+                    it["_classes"].append(dict(name=lib.tdnnf_profile_class_name(kc).decode(), launches=n_.value, ms=ms_.value, flops=fl_.value))
             j.close()
             torch.cuda.empty_cache()
             return it
@@ -529,9 +536,23 @@ def main():
         if world == 1 and args.gemm == "f32" and not args.no_alt:
             # the same step with the optional split-bf16 GEMM arithmetic (not the headline: its gradient parity sits AT the
             # 1e-3 bar), same workload, same steps
-            it = line_item("--gemm bf16x3", args.chunk, seqs, args.den_states, gemm="bf16x3")
+            it = line_item("--gemm bf16x3", args.chunk, seqs, args.den_states, gemm="bf16x3", profile=True)
             out["alt"] = {"gemm": "bf16x3 (split-bf16 MFMA, f32 accumulate; --gemm bf16x3)", "value": it["value"], "unit": "frames/s",
                           "ms_per_step": it["ms_per_step"]}
+            # its roofline against the bf16 matrix-core peak (BASELINE configs[4]: "fp32 objf / bf16 MFMA GEMM"): every f32 multiply-add of
+            # the algorithm is three bf16 MFMA multiply-adds here (a_hi b_hi + a_hi b_lo + a_lo b_hi), so the matrix cores do 3 x the
+            # algorithmic FLOPs; both rates are given, the fraction is of the DENSE bf16 peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s)
+            cl = [c for c in it.get("_classes", [])[:3] if c["ms"] > 0]
+            if cl:
+                dm = max(cl, key=lambda c: c["ms"])
+                eq = dm["flops"] / (dm["ms"] * 1e-3) / 1e12
+                out["alt"]["roofline"] = {"bound": "mfma", "kernel": dm["name"].replace("f32", "bf16x3"), "achieved": round(3.0 * eq, 2), "peak": BF16_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": round(3.0 * eq / BF16_PEAK_TFLOPS, 4), "f32_equivalent_tflops": round(eq, 2),
+                                          "bf16_mfma_flops_per_algorithmic_flop": 3, "traffic": None, "event_steps": it.get("_event_steps"),
+                                          "all_kernels": [{"kernel": c["name"].replace("f32", "bf16x3"), "launches": int(c["launches"]), "ms": round(c["ms"], 3),
+                                                           "f32_equivalent_tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2)} for c in cl],
+                                          "note": "the operands are split from f32 inside the kernels (global -> registers -> two bf16 planes -> LDS): "
+                                                  "the launches wait for that staging path, not for the matrix cores (DESIGN.md 4d, 4l)"}
         if world == 1 and not args.no_also:
             # further line items, same net and step: the reference's own egs shape (chunk 150 x 64, ...pretrain.sh:46,197) and
             # SWBD-scale denominator graphs (10 000 and 30 000 states)
