@@ -1660,11 +1660,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
     return TDNNF_OK;
   };
-  // Small minibatches (the ones whose weight gradients have a stream of their own) are launch-bound on the host around this point: the ~60
-  // launches of the statistics are enqueued after the xent head's backward pass, which the caller's stream is waiting for, not before it
-  // (150 x 64: 0.8 ms of the caller's stream idle behind the host otherwise)
-  const bool early_after_xent = n->wg_on;
-  if (!early_after_xent) CK(launch_early_in());
+  // (enqueued behind the xent head's backward pass instead, for the host-bound small minibatches: 13.03 -> 13.10 ms at 150 x 64, 23.16 -> 23.31 at
+  // 1500 x 16 -- measured, not kept)
+  CK(launch_early_in());
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
     TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");
@@ -1692,7 +1690,6 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
-      if (early_after_xent) CK(launch_early_in());
     } else {
       tdnnf_mat tmp = M(n->d_small2, No, S);
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &tmp, s));
