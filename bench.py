@@ -578,6 +578,10 @@ def main():
                                              args.chunk, seqs, args.den_states, steps=6, workload="darts-offset-cvupdate", stats=stats))
                 out["also"].append(line_item("bottleneck-dimension supernet, Onehot pretrain (--workload bn-supernet)", args.chunk, seqs, args.den_states, steps=6,
                                              workload="bn-supernet"))
+                if not args.no_alt:  # configs[4] as BASELINE.json words it: "fp32 objf / bf16 MFMA GEMM"
+                    out["also"].append(line_item("bottleneck-dimension supernet with the split-bf16 GEMM arithmetic (--workload bn-supernet --gemm bf16x3: "
+                                                 "BASELINE configs[4], fp32 objective / bf16 MFMA GEMMs)", args.chunk, seqs, args.den_states, steps=6,
+                                                 workload="bn-supernet", gemm="bf16x3"))
             # archive-fed: every minibatch read from a cegs archive, decompressed, merged and copied to the device inside the timed loop
             for (ch, sq, st, resident) in ((args.chunk, seqs, 8, 1e3 * dt / args.steps), (150, 64, 40, recipe["ms_per_step"])):
                 it = line_item("archive-fed (egs.minibatches(prefetch=2): read + decompress + merge on a worker thread, H2D included), --chunk %d --minibatch %d" % (ch, sq),
