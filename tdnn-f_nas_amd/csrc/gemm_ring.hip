@@ -65,7 +65,7 @@ __device__ __forceinline__ void hidden_wait16(float (&x)[16]) {
                : "memory");
 }
 
-template <int WM, int WN, int TM, int TN, bool B_KC>
+template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, TN == 5 ? 2 : 3) void rows_gemm_ring_kernel(const RowsGemmArgs p, int ntm, int ntn) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, BK = 16;
   constexpr int A_CH = BM * 4, B_CH = BN * 4, CH = A_CH + B_CH;  // 16-byte chunks of a stage: [A rows x 4 | B]
@@ -114,19 +114,10 @@ __global__ __launch_bounds__(256, TN == 5 ? 2 : 3) void rows_gemm_ring_kernel(co
         const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3), m = rq_m0 + row;
         ok = m < p.M && m >= sg.m_lo && m < sg.m_hi;
         src = p.A + sg.a_off + (long long)m * p.lda + c * 4;
-      } else if (B_KC) {
+      } else {
         const int qb = q - A_CH, row = qb >> 2, c = (qb & 3) ^ ((row >> 2) & 3), n = rq_n0 + row;
         ok = n < p.N;
         src = p.B + sg.b_off + (long long)n * p.ldb + c * 4;
-      } else {
-        // [k][n] image, 4 consecutive n per chunk; the rows with bit 2 of k set are rotated by 32 columns, so that the two half
-        // waves of a fragment read (k and k + 4) use different banks
-        const int e = (q - A_CH) * 4, k = e / BN, nn = e % BN;
-        int nl = nn + ((k >> 2) & 1) * 32;
-        if (nl >= BN) nl -= BN;
-        const int n = rq_n0 + nl;
-        ok = n + 3 < p.N;
-        src = p.B + sg.b_off + (long long)k * p.ldb + n;
       }
       srcp[j] = ok ? reinterpret_cast<const char *>(src) : zero;
       live = ok ? live | (1u << j) : live & ~(1u << j);
@@ -152,8 +143,7 @@ __global__ __launch_bounds__(256, TN == 5 ? 2 : 3) void rows_gemm_ring_kernel(co
 #pragma unroll
     for (int j = 0; j < PPT; j++) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcp[j]), (__attribute__((address_space(3))) void *)(dst + j * 4096), 16, 0, 0);
-      const bool is_b = !B_KC && (t + 256 * j >= CH ? t + 256 * j - CH : t + 256 * j) >= A_CH;  // [k][n] image of B: a K step is 16 rows
-      srcp[j] += ((live >> j) & 1u) ? (is_b ? (long long)p.ldb * (BK * 4) : (long long)(BK * 4)) : 0ll;
+      srcp[j] += ((live >> j) & 1u) ? (long long)(BK * 4) : 0ll;
     }
     if (--rq_left == 0) next_request_span();
   };
@@ -168,13 +158,7 @@ __global__ __launch_bounds__(256, TN == 5 ? 2 : 3) void rows_gemm_ring_kernel(co
 #pragma unroll
   for (int j = 0; j < TN; j++) {
     const int row = (wn * TN + j) * 32 + li;
-    if (B_KC) {
-      b_off[j] = A_CH * 16 + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
-    } else {
-      int nn = row - lh * 32;
-      if (nn < 0) nn += BN;
-      b_off[j] = A_CH * 16 + (lh * 4 * BN + nn) * 4;
-    }
+    b_off[j] = A_CH * 16 + row * 64 + ((lh ^ ((row >> 2) & 3)) << 4);
   }
 
   f32x16 acc[TM][TN];
@@ -192,73 +176,39 @@ __global__ __launch_bounds__(256, TN == 5 ? 2 : 3) void rows_gemm_ring_kernel(co
   // step are issued together; LDS returns in order, so the first half's MFMAs start when the second half's reads are still out.
   auto multiply = [&](int slot) {
     const unsigned st = (unsigned)(slot * STAGE);
-    if constexpr (B_KC) {
-      f32x4 a[2][TM], b[2][TN];
+    f32x4 a[2][TM], b[2][TN];
 #pragma unroll
-      for (int kg = 0; kg < 2; kg++) {
+    for (int kg = 0; kg < 2; kg++) {
 #pragma unroll
-        for (int i = 0; i < TM; i++) asm volatile("ds_read_b128 %0, %1" : "=v"(a[kg][i]) : "v"(st + (unsigned)(a_off[i] ^ (kg * 32))) : "memory");
+      for (int i = 0; i < TM; i++) asm volatile("ds_read_b128 %0, %1" : "=v"(a[kg][i]) : "v"(st + (unsigned)(a_off[i] ^ (kg * 32))) : "memory");
 #pragma unroll
-        for (int j = 0; j < TN; j++) asm volatile("ds_read_b128 %0, %1" : "=v"(b[kg][j]) : "v"(st + (unsigned)(b_off[j] ^ (kg * 32))) : "memory");
-      }
+      for (int j = 0; j < TN; j++) asm volatile("ds_read_b128 %0, %1" : "=v"(b[kg][j]) : "v"(st + (unsigned)(b_off[j] ^ (kg * 32))) : "memory");
+    }
 #pragma unroll
-      for (int kg = 0; kg < 2; kg++) {
-        if constexpr (TM == 2 && TN == 2) {
-          if (kg == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1])::"memory");
-          else {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[1][0]), "+v"(b[1][1])::"memory");
-          }
-        } else {
-          static_assert((TM == 2 && TN == 2) || (TM == 1 && TN == 5), "fragment waits are written out per tile shape");
-          if (kg == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][0]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[0][4])::"memory");
-          else {
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]), "+v"(b[1][4])::"memory");
-          }
+    for (int kg = 0; kg < 2; kg++) {
+      if constexpr (TM == 2 && TN == 2) {
+        if (kg == 0) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(b[0][0]), "+v"(b[0][1])::"memory");
+        else {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(a[1][1]), "+v"(b[1][0]), "+v"(b[1][1])::"memory");
         }
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].x, b[kg][j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].y, b[kg][j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].z, b[kg][j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].w, b[kg][j].w, acc[i][j], 0, 0, 0);
-          }
-      }
-    } else {
-      // B as [k][n]: four 4-byte reads per fragment (k = 8 kg + 4 lh + 0..3 of column li); one K half at a time
-#pragma unroll
-      for (int kg = 0; kg < 2; kg++) {
-        f32x4 a[TM];
-        float b[TN][4];
-#pragma unroll
-        for (int i = 0; i < TM; i++) asm volatile("ds_read_b128 %0, %1" : "=v"(a[i]) : "v"(st + (unsigned)(a_off[i] ^ (kg * 32))) : "memory");
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-          for (int e = 0; e < 4; e++)
-            asm volatile("ds_read_b32 %0, %1" : "=v"(b[j][e]) : "v"(st + (unsigned)(b_off[j] + (kg * 8 + e) * BN * 4)) : "memory");
-        if constexpr (TM == 2 && TN == 2) {
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(a[0]), "+v"(a[1]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3])::"memory");
-        } else {
-          asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+v"(a[0]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]), "+v"(b[2][0]),
-                         "+v"(b[2][1]), "+v"(b[2][2]), "+v"(b[2][3]), "+v"(b[3][0]), "+v"(b[3][1]), "+v"(b[3][2]), "+v"(b[3][3]), "+v"(b[4 % TN][0]), "+v"(b[4 % TN][1]),
-                         "+v"(b[4 % TN][2]), "+v"(b[4 % TN][3])::"memory");
+      } else {
+        static_assert((TM == 2 && TN == 2) || (TM == 1 && TN == 5), "fragment waits are written out per tile shape");
+        if (kg == 0) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[0][0]), "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[0][2]), "+v"(b[0][3]), "+v"(b[0][4])::"memory");
+        else {
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[1][0]), "+v"(b[1][0]), "+v"(b[1][1]), "+v"(b[1][2]), "+v"(b[1][3]), "+v"(b[1][4])::"memory");
         }
-#pragma unroll
-        for (int i = 0; i < TM; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j][2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j][3], acc[i][j], 0, 0, 0);
-          }
       }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].x, b[kg][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].y, b[kg][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].z, b[kg][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kg][i].w, b[kg][j].w, acc[i][j], 0, 0, 0);
+        }
     }
   };
 
@@ -411,20 +361,20 @@ int ring_cus() {
   return g_ring_cus;
 }
 
-template <int WM, int WN, int TM, int TN, bool B_KC>
+template <int WM, int WN, int TM, int TN>
 hipError_t launch_ring(const RowsGemmArgs &a, int blocks, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int CH = (BM + BN) * 4, PPT = (CH + 255) / 256;
   constexpr size_t lds = (size_t)kRing * PPT * 256 * 16 + sizeof(float) * WM * BN * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)rows_gemm_ring_kernel<WM, WN, TM, TN, B_KC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)rows_gemm_ring_kernel<WM, WN, TM, TN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   const int tiles = ntm * ntn;
-  hipLaunchKernelGGL((rows_gemm_ring_kernel<WM, WN, TM, TN, B_KC>), dim3(tiles < blocks ? tiles : blocks), dim3(256), lds, s, a, ntm, ntn);
+  hipLaunchKernelGGL((rows_gemm_ring_kernel<WM, WN, TM, TN>), dim3(tiles < blocks ? tiles : blocks), dim3(256), lds, s, a, ntm, ntn);
   return hipGetLastError();
 }
 
@@ -443,7 +393,7 @@ bool rows_gemm_ring_ok(const RowsGemmArgs &a, bool b_kc, bool vec) {
   if (!rows_gemm_ring_enabled() || a.prec != 0 || !vec || a.coef || a.sumsq || a.ksplit > 1 || a.nseg <= 0) return false;
   for (int i = 0; i < a.nseg; i++)
     if (a.seg[i].klen <= 0 || a.seg[i].klen % 16 != 0) return false;
-  if (!b_kc) return false;  // (the [k][n] form of B is written but not used: it spills at three blocks per CU; the trainer hands backward-data GEMMs W^T)
+  if (!b_kc) return false;  // (a [k][n] form of B was written too: 4-byte fragment reads, spills at three blocks per CU -- removed; TDNNF_WT=1 hands the backward-data GEMMs W^T)
   if ((a.init_mode == 1 && !a.bias) || a.M <= 0 || a.N <= 0) return false;
   return true;
 }
@@ -453,8 +403,8 @@ int rows_gemm_ring_slots(int tile_cols) { return (tile_cols == 160 ? 2 : 3) * ri
 hipError_t rows_gemm_ring(const RowsGemmArgs &a, bool b_kc, int tile_cols, hipStream_t s) {
   const int blocks = rows_gemm_ring_slots(tile_cols);
   if (!b_kc) return hipErrorInvalidValue;
-  if (tile_cols == 160) return launch_ring<4, 1, 1, 5, true>(a, blocks, s);
-  return launch_ring<2, 2, 2, 2, true>(a, blocks, s);
+  if (tile_cols == 160) return launch_ring<4, 1, 1, 5>(a, blocks, s);
+  return launch_ring<2, 2, 2, 2>(a, blocks, s);
 }
 
 }  // namespace tdnnf
