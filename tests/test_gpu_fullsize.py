@@ -336,11 +336,13 @@ def test_bench_shape_denominator_forms_agree(pkg, bench_egs):
     assert e < 1e-4, e
 
 
-@pytest.mark.parametrize("mode", [1, 2], ids=["persistent", "wide"])
-def test_chain_objective_at_500_frames_matches_oracle(pkg, ora, mode):
+@pytest.mark.parametrize("mode,mw", [(1, "1"), (1, "0"), (2, "1")], ids=["persistent-four-workgroups-per-sequence", "persistent-one-workgroup", "wide"])
+def test_chain_objective_at_500_frames_matches_oracle(pkg, ora, monkeypatch, mode, mw):
     """chain::ComputeChainObjfAndDeriv at the length of a 1500-frame chunk (500 output frames), 6034 pdfs, the bench's
     4 000-state graph, supervision paths drawn from the denominator graph: errors of a log-domain recursion grow with the
-    frame index (a float numerator was 6.8e-4 off here and its frame posteriors summed to 1 +- 2.2e-3: it runs in double now)."""
+    frame index (a float numerator was 6.8e-4 off here and its frame posteriors summed to 1 +- 2.2e-3: it runs in double now).
+    Eight sequences: the persistent form takes four workgroups per sequence (chain.hip, den_mw_kernel) unless TDNNF_DEN_MW=0."""
+    monkeypatch.setenv("TDNNF_DEN_MW", mw)
     hip = Hip(pkg)
     L = ora.lib()
     H, P, B, T = 4000, 6034, 8, 500
