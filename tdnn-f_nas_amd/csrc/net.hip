@@ -1660,9 +1660,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
     return TDNNF_OK;
   };
-  // (enqueued behind the xent head's backward pass instead, for the host-bound small minibatches: 13.03 -> 13.10 ms at 150 x 64, 23.16 -> 23.31 at
-  // 1500 x 16 -- measured, not kept)
-  CK(launch_early_in());
+  // Where in the host's order: minibatches whose GEMMs fill the chip start the statistics BEHIND the xent head's backward pass -- they then run
+  // while the caller's stream waits for the denominator instead of beside the xent head's GEMMs (same step time, 124.0 against 124.1 ms, and the
+  // 128 x 128 class is not slowed: 99.5 against 96.4 TFLOP/s, weight gradients 107 against 102); the small ones start them at once (behind the
+  // xent head: 13.03 -> 13.10 ms at 150 x 64, 23.16 -> 23.31 at 1500 x 16).  TDNNF_NG_EARLY_AFTER_XENT=0|1 forces one.
+  static const int after_env = getenv("TDNNF_NG_EARLY_AFTER_XENT") ? atoi(getenv("TDNNF_NG_EARLY_AFTER_XENT")) : -1;
+  const bool early_after_xent = after_env >= 0 ? after_env != 0 : !n->wg_on;
+  if (!early_after_xent) CK(launch_early_in());
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
     TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");
@@ -1690,6 +1694,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
+      if (early_after_xent) CK(launch_early_in());
     } else {
       tdnnf_mat tmp = M(n->d_small2, No, S);
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &tmp, s));
