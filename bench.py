@@ -481,8 +481,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom["name"], "kernel_choice": "the TDNN-F factored-GEMM class with the most time "
                          "(forward / backward-data 128x128, 128x160, weight gradient); the natural-gradient class is roofline_secondary",
                          "note": "launch durations are event-timed in the real step, i.e. with whatever runs beside the launch on other streams: since "
-                         "round 3 the natural-gradient input-side statistics (HBM-bound) run beside the first GEMMs of the backward pass and the xent head "
-                         "(TDNNF_NG_EARLY_IN=0 puts them back: this class then reads 4 TFLOP/s more and the step takes 2 ms longer, DESIGN.md 4n)",
+                         "round 3 the natural-gradient input-side statistics (HBM-bound) run on another stream while the caller's stream waits for the "
+                         "denominator and beside the first GEMMs of the backward pass (DESIGN.md 4n)",
                          "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes": round(alg_per_launch, 1),
