@@ -362,6 +362,9 @@ def main():
     ap.add_argument("--natural-gradient", type=int, default=1, choices=[0, 1],
                     help="1 (default, what the reference's recipes train with) = OnlineNaturalGradient preconditioning of every "
                          "updatable component's gradient; 0 = raw-gradient SGD step")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="a tuning option of the library (tdnnf_set_option: ng_grouped, ng_fuse, ng_early_in, wgrad_stream, gemm_ring, planes); "
+                         "repeatable -- same-box A/B runs of two code paths")
     args = ap.parse_args()
 
     import torch
@@ -388,6 +391,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
+    for spec in args.option:
+        name, _, value = spec.partition("=")
+        pkg.hipabi.check(lib.tdnnf_set_option(name.encode(), int(value)))
     if args.scaling == "strong":
         b0, b1 = pkg.trainer.shard_sequences(args.minibatch, rank, world)
         if args.minibatch % world:

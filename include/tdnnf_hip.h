@@ -49,6 +49,16 @@ typedef struct tdnnf_ng tdnnf_ng; /* OnlineNaturalGradient state (A8, below) */
 
 const char *tdnnf_last_error(void);
 int tdnnf_abi_version(void);
+/* Tuning options: process-wide integers selecting between code paths that are all held to the same parity tests (the library reads
+   no environment variable for them).  Unknown names fail with TDNNF_EINVAL.
+     "ng_grouped"    1 (default) natural-gradient side chain of a gradient bucket as grouped launches, 0 per object   [read by tdnnf_net_create]
+     "ng_fuse"       1 (default) output-side statistic inside the BatchNorm / ReLU backward sweep when that pays, 0 own GEMM, 2 always
+     "ng_early_in"   1 (default) input-side statistics ahead of the backward pass, 0 with the component's backward call [tdnnf_net_create]
+     "wgrad_stream"  -1 (default) parameter gradients on their own stream for small minibatches, 0 never, 1 always       [tdnnf_net_create]
+     "gemm_ring"     1 (default) persistent LDS-DMA-ring rows GEMM where it applies, 0 the plain tile kernel
+     "planes"        1 (default) gemm_precision 2 runs the pre-split bf16-plane GEMMs where they apply, 0 the in-kernel split */
+int tdnnf_set_option(const char *name, int value);
+int tdnnf_get_option(const char *name, int *value_out);
 
 /* ---- TdnnDARTSV3Component coefficient flags (nnet-tdnn-component.cc:150-163) */
 #define TDNNF_DARTS_USE_GUMBEL 1
@@ -100,6 +110,10 @@ int tdnnf_tdnn_update_simple(const tdnnf_tdnn_indexes *indexes, const tdnnf_mat 
                              float *bias_acc_dev, void *workspace_dev, size_t workspace_bytes,
                              tdnnf_stream stream);
 
+/* scratch of tdnnf_tdnn_darts_alpha_update: s_i (K doubles), then K x TDNNF_TAP_DOTS_SLABS row-slab partials (added in slab order) */
+#define TDNNF_TAP_DOTS_SLABS 64
+#define TDNNF_TAP_DOTS_DOUBLES(K) ((K) * (1 + TDNNF_TAP_DOTS_SLABS))
+
 /* Architecture-logit update of UpdateNaturalGradient :490-590.  s_i = <X_i W_i^T, dY>
    is obtained as <dW_i, W_i> from tap_grad_dev (K blocks of dY^T X_i, Do x K*Di,
    UNSCALED by coefficients and lr), avoiding the reference's extra forward GEMM
@@ -107,7 +121,7 @@ int tdnnf_tdnn_update_simple(const tdnnf_tdnn_indexes *indexes, const tdnnf_mat 
 int tdnnf_tdnn_darts_alpha_update(const float *tap_grad_dev, int ldg, const float *linear_params_dev,
                                   int ldw, int Do, int Di, int K, const float *coef_memo_dev,
                                   int flags, int share_index, float temp_proportion, float lr,
-                                  float *alpha_acc_dev, double *tap_dots_dev /* K doubles, receives s_i */,
+                                  float *alpha_acc_dev, double *tap_dots_dev /* TDNNF_TAP_DOTS_DOUBLES(K) doubles: the first K receive s_i */,
                                   tdnnf_stream stream);
 /* (in TDNNF_DARTS_UNIFORM_SAMPLE mode no gradient is added -- the reference computes and discards it, :502-507 --
    only the trailing scalings :565-590 run; tap_grad_dev may then be NULL) */
@@ -231,6 +245,9 @@ int tdnnf_sum_scaled(const tdnnf_mat *a, float sa, const tdnnf_mat *b, float sb,
 int tdnnf_add_scaled(const tdnnf_mat *a, float s, tdnnf_mat *out, tdnnf_stream);
 /* GeneralDropoutComponent (UPSTREAM), continuous mask shared over time: row r uses mask row r % num_seq */
 int tdnnf_general_dropout(const tdnnf_mat *in, const float *mask_dev, int num_seq, tdnnf_mat *out, tdnnf_stream);
+/* GeneralDropoutComponent::GetMemo (UPSTREAM; factory /root/reference/src/nnet3/nnet-component-itf.cc:194): the mask from n uniform
+   draws -- continuous: 1 - 2p + 4p U (expected value 1); otherwise Heaviside(U - p) / (1 - p) */
+int tdnnf_general_dropout_mask(const float *uniform_dev, long long n, float proportion, int continuous, float *mask_dev, tdnnf_stream);
 
 /* ========================================================================== A7
  * chain::ComputeChainObjfAndDeriv (UPSTREAM; options from
@@ -252,8 +269,11 @@ void tdnnf_supervision_destroy(tdnnf_supervision *);
 
 /* The denominator recursion has two forms: one persistent workgroup per sequence with the state vectors in LDS (graphs up
    to ~10 000 states), and one launch per frame over all sequences on sequence-minor arrays (larger graphs).  0 = chosen by
-   graph size (default), 1 / 2 force one (tests, experiments).  Affects the workspace size: set it before
-   tdnnf_chain_workspace_bytes / tdnnf_net_create. */
+   graph size (default), 1 / 2 force one (tests, experiments); 3 = the persistent form with ONE workgroup per sequence even for
+   few sequences (otherwise up to 32 sequences take four workgroups each, which must be co-resident: checked against the
+   occupancy calculator before the launch, a bounded poll behind it, and the one-workgroup kernels redo a minibatch whose
+   multi-workgroup launch gave up -- reported on stderr once, not used again in the process).  Affects the workspace size:
+   set it before tdnnf_chain_workspace_bytes / tdnnf_net_create. */
 int tdnnf_chain_set_denominator_mode(int mode);
 size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *, int num_sequences, int frames_per_sequence);
 /* results_dev (device doubles): [0] objf, [1] l2_term, [2] weight, [3] num logprob (weighted),

@@ -271,7 +271,7 @@ inline void AffinePropagate(const CuMat &in, const float *linear_params, int ldw
   tdnnf_mat vin = View(in), vout = View(*out);
   Check(tdnnf_affine_propagate(&vin, linear_params, ldw, bias, output_dim, &vout, stream));
 }
-// Backprop :1253-1279: in_deriv = out_deriv W (overwrites; may be null), then the update of `to_update` -- UpdateSimple :1246-1251
+// Backprop :1253-1279: in_deriv += out_deriv W (kBackpropAdds; may be null), then the update of `to_update` -- UpdateSimple :1246-1251
 // when ng == nullptr (is_gradient_ or use-natural-gradient=false), else the natural-gradient Update.
 // workspace: tdnnf_tdnn_update_workspace_bytes(Do, Di, 1, rows) / tdnnf_affine_update_natural_gradient_workspace_bytes.
 template <class CuMat>
@@ -279,9 +279,13 @@ inline void AffineBackprop(const CuMat &in_value, const CuMat &out_deriv, const 
                            float learning_rate, float *to_update_linear /* null: no update */, float *to_update_bias /* null: Linear */,
                            void *workspace_dev, size_t workspace_bytes, tdnnf_stream stream, const NaturalGradient *ng = nullptr) {
   tdnnf_mat vx = View(in_value), vdy = View(out_deriv);
-  if (in_deriv) {
+  if (in_deriv) {  // "add with coefficient 1.0 since property kBackpropAdds is true" (:1264-1269): the one-tap gather form adds
     tdnnf_mat vdx = View(*in_deriv);
-    Check(tdnnf_affine_backprop(&vdy, linear_params, ldw, vx.cols, &vdx, stream));
+    tdnnf_tdnn_indexes ix;
+    ix.row_stride = 1;
+    ix.num_offsets = 1;
+    ix.row_offsets[0] = 0;
+    Check(tdnnf_tdnn_backprop_data(&ix, &vdy, linear_params, ldw, vdy.cols, vx.cols, nullptr, &vdx, stream));
   }
   if (!to_update_linear || learning_rate == 0.0f) return;
   if (ng)
@@ -289,6 +293,45 @@ inline void AffineBackprop(const CuMat &in_value, const CuMat &out_deriv, const 
                                                workspace_bytes, stream));
   else
     Check(tdnnf_affine_update_simple(&vx, &vdy, learning_rate, to_update_linear, ldw, to_update_bias, workspace_dev, workspace_bytes, stream));
+}
+
+// FixedAffineComponent :3378-3399: out = bias + in W^T; in_deriv += out_deriv W (kBackpropAdds), nothing to update
+template <class CuMat>
+inline void FixedAffineBackprop(const CuMat &out_deriv, const float *linear_params, int ldw, int input_dim, CuMat *in_deriv, tdnnf_stream stream) {
+  if (!in_deriv) return;
+  tdnnf_mat vdy = View(out_deriv), vdx = View(*in_deriv);
+  tdnnf_tdnn_indexes ix;
+  ix.row_stride = 1;
+  ix.num_offsets = 1;
+  ix.row_offsets[0] = 0;
+  Check(tdnnf_tdnn_backprop_data(&ix, &vdy, linear_params, ldw, vdy.cols, input_dim, nullptr, &vdx, stream));
+}
+
+// NoOpComponent :437-456: out = in; in_deriv = backprop_scale * out_deriv (in place allowed)
+template <class CuMat>
+inline void NoOpPropagate(const CuMat &in, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vin = View(in), vout = View(*out);
+  if (vin.data != vout.data) Check(tdnnf_sum_scaled(&vin, 1.0f, nullptr, 0.f, &vout, stream));
+}
+template <class CuMat>
+inline void NoOpBackprop(const CuMat &out_deriv, float backprop_scale, CuMat *in_deriv, tdnnf_stream stream) {
+  tdnnf_mat vd = View(out_deriv), vdx = View(*in_deriv);
+  if (vd.data != vdx.data || backprop_scale != 1.0f) Check(tdnnf_sum_scaled(&vd, backprop_scale, nullptr, 0.f, &vdx, stream));
+}
+
+// GeneralDropoutComponent (UPSTREAM; factory nnet-component-itf.cc:194, edits nnet-utils.cc:1315): mask_dev = num_seq x dim
+// from tdnnf_general_dropout_mask, shared over time (row r uses mask row r % num_seq); Backprop applies the same mask
+template <class CuMat>
+inline void GeneralDropoutApply(const CuMat &in, const float *mask_dev, int num_seq, CuMat *out, tdnnf_stream stream) {
+  tdnnf_mat vin = View(in), vout = View(*out);
+  Check(tdnnf_general_dropout(&vin, mask_dev, num_seq, &vout, stream));
+}
+
+// FlopsConstraintComponent :9454-9478: Propagate copies; Backprop: in_deriv = rows of flops * scale / (rows * cols of in_value)
+template <class CuMat>
+inline void FlopsConstraintBackprop(const float *flops_dev, float scale, const CuMat &in_value, CuMat *in_deriv, tdnnf_stream stream) {
+  tdnnf_mat vdx = View(*in_deriv);
+  Check(tdnnf_flops_constraint_backprop(flops_dev, scale, in_value.NumRows(), in_value.NumCols(), &vdx, stream));
 }
 
 // LogSoftmaxComponent :3607-3632

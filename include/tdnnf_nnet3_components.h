@@ -56,9 +56,13 @@ struct DeviceHooks {
   void (*free)(void *p);
   void (*fill_uniform)(float *dev, int n);  // n uniform draws on (0, 1) into device memory, ordered on `stream`
   tdnnf_stream stream;
+  // host-side control decisions (Kaldi: RandUniform() / RandInt(), nnet-simple-component.cc:1017, :1084); optional -- without them
+  // RectifiedLinearComponent repairs / stores on every call unless told otherwise (SetRepairNow / SetStoreNow)
+  float (*rand_uniform)();
+  int (*rand_int)(int lo, int hi);
 };
 inline DeviceHooks &Hooks() {
-  static DeviceHooks h = {nullptr, nullptr, nullptr, nullptr};
+  static DeviceHooks h = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   return h;
 }
 inline void *DeviceAlloc(size_t bytes) {
@@ -84,6 +88,16 @@ class Scratch {
   Scratch(const Scratch &);
   void *p_;
   size_t bytes_;
+};
+
+// the uniform draws of a kRandomComponent: kept by the component (grown on demand) instead of allocated and freed around the
+// launch that reads them -- freeing right behind an asynchronous launch is only safe with a stream-ordered allocator
+class DrawBuffer {
+ public:
+  float *Get(int n) { return static_cast<float *>(buf_.Get(sizeof(float) * (size_t)std::max(n, 1))); }
+
+ private:
+  Scratch buf_;
 };
 
 class ComponentPrecomputedIndexes {
@@ -298,13 +312,12 @@ class SoftmaxFlopsComponentBase : public Component {
   virtual int32 Properties() const { return kBackpropInPlace | kSimpleComponent | kBackpropNeedsInput | kBackpropNeedsOutput | kRandomComponent; }
   virtual void *Propagate(const ComponentPrecomputedIndexes *, const CuMatrixBase &in, CuMatrixBase *out) const {
     float *u = nullptr;
-    if (gumbel_) {  // one Gumbel vector shared by all rows (:10095-10104)
-      u = static_cast<float *>(DeviceAlloc(sizeof(float) * dim_));
+    if (gumbel_) {  // one Gumbel vector shared by all rows (:10095-10104), in a buffer the component keeps
+      u = draws_.Get(dim_);
       if (!Hooks().fill_uniform) TDNNF_ADAPTER_FAIL("tdnnf_nnet3: DeviceHooks::fill_uniform is not installed");
       Hooks().fill_uniform(u, dim_);
     }
     tdnnf_adapter::SoftmaxFlopsPropagate(in, u, temp_, out, Hooks().stream);
-    if (u && Hooks().free) Hooks().free(u);  // (stream-ordered allocators only; otherwise keep it until the stream has passed)
     return nullptr;
   }
   virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *, const CuMatrixBase &, const CuMatrixBase &out_value,
@@ -318,6 +331,7 @@ class SoftmaxFlopsComponentBase : public Component {
   int32 dim_;
   float scale_, temp_;
   const float *flops_;
+  mutable DrawBuffer draws_;
 };
 class SoftmaxFlopsComponent : public SoftmaxFlopsComponentBase {
  public:
@@ -344,11 +358,10 @@ class OutputVectorComponent : public UpdatableComponent {
       tdnnf_adapter::ConstantFunctionPropagate(output_, out, Hooks().stream);
       return nullptr;
     }
-    float *u = static_cast<float *>(DeviceAlloc(sizeof(float)));
+    float *u = draws_.Get(1);
     if (!Hooks().fill_uniform) TDNNF_ADAPTER_FAIL("tdnnf_nnet3: DeviceHooks::fill_uniform is not installed");
     Hooks().fill_uniform(u, 1);
     tdnnf_adapter::OnehotPropagate(u, out, Hooks().stream);
-    if (Hooks().free) Hooks().free(u);
     return nullptr;
   }
   virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *, const CuMatrixBase &, const CuMatrixBase &,
@@ -365,6 +378,7 @@ class OutputVectorComponent : public UpdatableComponent {
   int32 in_dim_, out_dim_;
   float *output_;
   bool is_updatable_;
+  mutable DrawBuffer draws_;
 };
 class OnehotFunctionComponent : public OutputVectorComponent {
  public:
@@ -431,26 +445,34 @@ class RectifiedLinearComponent : public Component {  // :958-1091; statistics [c
     tdnnf_adapter::ReluPropagate(in, out, Hooks().stream);
     return nullptr;
   }
-  // (the reference's RepairGradients coin flip w.p. self-repair probability, :1017, stays with the caller: `repair_now`)
+  // RepairGradients runs "on about half of the minibatches" (:997-1018: `if (RandUniform() > repair_probability) return`): the
+  // coin comes from DeviceHooks::rand_uniform when the host installed it, else from SetRepairNow()
   virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *, const CuMatrixBase &, const CuMatrixBase &out_value,
                         const CuMatrixBase &out_deriv, void *, Component *to_update, CuMatrixBase *in_deriv) const {
     if (!in_deriv) return;
     tdnnf_adapter::ReluBackprop(out_value, out_deriv, in_deriv, Hooks().stream);
     RectifiedLinearComponent *tu = static_cast<RectifiedLinearComponent *>(to_update);
-    if (tu && tu->self_repair_scale_ > 0.f && tu->repair_now_)
-      tdnnf_adapter::ReluRepairGradients(tu->stats_, dim_, tu->self_repair_scale_, 0.05f, 0.95f, in_deriv, Hooks().stream);
+    if (!tu || tu->self_repair_scale_ <= 0.f || !tu->stored_once_) return;  // "self_repair_scale_ == 0.0 || count_ == 0.0" :1001
+    const bool repair = Hooks().rand_uniform ? !(Hooks().rand_uniform() > 0.5f) : tu->repair_now_;
+    if (repair) tdnnf_adapter::ReluRepairGradients(tu->stats_, dim_, tu->self_repair_scale_, 0.05f, 0.95f, in_deriv, Hooks().stream);
   }
+  // "Only store stats about every other minibatch (but on the first minibatch, always store it)" :1081-1085
   virtual void StoreStats(const CuMatrixBase &, const CuMatrixBase &out_value, void *) {
+    const bool skip = Hooks().rand_int ? (Hooks().rand_int(0, 1) == 0 && stored_once_) : !store_now_;
+    if (skip) return;
     const size_t wsb = tdnnf_colreduce_workspace_bytes(out_value.NumRows(), dim_);
     tdnnf_adapter::ReluStoreStats(out_value, stats_, ws_.Get(wsb), wsb, Hooks().stream);
+    stored_once_ = true;
   }
   void SetRepairNow(bool b) { repair_now_ = b; }
+  void SetStoreNow(bool b) { store_now_ = b; }
+  void SetStatsPresent(bool b) { stored_once_ = b; }  // a model read from disk with count_ != 0
 
  private:
   int32 dim_;
   float self_repair_scale_;
   double *stats_;
-  bool repair_now_ = true;
+  bool repair_now_ = true, store_now_ = true, stored_once_ = false;
   Scratch ws_;
 };
 
@@ -492,6 +514,162 @@ class LinearComponent : public AffineComponentBase {
   LinearComponent() : AffineComponentBase("LinearComponent") {}
 };
 
+// AffineComponent :1235-1279: Update() is UpdateSimple (no preconditioning), whatever use-natural-gradient says
+class AffineComponent : public AffineComponentBase {
+ public:
+  AffineComponent() : AffineComponentBase("AffineComponent") { use_natural_gradient_ = false; }
+  void SetUseNaturalGradient(bool) {}
+};
+
+// FixedAffineComponent :3378-3399 (the lda layer): not updatable, kBackpropAdds
+class FixedAffineComponent : public Component {
+ public:
+  FixedAffineComponent() : in_dim_(0), out_dim_(0), linear_(nullptr), bias_(nullptr) {}
+  void SetParams(int32 input_dim, int32 output_dim, const float *linear_dev, const float *bias_dev) { in_dim_ = input_dim; out_dim_ = output_dim; linear_ = linear_dev; bias_ = bias_dev; }
+  virtual std::string Type() const { return "FixedAffineComponent"; }
+  virtual int32 InputDim() const { return in_dim_; }
+  virtual int32 OutputDim() const { return out_dim_; }
+  virtual int32 Properties() const { return kSimpleComponent | kBackpropAdds; }  // nnet-simple-component.h:1010
+  virtual void *Propagate(const ComponentPrecomputedIndexes *, const CuMatrixBase &in, CuMatrixBase *out) const {
+    tdnnf_adapter::AffinePropagate(in, linear_, in_dim_, bias_, out_dim_, out, Hooks().stream);
+    return nullptr;
+  }
+  virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *, const CuMatrixBase &, const CuMatrixBase &,
+                        const CuMatrixBase &out_deriv, void *, Component *, CuMatrixBase *in_deriv) const {
+    tdnnf_adapter::FixedAffineBackprop(out_deriv, linear_, in_dim_, in_dim_, in_deriv, Hooks().stream);
+  }
+
+ private:
+  int32 in_dim_, out_dim_;
+  const float *linear_, *bias_;
+};
+
+class NoOpComponent : public Component {  // :437-456
+ public:
+  NoOpComponent() : dim_(0), backprop_scale_(1.0f) {}
+  void Init(int32 dim, float backprop_scale) { dim_ = dim; backprop_scale_ = backprop_scale; }
+  virtual std::string Type() const { return "NoOpComponent"; }
+  virtual int32 InputDim() const { return dim_; }
+  virtual int32 OutputDim() const { return dim_; }
+  virtual int32 Properties() const { return kSimpleComponent | kPropagateInPlace | kBackpropInPlace; }  // nnet-simple-component.h:1192-1194
+  virtual void *Propagate(const ComponentPrecomputedIndexes *, const CuMatrixBase &in, CuMatrixBase *out) const {
+    tdnnf_adapter::NoOpPropagate(in, out, Hooks().stream);
+    return nullptr;
+  }
+  virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *, const CuMatrixBase &, const CuMatrixBase &,
+                        const CuMatrixBase &out_deriv, void *, Component *, CuMatrixBase *in_deriv) const {
+    if (in_deriv) tdnnf_adapter::NoOpBackprop(out_deriv, backprop_scale_, in_deriv, Hooks().stream);
+  }
+
+ private:
+  int32 dim_;
+  float backprop_scale_;
+};
+
+// GeneralDropoutComponent (UPSTREAM; factory nnet-component-itf.cc:194, `set-dropout-proportion` nnet-utils.cc:1315-1321) in the
+// recipes' configuration: one mask row per sequence shared over time (time-period 0), block-dim == dim.  The precomputed indexes
+// reduce to the number of sequences: row r of a t-major matrix belongs to sequence r % num_seq.
+class GeneralDropoutPrecomputedIndexes : public ComponentPrecomputedIndexes {
+ public:
+  int32 num_mask_rows;
+};
+class GeneralDropoutComponent : public Component {
+ public:
+  GeneralDropoutComponent() : dim_(0), proportion_(0.5f), continuous_(false), test_mode_(false) {}
+  void Init(int32 dim, float dropout_proportion, bool continuous) { dim_ = dim; proportion_ = dropout_proportion; continuous_ = continuous; }
+  void SetDropoutProportion(BaseFloat p) { proportion_ = p; }
+  void SetTestMode(bool b) { test_mode_ = b; }
+  virtual std::string Type() const { return "GeneralDropoutComponent"; }
+  virtual int32 InputDim() const { return dim_; }
+  virtual int32 OutputDim() const { return dim_; }
+  virtual int32 Properties() const { return kRandomComponent | kPropagateInPlace | kBackpropInPlace | kUsesMemo; }
+  virtual void *Propagate(const ComponentPrecomputedIndexes *indexes_in, const CuMatrixBase &in, CuMatrixBase *out) const {
+    if (test_mode_ || proportion_ == 0.0f) {  // "if (test_mode_ || dropout_proportion_ == 0.0) return NULL" after the copy
+      tdnnf_adapter::NoOpPropagate(in, out, Hooks().stream);
+      return nullptr;
+    }
+    const int32 S = static_cast<const GeneralDropoutPrecomputedIndexes *>(indexes_in)->num_mask_rows;
+    const long long n = (long long)S * dim_;
+    float *memo = static_cast<float *>(DeviceAlloc(sizeof(float) * 2 * n));  // [mask | the uniform draws it was made from]
+    if (!Hooks().fill_uniform) TDNNF_ADAPTER_FAIL("tdnnf_nnet3: DeviceHooks::fill_uniform is not installed");
+    Hooks().fill_uniform(memo + n, (int)n);
+    tdnnf_adapter::Check(tdnnf_general_dropout_mask(memo + n, n, proportion_, continuous_ ? 1 : 0, memo, Hooks().stream));
+    tdnnf_adapter::GeneralDropoutApply(in, memo, S, out, Hooks().stream);
+    return memo;
+  }
+  virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *indexes_in, const CuMatrixBase &, const CuMatrixBase &,
+                        const CuMatrixBase &out_deriv, void *memo, Component *, CuMatrixBase *in_deriv) const {
+    if (!in_deriv) return;
+    if (!memo) {
+      tdnnf_adapter::NoOpBackprop(out_deriv, 1.0f, in_deriv, Hooks().stream);
+      return;
+    }
+    const int32 S = static_cast<const GeneralDropoutPrecomputedIndexes *>(indexes_in)->num_mask_rows;
+    tdnnf_adapter::GeneralDropoutApply(out_deriv, static_cast<const float *>(memo), S, in_deriv, Hooks().stream);
+  }
+  virtual void DeleteMemo(void *memo) const { if (memo && Hooks().free) Hooks().free(memo); }
+
+ private:
+  int32 dim_;
+  float proportion_;
+  bool continuous_, test_mode_;
+};
+
+// FlopsConstraintComponent :9454-9478 (add_flopsconstraint.py:18-30 puts it behind the choice softmax)
+class FlopsConstraintComponent : public Component {
+ public:
+  FlopsConstraintComponent() : in_dim_(0), out_dim_(0), scale_(1.0f), flops_(nullptr) {}
+  void Init(int32 input_dim, int32 output_dim, float scale, const float *flops_dev /* input_dim floats */) { in_dim_ = input_dim; out_dim_ = output_dim; scale_ = scale; flops_ = flops_dev; }
+  virtual std::string Type() const { return "FlopsConstraintComponent"; }
+  virtual int32 InputDim() const { return in_dim_; }
+  virtual int32 OutputDim() const { return out_dim_; }
+  // nnet-simple-component.h:2697-2699 -- the flags say "adds", yet both bodies overwrite (CopyFromMat :9458, CopyRowsFromVec :9475): reproduced
+  virtual int32 Properties() const { return kSimpleComponent | kPropagateAdds | kBackpropAdds | kBackpropNeedsInput; }
+  virtual void *Propagate(const ComponentPrecomputedIndexes *, const CuMatrixBase &in, CuMatrixBase *out) const {
+    tdnnf_adapter::NoOpPropagate(in, out, Hooks().stream);  // "out->CopyFromMat(in)" :9458
+    return nullptr;
+  }
+  virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *, const CuMatrixBase &in_value, const CuMatrixBase &,
+                        const CuMatrixBase &, void *, Component *, CuMatrixBase *in_deriv) const {
+    if (in_deriv) tdnnf_adapter::FlopsConstraintBackprop(flops_, scale_, in_value, in_deriv, Hooks().stream);
+  }
+
+ private:
+  int32 in_dim_, out_dim_;
+  float scale_;
+  const float *flops_;
+};
+
+// GumbelSoftmaxComponent :9774-9831: any width, no FLOPs penalty; the Gumbel draws are the memo-less part of Propagate
+class GumbelSoftmaxComponent : public Component {
+ public:
+  GumbelSoftmaxComponent() : dim_(0), temp_(1.0f) {}
+  void Init(int32 dim) { dim_ = dim; }
+  void SetTempProportion(BaseFloat p) { temp_ = p; }
+  virtual std::string Type() const { return "GumbelSoftmaxComponent"; }
+  virtual int32 InputDim() const { return dim_; }
+  virtual int32 OutputDim() const { return dim_; }
+  virtual int32 Properties() const { return kBackpropInPlace | kSimpleComponent | kBackpropNeedsInput | kBackpropNeedsOutput | kRandomComponent; }  // h:2878-2881
+  virtual void *Propagate(const ComponentPrecomputedIndexes *, const CuMatrixBase &in, CuMatrixBase *out) const {
+    float *u = draws_.Get(dim_);  // kept by the component: the kernel reads it after Propagate returns
+    if (!Hooks().fill_uniform) TDNNF_ADAPTER_FAIL("tdnnf_nnet3: DeviceHooks::fill_uniform is not installed");
+    Hooks().fill_uniform(u, dim_);
+    tdnnf_adapter::SoftmaxFlopsPropagate(in, u, temp_, out, Hooks().stream);
+    return nullptr;
+  }
+  virtual void Backprop(const std::string &, const ComponentPrecomputedIndexes *, const CuMatrixBase &, const CuMatrixBase &out_value,
+                        const CuMatrixBase &out_deriv, void *, Component *, CuMatrixBase *in_deriv) const {
+    if (!in_deriv) return;  // :9817-9818
+    CuMatrixBase d = out_deriv;  // (not mutated: no FLOPs vector)
+    tdnnf_adapter::SoftmaxFlopsBackprop(out_value, &d, 0.0f, (const float *)nullptr, 0, temp_, in_deriv, Hooks().stream);
+  }
+
+ private:
+  int32 dim_;
+  float temp_;
+  mutable DrawBuffer draws_;
+};
+
 class LogSoftmaxComponent : public Component {  // :3607-3632
  public:
   LogSoftmaxComponent() : dim_(0) {}
@@ -519,7 +697,8 @@ inline const std::vector<std::string> &RegisteredTypes() {
   static const std::vector<std::string> names = {
       "TdnnDARTSV3Component", "TdnnComponent", "BatchNormComponent", "BatchNormTestComponent", "GumbelSoftmaxFlopsComponent",
       "SoftmaxFlopsComponent", "OnehotFunctionComponent", "ConstantFunctionComponent", "CopyNComponent", "ElementwiseProductComponent",
-      "RectifiedLinearComponent", "NaturalGradientAffineComponent", "LinearComponent", "LogSoftmaxComponent"};
+      "RectifiedLinearComponent", "NaturalGradientAffineComponent", "LinearComponent", "LogSoftmaxComponent", "AffineComponent",
+      "FixedAffineComponent", "NoOpComponent", "GeneralDropoutComponent", "FlopsConstraintComponent", "GumbelSoftmaxComponent"};
   return names;
 }
 inline Component *Component::NewComponentOfType(const std::string &t) {
@@ -537,6 +716,12 @@ inline Component *Component::NewComponentOfType(const std::string &t) {
   if (t == "NaturalGradientAffineComponent") return new NaturalGradientAffineComponent();
   if (t == "LinearComponent") return new LinearComponent();
   if (t == "LogSoftmaxComponent") return new LogSoftmaxComponent();
+  if (t == "AffineComponent") return new AffineComponent();
+  if (t == "FixedAffineComponent") return new FixedAffineComponent();
+  if (t == "NoOpComponent") return new NoOpComponent();
+  if (t == "GeneralDropoutComponent") return new GeneralDropoutComponent();
+  if (t == "FlopsConstraintComponent") return new FlopsConstraintComponent();
+  if (t == "GumbelSoftmaxComponent") return new GumbelSoftmaxComponent();
   return nullptr;  // (the reference returns NULL for unknown types as well, :279)
 }
 

@@ -30,6 +30,11 @@ int hip_status(hipError_t e, const char *what) {
   return TDNNF_EHIP;
 }
 
+Options &options() {
+  static Options o;
+  return o;
+}
+
 namespace {
 typedef int (*roctx_push_t)(const char *);
 typedef int (*roctx_pop_t)();
@@ -76,6 +81,28 @@ extern "C" {
 
 const char *tdnnf_last_error(void) { return g_last_error.c_str(); }
 int tdnnf_abi_version(void) { return 1; }
+
+static int *option_slot(const char *name) {
+  Options &o = options();
+  if (!name) return nullptr;
+  const struct { const char *n; int *p; } table[] = {{"ng_grouped", &o.ng_grouped}, {"ng_fuse", &o.ng_fuse}, {"ng_early_in", &o.ng_early_in},
+                                                     {"wgrad_stream", &o.wgrad_stream}, {"gemm_ring", &o.gemm_ring}, {"planes", &o.planes}};
+  for (auto &e : table)
+    if (strcmp(e.n, name) == 0) return e.p;
+  return nullptr;
+}
+int tdnnf_set_option(const char *name, int value) {
+  int *p = option_slot(name);
+  TDNNF_REQUIRE(p, "set_option: unknown option '%s' (ng_grouped, ng_fuse, ng_early_in, wgrad_stream, gemm_ring, planes)", name ? name : "(null)");
+  *p = value;
+  return TDNNF_OK;
+}
+int tdnnf_get_option(const char *name, int *value) {
+  int *p = option_slot(name);
+  TDNNF_REQUIRE(p && value, "get_option: unknown option '%s'", name ? name : "(null)");
+  *value = *p;
+  return TDNNF_OK;
+}
 
 }  // extern "C"
 

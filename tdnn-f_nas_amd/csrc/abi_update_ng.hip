@@ -83,7 +83,7 @@ Layout layout(int Do, int Di, int K, int N, int ones, bool alpha) {
   L.dy = take(sizeof(float) * (size_t)N * L.ldy);
   L.t = take(sizeof(float) * (size_t)Do * L.ldt);
   L.tap = take(alpha ? sizeof(float) * (size_t)Do * K * Di : 0);
-  L.dots = take(sizeof(double) * TDNNF_MAX_OFFSETS);
+  L.dots = take(sizeof(double) * TDNNF_TAP_DOTS_DOUBLES(TDNNF_MAX_OFFSETS));
   L.upd_bytes = std::max(wgrad_workspace_bytes(Do, Dx, 1, N), wgrad_workspace_bytes(Do, Di, K, N));
   L.upd = take(L.upd_bytes);
   L.total = off + 256;

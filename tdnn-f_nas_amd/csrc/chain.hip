@@ -91,9 +91,10 @@ struct DenDev {
 template <bool LDS_STATE>
 __global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatView y, int B, int T, float leaky,
                                                                   float *alpha_all, float *asum_all, int Hs,
-                                                                  double *logprob, float *gstate) {
+                                                                  double *logprob, float *gstate, const unsigned *only_if) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[kDenThreads / 64];
+  if (only_if && *only_if == 0) return;  // fallback launch behind the multi-workgroup recursion: runs only when that one gave up
   const int s = blockIdx.x, tid = threadIdx.x;
   const int H = g.H, P = g.P;
   float *x = smem;  // P
@@ -239,9 +240,11 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
 // of its own, keeps the one-kernel backward pass: there the further stream bought nothing at 1500 x 128 (133.8 -> 134.6 ms) and
 // cost 7 ms at 150 x 64 (18.5 -> 25.7: with the weight-gradient stream that is a fifth stream in flight, and beyond four they
 // share hardware queues -- the same cliff as one side stream per natural-gradient buffer set).
-__global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView y, int B, int T, float leaky, float *b_all, float *S_all, int Hs) {
+__global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView y, int B, int T, float leaky, float *b_all, float *S_all, int Hs,
+                                                               const unsigned *only_if) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[kDenThreads / 64];
+  if (only_if && *only_if == 0) return;
   const int s = blockIdx.x, tid = threadIdx.x;
   const int H = g.H, P = g.P, P4 = (P + 3) & ~3;
   float *x = smem;       // P: exp of the frame's output row
@@ -493,11 +496,11 @@ __global__ __launch_bounds__(kDenThreads) void den_mw_kernel(DenDev g, MwCtl ctl
   }
 }
 
-// a multi-workgroup launch that gave up (mw_exchange's time-out): the denominator log-probs become NaN, which the objective's
-// not-finite path reports (chain_finish: the minibatch is skipped with a failure code, as for any other NaN)
-__global__ void den_mw_check_kernel(const unsigned *abort_flag, double *logprob, int B) {
-  if (*abort_flag == 0) return;
-  for (int s = threadIdx.x; s < B; s += blockDim.x) logprob[s] = __longlong_as_double(0x7ff8000000000000ll);
+// a multi-workgroup launch that gave up (mw_wait's time-out: its workgroups were not co-resident, e.g. under a CU mask or beside another
+// process): the one-workgroup kernels launched behind it redo both recursions (they look at the same word), and the host learns of it
+// through a counter in pinned memory -- chain_den() reports it once and stops using the multi-workgroup form in this process
+__global__ void den_mw_check_kernel(const unsigned *abort_flag, unsigned *host_fallbacks) {
+  if (*abort_flag != 0 && threadIdx.x == 0) __hip_atomic_fetch_add(host_fallbacks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Occupancies of one (frame, sequence): deriv[t*B+s][p] = deriv_weight * gamma_den(t, p) (overwrites the whole row)
@@ -1093,37 +1096,35 @@ struct ChainPlan {
   size_t alpha_floats, asum_floats, gstate_floats, la_floats;
   size_t lds_fwd, lds_bwd;
 };
-int g_den_mode = 0;  // tdnnf_chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide
+int g_den_mode = 0;  // tdnnf_chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide, 3 persistent with one workgroup per sequence
+unsigned *g_mw_fallbacks = nullptr;  // pinned host memory, written by den_mw_check_kernel
+bool g_mw_off = false;               // a multi-workgroup launch gave up once: not used again
 // exchange buffers and counters of the multi-workgroup recursions (den_mw_kernel), behind b_all / S_all in the split region
 size_t mw_slots(const tdnnf_den_graph *g) { return (size_t)std::max(g->by_dst.nslices, g->by_src.nslices) * 64; }
 size_t mw_extra_floats(const tdnnf_den_graph *g, int B) { return 4 * (size_t)B * mw_slots(g) + 4 * (size_t)B + 64; }
 // workgroups per sequence for B sequences (0: one workgroup per sequence, the other kernels): both recursions at once must fit the chip at one
-// workgroup per CU, every workgroup's arcs and state vectors its LDS, and a workgroup owns at most 64 slices.  TDNNF_DEN_MW=0 turns it off.
+// workgroup per CU, every workgroup's arcs and state vectors its LDS, and a workgroup owns at most 64 slices.
+// Four per sequence.  Measured in the step at 1500 x 16 (ms): one 27.3, two 27.5, four 23.8, eight 25.2 -- eight are faster alone (5.0 against
+// 5.6 ms for both recursions) but their 256 workgroups hold every CU while the xent head's backward pass wants them; two cost what they gain.
 int mw_groups(const tdnnf_den_graph *g, int B, int T) {
-  const char *e = getenv("TDNNF_DEN_MW");
-  if ((e && atoi(e) == 0) || T < 8) return 0;
-  static const int cus = [] {
-    int dev = 0, n = 256;
+  if (g_den_mode == 3 || g_mw_off || T < 8) return 0;
+  constexpr int kMaxDev = 64;
+  static int cus_of[kMaxDev];  // per device (a process may drive several; zero = not asked yet)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
+  if (cus_of[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
     (void)hipGetLastError();
-    return n;
-  }();
-  // Four per sequence.  Measured in the step at 1500 x 16 (ms): one 27.3, two 27.5, four 23.8, eight 25.2 -- eight are faster alone (5.0 against
-  // 5.6 ms for both recursions) but their 256 workgroups hold every CU while the xent head's backward pass wants them; two cost what they gain.
-  // TDNNF_DEN_MW_G=8 (experiments): eight where they fit
-  const int gmax = getenv("TDNNF_DEN_MW_G") ? atoi(getenv("TDNNF_DEN_MW_G")) : 4;
-  for (int G = 8; G >= 4; G /= 2) {
-    if (G > gmax) continue;
-    if (2 * B * G > cus) continue;
-    const int ns = std::min(g->by_dst.nslices, g->by_src.nslices), nsmax = std::max(g->by_dst.nslices, g->by_src.nslices);
-    if (ns < G || (nsmax + G - 1) / G > 64) continue;
-    const size_t arcs = (size_t)std::max(g->by_dst.mw_max_arcs[G], g->by_src.mw_max_arcs[G]);
-    const size_t lds = sizeof(float) * (((g->P + 3) & ~3) + ((g->H + 3) & ~3)) + 8 * arcs + 256 * (size_t)((nsmax + G - 1) / G);
-    if (lds > 150 * 1024 || g->P > 8 * 960) continue;
-    return G;
   }
-  return 0;
+  const int cus = cus_of[dev], G = 4;
+  if (cus <= 0 || 2 * B * G > cus) return 0;
+  const int ns = std::min(g->by_dst.nslices, g->by_src.nslices), nsmax = std::max(g->by_dst.nslices, g->by_src.nslices);
+  if (ns < G || (nsmax + G - 1) / G > 64) return 0;
+  const size_t arcs = (size_t)std::max(g->by_dst.mw_max_arcs[G], g->by_src.mw_max_arcs[G]);
+  const size_t lds = sizeof(float) * (((g->P + 3) & ~3) + ((g->H + 3) & ~3)) + 8 * arcs + 256 * (size_t)((nsmax + G - 1) / G);
+  if (lds > 150 * 1024 || g->P > 8 * 960) return 0;
+  return G;
 }
 
 ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup) {
@@ -1137,19 +1138,13 @@ ChainPlan chain_plan(const tdnnf_den_graph *g, int B, int T, int num_states_sup)
     p.lds_fwd = sizeof(float) * P4;
     p.lds_bwd = sizeof(float) * P4;
   }
-  static const int env_mode = getenv("TDNNF_DEN_MODE") ? atoi(getenv("TDNNF_DEN_MODE")) : 0;  // experiments: 1 persistent, 2 wide
-  const int mode = g_den_mode ? g_den_mode : env_mode;
+  const int mode = g_den_mode;
   p.wide = mode == 2 || (mode == 0 && !p.lds_state);
-  static const bool no_split = getenv("TDNNF_DEN_SPLIT") && atoi(getenv("TDNNF_DEN_SPLIT")) == 0;  // experiments: the one-kernel backward pass
-  p.split = !p.wide && p.lds_state && !no_split;
+  p.split = !p.wide && p.lds_state;
   const int rows = std::max(std::max(g->by_dst.nslices, g->by_src.nslices), g->by_pdf.nslices) * 64;
   p.wide_blocks = (rows / 64 + 3) & ~3;  // partial sums per sequence (at most one per slice), padded to float4
-  // 32 sequences per group (a whole 128-byte line per state) unless the minibatch has no more than 16; TDNNF_WIDE_SG=16|32 forces one
-  static const int sg_env = [] {
-    const char *e = getenv("TDNNF_WIDE_SG");
-    return e && atoi(e) == 32 ? 32 : 16;
-  }();
-  p.SG = getenv("TDNNF_WIDE_SG") ? sg_env : (B > 16 ? 32 : 16);
+  // 32 sequences per group (a whole 128-byte line per state) unless the minibatch has no more than 16
+  p.SG = B > 16 ? 32 : 16;
   p.NG = (B + p.SG - 1) / p.SG;
   const size_t Bw = p.wide ? (size_t)p.NG * p.SG : (size_t)B;  // the wide arrays hold whole groups
   p.alpha_floats = Bw * (T + 1) * p.Hs;
@@ -1313,7 +1308,7 @@ void tdnnf_supervision_destroy(tdnnf_supervision *sp) {
 // workspace layout: [doubles: den_lp[B], num_lp[B], xent[B], l2sum[1]] [alpha] [asum] [gstate] [la, lb]
 // (the numerator scratch is sized for up to 4*(T+1) states per sequence; larger graphs are rejected)
 int tdnnf_chain_set_denominator_mode(int mode) {
-  TDNNF_REQUIRE(mode >= 0 && mode <= 2, "chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide");
+  TDNNF_REQUIRE(mode >= 0 && mode <= 3, "chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide, 3 persistent with one workgroup per sequence");
   g_den_mode = mode;
   return TDNNF_OK;
 }
@@ -1404,11 +1399,7 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     const int Hs = b.p.Hs, P = g->P;
     const WideDims d{B, b.p.NG, b.p.SG};
     const size_t Bw = (size_t)d.NG * d.SG, frame = Bw * Hs, prow = Bw * b.p.wide_blocks;
-    static const int nsl = [] {
-      const char *e = getenv("TDNNF_WIDE_SLICES");
-      return e && atoi(e) >= 1 && atoi(e) <= 16 ? atoi(e) : kWideSlices;
-    }();
-    static const bool serial = getenv("TDNNF_WIDE_SERIAL") != nullptr;  // experiments: the backward recursion behind the forward one
+    const int nsl = kWideSlices;
     auto blocks = [&](const tdnnf_den_graph::Sell &t) { return (t.nslices + nsl - 1) / nsl; };
     const int nb_dst = blocks(g->by_dst), nb_src = blocks(g->by_src);
     float *alphaT = b.alpha, *asum = b.asum, *S = asum + (size_t)(T + 1) * B, *Zd = S + (size_t)(T + 1) * B;
@@ -1420,7 +1411,7 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
       int rc = den_aux_stream(&aux_stream, &ev_fork, &ev_join);
       if (rc) return rc;
     }
-    hipStream_t aux = serial ? s : aux_stream;
+    hipStream_t aux = aux_stream;
     hipLaunchKernelGGL(den_wide_prep_kernel, tr, blk, 0, s, yv, d, P, xT);
     TDNNF_HIP(hipEventRecord(ev_fork, s));
     TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
@@ -1466,8 +1457,39 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gamma));
     TDNNF_HIP(hipEventRecord(ev_fork, s));
     TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
-    const int G = mw_groups(g, B, T);
-    const unsigned *mw_abort = nullptr;
+    int G = mw_groups(g, B, T);
+    if (G > 0 && !g_mw_fallbacks) {  // (first use: the host-visible fallback counter)
+      if (hipHostMalloc((void **)&g_mw_fallbacks, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+        (void)hipGetLastError();
+        g_mw_fallbacks = nullptr;
+        G = 0;
+      } else {
+        *g_mw_fallbacks = 0;
+      }
+    }
+    if (G > 0 && *(volatile unsigned *)g_mw_fallbacks != 0) {
+      fprintf(stderr, "tdnnf: the multi-workgroup denominator recursion timed out (its workgroups were not co-resident); the one-workgroup kernels redid the "
+                      "minibatch and are used from here on\n");
+      g_mw_off = true;
+      G = 0;
+    }
+    const size_t stage_b = G > 0 ? 256 * (size_t)((std::max(g->by_dst.nslices, g->by_src.nslices) + G - 1) / G) : 0;
+    const size_t lds_f = G > 0 ? sizeof(float) * (P4 + H4) + 8 * (size_t)g->by_dst.mw_max_arcs[G] + stage_b : 0;
+    const size_t lds_b = G > 0 ? sizeof(float) * (P4 + H4) + 8 * (size_t)g->by_src.mw_max_arcs[G] + stage_b : 0;
+    if (G > 0) {
+      // Every workgroup of a recursion polls for its G - 1 partners: the two launches must be resident together.  HIP gives no such guarantee
+      // (a CU mask, another process), so ask the occupancy calculator with the actual LDS sizes, and keep the bounded poll as the last resort.
+      TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+      TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+      int occ_f = 0, occ_b = 0, dev = 0;
+      hipDeviceProp_t prop;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, den_mw_kernel<0>, kDenThreads, lds_f) != hipSuccess ||
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, den_mw_kernel<1>, kDenThreads, lds_b) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+          hipGetDeviceProperties(&prop, dev) != hipSuccess || occ_f < 1 || occ_b < 1 || 2 * B * G > prop.multiProcessorCount) {
+        (void)hipGetLastError();
+        G = 0;
+      }
+    }
     if (G > 0) {  // several workgroups per sequence
       float *mw = S_all + (size_t)B * (T + 1) + 32;
       MwCtl ctl;
@@ -1476,31 +1498,32 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
       ctl.abort_flag = reinterpret_cast<unsigned *>(ctl.ctr + 2 * B);
       ctl.xf = reinterpret_cast<float *>(ctl.ctr + 2 * B + 2);
       ctl.xb = ctl.xf + (size_t)B * 2 * ctl.NSp;
-      const size_t stage_b = 256 * (size_t)((std::max(g->by_dst.nslices, g->by_src.nslices) + G - 1) / G);
-      const size_t lds_f = sizeof(float) * (P4 + H4) + 8 * (size_t)g->by_dst.mw_max_arcs[G] + stage_b, lds_b = sizeof(float) * (P4 + H4) + 8 * (size_t)g->by_src.mw_max_arcs[G] + stage_b;
-      TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
-      TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
       TDNNF_HIP(hipMemsetAsync(ctl.ctr, 0, sizeof(unsigned long long) * (2 * B + 2), s));  // (in front of the fork: both streams see it)
       TDNNF_HIP(hipEventRecord(ev_fork, s));
       TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
       hipLaunchKernelGGL(den_mw_kernel<0>, dim3(B * G), dim3(kDenThreads), lds_f, s, gd, ctl, G, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp);
       hipLaunchKernelGGL(den_mw_kernel<1>, dim3(B * G), dim3(kDenThreads), lds_b, aux, gd, ctl, G, yv, B, T, leaky, b_all, S_all, b.p.Hs, (double *)nullptr);
-      mw_abort = ctl.abort_flag;
+      // behind them, the one-workgroup kernels: they return at once unless the abort word is set (then they redo the recursion, so that
+      // the occupancy pass never reads half-written vectors and the minibatch is not lost)
+      hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate,
+                         (const unsigned *)ctl.abort_flag);
+      hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)ctl.abort_flag);
+      hipLaunchKernelGGL(den_mw_check_kernel, dim3(1), dim3(64), 0, s, (const unsigned *)ctl.abort_flag, g_mw_fallbacks);
     } else {
-      hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
-      hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs);
+      hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate,
+                         (const unsigned *)nullptr);
+      hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)nullptr);
     }
     TDNNF_HIP(hipEventRecord(ev_join, aux));
     TDNNF_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    if (mw_abort) hipLaunchKernelGGL(den_mw_check_kernel, dim3(1), dim3(64), 0, s, mw_abort, b.den_lp, B);
     hipLaunchKernelGGL(den_gamma_kernel, dim3(T, B), dim3(kGammaThreads), lds_gamma, s, gd, yv, B, T, leaky, b.alpha, b_all, S_all, b.p.Hs, -sp->weight, dv);
   } else if (b.p.lds_state) {
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_bwd));
-    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
+    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate, (const unsigned *)nullptr);
     hipLaunchKernelGGL(den_backward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_bwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, -sp->weight, dv, b.gstate);
   } else {
-    hipLaunchKernelGGL(den_forward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate);
+    hipLaunchKernelGGL(den_forward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate, (const unsigned *)nullptr);
     hipLaunchKernelGGL(den_backward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_bwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, -sp->weight, dv, b.gstate);
   }
   TDNNF_LAUNCH_CHECK();

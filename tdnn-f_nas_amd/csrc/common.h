@@ -42,6 +42,18 @@ inline bool vec4_ok(const MatView &m) {
 
 #define TDNNF_LAUNCH_CHECK(name) TDNNF_HIP(hipGetLastError())
 
+// Tuning options (tdnnf_set_option / tdnnf_get_option, include/tdnnf_hip.h): process-wide integers that select between code paths
+// which are all parity-tested; the library reads no environment variable for them.
+struct Options {
+  int ng_grouped = 1;     // natural gradient: 1 the side chain of a gradient bucket as grouped launches, 0 per object (read by tdnnf_net_create)
+  int ng_fuse = 1;        // output-side statistic H = dY Wy^T: 0 by its own GEMM, 1 inside the BatchNorm / ReLU backward sweep when that pays, 2 always
+  int ng_early_in = 1;    // input-side statistics ahead of the backward pass (read by tdnnf_net_create)
+  int wgrad_stream = -1;  // parameter gradients on a stream of their own: -1 by minibatch size, 0 off, 1 on (read by tdnnf_net_create)
+  int gemm_ring = 1;      // the persistent LDS-DMA-ring form of the rows GEMM where it applies
+  int planes = 1;         // gemm_precision 2: the pre-split bf16-plane GEMMs where they apply (0: the in-kernel split everywhere)
+};
+Options &options();
+
 // Named ranges for profilers (rocprofv3 --marker-trace; the reference's NVTX_RANGE at nnet-normalize-component.cc:185,476 is
 // the same idea): roctxRangePush / Pop from librocprofiler-sdk-roctx.so (or libroctx64.so), resolved with dlopen on first use so
 // that the library has no link-time dependency on a profiler; without the library (or with TDNNF_ROCTX=0) a range is a no-op.

@@ -441,6 +441,13 @@ __global__ void ewprod_bwd_kernel(MatView in, MatView dout, int od, MatView din)
     din.data[(long long)r * din.stride + cc] = p;
   }
 }
+// GeneralDropoutComponent::GetMemo (UPSTREAM): continuous: 1 - 2p + 4p U; else (U - p > 0 ? 1 : 0) / (1 - p)
+__global__ void general_dropout_mask_kernel(const float *u, long long n, float p, int continuous, float *mask) {
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < n; i += gridDim.x * 256LL) {
+    const float v = u[i];
+    mask[i] = continuous ? v * (p * 4.0f) + (1.0f - 2.0f * p) : ((v + -p > 0.0f) ? 1.0f : 0.0f) * (1.0f / (1.0f - p));
+  }
+}
 __global__ void dropout_kernel(MatView in, const float *mask, int num_seq, MatView out) {
   const int C = in.cols;
   const long long total = (long long)in.rows * C;
@@ -638,26 +645,43 @@ __global__ void darts_coef_kernel(const float *log_alpha, int K, int flags, floa
   }
 }
 
-// s_i = <dW_i, W_i> per tap (one block per tap), then the alpha update of :516-590 by block 0's
-// last arriver is avoided: a second tiny kernel applies it.
-__global__ __launch_bounds__(256) void tap_dots_kernel(const float *G, int ldg, const float *W, int ldw, int Do, int Di,
+// s_i = <dW_i, W_i> per tap, two-stage and ordered: block (tap, slab) reduces a slab of output rows into partial[tap][slab]
+// (float4 reads, no index arithmetic per element), alpha_update_kernel adds a tap's slabs in slab order.
+// dots: [K | K * TDNNF_TAP_DOTS_SLABS] doubles (s_i, then the partials).
+__global__ __launch_bounds__(256) void tap_dots_kernel(const float *G, int ldg, const float *W, int ldw, int Do, int Di, int K, int vec,
                                                        double *dots) {
   __shared__ double red[4];
-  const int tap = blockIdx.x;
+  const int tap = blockIdx.x, slab = blockIdx.y, nslab = gridDim.y;
+  const int rows = (Do + nslab - 1) / nslab, o0 = slab * rows, o1 = min(Do, o0 + rows);
   double s = 0;
-  const long long total = (long long)Do * Di;
-  for (long long e = threadIdx.x; e < total; e += 256) {
-    const int o = (int)(e / Di), d = (int)(e % Di);
-    s += (double)G[(long long)o * ldg + tap * Di + d] * (double)W[(long long)o * ldw + tap * Di + d];
+  if (vec) {  // Di, both leading dimensions and both pointers allow 16-byte reads
+    const int q = Di >> 2;
+    for (int e = threadIdx.x; e < (o1 - o0) * q; e += 256) {
+      const int o = o0 + e / q, d = (e % q) << 2;
+      const float4 g = *reinterpret_cast<const float4 *>(G + (long long)o * ldg + tap * Di + d);
+      const float4 w = *reinterpret_cast<const float4 *>(W + (long long)o * ldw + tap * Di + d);
+      s += ((double)g.x * (double)w.x + (double)g.y * (double)w.y) + ((double)g.z * (double)w.z + (double)g.w * (double)w.w);
+    }
+  } else {
+    for (int e = threadIdx.x; e < (o1 - o0) * Di; e += 256) {
+      const int o = o0 + e / Di, d = e % Di;
+      s += (double)G[(long long)o * ldg + tap * Di + d] * (double)W[(long long)o * ldw + tap * Di + d];
+    }
   }
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) dots[tap] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) dots[K + tap * nslab + slab] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-__global__ void alpha_update_kernel(const double *dots, const float *coef, int K, int flags, int share, float temp,
+__global__ void alpha_update_kernel(double *dots, int nslab, const float *coef, int K, int flags, int share, float temp,
                                     float lr, float *acc) {
   if (threadIdx.x != 0) return;
+  if (nslab > 0)
+    for (int i = 0; i < K; i++) {
+      double s = 0;
+      for (int j = 0; j < nslab; j++) s += dots[K + i * nslab + j];
+      dots[i] = s;
+    }
   if (!(flags & TDNNF_DARTS_UNIFORM_SAMPLE)) {
     for (int i = 0; i < K; i++) {
       const float si = (float)dots[i];
@@ -1035,6 +1059,14 @@ int tdnnf_general_dropout(const tdnnf_mat *in, const float *mask, int num_seq, t
   return TDNNF_OK;
 }
 
+int tdnnf_general_dropout_mask(const float *uniform, long long n, float proportion, int continuous, float *mask, tdnnf_stream stream) {
+  TDNNF_REQUIRE(n >= 0 && (n == 0 || (uniform && mask)) && proportion >= 0.f && proportion < 1.f, "general_dropout_mask: bad arguments (proportion in [0, 1))");
+  if (n == 0) return TDNNF_OK;
+  hipLaunchKernelGGL(general_dropout_mask_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, uniform, n, proportion, continuous, mask);
+  TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
 int tdnnf_tdnn_darts_coef(const float *log_alpha, int K, int flags, float temp, const float *gumbel_u, const float *sample_u,
                           int share_index, float *coef_memo, float *eff_coef, tdnnf_stream stream) {
   TDNNF_REQUIRE(log_alpha && coef_memo && eff_coef && K >= 1 && K <= TDNNF_MAX_OFFSETS, "tdnn_darts_coef: K out of range");
@@ -1052,10 +1084,14 @@ int tdnnf_tdnn_darts_alpha_update(const float *tap_grad, int ldg, const float *W
   // uniform-sample mode adds no gradient (the reference computes and discards it, :502-507): only the scalings run and
   // tap_grad may be null
   const bool uniform = (flags & TDNNF_DARTS_UNIFORM_SAMPLE) != 0;
-  TDNNF_REQUIRE((tap_grad || uniform) && W && coef_memo && alpha_acc && tap_dots, "tdnn_darts_alpha_update: null pointer (tap_dots_dev is required scratch of K doubles)");
+  TDNNF_REQUIRE((tap_grad || uniform) && W && coef_memo && alpha_acc && tap_dots, "tdnn_darts_alpha_update: null pointer (tap_dots_dev is required scratch of TDNNF_TAP_DOTS_DOUBLES(K) doubles)");
   TDNNF_REQUIRE(K >= 1 && K <= TDNNF_MAX_OFFSETS && Do > 0 && Di > 0 && ldg >= K * Di && ldw >= K * Di, "tdnn_darts_alpha_update: bad dimensions");
-  if (tap_grad) hipLaunchKernelGGL(tap_dots_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, tap_grad, ldg, W, ldw, Do, Di, tap_dots);
-  hipLaunchKernelGGL(alpha_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tap_dots, coef_memo, K, flags, share_index, temp, lr, alpha_acc);
+  const int nslab = std::min(TDNNF_TAP_DOTS_SLABS, Do);
+  if (tap_grad) {
+    const int vec = Di % 4 == 0 && ldg % 4 == 0 && ldw % 4 == 0 && ((reinterpret_cast<uintptr_t>(tap_grad) | reinterpret_cast<uintptr_t>(W)) & 15) == 0;
+    hipLaunchKernelGGL(tap_dots_kernel, dim3(K, nslab), dim3(256), 0, (hipStream_t)stream, tap_grad, ldg, W, ldw, Do, Di, K, vec, tap_dots);
+  }
+  hipLaunchKernelGGL(alpha_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tap_dots, tap_grad ? nslab : 0, coef_memo, K, flags, share_index, temp, lr, alpha_acc);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }

@@ -55,7 +55,7 @@ struct RowsGemmArgs {
   // 0: exact f32 MFMA (v_mfma_f32_32x32x2_f32).  1: split-bf16 (three v_mfma_f32_32x32x16_bf16 per 16 k, products accurate
   // to ~2^-16 relative, f32 accumulation); needs a k-contiguous B and 16-byte alignment, otherwise the f32 kernel runs.
   int prec;
-  int serial_epilogue;  // set by rows_gemm() from TDNNF_GEMM_SERIAL_EPILOGUE (A/B runs): the one-segment-at-a-time epilogue for every tile
+  int serial_epilogue;  // 1: the one-segment-at-a-time epilogue for every tile (rows_gemm() sets 0)
   int nseg;
   GemmSeg seg[kMaxSeg];
 };

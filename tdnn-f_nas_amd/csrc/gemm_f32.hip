@@ -309,9 +309,6 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
     }
   };
   auto compute = [&](int buf) {
-#ifdef TDNNF_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(TDNNF_GEMM_SETPRIO);
-#endif
     const float *as = As + buf * A_TILE + (wm * TM * 32 + li) * LDAS + lh * 4;
     const float *bs = B_KC ? Bs + buf * B_TILE + (wn * TN * 32 + li) * LDBS + lh * 4
                            : Bs + buf * B_TILE + (lh * 4) * LDBS + wn * TN * 32 + li;
@@ -339,9 +336,6 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
         }
     }
-#ifdef TDNNF_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
 
   if (seg < p.nseg) {
@@ -1068,11 +1062,6 @@ template <int WM, int WN, int TM, int TN, int BK>
 hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int cls, double flops, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  static const bool nobal = getenv("TDNNF_GEMM_NOBAL") != nullptr;  // experiments: plain launch, no split-K balancing
-  if (nobal) {
-    ProfScope ps(cls, flops, s);
-    return launch_rows<WM, WN, TM, TN, BK>(a, b_kc, vec, s);
-  }
   int slots = rows_slots<WM, WN, TM, TN, BK>(b_kc, (b_kc && vec) ? a.prec : 0);
   if constexpr (kRingTile<WM, WN, TM, TN>) {
     if (ring_applies(a, b_kc, vec, BN)) slots = rows_gemm_ring_slots(BN);
@@ -1197,8 +1186,7 @@ hipError_t launch_rows_sumsq(const RowsGemmArgs &a, bool b_kc, bool vec, hipStre
   }
   float *scratch = nullptr;
   size_t scratch_bytes = 0;
-  static const bool nobal = getenv("TDNNF_GEMM_NOBAL") != nullptr;
-  if (!nobal && tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
+  if (tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
     const long long kt = (ktot + BK - 1) / BK;
     int S = slots / tiles;
     if (S > kt / 4) S = (int)(kt / 4);
@@ -1259,17 +1247,9 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     g_prof_next_bytes = 4.0 * (a_elems + b_elems + c_elems);
     g_prof_next_flops = flops;
   }
-  {
-    static const int serial = getenv("TDNNF_GEMM_SERIAL_EPILOGUE") ? 1 : 0;
-    a.serial_epilogue = serial;
-  }
+  a.serial_epilogue = 0;
   if (a.prec == 0) a.prec = g_gemm_prec;
   if (a.prec == 2) a.prec = 0;  // 2 = exact f32 regardless of the default
-  {
-    static int force = -1;  // experiments: TDNNF_GEMM_PREC=1 runs every eligible GEMM of the process in split-bf16
-    if (force < 0) force = getenv("TDNNF_GEMM_PREC") ? atoi(getenv("TDNNF_GEMM_PREC")) : 0;
-    if (force) a.prec = force;
-  }
   if (!(b_kc && vec)) a.prec = 0;  // the split-bf16 kernels need a k-contiguous B and 16-byte alignment
   if (a.colstats_rows) *a.colstats_rows = 0;
   if (!a.colstats_rows || a.prec != 0 || a.sumsq || a.N <= 32 || waste160 < waste128 || a.ksplit > 1) a.colstats = nullptr;
@@ -1295,9 +1275,8 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     for (int i = 0; i < a.nseg; i++) kt += a.seg[i].klen;
     // launches that leave most of the chip's block slots empty with 128 x 128 tiles (the recipes' minibatch: 3 200 rows) take
     // 64 x 128 tiles: twice the blocks, so the busiest CU carries 3 half tiles instead of 2 whole ones
-    static const int small_env = getenv("TDNNF_GEMM_SMALL_TILE") ? atoi(getenv("TDNNF_GEMM_SMALL_TILE")) : -1;
     const long long tiles128 = (long long)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    const bool small = tiles128 < 768 && small_env != 0;  // measured at 150 x 64: 13.45 -> 13.28 ms per step; 1500 x 16 unchanged
+    const bool small = tiles128 < 768;  // measured at 150 x 64: 13.45 -> 13.28 ms per step; 1500 x 16 unchanged
     if (small && a.prec == 0 && !a.sumsq) return launch_rows_balanced<2, 2, 1, 2, 16>(a, b_kc, vec, 0, flops, s);
     if ((kt <= 512 && a.prec == 0) || a.prec == 3) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
   }
@@ -1845,10 +1824,7 @@ int wgrad_slots(int variant) {
                                                                                                    : wgrad_slots_of<2, 2, 2, 2>();
 }
 
-inline int wgrad_min_rounds() {
-  static const int r = getenv("TDNNF_WGRAD_ROUNDS") ? std::min(8, std::max(1, atoi(getenv("TDNNF_WGRAD_ROUNDS")))) : 2;
-  return r;
-}
+inline int wgrad_min_rounds() { return 2; }
 
 // Split the row (reduction) range so that tiles * splits fills whole rounds of resident blocks: every block
 // runs equally long, so a grid of q*slots + r blocks costs q+1 rounds; we want r == 0 (just under a multiple).
@@ -1898,19 +1874,17 @@ size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
 hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hipStream_t s) {
   if (a.N <= 0 || a.Do <= 0 || a.Di <= 0) return hipSuccess;
   if (workspace_bytes < wgrad_workspace_bytes(a.Do, a.Di, a.K, a.N)) return hipErrorInvalidValue;
-  static const int force_prec = getenv("TDNNF_GEMM_PREC") ? atoi(getenv("TDNNF_GEMM_PREC")) : 0;
   int planes = 0;  // 0: f32 MFMA; 2 / 3: split-bf16 with that many planes per operand
   {
     int prec = a.prec;
-    if (prec == 0) prec = force_prec ? force_prec : g_gemm_prec;
+    if (prec == 0) prec = g_gemm_prec;
     planes = prec == 1 ? 2 : prec == 3 ? 3 : 0;
   }
   const bool use_x3 = planes != 0;
   const WgradTile wt = wgrad_tile(a.Do, a.Di, use_x3);
   const int ktaps = a.active && a.max_active > 0 && a.max_active < a.K ? a.max_active : a.K;
-  static const int xcd_env = getenv("TDNNF_WGRAD_XCD") ? atoi(getenv("TDNNF_WGRAD_XCD")) : 1;  // 0: the plain (tile, split) grid order (A/B runs)
   WgradArgs a_x = a;
-  a_x.xcd_order = xcd_env && ktaps > 1 ? 1 : 0;
+  a_x.xcd_order = ktaps > 1 ? 1 : 0;  // the taps of a tile side by side on one XCD
   WgradPlan pl = wgrad_plan(a.Do, a.Di, a.K, a.N, wgrad_slots(wt.variant), ktaps == a.K ? 0 : ktaps, use_x3);
   if (sizeof(float) * pl.slab_floats > workspace_bytes) return hipErrorInvalidValue;
   float *partial = reinterpret_cast<float *>(workspace);

@@ -380,13 +380,10 @@ hipError_t launch_ring(const RowsGemmArgs &a, int blocks, hipStream_t s) {
 
 }  // namespace
 
-// TDNNF_GEMM_RING: 0 off, 1 (default) the 128 x 128 tile, 2 the 128 x 160 tile as well.  Same-box A/B of the 7q step (ms per step, two runs
-// each): off 127.18 / 127.33; 128-wide tile 126.59 / 126.30; both tiles and transposed weights for the backward-data GEMMs (TDNNF_WT=1)
-// 127.80 / 127.65 -- alone the kernel is 3-7 % faster on seven of nine layer shapes (tools/ab_ring.sh), in the step that is what is left of it.
-int rows_gemm_ring_mode() {
-  static const int env = getenv("TDNNF_GEMM_RING") ? atoi(getenv("TDNNF_GEMM_RING")) : 1;
-  return env;
-}
+// option "gemm_ring": 0 off, 1 (default) the 128 x 128 tile, 2 the 128 x 160 tile as well.  Same-box A/B of the 7q step (ms per step, two
+// runs each): off 127.18 / 127.33; 128-wide tile 126.59 / 126.30; both tiles and transposed weights for the backward-data GEMMs 127.80 / 127.65
+// -- alone the kernel is 3-7 % faster on seven of nine layer shapes, in the step that is what is left of it.
+int rows_gemm_ring_mode() { return options().gemm_ring; }
 bool rows_gemm_ring_enabled() { return rows_gemm_ring_mode() != 0; }
 
 bool rows_gemm_ring_ok(const RowsGemmArgs &a, bool b_kc, bool vec) {

@@ -388,23 +388,16 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   for (auto &L : n->layers)
     if (L.lin.darts) tg = std::max(tg, (size_t)L.bn * L.lin.K * Hd);
   n->tapgrad = tg ? A.take<float>(tg) : nullptr;
-  n->tapdots = A.take<double>(TDNNF_MAX_OFFSETS);
+  n->tapdots = A.take<double>(TDNNF_TAP_DOTS_DOUBLES(TDNNF_MAX_OFFSETS));
   n->bn_sync.buf = A.take<double>(5 * (size_t)std::max(std::max(Hd, S), 1) + 8);  // (the ReLU backward sweep stages five column sums)
   n->dropout_masks = (c.use_dropout && !c.cv_update) ? A.take<float>((size_t)(c.num_layers + 1) * B * Hd) : nullptr;
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
-  // transposed copy of every weight matrix for the split-bf16 backward-data GEMMs (k-contiguous B operand).  Measured for
-  // exact f32 too (TDNNF_WT=1: the k-contiguous kernel variant instead of four 4-byte LDS reads per B fragment): the
-  // backward-data classes did not move (36.8 / 26.2 against 36.4 / 26.1 ms per step), the step got 1-2 ms slower -- not kept
-  // [r3] TDNNF_WT=1 with the persistent ring kernel (gemm_ring.hip takes k-contiguous B operands only) puts the backward-data GEMMs on it as
-  // well: 127.7 against 126.4 ms per step with the ring on the forward GEMMs alone -- their epilogue reads the old C and the bypass addend
-  static const bool use_wt = getenv("TDNNF_WT") ? atoi(getenv("TDNNF_WT")) != 0 : false;
-  n->paramsT = (n->cfg.gemm_precision != 0 || use_wt) ? A.take<float>((size_t)n->num_params + 16) : nullptr;
+  // transposed copy of every weight matrix for the split-bf16 backward-data GEMMs (k-contiguous B operand).  (Measured for exact
+  // f32 too, twice: no gain -- docs/experiments.md.)
+  n->paramsT = n->cfg.gemm_precision != 0 ? A.take<float>((size_t)n->num_params + 16) : nullptr;
   n->s3_scratch = nullptr;
   n->s3_scratch_bytes = 0;
-  {
-    const char *e = getenv("TDNNF_NG_GROUPED");  // 0: the per-object side chain for every component (A/B runs)
-    n->ng_grouped = e ? atoi(e) != 0 : true;
-  }
+  n->ng_grouped = options().ng_grouped != 0;  // 0: the per-object side chain for every component
   size_t tall = 0, tall_ws = 0;
   for (auto &cd : n->comps)
     if (cd.orthonormal != 0.f && cd.rows > cd.cols) {
@@ -488,14 +481,8 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   if (n->cfg.bn_num_choices > 0) upd(sizeof(float) * (size_t)((max_lin_rows + 511) / 512 + 1) * 512);
   n->ws_bytes = ws + 256;
   n->ws = A.take<char>(n->ws_bytes);
-  {
-    const char *e = getenv("TDNNF_WGRAD_STREAM");
-    n->wg_on = e ? atoi(e) != 0 : std::max(max_rows, N0) <= 32768;
-  }
-  {
-    const char *e = getenv("TDNNF_NG_EARLY_IN");  // 0: input-side statistics with the component's backward call, as before (A/B runs)
-    n->early_on = n->cfg.use_natural_gradient && n->ng_grouped && (e ? atoi(e) != 0 : true);
-  }
+  n->wg_on = options().wgrad_stream >= 0 ? options().wgrad_stream != 0 : std::max(max_rows, N0) <= 32768;
+  n->early_on = n->cfg.use_natural_gradient && n->ng_grouped && options().ng_early_in != 0;
   const bool s4_used = n->wg_on || n->early_on;
   n->ws4 = s4_used ? A.take<char>(n->ws_bytes) : nullptr;
   n->s4_scratch_bytes = s4_used ? (32u << 20) : 0;
@@ -1149,12 +1136,9 @@ namespace {
 // Few sequences leave most CUs idle while one workgroup per sequence walks the frames: there the backward recursion of the denominator runs beside
 // the forward one and the occupancies of all frames at once (the split form).  Measured (ms per step, one-kernel backward -> split): 1500 x 16
 // 37.3 -> 28.5, x 32 53.1 -> 45.3, x 64 80.9 -> 75.2, x 128 127.6 -> 128.2; 150 x 64 14.2 -> 13.8.  The second recursion runs on the
-// natural-gradient side stream, which is idle until the backward pass (on a stream of its own -- a fifth in flight -- the step at 150 x 64 took
-// 20.0 ms: they then share hardware queues).  TDNNF_DEN_TRAINER_SPLIT=0|1 forces one.
-bool den_uses_split(int B) {
-  static const int env = getenv("TDNNF_DEN_TRAINER_SPLIT") ? atoi(getenv("TDNNF_DEN_TRAINER_SPLIT")) : -1;
-  return env >= 0 ? env != 0 : B <= 96;
-}
+// weight-gradient stream (or the natural-gradient side stream), idle until the backward pass (on a stream of its own -- a fifth in flight -- the
+// step at 150 x 64 took 20.0 ms: they then share hardware queues).
+bool den_uses_split(int B) { return B <= 96; }
 }  // namespace
 
 int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *den,
@@ -1178,9 +1162,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     {
       // the natural-gradient side stream carries small latency-bound launches that should fill idle slots, not take slots from
       // the backward pass (a launch sized for one round of resident blocks runs two when a few slots are taken): lowest priority
+      // -- except for few sequences: there the stream also carries the second denominator recursion, whose workgroups (four per sequence,
+      // den_mw_kernel) poll for partners and must not be kept from the chip by the other streams' launches: normal priority
       int lo = 0, hi = 0;
-      static const bool flat_prio = getenv("TDNNF_S3_PRIO") && atoi(getenv("TDNNF_S3_PRIO")) == 0;  // experiments
-      if (!flat_prio && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) TDNNF_HIP(hipStreamCreateWithPriority(&n->s3, hipStreamNonBlocking, lo));
+      if (B > 32 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) TDNNF_HIP(hipStreamCreateWithPriority(&n->s3, hipStreamNonBlocking, lo));
       else TDNNF_HIP(hipStreamCreateWithFlags(&n->s3, hipStreamNonBlocking));
       (void)hipGetLastError();
     }
@@ -1217,8 +1202,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     return v;
   };
   if (c.use_natural_gradient && n->s3) {
-    static const bool off = getenv("TDNNF_NG_EARLY_REFRESH") && atoi(getenv("TDNNF_NG_EARLY_REFRESH")) == 0;
-    if (!off) {
+    {
       TDNNF_HIP(hipEventRecord(n->ev_fin0, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fin0, 0));
       SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
@@ -1401,11 +1385,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   auto out_stats_fuse = [&](int comp, MatView xv, MatView dzv, MatView dv, NgFuse &f) -> int {  // 1: f is to be passed on
     fused_comp = -1;
     if (!c.use_natural_gradient || n->ng_out.empty() || !n->ng_out[comp] || n->comps[comp].lr_factor == 0.f) return 0;
-    bool fuse_always = false;
-    if (const char *e = getenv("TDNNF_NG_FUSE")) {  // test switch: 0 = the statistic by its own GEMM, 2 = fused whatever the row count
-      if (atoi(e) == 0) return 0;
-      fuse_always = atoi(e) == 2;
-    }
+    if (options().ng_fuse == 0) return 0;  // the statistic by its own GEMM
+    const bool fuse_always = options().ng_fuse == 2;  // fused whatever the row count
     auto &S = n->ngc[comp];
     const float *W = nullptr;
     int Rp = 0, ldw = 0;
@@ -1615,8 +1596,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   if (use_ng && n->ng_grouped) {
     // refreshes still pending when the step began: W_{t+1} of ALL of them now, as grouped launches on the side stream (the host
     // waits for the eigen-decompositions here; the GPU has the forward pass and the denominator in its queues meanwhile)
-    static const bool fin_off = getenv("TDNNF_NG_GROUPED_FIN") && atoi(getenv("TDNNF_NG_GROUPED_FIN")) == 0;  // bisecting aid
-    if (!n->ngfin && !fin_off) {
+    if (!n->ngfin) {
       bool ready = false;
       for (tdnnf_ng *g : all_ng()) ready = ready || ng_dim(g) != 0;
       if (ready) CK(ng_fin_create(all_ng(), &n->ngfin));
@@ -1663,9 +1643,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // Where in the host's order: minibatches whose GEMMs fill the chip start the statistics BEHIND the xent head's backward pass -- they then run
   // while the caller's stream waits for the denominator instead of beside the xent head's GEMMs (same step time, 124.0 against 124.1 ms, and the
   // 128 x 128 class is not slowed: 99.5 against 96.4 TFLOP/s, weight gradients 107 against 102); the small ones start them at once (behind the
-  // xent head: 13.03 -> 13.10 ms at 150 x 64, 23.16 -> 23.31 at 1500 x 16).  TDNNF_NG_EARLY_AFTER_XENT=0|1 forces one.
-  static const int after_env = getenv("TDNNF_NG_EARLY_AFTER_XENT") ? atoi(getenv("TDNNF_NG_EARLY_AFTER_XENT")) : -1;
-  const bool early_after_xent = after_env >= 0 ? after_env != 0 : !n->wg_on;
+  // xent head: 13.03 -> 13.10 ms at 150 x 64, 23.16 -> 23.31 at 1500 x 16).
+  const bool early_after_xent = !n->wg_on;
   if (!early_after_xent) CK(launch_early_in());
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];

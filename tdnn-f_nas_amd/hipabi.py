@@ -154,6 +154,25 @@ def workspace(nbytes, device="cuda"):
     return torch.empty((int(nbytes) + 3) // 4 + 4, dtype=torch.float32, device=device)
 
 
+class option:
+    """`with option("ng_fuse", 0): ...` -- a tuning option of the library (tdnnf_set_option) for the duration of a block."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name.encode(), int(value)
+
+    def __enter__(self):
+        lib = load()
+        old = C.c_int()
+        check(lib.tdnnf_get_option(self.name, C.byref(old)))
+        self.old = old.value
+        check(lib.tdnnf_set_option(self.name, self.value))
+        return self
+
+    def __exit__(self, *exc):
+        check(load().tdnnf_set_option(self.name, self.old))
+        return False
+
+
 class DenGraph:
     def __init__(self, g):
         lib = load()

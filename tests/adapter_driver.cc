@@ -442,9 +442,94 @@ static void run_tdnn_classes(const Blob &in, FILE *out) {
   delete upd;
 }
 
+// The remaining factory names of the 7q / supernet graphs (nnet-component-itf.cc:136,150,156,194,260,266), each created by name and
+// driven through the virtual interface: FixedAffine -> Affine (UpdateSimple) -> NoOp (backprop-scale) -> GeneralDropout and back,
+// with in_deriv matrices pre-filled to show kBackpropAdds; GumbelSoftmax (any width) -> FlopsConstraint.
+// cfg = [num_seq, dropout_proportion, continuous, temp, flops_scale, lr, noop_backprop_scale]
+static void run_rest_classes(const Blob &in, FILE *out) {
+  install_hooks();
+  const HostMat &cfg = in.at("cfg");
+  const int S = (int)cfg.at(0);
+  const float p = cfg.at(1), temp = cfg.at(3), fscale = cfg.at(4), lr = cfg.at(5), nbs = cfg.at(6);
+  const bool continuous = cfg.at(2) != 0.f;
+  const HostMat &hWf = in.at("Wf"), &hbf = in.at("bf"), &hWa = in.at("Wa"), &hba = in.at("ba"), &hfl = in.at("flops");
+  const int Di = hWf.cols, H = hWf.rows, Cn = (int)hfl.v.size();
+  DenseParams Wf(H, Di, &hWf), bf(1, H, &hbf), Wa(H, H, &hWa), ba(1, H, &hba), Wa_acc(H, H, nullptr), ba_acc(1, H, nullptr), flops(1, Cn, &hfl);
+  auto *fixed = make<n3::FixedAffineComponent>("FixedAffineComponent");
+  auto *aff = make<n3::AffineComponent>("AffineComponent");
+  auto *aff_upd = make<n3::AffineComponent>("AffineComponent");
+  auto *noop = make<n3::NoOpComponent>("NoOpComponent");
+  auto *drop = make<n3::GeneralDropoutComponent>("GeneralDropoutComponent");
+  auto *gs = make<n3::GumbelSoftmaxComponent>("GumbelSoftmaxComponent");
+  auto *fc = make<n3::FlopsConstraintComponent>("FlopsConstraintComponent");
+  fixed->SetParams(Di, H, Wf.d, bf.d);
+  aff->SetParams(H, H, Wa.d, ba.d);
+  aff_upd->SetParams(H, H, Wa_acc.d, ba_acc.d);
+  aff_upd->SetUseNaturalGradient(true);  // an AffineComponent still updates with UpdateSimple
+  aff_upd->SetUnderlyingLearningRate(lr);
+  noop->Init(H, nbs);
+  drop->Init(H, p, continuous);
+  gs->Init(Cn);
+  gs->SetTempProportion(temp);
+  fc->Init(Cn, Cn, fscale, flops.d);
+  g_draws = in.at("draws").v;
+  g_draw_pos = 0;
+  CuMatrixStub x(in.at("x")), d(in.at("d")), d0(in.at("d0_init")), dx(in.at("dx_init")), xs(in.at("xs")), dgs(in.at("dgs"));
+  const int N = x.NumRows();
+  CuMatrixStub y0(N, H), y1(N, H), y2(N, H), y3(N, H), d2(N, H), d1(N, H), P(N, Cn), Fo(N, Cn), dxs(N, Cn), dP(N, Cn);
+  n3::CuMatrixBase vx = V(x), vd = V(d), vd0 = V(d0), vdx = V(dx), vy0 = V(y0), vy1 = V(y1), vy2 = V(y2), vy3 = V(y3), vd2 = V(d2), vd1 = V(d1);
+  n3::GeneralDropoutPrecomputedIndexes dix;
+  dix.num_mask_rows = S;
+  fixed->Propagate(nullptr, vx, &vy0);
+  aff->Propagate(nullptr, vy0, &vy1);
+  noop->Propagate(nullptr, vy1, &vy2);
+  void *memo = drop->Propagate(&dix, vy2, &vy3);
+  drop->Backprop("", &dix, vy2, vy3, vd, memo, nullptr, &vd2);
+  noop->Backprop("", nullptr, vy1, vy2, vd2, nullptr, nullptr, &vd1);
+  aff->Backprop("", nullptr, vy0, vy1, vd1, nullptr, aff_upd, &vd0);
+  fixed->Backprop("", nullptr, vx, vy0, vd0, nullptr, nullptr, &vdx);
+  n3::CuMatrixBase vxs = V(xs), vP = V(P), vF = V(Fo), vdgs = V(dgs), vdxs = V(dxs), vdP = V(dP);
+  gs->Propagate(nullptr, vxs, &vP);
+  fc->Propagate(nullptr, vP, &vF);
+  gs->Backprop("", nullptr, vxs, vP, vdgs, nullptr, nullptr, &vdxs);
+  fc->Backprop("", nullptr, vP, vF, vdgs, nullptr, nullptr, &vdP);
+  HIPCK(hipDeviceSynchronize());
+  drop->DeleteMemo(memo);
+  // test mode / proportion 0: a copy and no memo
+  drop->SetTestMode(true);
+  CuMatrixStub y3t(N, H);
+  n3::CuMatrixBase vy3t = V(y3t);
+  if (drop->Propagate(&dix, vy2, &vy3t) != nullptr) { std::fprintf(stderr, "test-mode dropout returned a memo\n"); std::exit(6); }
+  write_mat(out, "y0", y0.Host());
+  write_mat(out, "y1", y1.Host());
+  write_mat(out, "y2", y2.Host());
+  write_mat(out, "y3", y3.Host());
+  write_mat(out, "y3_test_mode", y3t.Host());
+  write_mat(out, "d2", d2.Host());
+  write_mat(out, "d1", d1.Host());
+  write_mat(out, "d0", d0.Host());
+  write_mat(out, "dx", dx.Host());
+  write_mat(out, "Wa_acc", Wa_acc.Host());
+  write_mat(out, "ba_acc", ba_acc.Host());
+  write_mat(out, "P", P.Host());
+  write_mat(out, "F", Fo.Host());
+  write_mat(out, "dxs", dxs.Host());
+  write_mat(out, "dP", dP.Host());
+  write_mat(out, "dgs_after", dgs.Host());
+  HIPCK(hipDeviceSynchronize());
+  for (n3::Component *c : std::vector<n3::Component *>{fixed, aff, aff_upd, noop, drop, gs, fc}) delete c;
+  // every registered name comes out of the factory with its own Type()
+  for (const std::string &t : n3::RegisteredTypes()) {
+    n3::Component *c = n3::Component::NewComponentOfType(t);
+    if (!c || c->Type() != t) { std::fprintf(stderr, "factory: %s\n", t.c_str()); std::exit(5); }
+    delete c;
+  }
+  if (n3::RegisteredTypes().size() != 20 || n3::Component::NewComponentOfType("NoSuchComponent") != nullptr) std::exit(7);
+}
+
 int main(int argc, char **argv) {
   if (argc != 4) {
-    std::fprintf(stderr, "usage: adapter_driver tdnn|stack|mixing|tdnn_classes|stack_classes in.bin out.bin\n");
+    std::fprintf(stderr, "usage: adapter_driver tdnn|stack|mixing|tdnn_classes|stack_classes|rest_classes in.bin out.bin\n");
     return 2;
   }
   try {
@@ -457,6 +542,7 @@ int main(int argc, char **argv) {
     else if (what == "mixing") run_mixing(in, out);
     else if (what == "stack_classes") run_stack_classes(in, out);
     else if (what == "tdnn_classes") run_tdnn_classes(in, out);
+    else if (what == "rest_classes") run_rest_classes(in, out);
     else return 2;
     std::fclose(out);
   } catch (const std::exception &e) {

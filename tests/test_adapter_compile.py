@@ -53,7 +53,8 @@ def test_adapter_driver_instantiates_every_adapter_function(tmp_path, pkg):
     subprocess.check_call([hipcc, "-std=c++17", "-O0", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "adapter_driver.cc"),
                            "-L", lib_dir, "-ltdnnf_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
     header = open(os.path.join(ROOT, "include", "tdnnf_nnet3_adapter.h")).read()
-    driver = open(os.path.join(ROOT, "tests", "adapter_driver.cc")).read()
+    # (called by the driver directly, or through the Component classes the driver instantiates)
+    driver = open(os.path.join(ROOT, "tests", "adapter_driver.cc")).read() + open(os.path.join(ROOT, "include", "tdnnf_nnet3_components.h")).read()
     import re
     funcs = set(re.findall(r"^inline \w[\w \*]*?(\w+)\(", header, flags=re.M)) - {"Check", "View", "Indexes"}
     unused = sorted(f for f in funcs if not re.search(r"\b%s\(" % f, driver))
@@ -108,4 +109,12 @@ def test_component_classes_register_under_the_factory_names(tmp_path, pkg):
     assert int(props["ElementwiseProductComponent"]) == k["simple"] | k["needs_in"]
     assert int(props["RectifiedLinearComponent"]) == k["simple"] | k["needs_out"] | k["prop_in_place"] | k["stores"]
     assert int(props["LogSoftmaxComponent"]) == k["simple"] | k["needs_out"] | k["stores"]
-    assert len(props) == 14
+    # nnet-simple-component.h:418-421 (Affine), :1010 (FixedAffine), :1192-1194 (NoOp), :2697-2699 (FlopsConstraint), :2878-2881 (GumbelSoftmax);
+    # GeneralDropoutComponent is UPSTREAM (block-dim == dim)
+    assert int(props["AffineComponent"]) == k["simple"] | k["updatable"] | k["needs_in"] | k["prop_adds"] | k["bp_adds"]  # (no bias set yet, as LinearComponent)
+    assert int(props["FixedAffineComponent"]) == k["simple"] | k["bp_adds"]
+    assert int(props["NoOpComponent"]) == k["simple"] | k["prop_in_place"] | k["bp_in_place"]
+    assert int(props["FlopsConstraintComponent"]) == k["simple"] | k["prop_adds"] | k["bp_adds"] | k["needs_in"]
+    assert int(props["GumbelSoftmaxComponent"]) == k["bp_in_place"] | k["simple"] | k["needs_in"] | k["needs_out"] | k["random"]
+    assert int(props["GeneralDropoutComponent"]) == k["random"] | k["prop_in_place"] | k["bp_in_place"] | k["memo"]
+    assert len(props) == 20

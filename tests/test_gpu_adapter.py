@@ -236,3 +236,59 @@ def test_darts_mixing_components_through_the_adapter(driver, ora, tmp_path):
     L.oracle_onehot_propagate(float(draw[0]), ora.omat(oh))
     assert np.array_equal(got["onehot"], oh) and oh.sum() == N
     assert rel_l2(got["onehot_acc"].ravel(), lr * dP2.astype(np.float64).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("continuous", [1, 0], ids=["continuous-mask", "binary-mask"])
+def test_remaining_factory_names_through_the_component_classes(driver, ora, tmp_path, continuous):
+    """AffineComponent, FixedAffineComponent, NoOpComponent, GeneralDropoutComponent, FlopsConstraintComponent, GumbelSoftmaxComponent
+    (/root/reference/src/nnet3/nnet-component-itf.cc:136,150,156,194,260,266) created by factory name and driven through the virtual
+    interface; every output against the oracle."""
+    L = ora.lib()
+    rng = np.random.default_rng(123 + continuous)
+    S, nt, Di, H, Cn, p, temp, fscale, lr, nbs = 6, 30, 24, 40, 5, 0.3, 0.6, 1.5, 0.05, 0.7
+    N = S * nt
+    Wf, bf = (_rand(rng, H, Di) / np.sqrt(Di)).astype(F), _rand(rng, H)
+    Wa, ba = (_rand(rng, H, H) / np.sqrt(H)).astype(F), _rand(rng, H)
+    flops = -np.cumsum(rng.integers(10, 40, Cn)).astype(F)
+    x, d, d0_init, dx_init = _rand(rng, N, Di), _rand(rng, N, H), _rand(rng, N, H), _rand(rng, N, Di)
+    xs, dgs = _rand(rng, N, Cn), _rand(rng, N, Cn)
+    draws = rng.uniform(0.02, 0.98, S * H + Cn).astype(F)
+    got = driver("rest_classes", {"cfg": [S, p, continuous, temp, fscale, lr, nbs], "Wf": Wf, "bf": bf, "Wa": Wa, "ba": ba, "flops": flops, "x": x, "d": d,
+                                  "d0_init": d0_init, "dx_init": dx_init, "xs": xs, "dgs": dgs, "draws": draws}, tmp_path)
+    y0, y1 = np.zeros((N, H), F), np.zeros((N, H), F)
+    L.oracle_affine_propagate(ora.omat(x), ora.fptr(Wf), Di, ora.fptr(bf), H, ora.omat(y0))
+    L.oracle_affine_propagate(ora.omat(y0), ora.fptr(Wa), H, ora.fptr(ba), H, ora.omat(y1))
+    assert rel_l2(got["y0"], y0) < 2e-5 and rel_l2(got["y1"], y1) < 2e-5
+    assert np.array_equal(got["y2"], got["y1"])  # NoOp: a copy
+    u = draws[:S * H].reshape(S, H)
+    mask = (u * F(p * 4.0) + F(1.0 - 2.0 * p)).astype(F) if continuous else ((u + F(-p) > 0).astype(F) * F(1.0 / (1.0 - p))).astype(F)
+    y3 = np.zeros_like(y1)
+    L.oracle_general_dropout_propagate(ora.omat(np.ascontiguousarray(got["y2"])), ora.fptr(np.ascontiguousarray(mask)), S, ora.omat(y3))
+    assert rel_l2(got["y3"], y3) < 1e-6
+    if not continuous:
+        assert 0.15 < (got["y3"] == 0).mean() < 0.45  # a proportion p of the units is dropped
+    assert np.array_equal(got["y3_test_mode"], got["y2"])
+    d2 = np.zeros_like(d)
+    L.oracle_general_dropout_propagate(ora.omat(d), ora.fptr(np.ascontiguousarray(mask)), S, ora.omat(d2))
+    assert rel_l2(got["d2"], d2) < 1e-6
+    assert rel_l2(got["d1"], d2 * F(nbs)) < 1e-6
+    d1 = np.ascontiguousarray(got["d1"])
+    back = np.zeros((N, H), F)
+    L.oracle_affine_backprop(ora.omat(d1), ora.fptr(Wa), H, H, ora.omat(back))
+    assert rel_l2(got["d0"], d0_init + back) < 2e-5  # kBackpropAdds: added to what in_deriv held
+    Wa_acc, ba_acc = np.zeros_like(Wa), np.zeros(H, F)
+    L.oracle_affine_update_simple(ora.omat(np.ascontiguousarray(got["y0"])), ora.omat(d1), lr, ora.fptr(Wa_acc), H, ora.fptr(ba_acc))
+    assert rel_l2(got["Wa_acc"], Wa_acc) < 2e-5 and rel_l2(got["ba_acc"].ravel(), ba_acc) < 2e-5  # UpdateSimple: no preconditioning
+    d0 = np.ascontiguousarray(got["d0"])
+    backx = np.zeros((N, Di), F)
+    L.oracle_affine_backprop(ora.omat(d0), ora.fptr(Wf), Di, Di, ora.omat(backx))
+    assert rel_l2(got["dx"], dx_init + backx) < 2e-5
+    P = np.zeros((N, Cn), F)
+    L.oracle_softmax_flops_propagate(ora.omat(xs), ora.fptr(np.ascontiguousarray(draws[S * H:])), temp, ora.omat(P))
+    assert rel_l2(got["P"], P) < 1e-5 and np.array_equal(got["F"], got["P"])
+    dg, dxs = dgs.copy(), np.zeros((N, Cn), F)
+    L.oracle_softmax_flops_backprop(ora.omat(P), ora.omat(dg), 0.0, None, 0, temp, ora.omat(dxs))
+    assert rel_l2(got["dxs"], dxs) < 1e-4 and np.array_equal(got["dgs_after"], dgs)
+    dP = np.zeros((N, Cn), F)
+    L.oracle_flops_constraint_backprop(ora.fptr(flops), fscale, N, Cn, ora.omat(dP))
+    assert rel_l2(got["dP"], dP) < 1e-6

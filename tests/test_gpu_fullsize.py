@@ -273,13 +273,12 @@ def test_bench_shape_supernets(pkg, bench_egs, name):
         assert frozen and all(not g[c["begin"]:c["begin"] + c["rows"] * c["cols"]].any() for c in frozen)
 
 
-def test_bench_shape_fused_statistics_against_separate_passes(pkg, bench_egs, monkeypatch):
-    """TDNNF_NG_FUSE=0 (the output-side statistic by its own GEMM) against the default (formed by the BatchNorm/ReLU backward
+def test_bench_shape_fused_statistics_against_separate_passes(pkg, bench_egs):
+    """Option ng_fuse = 0 (the output-side statistic by its own GEMM) against the default (formed by the BatchNorm/ReLU backward
     sweep) at the bench shape.  The parameters are held fixed, so every step of both variants sees the same activations and
     the preconditioners evolve from the same inputs: what differs is the summation order of H = dY Wy^T."""
-    monkeypatch.setenv("TDNNF_NG_FUSE", "0")
-    sep, _ = run_bench_shape(pkg, bench_egs, 4, update=False, use_natural_gradient=1)
-    monkeypatch.delenv("TDNNF_NG_FUSE")
+    with pkg.hipabi.option("ng_fuse", 0):
+        sep, _ = run_bench_shape(pkg, bench_egs, 4, update=False, use_natural_gradient=1)
     fus, _ = run_bench_shape(pkg, bench_egs, 4, update=False, use_natural_gradient=1)
     assert torch.equal(fus[0][1], sep[0][1])  # the first minibatch initialises the preconditioners: nothing to fuse yet
     for i, ((ra, ga), (rb, gb)) in enumerate(zip(fus, sep)):
@@ -336,13 +335,12 @@ def test_bench_shape_denominator_forms_agree(pkg, bench_egs):
     assert e < 1e-4, e
 
 
-@pytest.mark.parametrize("mode,mw", [(1, "1"), (1, "0"), (2, "1")], ids=["persistent-four-workgroups-per-sequence", "persistent-one-workgroup", "wide"])
-def test_chain_objective_at_500_frames_matches_oracle(pkg, ora, monkeypatch, mode, mw):
+@pytest.mark.parametrize("mode", [1, 3, 2], ids=["persistent-four-workgroups-per-sequence", "persistent-one-workgroup", "wide"])
+def test_chain_objective_at_500_frames_matches_oracle(pkg, ora, mode):
     """chain::ComputeChainObjfAndDeriv at the length of a 1500-frame chunk (500 output frames), 6034 pdfs, the bench's
     4 000-state graph, supervision paths drawn from the denominator graph: errors of a log-domain recursion grow with the
     frame index (a float numerator was 6.8e-4 off here and its frame posteriors summed to 1 +- 2.2e-3: it runs in double now).
-    Eight sequences: the persistent form takes four workgroups per sequence (chain.hip, den_mw_kernel) unless TDNNF_DEN_MW=0."""
-    monkeypatch.setenv("TDNNF_DEN_MW", mw)
+    Eight sequences: the persistent form takes four workgroups per sequence (chain.hip, den_mw_kernel) unless the mode is 3."""
     hip = Hip(pkg)
     L = ora.lib()
     H, P, B, T = 4000, 6034, 8, 500

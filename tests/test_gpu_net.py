@@ -1,6 +1,8 @@
 """-m gpu: the C++ chain trainer (tdnnf_net_*) against the CPU reference of the whole step
 (tests/oracle_net.py) on identical seeded egs and parameters: activations, LF-MMI objective
 (BASELINE bar 1e-4 relative), raw parameter gradients (bar 1e-3 relative L2) and the optimizer step."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -279,16 +281,16 @@ def test_net_cv_update_after_pretrain_matches_oracle(pkg, name, pre_kw, cv_kw):
 
 
 @pytest.mark.parametrize("hidden", [64, 160], ids=["rank32", "rank80"])
-def test_fused_output_statistics_match_the_separate_pass(pkg, hidden, monkeypatch):
+def test_fused_output_statistics_match_the_separate_pass(pkg, hidden):
     """With natural gradient the BatchNorm/ReLU backward sweep also forms H = dY Wy^T of the affine in front (fused.hip); with
-    TDNNF_NG_FUSE=0 the statistic comes from its own GEMM.  Same net, same minibatches: the gradients agree step after step
+    option ng_fuse = 0 the statistic comes from its own GEMM.  Same net, same minibatches: the gradients agree step after step
     (refresh steps included: the first ten minibatches refresh every time)."""
     T = pkg.trainer
     kw = dict(frames_per_chunk=30, num_sequences=8, strides=[1, 1, 0, 3, 3], bottleneck=16, feat_dim=8, ivector_dim=4, hidden_dim=hidden, small_dim=32,
               num_pdfs=50, use_natural_gradient=1, use_dropout=1)
 
     def run(fuse):
-        monkeypatch.setenv("TDNNF_NG_FUSE", str(fuse))
+        pkg.hipabi.check(pkg.hipabi.load().tdnnf_set_option(b"ng_fuse", fuse))
         cfg = T.make_config(**kw)
         net = T.ChainNet(cfg)
         net.set_params(net.init_params_numpy(seed=1, output_stddev=0.1))
@@ -305,7 +307,10 @@ def test_fused_output_statistics_match_the_separate_pass(pkg, hidden, monkeypatc
         net.close()
         return out
 
-    fused, separate = run(2), run(0)
+    try:
+        fused, separate = run(2), run(0)
+    finally:
+        pkg.hipabi.check(pkg.hipabi.load().tdnnf_set_option(b"ng_fuse", 1))
     assert np.array_equal(fused[0][0], separate[0][0])  # the first minibatch initialises the preconditioners: nothing to fuse yet
     for (ga, ra), (gb, rb) in zip(fused, separate):
         assert ra[5] == 1.0 and abs(ra[0] - rb[0]) <= 1e-5 * (abs(rb[3]) + abs(rb[4])), (ra, rb)  # objf = num - den log-probs
@@ -463,3 +468,45 @@ def test_nets_for_several_chunk_widths_share_the_model(pkg):
         pkg.trainer.ChainNet(other, share=nets[0])
     for n in reversed(nets):
         n.close()
+
+
+@pytest.mark.parametrize("kind", ["7q", "darts-softmax", "darts-uniform"])
+@pytest.mark.parametrize("wg", [0, 1], ids=["one-stream", "wgrad-stream"])
+def test_early_input_statistics_are_bit_identical_to_the_in_order_ones(pkg, kind, wg):
+    """The input-side natural-gradient statistics launched ahead of the backward pass (net.hip, option ng_early_in, from the arguments a
+    component's backward call recorded one minibatch earlier) against the same statistics formed with the backward call: the same kernels on
+    the same operands, so gradients and parameters must agree BIT FOR BIT over a refresh schedule -- a forward activation rewritten in place
+    during the backward pass, or stale coefficient / active-tap contents behind an unchanged pointer, would show here."""
+    T = pkg.trainer
+    kw = dict(frames_per_chunk=30, num_sequences=8, strides=[1, 1, 0, 3, 3], bottleneck=16, feat_dim=8, ivector_dim=4, hidden_dim=64, small_dim=32,
+              num_pdfs=50, use_natural_gradient=1)
+    if kind != "7q":
+        kw.update(darts_num_offsets=3, darts_flags=4 if kind == "darts-uniform" else 0)
+    lib = pkg.hipabi.load()
+
+    def run(early):
+        with pkg.hipabi.option("ng_early_in", early), pkg.hipabi.option("wgrad_stream", wg):
+            net = T.ChainNet(T.make_config(**kw))
+        cfg = net.cfg
+        net.set_params(net.init_params_numpy(seed=1, output_stddev=0.1))
+        den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+        out = []
+        for i in range(7):
+            feats, iv = T.synthetic_egs(net, seed=100 + i)
+            sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=200 + i))
+            net.set_random_draws(np.random.default_rng(300 + i).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(np.float32))
+            net.grads.zero_()
+            r = host(net.forward_backward(dev(feats), dev(iv), den, sup, step=i))
+            out.append((host(net.grads).copy(), r.copy()))
+            net.update(1e-3, step=i)
+        out.append((host(net.params).copy(), None))
+        net.close()
+        return out
+
+    a, b = run(1), run(0)
+    for i, ((ga, ra), (gb, rb)) in enumerate(zip(a, b)):
+        assert np.array_equal(ga, gb), (kind, wg, i, rel_l2(ga, gb))
+        assert ra is None or np.array_equal(ra, rb)
+    v = C.c_int()
+    pkg.hipabi.check(lib.tdnnf_get_option(b"ng_early_in", C.byref(v)))
+    assert v.value == 1  # the context managers restored the defaults

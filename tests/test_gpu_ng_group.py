@@ -1,8 +1,6 @@
 """The grouped natural-gradient side chain (csrc/ng_group.hip: one launch per stage for all components of a gradient bucket)
-against the per-object chain it replaces (TDNNF_NG_GROUPED=0: the round-2 path, itself held to the oracle's literal
+against the per-object chain it replaces (option ng_grouped = 0: the round-2 path, itself held to the oracle's literal
 formulation in test_gpu_net.py) over a whole refresh schedule: first 10 minibatches refresh every time, then every 4th."""
-import os
-
 import numpy as np
 import pytest
 
@@ -12,11 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 def make_net(pkg, grouped, **kw):
-    os.environ["TDNNF_NG_GROUPED"] = "1" if grouped else "0"  # read when the net is created
-    try:
+    with pkg.hipabi.option("ng_grouped", 1 if grouped else 0):  # read when the net is created
         return pkg.trainer.ChainNet(pkg.trainer.make_config(use_natural_gradient=1, **kw))
-    finally:
-        del os.environ["TDNNF_NG_GROUPED"]
 
 
 def run_steps(pkg, nets, steps):

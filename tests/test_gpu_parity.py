@@ -139,10 +139,10 @@ def test_darts_coef_and_alpha_update(hip, ora, pkg, flags):
     ws = hip.ws(nbytes)
     hip.tdnn_update_simple(C.byref(ix), dev(x), dev(dy), Do, Di, None, 1.0, hip.vec(G), K * Di, None, hip.vec(ws), nbytes, hip.stream())
     accd = dev(acc0)
-    dots = torch.zeros(K, dtype=torch.float64, device="cuda")
+    dots = torch.zeros(K * 65, dtype=torch.float64, device="cuda")  # TDNNF_TAP_DOTS_DOUBLES(K)
     hip.tdnn_darts_alpha_update(hip.vec(G), K * Di, hip.vec(dev(W)), K * Di, Do, Di, K, hip.vec(cm), flags, share, 0.7, 0.01,
                                 hip.vec(accd), hip.vec(dots), hip.stream())
-    np.testing.assert_allclose(host(dots), s, rtol=1e-4)
+    np.testing.assert_allclose(host(dots)[:K], s, rtol=1e-4)
     np.testing.assert_allclose(host(accd), acc, rtol=2e-4, atol=1e-6)
 
 
@@ -217,6 +217,34 @@ def test_softmax_flops(hip, ora, gumbel):
     hip.softmax_flops_backprop(p, dpd, eta, hip.vec(dev(flops)), Cc, tau, dxd, hip.stream())
     np.testing.assert_allclose(host(dpd), dp_ref, rtol=1e-6)  # in-place mutation reproduced
     np.testing.assert_allclose(host(dxd), dx_ref, rtol=2e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("N,Cc", [(700, 5), (257, 13), (64, 3)])
+def test_plain_gumbel_softmax_without_flops_vector(hip, ora, N, Cc):
+    """GumbelSoftmaxComponent (nnet-simple-component.cc:9774-9831): any width, no FLOPs penalty (flops_dev NULL),
+    out_deriv is left untouched, in_deriv = DiffSoftmax / temp."""
+    L = ora.lib()
+    rng = np.random.default_rng(90 + Cc)
+    tau = 0.45
+    x = _rand(rng, N, Cc)
+    u = rng.random(Cc).astype(F)
+    p_ref = np.zeros_like(x)
+    L.oracle_softmax_flops_propagate(ora.omat(x), ora.fptr(u), tau, ora.omat(p_ref))
+    p = torch.zeros(N, Cc, device="cuda")
+    hip.softmax_flops_propagate(dev(x), hip.vec(dev(u)), tau, p, hip.stream())
+    np.testing.assert_allclose(host(p), p_ref, rtol=2e-5, atol=1e-20)
+    np.testing.assert_allclose(host(p).sum(1), 1.0, rtol=1e-5)
+    dp = _rand(rng, N, Cc)
+    dp_ref, dx_ref = dp.copy(), np.zeros_like(x)
+    L.oracle_softmax_flops_backprop(ora.omat(p_ref), ora.omat(dp_ref), 0.3, None, 0, tau, ora.omat(dx_ref))
+    dpd, dxd = dev(dp), torch.zeros(N, Cc, device="cuda")
+    hip.softmax_flops_backprop(p, dpd, 0.3, None, 0, tau, dxd, hip.stream())
+    assert (host(dpd) == dp).all()  # no penalty: the output derivative is not mutated
+    np.testing.assert_allclose(host(dxd), dx_ref, rtol=2e-4, atol=1e-7)
+    # independent check: float64 Jacobian (diag(p) - p p^T) / temp
+    pd = p_ref.astype(np.float64)
+    want = pd * (dp - (pd * dp).sum(1, keepdims=True)) / tau
+    np.testing.assert_allclose(host(dxd), want, rtol=2e-4, atol=1e-7)
 
 
 def test_small_ops(hip, ora):
@@ -508,15 +536,14 @@ def test_natural_gradient(hip, ora):
 
 
 # the recursions with several workgroups per sequence (few sequences: chain.hip, den_mw_kernel), against the oracle like the other forms
-# and bit for bit against themselves; B = 16 / 8: eight workgroups per sequence on one XCD; B = 12: the plain block order; B = 24: four
+# and against the one-workgroup kernels; four workgroups per sequence (B = 16 / 8: a sequence's workgroups on one XCD; B = 12: the plain block order)
 @pytest.mark.parametrize("H,P,B,T,leaky", [(4000, 6034, 16, 40, 0.1), (1500, 700, 8, 60, 1e-5), (900, 400, 12, 30, 0.05), (2100, 900, 24, 25, 0.1)])
-def test_chain_denominator_several_workgroups_per_sequence(hip, ora, pkg, monkeypatch, H, P, B, T, leaky):
-    monkeypatch.delenv("TDNNF_DEN_MW", raising=False)
+def test_chain_denominator_several_workgroups_per_sequence(hip, ora, pkg, H, P, B, T, leaky):
     pkg.hipabi.check(pkg.hipabi.load().tdnnf_chain_set_denominator_mode(1))
     try:
         _chain_case(hip, ora, pkg, H, P, B, T, leaky, 0.0)  # (the entry point takes the split form, whose recursions these are)
         got = _chain_deriv(hip, pkg, H, P, B, T, leaky)
-        monkeypatch.setenv("TDNNF_DEN_MW", "0")
+        pkg.hipabi.check(pkg.hipabi.load().tdnnf_chain_set_denominator_mode(3))  # one workgroup per sequence
         one = _chain_deriv(hip, pkg, H, P, B, T, leaky)
     finally:
         pkg.hipabi.load().tdnnf_chain_set_denominator_mode(0)
