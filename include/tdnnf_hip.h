@@ -492,21 +492,31 @@ int tdnnf_net_update(tdnnf_net *, float learning_rate, float l2_regularize_scale
 /* "nnet3-copy --edits='set-dropout-proportion name=* proportion=p'" of train.py's dropout schedule */
 int tdnnf_net_set_dropout_proportion(tdnnf_net *, float proportion);
 int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
-/* ---- f32-equivalent GEMMs on the bf16 matrix cores from pre-split operands (csrc/planes_gemm.hip; gemm_precision 2, "bf16x6").
-   An operand is split ONCE into three bf16 planes (x = p0 + p1 + p2, 24 mantissa bits) laid out for the consumer ("P16":
-   [K block of 16][plane][row][16], 32-byte row records, `lead_rows` / `tail_rows` zero rows around the matrix so that row-shifted
-   tap views and tile overhang read zeros); the GEMM forms the six plane products with i + j <= 2 in f32 accumulators.
+/* ---- f32-equivalent GEMMs on the 16-bit matrix cores from pre-split operands (csrc/planes_gemm.hip).
+   An operand is split ONCE into 16-bit planes laid out for the consumer ("P16": [K block of 16][plane][row][16], 32-byte row
+   records, zero rows in front of and behind the matrix so that row-shifted tap views and tile overhang read zeros):
+     num_planes 3 ("bf16x6", gemm_precision 2): x = p0 + p1 + p2, three bf16 planes, the six products p_i q_j with i + j <= 2;
+     num_planes 2 ("f16x3",  gemm_precision 3): x s = h + l, two f16 planes of the operand scaled by the power of two s that its
+       Frobenius norm allows (s ||X||_F <= 65504: no element can overflow, whatever the data), the three products h h', h l', l h';
+       the split writes [s, 1 / s] to scale_dev and the GEMM multiplies its result by 1 / (s s').
+   Both accumulate in f32.  tdnnf_planes_split writes the row-major planes (k = column; `planes`, rows_total = lead_rows + rows +
+   zero tail rows) and / or the planes of the TRANSPOSE (k = row; `planes_t`, t_rows_total >= cols), for the products that reduce over
+   the matrix's rows.  Sizes: tdnnf_planes_bytes(num_planes, rows_total, k_blocks) with k_blocks = ceil(cols / 16), resp.
+   4 ceil(rows / 64) for the transposed planes.  workspace_dev: tdnnf_planes_split_workspace_bytes() (num_planes 2 only).
    tdnnf_planes_gemm: C (rows x cols) (op)= sum over segments s of  A[a_row[s] + m][a_first_col[s] .. + seg_cols[s]) .
-   B[n][b_first_col[s] .. + seg_cols[s])  -- segments = the taps of TdnnComponent::Propagate
-   (/root/reference/src/nnet3/nnet-tdnn-component.cc:302-324): row-shifted views of one activation matrix against column blocks of
-   the weight matrix (B: one row per output column, k contiguous).  a_row counts rows of the A plane buffer (lead rows included);
-   first columns must be multiples of 16; the A buffer needs tail rows up to the next multiple of 256 output rows, the B buffer its
-   rows padded to a multiple of 160 (cols nearer a multiple of 160) or 128.  init_mode 0: C += , 1: C = bias + , 2: C = . */
-size_t tdnnf_planes_bytes(int rows, int cols, int lead_rows, int tail_rows);
-int tdnnf_planes_split(const tdnnf_mat *x, int lead_rows, int tail_rows, void *planes, tdnnf_stream);
-int tdnnf_planes_gemm(const void *a_planes, long long a_rows_total, const void *b_planes, long long b_rows_total, int num_segments, const long long *a_row,
-                      const int *a_first_col, const int *b_first_col, const int *seg_cols, const float *bias, int init_mode, int relu, tdnnf_mat *c,
-                      tdnnf_stream);
+   B[b_row[s] + n][b_first_col[s] .. + seg_cols[s])  -- segments = the taps of TdnnComponent::Propagate / Backprop
+   (/root/reference/src/nnet3/nnet-tdnn-component.cc:302-324, :378-411): row-shifted views of one activation matrix against column
+   blocks of the weight matrix (B: one row per output column, k contiguous).  a_row / b_row count rows of the plane buffers (lead rows
+   included; b_row may be NULL = zeros); first columns must be multiples of 16; the A buffer needs zero rows up to the next multiple of
+   256 output rows, the B buffer its rows padded to a multiple of 160 (cols nearer a multiple of 160), 256 or 128.
+   init_mode 0: C += , 1: C = bias + , 2: C = . */
+size_t tdnnf_planes_bytes(int num_planes, long long rows_total, long long k_blocks);
+size_t tdnnf_planes_split_workspace_bytes(void);
+int tdnnf_planes_split(int num_planes, const tdnnf_mat *x, int lead_rows, long long rows_total, void *planes, long long t_rows_total, void *planes_t,
+                       float *scale_dev, void *workspace_dev, tdnnf_stream);
+int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
+                      const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col,
+                      const int *b_first_col, const int *seg_cols, const float *bias, int init_mode, int relu, tdnnf_mat *c, tdnnf_stream);
 /* Synchronised BatchNorm for a data-parallel caller ("BN [sum x, sum x^2] (2 D floats per BN) for exact single-GPU
    equivalence").  The reference's BatchNormComponent takes its statistics over ALL rows of the minibatch
    (/root/reference/src/nnet3/nnet-normalize-component.cc:433-445); when the minibatch is sharded over world_size ranks, every

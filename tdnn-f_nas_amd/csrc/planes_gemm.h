@@ -1,5 +1,10 @@
-// planes_gemm.h -- host interface of the pre-split bf16-plane GEMMs (planes_gemm.hip): f32-equivalent products on the bf16
-// matrix cores (gemm_precision 2, "bf16x6").
+// planes_gemm.h -- host interface of the pre-split plane GEMMs (planes_gemm.hip): f32-equivalent products on the 16-bit matrix cores
+// from operands split ONCE into 16-bit planes in HBM.
+//
+//   np = 3  "bf16x6": x = p0 + p1 + p2 (three bf16 planes, 24 mantissa bits), the six products p_i q_j with i + j <= 2.
+//   np = 2  "f16x3" : x s = h + l (two f16 planes of the operand scaled by a power of two s chosen from its Frobenius norm so that
+//                     no element can overflow), the three products h h', h l', l h'; the result is multiplied by 1 / (s s').
+// Both accumulate in f32, smallest products first.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stddef.h>
@@ -11,16 +16,19 @@ namespace tdnnf {
 // One K-segment (a tap of a TdnnComponent: a row-shifted view of the A matrix against a column block of the weights).
 struct PlanesSeg {
   long long a_row;  // first row of the segment's view in the A plane buffer (lead rows included): tile row m reads a_row + m
+  long long b_row;  // first row of the segment's view in the B plane buffer: output column n reads b_row + n
   int a_kb0;        // first K block (of 16) of A
   int b_kb0;        // first K block of B
   int nkb;          // K blocks in the segment
 };
 
 struct PlanesGemmArgs {
+  int np;         // 3: bf16 triples, 2: scaled f16 pairs
   const void *A;  // P16 planes of the A operand (planes_split)
   long long RA;   // rows per (K block, plane) chunk of A: lead + rows + tail
-  const void *B;  // P16 planes of the B operand, row n = output column n, k contiguous (weights: one row per output)
+  const void *B;  // P16 planes of the B operand, row n = output column n, k contiguous
   long long RB;
+  const float *scale_a, *scale_b;  // np == 2: device pointers to the operands' [s, 1 / s] pairs (planes_split); null = 1
   float *C;
   long long ldc;
   int M, N;
@@ -33,13 +41,47 @@ struct PlanesGemmArgs {
   int add_lo, add_hi;
   int nseg;
   PlanesSeg seg[16];
+  // Tap mode (weight gradients, nseg == 1): `ntap` products per output tile position; product t runs with the A operand advanced by
+  // tap_a_kb[t] K blocks and the B operand by tap_b_kb[t], and lands tap_off_c * t floats further in C (tap_off_p * t in a partial slab).
+  // ntap <= 1: off.
+  int ntap;
+  int tap_a_kb[16], tap_b_kb[16];
+  long long tap_off_c, tap_off_p;
+  // Split-K (ksplit > 1): block (tile, sp) multiplies K blocks [sp * kb_per_split, (sp + 1) * kb_per_split) of the concatenated range and
+  // stores its raw accumulators (no scale, bias, ...) to partial[sp * partial_stride + m * ldp_m + n * ldp_n]; the caller reduces.
+  int ksplit, kb_per_split;
+  float *partial;
+  long long partial_stride, ldp_m, ldp_n;
 };
 
-// bytes of the P16 plane buffer of a rows x cols matrix with `lead` zero rows in front and `tail` behind
-size_t planes_bytes(int rows, int cols, int lead, int tail);
-// x (f32) -> planes; the lead / tail rows are zeroed
-hipError_t planes_split(MatView x, int lead, int tail, void *planes, hipStream_t s);
-// tile shape the GEMM will use for an N-column output: the A buffer needs tail >= tile rows, the B buffer rows padded to the tile's columns
+// P16 layout of an R x C matrix:  e16 P[kb][plane][row][16],  kb = c / 16, plane 0..np-1, row 0..R-1, R = lead + rows + tail
+// (lead / tail rows are zeros); the two 16-byte halves of a 32-byte row record are swapped when bit 3 of the row is set.
+// The TRANSPOSED planes of the same matrix (the operand of a product that reduces over the matrix's rows: weight gradients) are the
+// P16 planes of its transpose: "row" = column c of the matrix (Rt = cols + tail_t of them), k = row r.
+size_t planes_bytes(int np, long long rows_total, long long k_blocks);
+inline long long planes_kblocks(int cols) { return (cols + 15) / 16; }
+inline long long planes_t_kblocks(int rows) { return ((rows + 63) / 64) * 4; }  // the split kernel writes whole 64-row tiles
+// a chunk stride (rows x 32 bytes) that is a multiple of 8 KB puts every plane and K block on the same memory channels (2.7 x slower):
+// the row count to allocate for `rows` data rows + `pad` zero rows
+inline long long planes_rows_padded(long long rows) { return rows % 256 == 0 ? rows + 8 : rows; }
+
+struct PlanesSplitArgs {
+  int np;
+  MatView x;
+  // row-major planes (k = column), null to skip
+  void *P;
+  int lead;
+  long long R;
+  // transposed planes (k = row), null to skip
+  void *PT;
+  long long Rt;
+  // np == 2: [s, 1 / s] (device, 2 floats) receives the scale; `sumsq_ws` (device, planes_sumsq_ws_bytes()) is scratch of the norm pass
+  float *scale;
+  void *sumsq_ws;
+};
+size_t planes_sumsq_ws_bytes();
+hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s);
+// tile shape the GEMM uses for an N-column output: the A buffer needs tail >= tile rows beyond the last row read, the B buffer rows padded to the tile's columns
 int planes_gemm_tile_rows(int N);
 int planes_gemm_tile_cols(int N);
 hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s);

@@ -1,26 +1,30 @@
-// planes_gemm.hip -- f32-equivalent GEMMs on the bf16 matrix cores from operands PRE-SPLIT into bf16 planes in HBM.
+// planes_gemm.hip -- f32-equivalent GEMMs on the 16-bit matrix cores from operands PRE-SPLIT into 16-bit planes in HBM.
 //
-// gemm_precision 2 ("bf16x6"): a = a0 + a1 + a2 (three bf16 planes, 24 mantissa bits), a.b ~ the six products
-// a_i b_j with i + j <= 2, accumulated in f32, smallest first -- results inside every exact-f32 tolerance of the parity tests
-// at 6/16 of the f32 MFMA's cycles.  The round-2 kernels (gemm_f32.hip, rows_gemm_x3_kernel) split the f32 operands when a
-// staged tile goes to LDS; what they wait for is that staging path (global load -> split in registers -> LDS write -> barrier,
-// one 128 x 128 tile, K step 16), not the matrix cores.  Here the split happens ONCE per operand, in a pass of its own
-// (planes_split_kernel: every activation / derivative matrix is the A operand of one GEMM and of its weight-gradient twin),
-// into a layout made for the consumer:
+// Two arithmetics (planes_gemm.h):
+//   np = 3 "bf16x6": a = a0 + a1 + a2 (three bf16 planes, 24 mantissa bits), a.b ~ the six products a_i b_j with i + j <= 2: 6/16 of
+//     the f32 MFMA's cycles, 6 bytes per operand element.
+//   np = 2 "f16x3":  a s = h + l with s a power of two taken from the operand's Frobenius norm (|x| <= ||X||_F, so s ||X||_F <= 65504
+//     means NO element can overflow, whatever the data), two f16 planes (11 + 11 bits and the sign of the remainder); a.b ~ h h' + h l' +
+//     l h': 3/16 of the f32 MFMA's cycles and 4 bytes per operand element -- what an f32 operand costs.  Norm-wise the error sits below
+//     the exact-f32 kernel's own summation error (tests/test_gpu_planes_gemm.py, against float64): an element that is small against
+//     its matrix's rms loses relative precision (its low plane becomes subnormal: absolute error <= 2^-25 of the scaled value 1), which a
+//     product that sums thousands of typical elements does not see.
+// The round-2 kernels (gemm_f32.hip, rows_gemm_x3_kernel) split f32 operands when a staged tile goes to LDS and wait for exactly that
+// path.  Here the split happens ONCE per operand, in a pass of its own (planes_split_kernel), into a layout made for the consumer:
 //
-//   P16 planes of an R x C matrix:  bf16 P[kb][plane][row][16],  kb = c / 16 (K blocks of 16), plane 0..2, row 0..R-1
+//   P16 planes of an R x C matrix:  e16 P[kb][plane][row][16],  kb = c / 16 (K blocks of 16), row 0..R-1
 //   (R = lead + rows + tail: zero rows in front and behind, so that row-shifted tap views and tile overhang read zeros);
 //   a row record is 32 bytes, its two 16-byte halves (k 0..7 | k 8..15) swapped when bit 3 of the row index is set, which makes
 //   the 16-byte fragment reads of 16 consecutive rows fall on 16 different 16-byte columns of the 256-byte LDS bank row.
+//   The same pass writes the planes of the TRANSPOSE (k = row index) for the products that reduce over rows (weight gradients).
 //
-// A K step of a (BM x BN) tile is then 3 CONTIGUOUS chunks of BM x 32 bytes of A and 3 of BN x 32 bytes of B: the kernel moves
+// A K step of a (BM x BN) tile is then np CONTIGUOUS chunks of BM x 32 bytes of A and np of BN x 32 bytes of B: the kernel moves
 // them with LDS-DMA (global_load_lds_dwordx4: no registers, no conversion, no LDS write instructions) into a ring of three
 // stages, two K steps ahead of the one being multiplied, with counted vmcnt waits and one raw barrier per step
-// (MI355X guide, "Pipelining across barriers").  One block per CU; a wave owns a 64 x 160 (or 64 x 128) block of the tile:
-// 10 (8) accumulator tiles of v_mfma_f32_32x32x16_bf16, 60 (48) MFMAs per K step between two barriers.
+// (MI355X guide, "Pipelining across barriers").  One block of 8 waves per CU.
 //
-// Reference semantics: the GEMMs of TdnnComponent::Propagate / Backprop (/root/reference/src/nnet3/nnet-tdnn-component.cc:302-324,
-// :378-411) with K-segments = taps (row-shifted views of one matrix), as rows_gemm().
+// Reference semantics: the GEMMs of TdnnComponent::Propagate / Backprop / UpdateSimple (/root/reference/src/nnet3/nnet-tdnn-component.cc:302-324,
+// :378-411, :452) with K-segments = taps (row-shifted views of one matrix), as rows_gemm() / wgrad().
 #include <hip/hip_runtime.h>
 #include <string.h>
 
@@ -34,56 +38,189 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kStages = 3;
 
-__device__ __forceinline__ void split3(float x, __bf16 &p0, __bf16 &p1, __bf16 &p2) {
-  p0 = (__bf16)x;
-  float r = x - (float)p0;
-  p1 = (__bf16)r;
-  r -= (float)p1;
-  p2 = (__bf16)r;
+template <int NP>
+struct Plane;
+template <>
+struct Plane<3> {
+  typedef __bf16 E;
+  typedef bf16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(float x, E (&p)[3]) {
+    p[0] = (__bf16)x;
+    float r = x - (float)p[0];
+    p[1] = (__bf16)r;
+    r -= (float)p[1];
+    p[2] = (__bf16)r;
+  }
+};
+template <>
+struct Plane<2> {
+  typedef _Float16 E;
+  typedef f16x8 V8;
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(float x, E (&p)[2]) {  // x already scaled
+    p[0] = (_Float16)x;
+    p[1] = (_Float16)(x - (float)p[0]);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------ the split pass
+constexpr int kSumsqBlocks = 1024;
+// partial[b] = sum of squares of the elements block b walks (fixed assignment: deterministic)
+__global__ __launch_bounds__(256) void planes_sumsq_kernel(MatView x, double *partial) {
+  __shared__ double red[4];
+  const long long total = (long long)x.rows * x.cols;
+  double acc = 0;
+  float run = 0.f;
+  int cnt = 0;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int r = (int)(e / x.cols), c = (int)(e % x.cols);
+    const float v = x.data[(long long)r * x.stride + c];
+    run += v * v;
+    if (++cnt == 64) {  // short float runs, double across them
+      acc += run;
+      run = 0.f;
+      cnt = 0;
+    }
+  }
+  acc += run;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// the same with 16-byte reads (rows and base 16-byte aligned, cols % 4 == 0): a thread owns float4 columns
+__global__ __launch_bounds__(256) void planes_sumsq4_kernel(MatView x, double *partial) {
+  __shared__ double red[4];
+  const int c4 = x.cols >> 2;
+  const long long total = (long long)x.rows * c4;
+  double acc = 0;
+  float run = 0.f;
+  int cnt = 0;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int r = (int)(e / c4), c = (int)(e % c4);
+    const float4 v = *reinterpret_cast<const float4 *>(x.data + (long long)r * x.stride + 4 * c);
+    run += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    if (++cnt == 16) {
+      acc += run;
+      run = 0.f;
+      cnt = 0;
+    }
+  }
+  acc += run;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// scale[0] = s = 2^e, the largest power of two with s ||X||_F <= 65504 (every |x| <= ||X||_F: nothing overflows) and s rms(X) <= 64;
+// scale[1] = 1 / s.  An all-zero matrix gets s = 1; a NaN / Inf norm gives a NaN scale (the product is then NaN, as in f32).
+__global__ void planes_scale_kernel(const double *partial, int nb, double numel, float *scale) {
+  __shared__ double red[256];
+  double a = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double sum = red[0];
+  float s = 1.0f;
+  if (sum != sum || sum > 1.0e300) {
+    s = __int_as_float(0x7fc00000);
+  } else if (sum > 0) {
+    const double fro = sqrt(sum), rms = sqrt(sum / numel);
+    int e = (int)floor(log2(65504.0 / fro));
+    const int e2 = (int)floor(log2(64.0 / rms));
+    if (e2 < e) e = e2;
+    if (e > 120) e = 120;
+    if (e < -120) e = -120;
+    s = ldexpf(1.0f, e);
+  }
+  scale[0] = s;
+  scale[1] = 1.0f / s;
 }
 
-// X (rows x cols, ld) -> P16 planes with `lead` zero rows in front and `tail` behind.  A block: 32 rows x 2 K blocks per pass
-// (a thread: 4 floats = 16 bytes in, 3 x 8 bytes out; a row's 128 bytes are read by 8 neighbouring threads).
-__global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long long ld, int rows, int cols, int lead, long long R, __bf16 *P) {
-  const int t = threadIdx.x, lr = t >> 3, q = t & 7;
-  const int kb = blockIdx.y * 2 + (q >> 2), c0 = kb * 16 + (q & 3) * 4;
-  const int nkb = (cols + 15) / 16;
-  if (kb >= nkb) return;
-  for (int r = blockIdx.x * 32 + lr; r < rows; r += gridDim.x * 32) {
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
+// X (rows x cols, ld) -> P16 planes (k = column; `lead` zero rows in front) and / or the planes of the transpose (k = row).
+// A block: a 64 x 64 tile; thread t reads 16 consecutive floats of row t / 4 (one row record of P), the transposed records go
+// through LDS (thread t then owns column t % 64, rows 16 (t / 64) ..+15).
+template <int NP>
+__global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long long ld, int rows, int cols, const float *scale, int lead, long long R, void *Pv,
+                                                           long long Rt, void *PTv, int vec_ok) {
+  typedef typename Plane<NP>::E E;
+  __shared__ E tile[NP][64][64 + 2];
+  E *P = reinterpret_cast<E *>(Pv), *PT = reinterpret_cast<E *>(PTv);
+  const int t = threadIdx.x, lr = t >> 2, cq = t & 3;
+  const int r = blockIdx.x * 64 + lr, c0 = blockIdx.y * 64 + cq * 16;
+  const float s = scale ? scale[0] : 1.0f;
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) v[j] = 0.f;
+  if (r < rows && c0 < cols) {
     const float *src = X + (long long)r * ld + c0;
-    if (c0 + 3 < cols && (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
-      const float4 f = *reinterpret_cast<const float4 *>(src);
-      v[0] = f.x; v[1] = f.y; v[2] = f.z; v[3] = f.w;
+    if (vec_ok && c0 + 15 < cols) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float4 f = *reinterpret_cast<const float4 *>(src + 4 * q);
+        v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w;
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int j = 0; j < 16; j++)
         if (c0 + j < cols) v[j] = src[j];
     }
-    bf16x4 pl[3];
+  }
+  E pl[NP][16];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      __bf16 a, b, c;
-      split3(v[j], a, b, c);
-      pl[0][j] = a; pl[1][j] = b; pl[2][j] = c;
+  for (int j = 0; j < 16; j++) {
+    E e[NP];
+    Plane<NP>::split(v[j] * s, e);
+#pragma unroll
+    for (int p = 0; p < NP; p++) pl[p][j] = e[p];
+  }
+  const int nkb = (cols + 15) / 16, kb = c0 >> 4;
+  if (P && r < rows && kb < nkb) {
+    const long long ra = (long long)lead + r;
+    const int sw = (int)((ra >> 3) & 1);
+#pragma unroll
+    for (int p = 0; p < NP; p++) {
+      E *dst = P + (((long long)kb * NP + p) * R + ra) * 16;
+      *reinterpret_cast<uint4 *>(dst + (0 ^ sw) * 8) = *reinterpret_cast<const uint4 *>(&pl[p][0]);
+      *reinterpret_cast<uint4 *>(dst + (1 ^ sw) * 8) = *reinterpret_cast<const uint4 *>(&pl[p][8]);
     }
-    const long long ra = lead + r;
-    const int k = (q & 3) * 4;                       // k offset inside the record: 0, 4, 8, 12
-    const int half = (k >> 3) ^ (int)((ra >> 3) & 1);  // swizzled half
-    const int off = half * 8 + (k & 7);
+  }
+  if (!PT) return;
 #pragma unroll
-    for (int p = 0; p < 3; p++) *reinterpret_cast<bf16x4 *>(P + (((long long)kb * 3 + p) * R + ra) * 16 + off) = pl[p];
+  for (int p = 0; p < NP; p++)
+#pragma unroll
+    for (int j = 0; j < 16; j++) tile[p][lr][cq * 16 + j] = pl[p][j];
+  __syncthreads();
+  const int c = blockIdx.y * 64 + (t & 63), kq = t >> 6;
+  if (c >= cols) return;  // (rows of PT beyond `cols` are zeroed by the pad kernel)
+  const long long kbt = (long long)blockIdx.x * 4 + kq;
+  const int sw = (c >> 3) & 1;
+#pragma unroll
+  for (int p = 0; p < NP; p++) {
+    E rec[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) rec[j] = tile[p][kq * 16 + j][t & 63];
+    E *dst = PT + ((kbt * NP + p) * Rt + c) * 16;
+    *reinterpret_cast<uint4 *>(dst + (0 ^ sw) * 8) = *reinterpret_cast<const uint4 *>(&rec[0]);
+    *reinterpret_cast<uint4 *>(dst + (1 ^ sw) * 8) = *reinterpret_cast<const uint4 *>(&rec[8]);
   }
 }
 
-// zero the lead / tail rows of every (kb, plane) chunk
-__global__ __launch_bounds__(256) void planes_pad_kernel(__bf16 *P, int nkb, long long R, int lead, int rows) {
+// zero the rows [0, lead) and [lead + rows, R) of every (kb, plane) chunk (32-byte records of 2-byte elements, whatever the type)
+__global__ __launch_bounds__(256) void planes_pad_kernel(void *Pv, long long nchunks, long long R, int lead, long long rows) {
+  unsigned short *P = reinterpret_cast<unsigned short *>(Pv);
   const long long pad = R - rows;  // per chunk
-  const long long total = (long long)nkb * 3 * pad * 2;  // 16-byte pieces
+  const long long total = nchunks * pad * 2;  // 16-byte pieces
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
     const long long chunk = e / (pad * 2), w = e % (pad * 2);
     long long row = w / 2;
@@ -94,22 +231,25 @@ __global__ __launch_bounds__(256) void planes_pad_kernel(__bf16 *P, int nkb, lon
 
 // ------------------------------------------------------------------------------------------------------ the GEMM
 // block = WM x WN waves, a wave owns TM x TN accumulator tiles of 32 x 32; BM = WM TM 32, BN = WN TN 32.
-template <int WM, int WN, int TM, int TN, bool DB>
+template <int NP, int WM, int WN, int TM, int TN, bool DB>
 __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGemmArgs p, int ntm, int ntn) {
+  typedef typename Plane<NP>::V8 V8;
   constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int A_BYTES = 3 * BM * 32, B_BYTES = 3 * BN * 32, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, STAGE = A_BYTES + B_BYTES;
   constexpr int PIECES = STAGE / 16, PPT = (PIECES + NT - 1) / NT;  // 16-byte pieces per stage / per thread
   constexpr int STAGE_PAD = PPT * NT * 16;  // every thread copies PPT pieces per stage (the surplus ones into the pad): one vmcnt count for all waves
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // XCD-aware tile order (workgroups are dealt to the eight XCDs round-robin): each XCD a contiguous run of tiles, tile_n fastest
-  const int nblk = ntm * ntn;
+  // XCD-aware tile order (workgroups are dealt to the eight XCDs round-robin): each XCD a contiguous run of tiles, column tiles
+  // (and taps) fastest so that neighbours share the A chunk, K splits slowest
+  const int ntaps = p.ntap > 1 ? p.ntap : 1, ncol = ntn * ntaps, nsplit = p.ksplit > 1 ? p.ksplit : 1;
+  const int nblk = ntm * ncol * nsplit;
   int bid = blockIdx.x;
   {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
-  const int tile_m = bid / ntn, tile_n = bid % ntn;
+  const int sp = bid / (ntm * ncol), tile_m = (bid / ncol) % ntm, tcol = bid % ncol, tap = tcol / ntn, tile_n = tcol % ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN, li = lane & 31, lh = lane >> 5;
 
@@ -121,10 +261,13 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-  // ---- the stages in K order: (segment, K block).  Stage g -> ring slot g % 3.
-  int total = 0;
-  for (int s = 0; s < p.nseg; s++) total += p.seg[s].nkb;
-  // what this thread copies per stage: piece q = t + NT j of the stage image [A p0 | A p1 | A p2 | B p0 | B p1 | B p2]
+  // ---- the stages in K order: (segment, K block).  This block multiplies stages [g_begin, g_begin + total).
+  int all = 0;
+  for (int s = 0; s < p.nseg; s++) all += p.seg[s].nkb;
+  const int g_begin = nsplit > 1 ? sp * p.kb_per_split : 0;
+  const int total = nsplit > 1 ? max(0, min(all - g_begin, p.kb_per_split)) : all;
+  const int tap_akb = ntaps > 1 ? p.tap_a_kb[tap] : 0, tap_bkb = ntaps > 1 ? p.tap_b_kb[tap] : 0;
+  // what this thread copies per stage: piece q = t + NT j of the stage image [A planes | B planes]
   // (a plane chunk is contiguous in global memory as well: BM / BN row records of 32 bytes)
   int lds_off[PPT];
   bool isA[PPT], live[PPT];
@@ -145,17 +288,25 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
   const char *srcp[PPT];
   long long kstride[PPT];
 #pragma unroll
-  for (int j = 0; j < PPT; j++) kstride[j] = (isA[j] ? p.RA : p.RB) * 96;  // 3 planes x 32 bytes x rows
-  int ld_seg = -1, ld_left = 0;
+  for (int j = 0; j < PPT; j++) kstride[j] = (isA[j] ? p.RA : p.RB) * (32 * NP);
+  int ld_seg = -1, ld_left = 0, ld_skip = g_begin;
   auto next_request_segment = [&]() {
-    ld_seg++;
-    if (ld_seg >= p.nseg) return;
-    const PlanesSeg sg = p.seg[ld_seg];
-    ld_left = sg.nkb;
-    const char *ga = reinterpret_cast<const char *>(p.A) + ((long long)sg.a_kb0 * 3 * p.RA + sg.a_row + m0) * 32;
-    const char *gb = reinterpret_cast<const char *>(p.B) + ((long long)sg.b_kb0 * 3 * p.RB + n0) * 32;
+    for (;;) {
+      ld_seg++;
+      if (ld_seg >= p.nseg) return;
+      const PlanesSeg sg = p.seg[ld_seg];
+      if (ld_skip >= sg.nkb) {  // (a split that starts behind this segment)
+        ld_skip -= sg.nkb;
+        continue;
+      }
+      ld_left = sg.nkb - ld_skip;
+      const char *ga = reinterpret_cast<const char *>(p.A) + ((long long)(sg.a_kb0 + tap_akb + ld_skip) * NP * p.RA + sg.a_row + m0) * 32;
+      const char *gb = reinterpret_cast<const char *>(p.B) + ((long long)(sg.b_kb0 + tap_bkb + ld_skip) * NP * p.RB + sg.b_row + n0) * 32;
+      ld_skip = 0;
 #pragma unroll
-    for (int j = 0; j < PPT; j++) srcp[j] = (isA[j] ? ga : gb) + rel[j];
+      for (int j = 0; j < PPT; j++) srcp[j] = (isA[j] ? ga : gb) + rel[j];
+      return;
+    }
   };
   next_request_segment();
   auto request = [&](int slot) {
@@ -169,56 +320,64 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
   };
 
   // fragment addressing: lane (li, lh) of a 32 x 32 x 16 MFMA holds k = 8 lh .. 8 lh + 7 of row li; the halves of a row record are
-  // swapped when bit 3 of its absolute row is set (B: n0 is a multiple of 32; A: the segment's first row decides)
-  int cs_seg = 0, cs_left = p.seg[0].nkb;
-  int arow0 = (int)((p.seg[0].a_row + m0) & 15);  // only bit 3 of (a_row + m0 + local) matters
+  // swapped when bit 3 of its absolute row is set (the segment's first row decides)
+  int cs_seg = -1, cs_left = 0, cs_skip = g_begin;
   int a_off[TM], b_off[TN];  // byte offsets of this lane's fragments inside plane 0 of a stage
-  auto set_a_off = [&]() {
+  auto next_compute_segment = [&]() {
+    for (;;) {
+      cs_seg++;
+      if (cs_seg >= p.nseg) return;
+      const PlanesSeg sg = p.seg[cs_seg];
+      if (cs_skip >= sg.nkb) {
+        cs_skip -= sg.nkb;
+        continue;
+      }
+      cs_left = sg.nkb - cs_skip;
+      cs_skip = 0;
+      const int arow0 = (int)((sg.a_row + m0) & 15), brow0 = (int)((sg.b_row + n0) & 15);
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
-      const int row = wm * TM * 32 + i * 32 + li;
-      a_off[i] = row * 32 + ((lh ^ (((row + arow0) >> 3) & 1)) << 4);
+      for (int i = 0; i < TM; i++) {
+        const int row = wm * TM * 32 + i * 32 + li;
+        a_off[i] = row * 32 + ((lh ^ (((row + arow0) >> 3) & 1)) << 4);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int row = wn * TN * 32 + j * 32 + li;
+        b_off[j] = A_BYTES + row * 32 + ((lh ^ (((row + brow0) >> 3) & 1)) << 4);
+      }
+      return;
     }
   };
-  set_a_off();
-#pragma unroll
-  for (int j = 0; j < TN; j++) {
-    const int row = wn * TN * 32 + j * 32 + li;
-    b_off[j] = A_BYTES + row * 32 + ((lh ^ ((row >> 3) & 1)) << 4);
-  }
+  next_compute_segment();
   // Fragments of stage g + 1 are read into a second register set while stage g is multiplied: a wave has its SIMD to itself, so
-  // LDS latency (and the LDS bandwidth of four waves reading 18 KB each) would otherwise sit in front of every K step's MFMAs.
-  auto read_frags = [&](int slot, bf16x8 (&a)[3][TM], bf16x8 (&b)[3][TN]) {
+  // LDS latency (and the LDS bandwidth of the waves reading their fragments) would otherwise sit in front of every K step's MFMAs.
+  auto read_frags = [&](int slot, V8 (&a)[NP][TM], V8 (&b)[NP][TN]) {
     const char *st = smem + slot * STAGE_PAD;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
+    for (int q = 0; q < NP; q++) {
 #pragma unroll
-      for (int j = 0; j < TN; j++) b[q][j] = *reinterpret_cast<const bf16x8 *>(st + q * BN * 32 + b_off[j]);
+      for (int j = 0; j < TN; j++) b[q][j] = *reinterpret_cast<const V8 *>(st + q * BN * 32 + b_off[j]);
 #pragma unroll
-      for (int i = 0; i < TM; i++) a[q][i] = *reinterpret_cast<const bf16x8 *>(st + q * BM * 32 + a_off[i]);
+      for (int i = 0; i < TM; i++) a[q][i] = *reinterpret_cast<const V8 *>(st + q * BM * 32 + a_off[i]);
     }
-    if (--cs_left == 0 && ++cs_seg < p.nseg) {  // (the NEXT read belongs to the next segment: its rows may swap other halves)
-      cs_left = p.seg[cs_seg].nkb;
-      arow0 = (int)((p.seg[cs_seg].a_row + m0) & 15);
-      set_a_off();
-    }
+    if (--cs_left == 0) next_compute_segment();  // (the NEXT read belongs to the next segment: its rows may swap other halves)
   };
-  auto multiply = [&](const bf16x8 (&a)[3][TM], const bf16x8 (&b)[3][TN]) {
-    // six products per accumulator tile, smallest terms first, the leading term last
+  auto multiply = [&](const V8 (&a)[NP][TM], const V8 (&b)[NP][TN]) {
+    // the products a_q b_(d - q), d = np - 1 .. 0: smallest terms first, the leading term last
 #pragma unroll
-    for (int d = 2; d >= 0; d--)
+    for (int d = NP - 1; d >= 0; d--)
 #pragma unroll
       for (int q = 0; q <= d; q++)
 #pragma unroll
         for (int i = 0; i < TM; i++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q][i], b[d - q][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; j++) acc[i][j] = Plane<NP>::mfma(a[q][i], b[d - q][j], acc[i][j]);
   };
   // One K step.  On entry the fragments of stage g are in (a0, b0) and the requests of stages g + 1, g + 2 are in flight.
   //   wait until stage g + 1 has landed (at most stage g + 2's pieces outstanding); barrier: everybody's pieces of stage g + 1 are
   //   in LDS and everybody has read stage g's fragments, so slot g % 3 is free: request stage g + 3 into it; read the fragments of
   //   stage g + 1 into (a1, b1) while stage g is multiplied.
-  auto step = [&](int g, bf16x8 (&a0)[3][TM], bf16x8 (&b0)[3][TN], bf16x8 (&a1)[3][TM], bf16x8 (&b1)[3][TN]) {
+  auto step = [&](int g, V8 (&a0)[NP][TM], V8 (&b0)[NP][TN], V8 (&a1)[NP][TM], V8 (&b1)[NP][TN]) {
     if (g + 1 < total) {
       if (g + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -231,7 +390,7 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
 
   if constexpr (DB) {
     // prologue: three stages requested, the first one's fragments read
-    bf16x8 fa0[3][TM], fb0[3][TN], fa1[3][TM], fb1[3][TN];
+    V8 fa0[NP][TM], fb0[NP][TN], fa1[NP][TM], fb1[NP][TN];
     if (total > 0) request(0);
     if (total > 1) request(1);
     if (total > 2) request(2);
@@ -249,7 +408,7 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
   } else {
     // One register set (tiles whose accumulators leave no room for a second): stage g is read and multiplied behind the barrier
     // that follows its wait; two stages are in flight meanwhile.
-    bf16x8 fa[3][TM], fb[3][TN];
+    V8 fa[NP][TM], fb[NP][TN];
     if (total > 0) request(0);
     if (total > 1) request(1);
     for (int g = 0; g < total; g++) {
@@ -264,6 +423,24 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
 
   // ---- epilogue: straight from the accumulators (C/D map: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)):
   // a store instruction writes two 128-byte row segments
+  if (nsplit > 1) {  // raw partial tile into this split's slab (the caller reduces, scales, accumulates)
+    float *P = p.partial + (long long)sp * p.partial_stride + (long long)tap * p.tap_off_p;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int n = n0 + (wn * TN + j) * 32 + li;
+        if (n >= p.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m < p.M) P[(long long)m * p.ldp_m + (long long)n * p.ldp_n] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+  float sc = 1.0f;
+  if (NP == 2) sc = (p.scale_a ? p.scale_a[1] : 1.0f) * (p.scale_b ? p.scale_b[1] : 1.0f);
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -275,8 +452,8 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
       for (int r = 0; r < 16; r++) {
         const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= p.M) continue;
-        float *c = p.C + (long long)m * p.ldc + n;
-        float v = acc[i][j][r] + bias;
+        float *c = p.C + (long long)m * p.ldc + (long long)tap * p.tap_off_c + n;
+        float v = acc[i][j][r] * sc + bias;
         if (p.init_mode == 0) v += *c;
         if (p.add && m >= p.add_lo && m < p.add_hi) v += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n];
         if (p.relu) v = floor_keep_nan(v, 0.f);
@@ -285,39 +462,49 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
     }
 }
 
-template <int WM, int WN, int TM, int TN, bool DB = false>
+template <int NP, int WM, int WN, int TM, int TN, bool DB = false>
 hipError_t launch(const PlanesGemmArgs &a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int NT = WM * WN * 64, PIECES = (3 * BM * 32 + 3 * BN * 32) / 16, PPT = (PIECES + NT - 1) / NT;
+  constexpr int NT = WM * WN * 64, PIECES = (NP * BM * 32 + NP * BN * 32) / 16, PPT = (PIECES + NT - 1) / NT;
   constexpr size_t lds = (size_t)kStages * PPT * NT * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)planes_gemm_kernel<WM, WN, TM, TN, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)planes_gemm_kernel<NP, WM, WN, TM, TN, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-  hipLaunchKernelGGL((planes_gemm_kernel<WM, WN, TM, TN, DB>), dim3(ntm * ntn), dim3(WM * WN * 64), lds, s, a, ntm, ntn);
+  const int nblk = ntm * ntn * (a.ntap > 1 ? a.ntap : 1) * (a.ksplit > 1 ? a.ksplit : 1);
+  hipLaunchKernelGGL((planes_gemm_kernel<NP, WM, WN, TM, TN, DB>), dim3(nblk), dim3(WM * WN * 64), lds, s, a, ntm, ntn);
   return hipGetLastError();
 }
 
 }  // namespace
 
-size_t planes_bytes(int rows, int cols, int lead, int tail) {
-  const long long R = (long long)lead + rows + tail, nkb = (cols + 15) / 16;
-  return (size_t)(nkb * 3 * R * 32);
-}
+size_t planes_bytes(int np, long long rows_total, long long k_blocks) { return (size_t)(k_blocks * np * rows_total * 32); }
+size_t planes_sumsq_ws_bytes() { return sizeof(double) * kSumsqBlocks; }
 
-hipError_t planes_split(MatView x, int lead, int tail, void *planes, hipStream_t s) {
-  if (x.rows <= 0 || x.cols <= 0) return hipSuccess;
-  const long long R = (long long)lead + x.rows + tail;
-  const int nkb = (x.cols + 15) / 16;
-  if (lead + tail > 0) {
-    const long long pieces = (long long)nkb * 3 * (lead + tail) * 2;
-    hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(pieces, 256)), dim3(256), 0, s, (__bf16 *)planes, nkb, R, lead, x.rows);
+hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
+  const MatView &x = a.x;
+  if (x.rows <= 0 || x.cols <= 0 || (!a.P && !a.PT)) return hipSuccess;
+  if (a.np != 2 && a.np != 3) return hipErrorInvalidValue;
+  const long long nkb = planes_kblocks(x.cols), nkbt = planes_t_kblocks(x.rows);
+  const bool vec4 = (reinterpret_cast<uintptr_t>(x.data) & 15) == 0 && x.stride % 4 == 0;
+  if (a.np == 2) {
+    if (!a.scale || !a.sumsq_ws) return hipErrorInvalidValue;
+    if (vec4 && x.cols % 4 == 0) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
+    else hipLaunchKernelGGL(planes_sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
+    hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)a.sumsq_ws, kSumsqBlocks, (double)x.rows * x.cols, a.scale);
   }
-  hipLaunchKernelGGL(planes_split_kernel, dim3((unsigned)std::min(2048, (x.rows + 31) / 32), (nkb + 1) / 2), dim3(256), 0, s, x.data, (long long)x.stride, x.rows,
-                     x.cols, lead, R, (__bf16 *)planes);
+  if (a.P && a.R > x.rows)
+    hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(nkb * a.np * (a.R - x.rows) * 2, 256)), dim3(256), 0, s, a.P, nkb * a.np, a.R, a.lead, (long long)x.rows);
+  if (a.PT && a.Rt > x.cols)
+    hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(nkbt * a.np * (a.Rt - x.cols) * 2, 256)), dim3(256), 0, s, a.PT, nkbt * a.np, a.Rt, 0, (long long)x.cols);
+  const dim3 grid((unsigned)((x.rows + 63) / 64), (unsigned)((x.cols + 63) / 64));
+  if (a.np == 2)
+    hipLaunchKernelGGL(planes_split_kernel<2>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)a.scale, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0);
+  else
+    hipLaunchKernelGGL(planes_split_kernel<3>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)nullptr, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -330,17 +517,23 @@ int planes_gemm_tile_cols(int N) {
 
 hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.nseg <= 0) return hipSuccess;
-  // 160-wide tiles for the TDNN-F bottleneck, 128-wide otherwise; 4 waves, a wave = 64 rows x the tile's width
-  // Measured on MI355X (tools/planes_bench.py, f32-equivalent TFLOP/s; exact-f32 kernel of gemm_f32.hip in brackets):
+  if (a.np != 2 && a.np != 3) return hipErrorInvalidValue;
+  if (a.ntap > 1 && a.nseg != 1) return hipErrorInvalidValue;
+  // 160-wide tiles for the TDNN-F bottleneck, 256- / 128-wide otherwise; 8 waves (two per SIMD)
+  // Measured on MI355X for np = 3 (tools/planes_bench.py, f32-equivalent TFLOP/s; exact-f32 kernel of gemm_f32.hip in brackets):
   //   256 x 256 tile, 8 waves of 64 x 128:  N = 1536, K = 2 x 1536: 227 [130];  K = 2 x 160 (.affine forward): 162 [116]
-  //   256 x 160 tile, 8 waves of 32 x 160:  N = 160, K = 2 x 1536 (.linear forward): 151 [117] -- one column tile, so A (6 bytes per
-  //   element as planes) is streamed from HBM once: 53 flop per byte, ~250 TFLOP/s at 5 TB/s; 782 tiles on 256 CUs = 4 rounds for 3.05
+  //   256 x 160 tile, 8 waves of 32 x 160:  N = 160, K = 2 x 1536 (.linear forward): 151 [117]
   //   256 x 128 tile, 4 x 2 waves of 64 x 64: 201 / 150.  Four waves of 64 rows x the tile's width: 194 / 121 (one wave per SIMD
   //   leaves every LDS / barrier wait exposed); fragments double-buffered in registers: no gain, spills on the wide tiles.
   const int bn = planes_gemm_tile_cols(a.N);
-  if (bn == 160) return launch<8, 1, 1, 5>(a, s);
-  if (bn == 256) return launch<4, 2, 2, 4>(a, s);
-  return launch<4, 2, 2, 2>(a, s);
+  if (a.np == 3) {
+    if (bn == 160) return launch<3, 8, 1, 1, 5>(a, s);
+    if (bn == 256) return launch<3, 4, 2, 2, 4>(a, s);
+    return launch<3, 4, 2, 2, 2>(a, s);
+  }
+  if (bn == 160) return launch<2, 8, 1, 1, 5>(a, s);
+  if (bn == 256) return launch<2, 4, 2, 2, 4>(a, s);
+  return launch<2, 4, 2, 2, 2>(a, s);
 }
 
 }  // namespace tdnnf
@@ -349,38 +542,49 @@ using namespace tdnnf;
 
 extern "C" {
 
-size_t tdnnf_planes_bytes(int rows, int cols, int lead_rows, int tail_rows) {
-  if (rows < 0 || cols <= 0 || lead_rows < 0 || tail_rows < 0) return 0;
-  return planes_bytes(rows, cols, lead_rows, tail_rows);
+size_t tdnnf_planes_bytes(int num_planes, long long rows_total, long long k_blocks) {
+  if ((num_planes != 2 && num_planes != 3) || rows_total <= 0 || k_blocks <= 0) return 0;
+  return planes_bytes(num_planes, rows_total, k_blocks);
 }
+size_t tdnnf_planes_split_workspace_bytes(void) { return planes_sumsq_ws_bytes(); }
 
-int tdnnf_planes_split(const tdnnf_mat *x, int lead_rows, int tail_rows, void *planes, tdnnf_stream stream) {
-  TDNNF_REQUIRE(mat_ok(x) && planes && lead_rows >= 0 && tail_rows >= 0 && x->cols > 0, "planes_split: bad arguments");
-  TDNNF_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "planes_split: the plane buffer must be 16-byte aligned");
-  TDNNF_HIP(planes_split(view(x), lead_rows, tail_rows, planes, (hipStream_t)stream));
+int tdnnf_planes_split(int num_planes, const tdnnf_mat *x, int lead_rows, long long rows_total, void *planes, long long t_rows_total, void *planes_t,
+                       float *scale_dev, void *workspace_dev, tdnnf_stream stream) {
+  TDNNF_REQUIRE((num_planes == 2 || num_planes == 3) && mat_ok(x) && x->cols > 0 && lead_rows >= 0 && (planes || planes_t), "planes_split: bad arguments (2 or 3 planes)");
+  TDNNF_REQUIRE(!planes || rows_total >= (long long)lead_rows + x->rows, "planes_split: rows_total must cover lead + rows");
+  TDNNF_REQUIRE(!planes_t || t_rows_total >= x->cols, "planes_split: t_rows_total must cover the matrix's columns");
+  TDNNF_REQUIRE(((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(planes_t)) & 15) == 0, "planes_split: the plane buffers must be 16-byte aligned");
+  TDNNF_REQUIRE(num_planes == 3 || (scale_dev && workspace_dev), "planes_split: two f16 planes need the scale output and the workspace");
+  PlanesSplitArgs a;
+  a.np = num_planes; a.x = view(x); a.P = planes; a.lead = lead_rows; a.R = rows_total; a.PT = planes_t; a.Rt = t_rows_total; a.scale = scale_dev; a.sumsq_ws = workspace_dev;
+  TDNNF_HIP(planes_split(a, (hipStream_t)stream));
   return TDNNF_OK;
 }
 
-int tdnnf_planes_gemm(const void *a_planes, long long a_rows_total, const void *b_planes, long long b_rows_total, int num_segments, const long long *a_row,
-                      const int *a_first_col, const int *b_first_col, const int *seg_cols, const float *bias, int init_mode, int relu, tdnnf_mat *c,
-                      tdnnf_stream stream) {
-  TDNNF_REQUIRE(a_planes && b_planes && mat_ok(c) && num_segments >= 1 && num_segments <= 16 && a_row && a_first_col && b_first_col && seg_cols,
-                "planes_gemm: bad arguments (1..16 segments)");
+int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
+                      const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col, const int *b_first_col,
+                      const int *seg_cols, const float *bias, int init_mode, int relu, tdnnf_mat *c, tdnnf_stream stream) {
+  TDNNF_REQUIRE((num_planes == 2 || num_planes == 3) && a_planes && b_planes && mat_ok(c) && num_segments >= 1 && num_segments <= 16 && a_row && a_first_col &&
+                    b_first_col && seg_cols,
+                "planes_gemm: bad arguments (2 or 3 planes, 1..16 segments)");
   TDNNF_REQUIRE(init_mode >= 0 && init_mode <= 2 && (init_mode != 1 || bias), "planes_gemm: init_mode 0 (+=), 1 (bias), 2 (=)");
   PlanesGemmArgs a;
   memset(&a, 0, sizeof(a));
-  a.A = a_planes; a.RA = a_rows_total; a.B = b_planes; a.RB = b_rows_total;
+  a.np = num_planes;
+  a.A = a_planes; a.RA = a_rows_total; a.B = b_planes; a.RB = b_rows_total; a.scale_a = a_scale_dev; a.scale_b = b_scale_dev;
   a.C = c->data; a.ldc = c->stride; a.M = c->rows; a.N = c->cols;
   a.bias = bias; a.init_mode = init_mode; a.relu = relu; a.nseg = num_segments;
   const int BM = planes_gemm_tile_rows(c->cols), BN = planes_gemm_tile_cols(c->cols);
-  TDNNF_REQUIRE(b_rows_total >= (long long)((c->cols + BN - 1) / BN) * BN, "planes_gemm: the B plane buffer needs %d rows (output columns padded to the %d-column tile)",
-                ((c->cols + BN - 1) / BN) * BN, BN);
   for (int i = 0; i < num_segments; i++) {
-    TDNNF_REQUIRE(a_first_col[i] % 16 == 0 && b_first_col[i] % 16 == 0 && seg_cols[i] > 0 && a_row[i] >= 0, "planes_gemm: segment %d: columns must start on a multiple of 16", i);
+    const long long br = b_row ? b_row[i] : 0;
+    TDNNF_REQUIRE(a_first_col[i] % 16 == 0 && b_first_col[i] % 16 == 0 && seg_cols[i] > 0 && a_row[i] >= 0 && br >= 0, "planes_gemm: segment %d: columns must start on a multiple of 16", i);
     TDNNF_REQUIRE(a_row[i] + (long long)((c->rows + BM - 1) / BM) * BM <= a_rows_total,
                   "planes_gemm: segment %d reads rows %lld..%lld of an A plane buffer of %lld rows (tail rows must cover the %d-row tile)", i, a_row[i],
                   a_row[i] + (long long)((c->rows + BM - 1) / BM) * BM, a_rows_total, BM);
+    TDNNF_REQUIRE(br + (long long)((c->cols + BN - 1) / BN) * BN <= b_rows_total, "planes_gemm: segment %d: the B plane buffer needs %lld rows (output columns padded to the %d-column tile)", i,
+                  br + (long long)((c->cols + BN - 1) / BN) * BN, BN);
     a.seg[i].a_row = a_row[i];
+    a.seg[i].b_row = br;
     a.seg[i].a_kb0 = a_first_col[i] / 16;
     a.seg[i].b_kb0 = b_first_col[i] / 16;
     a.seg[i].nkb = (seg_cols[i] + 15) / 16;

@@ -240,11 +240,14 @@ def test_plain_gumbel_softmax_without_flops_vector(hip, ora, N, Cc):
     dpd, dxd = dev(dp), torch.zeros(N, Cc, device="cuda")
     hip.softmax_flops_backprop(p, dpd, 0.3, None, 0, tau, dxd, hip.stream())
     assert (host(dpd) == dp).all()  # no penalty: the output derivative is not mutated
-    np.testing.assert_allclose(host(dxd), dx_ref, rtol=2e-4, atol=1e-7)
+    # (e_c - <p, e> cancels for some elements: float rounding of the row dot product shows there, so the bound is absolute)
+    np.testing.assert_allclose(host(dxd), dx_ref, rtol=2e-4, atol=2e-6)
+    assert rel_l2(host(dxd), dx_ref) < 1e-5
     # independent check: float64 Jacobian (diag(p) - p p^T) / temp
     pd = p_ref.astype(np.float64)
     want = pd * (dp - (pd * dp).sum(1, keepdims=True)) / tau
-    np.testing.assert_allclose(host(dxd), want, rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(host(dxd), want, rtol=2e-4, atol=2e-6)
+    assert rel_l2(host(dxd), want) < 1e-5
 
 
 def test_small_ops(hip, ora):

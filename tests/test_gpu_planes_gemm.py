@@ -1,7 +1,8 @@
-"""-m gpu: the pre-split bf16-plane GEMM (csrc/planes_gemm.hip, gemm_precision 2's f32-equivalent arithmetic: three planes, six
-products) through the C-ABI against float64 on the same inputs: single segments, taps as row-shifted segments, ragged tiles,
-K not a multiple of 16, the three init modes and ReLU.  Tolerance: f32-equivalent (1e-6 of the result's norm; an exact-f32 GEMM of
-these sizes sits at ~1e-7)."""
+"""-m gpu: the pre-split plane GEMMs (csrc/planes_gemm.hip) through the C-ABI against float64 on the same inputs, for both
+arithmetics -- three bf16 planes / six products ("bf16x6", gemm_precision 2) and two scaled f16 planes / three products ("f16x3",
+gemm_precision 3): single segments, taps as row-shifted segments, ragged tiles, K not a multiple of 16, the three init modes and
+ReLU, the transposed planes, and data chosen to break a scaled 16-bit split (huge dynamic range, one spike, tiny values).
+Tolerance: f32-equivalent (1e-6 of the result's norm; an exact-f32 GEMM of these sizes sits at ~1e-7 to 4e-7)."""
 import ctypes as C
 
 import numpy as np
@@ -11,17 +12,30 @@ import torch
 from tests.gpu_util import dev, host, rel_l2
 
 pytestmark = pytest.mark.gpu
+ELEM = {3: torch.bfloat16, 2: torch.float16}
 
 
-def planes_of(pkg, x, lead, tail):
+def tile_cols(N):
+    return 160 if ((N + 159) // 160) * 160 - N < ((N + 127) // 128) * 128 - N else (256 if N % 256 == 0 else 128)
+
+
+def planes_of(pkg, np_, x, lead=0, tail=0, t_tail=None):
+    """(P, R, PT, Rt, scale) of a device matrix; NaN-filled buffers: pads must be written."""
     lib, abi = pkg.hipabi.load(), pkg.hipabi
-    nbytes = lib.tdnnf_planes_bytes(x.shape[0], x.shape[1], lead, tail)
-    buf = torch.full((nbytes // 2,), float("nan"), dtype=torch.bfloat16, device="cuda")  # NaN-filled: pads must be written
-    abi.check(lib.tdnnf_planes_split(abi.pmat(x), lead, tail, abi.ptr(buf), abi.stream()))
-    return buf
+    rows, cols = x.shape
+    R = lead + rows + tail
+    P = torch.full((lib.tdnnf_planes_bytes(np_, R, (cols + 15) // 16) // 2,), float("nan"), dtype=ELEM[np_], device="cuda")
+    PT, Rt = None, 0
+    if t_tail is not None:
+        Rt = cols + t_tail
+        PT = torch.full((lib.tdnnf_planes_bytes(np_, Rt, ((rows + 63) // 64) * 4) // 2,), float("nan"), dtype=ELEM[np_], device="cuda")
+    scale = torch.zeros(2, device="cuda")
+    ws = torch.zeros(lib.tdnnf_planes_split_workspace_bytes() // 4 + 4, device="cuda")
+    abi.check(lib.tdnnf_planes_split(np_, abi.pmat(x), lead, R, abi.ptr(P), Rt, abi.ptr(PT) if PT is not None else None, abi.ptr(scale), abi.ptr(ws), abi.stream()))
+    return P, R, PT, Rt, scale
 
 
-def run(pkg, M, N, Di, offs, init_mode=2, relu=0, seed=0):
+def run(pkg, np_, M, N, Di, offs, init_mode=2, relu=0, seed=0, make=None):
     """C[m] = sum_i X[base + m + offs[i]] . W[:, i Di : (i + 1) Di]^T"""
     lib, abi = pkg.hipabi.load(), pkg.hipabi
     rng = np.random.default_rng(seed)
@@ -30,19 +44,21 @@ def run(pkg, M, N, Di, offs, init_mode=2, relu=0, seed=0):
     rows_in = M + hi - lo
     X = rng.standard_normal((rows_in, Di)).astype(np.float32)
     W = (rng.standard_normal((N, K * Di)) / np.sqrt(K * Di)).astype(np.float32)
+    if make is not None:
+        X, W = make(rng, X, W)
     bias = rng.standard_normal(N).astype(np.float32)
     C0 = rng.standard_normal((M, N)).astype(np.float32)
-    BN = 160 if ((N + 159) // 160) * 160 - N < ((N + 127) // 128) * 128 - N else (256 if N % 256 == 0 else 128)
+    BN = tile_cols(N)
     Xd, Wd = dev(X), dev(W)
     lead, tail = 3, 256 + 5  # any lead; the tail covers the 256-row tile
-    ap = planes_of(pkg, Xd, lead, tail)
-    bp = planes_of(pkg, Wd, 0, ((N + BN - 1) // BN) * BN - N)
+    ap, RA, _, _, sa = planes_of(pkg, np_, Xd, lead, tail)
+    bp, RB, _, _, sb = planes_of(pkg, np_, Wd, 0, ((N + BN - 1) // BN) * BN - N)
     Cd = dev(C0.copy())
     a_row = (C.c_longlong * K)(*[lead + (o - lo) for o in offs])
     a_col = (C.c_int * K)(*([0] * K))
     b_col = (C.c_int * K)(*[i * Di for i in range(K)])
     cols = (C.c_int * K)(*([Di] * K))
-    abi.check(lib.tdnnf_planes_gemm(abi.ptr(ap), lead + rows_in + tail, abi.ptr(bp), ((N + BN - 1) // BN) * BN, K, a_row, a_col, b_col, cols,
+    abi.check(lib.tdnnf_planes_gemm(np_, abi.ptr(ap), RA, abi.ptr(sa), abi.ptr(bp), RB, abi.ptr(sb), K, a_row, None, a_col, b_col, cols,
                                     abi.ptr(dev(bias)), init_mode, relu, abi.pmat(Cd), abi.stream()))
     ref = np.zeros((M, N))
     for i, o in enumerate(offs):
@@ -56,40 +72,91 @@ def run(pkg, M, N, Di, offs, init_mode=2, relu=0, seed=0):
     return host(Cd), ref
 
 
-@pytest.mark.parametrize("M,N,Di,offs", [
+SHAPES = [
     (256, 160, 64, [0]),              # one tile, one segment
     (700, 160, 1536, [-3, 0]),        # the TDNN-F .linear shape: two taps, ragged rows
     (513, 1536, 160, [0, 1]),         # the .affine shape: 256-wide tiles, N = 6 tiles
     (400, 384, 96, [0, 2]),           # 128-wide tiles
     (300, 96, 48, [-1, 0, 1]),        # narrow output, three taps
     (260, 200, 40, [0]),              # K not a multiple of 16 (zero-padded K block), ragged columns
-])
-def test_planes_gemm_matches_float64(pkg, M, N, Di, offs):
-    got, ref = run(pkg, M, N, Di, offs)
+]
+
+
+@pytest.mark.parametrize("np_", [3, 2], ids=["bf16x6", "f16x3"])
+@pytest.mark.parametrize("M,N,Di,offs", SHAPES)
+def test_planes_gemm_matches_float64(pkg, np_, M, N, Di, offs):
+    got, ref = run(pkg, np_, M, N, Di, offs)
     assert np.isfinite(got).all()
     assert rel_l2(got, ref) < 1e-6, rel_l2(got, ref)
 
 
-def test_planes_gemm_init_modes_and_relu(pkg):
+@pytest.mark.parametrize("np_", [3, 2], ids=["bf16x6", "f16x3"])
+def test_planes_gemm_init_modes_and_relu(pkg, np_):
     for mode in (0, 1, 2):
         for relu in (0, 1):
-            got, ref = run(pkg, 300, 160, 320, [0, 2], init_mode=mode, relu=relu, seed=mode * 2 + relu)
+            got, ref = run(pkg, np_, 300, 160, 320, [0, 2], init_mode=mode, relu=relu, seed=mode * 2 + relu)
             assert rel_l2(got, ref) < 1e-6, (mode, relu, rel_l2(got, ref))
 
 
-def test_planes_split_is_three_bf16_planes(pkg):
-    """x = p0 + p1 + p2 to 2^-24 relative, lead / tail rows are zeros, the layout is [K block][plane][row][16] with the halves of a
-    32-byte row record swapped when bit 3 of the row is set."""
+def _wide(rng, X, W):  # log-normal magnitudes over ~10 decades
+    return (X * np.exp(2.5 * rng.standard_normal(X.shape))).astype(np.float32), (W * np.exp(2.0 * rng.standard_normal(W.shape))).astype(np.float32)
+
+
+def _spike(rng, X, W):  # one element carries almost all of the matrix's norm: the scale must still not overflow it
+    X = (X * 1e-3).astype(np.float32)
+    X[5, 7] = 3.0e4
+    return X, W
+
+
+def _tiny(rng, X, W):  # derivative-like magnitudes far below f16's range before scaling
+    return (X * 1e-9).astype(np.float32), (W * 1e-4).astype(np.float32)
+
+
+def _huge(rng, X, W):  # and far above it
+    return (X * 1e12).astype(np.float32), (W * 1e6).astype(np.float32)
+
+
+@pytest.mark.parametrize("make", [_wide, _spike, _tiny, _huge], ids=["ten-decades", "one-spike", "tiny", "huge"])
+def test_scaled_f16_planes_on_hostile_data(pkg, make):
+    """f16x3's scale comes from the Frobenius norm (s ||X||_F <= 65504), so no element can overflow whatever the data; the result stays
+    f32-equivalent in norm.  The same data through exact f32 (torch) for comparison: f16x3 must not be more than 4x worse."""
+    got, ref = run(pkg, 2, 700, 160, 1536, [-3, 0], seed=11, make=make)
+    assert np.isfinite(got).all()
+    e = rel_l2(got, ref)
+    assert e < 1e-6, e
+
+
+def test_planes_split_layout_and_transposed_planes(pkg):
+    """x s = sum of the planes to 2^-22 relative (f16 pairs) / x = sum to 2^-24 (bf16 triples); lead / tail rows are zeros; the layout is
+    [K block][plane][row][16] with the halves of a 32-byte row record swapped when bit 3 of the row is set; the transposed planes
+    hold the same values with k = row index."""
     rng = np.random.default_rng(1)
-    X = (rng.standard_normal((37, 40)) * np.exp(rng.uniform(-8, 8, (37, 40)))).astype(np.float32)
-    lead, tail = 5, 9
-    buf = host(planes_of(pkg, dev(X), lead, tail).float())
-    R, nkb = lead + 37 + tail, 3
-    P = buf.reshape(nkb, 3, R, 2, 8)
-    rows = np.arange(R)
-    sw = (rows >> 3) & 1
-    P = np.where(sw[None, None, :, None, None] == 1, P[:, :, :, ::-1, :], P).reshape(nkb, 3, R, 16)
-    assert not P[:, :, :lead].any() and not P[:, :, lead + 37:].any()
-    rec = P[:, :, lead:lead + 37].sum(1).transpose(1, 0, 2).reshape(37, nkb * 16)
-    assert not rec[:, 40:].any()
-    assert np.abs(rec[:, :40] - X).max() <= 2.0 ** -23 * np.abs(X).max() and rel_l2(rec[:, :40], X) < 2.0 ** -24
+    rows, cols = 137, 40
+    X = (rng.standard_normal((rows, cols)) * np.exp(rng.uniform(-3, 3, (rows, cols)))).astype(np.float32)
+    lead, tail, t_tail = 5, 9, 24
+
+    def unswizzle(buf, nkb, np_, R):
+        P = buf.reshape(nkb, np_, R, 2, 8)
+        sw = (np.arange(R) >> 3) & 1
+        return np.where(sw[None, None, :, None, None] == 1, P[:, :, :, ::-1, :], P).reshape(nkb, np_, R, 16)
+
+    for np_, tol in ((3, 2.0 ** -23), (2, 2.0 ** -21)):
+        P, R, PT, Rt, scale = planes_of(pkg, np_, dev(X), lead, tail, t_tail)
+        s, inv = host(scale)
+        if np_ == 2:
+            fro = np.sqrt((X.astype(np.float64) ** 2).sum())
+            assert s == 2.0 ** np.floor(np.log2(min(65504.0 / fro, 64.0 / (fro / np.sqrt(X.size))))) and inv == 1.0 / s
+        else:
+            s = 1.0
+        nkb = (cols + 15) // 16
+        Pn = unswizzle(host(P.float()), nkb, np_, R)
+        assert not Pn[:, :, :lead].any() and not Pn[:, :, lead + rows:].any()
+        rec = Pn[:, :, lead:lead + rows].astype(np.float64).sum(1).transpose(1, 0, 2).reshape(rows, nkb * 16)
+        assert not rec[:, cols:].any()
+        assert np.abs(rec[:, :cols] / s - X).max() <= tol * np.abs(X).max() and rel_l2(rec[:, :cols] / s, X) < tol
+        nkbt = ((rows + 63) // 64) * 4
+        Tn = unswizzle(host(PT.float()), nkbt, np_, Rt)
+        assert not Tn[:, :, cols:].any()  # rows of the transposed planes beyond the matrix's columns
+        rect = Tn[:, :, :cols].astype(np.float64).sum(1).transpose(1, 0, 2).reshape(cols, nkbt * 16)  # [column][row index]
+        assert not rect[:, rows:].any()  # the K padding behind the last row
+        assert np.array_equal(rect[:, :rows].T, rec[:, :cols])  # the same values, transposed

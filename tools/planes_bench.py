@@ -29,6 +29,19 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps
 
 
+ELEM = {3: torch.bfloat16, 2: torch.float16}
+
+
+def planes(np_, x, lead, R, t_rows=0):
+    P = torch.zeros(lib.tdnnf_planes_bytes(np_, R, (x.shape[1] + 15) // 16) // 2, dtype=ELEM[np_], device="cuda")
+    PT = torch.zeros(lib.tdnnf_planes_bytes(np_, t_rows, ((x.shape[0] + 63) // 64) * 4) // 2, dtype=ELEM[np_], device="cuda") if t_rows else None
+    scale = torch.zeros(2, device="cuda")
+    ws = torch.zeros(lib.tdnnf_planes_split_workspace_bytes() // 4 + 4, device="cuda")
+    s = abi.stream()
+    fn = lambda: abi.check(lib.tdnnf_planes_split(np_, abi.pmat(x), lead, R, abi.ptr(P), t_rows, abi.ptr(PT) if PT is not None else None, abi.ptr(scale), abi.ptr(ws), s))
+    return P, PT, scale, fn
+
+
 def run(name, M, N, Di, offs):
     K = len(offs)
     rows_in = M + max(offs) - min(offs)
@@ -42,21 +55,29 @@ def run(name, M, N, Di, offs):
     lead, tail = 0, 256
     if (rows_in + tail) % 256 == 0:
         tail += 8
-    ap = torch.zeros(lib.tdnnf_planes_bytes(rows_in, Di, lead, tail) // 2, dtype=torch.bfloat16, device="cuda")
-    bp = torch.zeros(lib.tdnnf_planes_bytes(N, K * Di, 0, Nb - N) // 2, dtype=torch.bfloat16, device="cuda")
-    s = abi.stream()
-    t_split = timed(lambda: abi.check(lib.tdnnf_planes_split(abi.pmat(X), lead, tail, abi.ptr(ap), s)))
-    abi.check(lib.tdnnf_planes_split(abi.pmat(W), 0, Nb - N, abi.ptr(bp), s))
-    a_row = (C.c_longlong * K)(*[lead + o - min(offs) for o in offs])
-    zero = (C.c_int * K)(*([0] * K))
-    b_col = (C.c_int * K)(*[i * Di for i in range(K)])
-    cols = (C.c_int * K)(*([Di] * K))
-    t = timed(lambda: abi.check(lib.tdnnf_planes_gemm(abi.ptr(ap), lead + rows_in + tail, abi.ptr(bp), Nb, K, a_row, zero, b_col, cols, None, 2, 0, abi.pmat(Cm), s)))
-    flops = 2.0 * M * N * K * Di
     ref = sum(X[o - min(offs):o - min(offs) + M].double() @ W[:, i * Di:(i + 1) * Di].double().T for i, o in enumerate(offs))
-    err = float((Cm.double() - ref).norm() / ref.norm())
-    print(f"{name:34s} M={M:7d} N={N:5d} K={K}x{Di:5d}  planes {t * 1e3:8.1f} us {flops / t / 1e9:7.1f} TF-eq   split of A {t_split * 1e3:7.1f} us "
-          f"({X.numel() * 10 / t_split / 1e9:6.2f} TB/s)   err {err:.1e}", flush=True)
+    flops = 2.0 * M * N * K * Di
+    out = f"{name:30s} M={M:7d} N={N:5d} K={K}x{Di:5d}"
+    for np_, tag in ((3, "bf16x6"), (2, "f16x3")):
+        ap, _, sa, split_a = planes(np_, X, lead, lead + rows_in + tail)
+        apt_rows = Di + 8
+        _, _, _, split_both = planes(np_, X, lead, lead + rows_in + tail, apt_rows)
+        bp, _, sb, split_b = planes(np_, W, 0, Nb)
+        t_split = timed(split_a)
+        t_both = timed(split_both)
+        split_a()
+        split_b()
+        a_row = (C.c_longlong * K)(*[lead + o - min(offs) for o in offs])
+        zero = (C.c_int * K)(*([0] * K))
+        b_col = (C.c_int * K)(*[i * Di for i in range(K)])
+        cols = (C.c_int * K)(*([Di] * K))
+        s = abi.stream()
+        t = timed(lambda: abi.check(lib.tdnnf_planes_gemm(np_, abi.ptr(ap), lead + rows_in + tail, abi.ptr(sa), abi.ptr(bp), Nb, abi.ptr(sb), K, a_row, None, zero, b_col, cols,
+                                                          None, 2, 0, abi.pmat(Cm), s)))
+        err = float((Cm.double() - ref).norm() / ref.norm())
+        out += f" | {tag} {t * 1e3:7.1f} us {flops / t / 1e9:6.1f} TF-eq  split {t_split * 1e3:6.1f} us (+T {t_both * 1e3:6.1f})  err {err:.1e}"
+    t32 = timed(lambda: torch.matmul(X[:M], W[:, :Di].T))
+    print(out, flush=True)
 
 
 B = 128
