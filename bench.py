@@ -124,7 +124,7 @@ def parity_and_cpu_baseline(pkg, args, want_baseline=True):
     import numpy as np
     from tests.oracle_net import OracleNet
     B, T = args.cpu_sequences, 150
-    prec = {"f32": 0, "bf16x3": 1, "bf16x6": 2}[args.gemm]
+    prec = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}[args.gemm]
     parity, state = hip_step_against_oracle(pkg, args, prec, 2e-3 if prec == 1 else 1e-4)
     parity["sample"] = (f"one training step (natural gradient {'on' if args.natural_gradient else 'off'}, --gemm {args.gemm}) of the full-width net on {B} sequences x "
                         f"{T} frames, {args.den_states}-state denominator graph; HIP through the C-ABI against oracle/ (double-accumulating CPU "
@@ -206,7 +206,7 @@ class Job:
         ng = args.natural_gradient if natural_gradient is None else natural_gradient
         kw = workload_kwargs(args, workload)
         self.cfg = pkg.trainer.make_config(frames_per_chunk=chunk, num_sequences=sequences, use_natural_gradient=ng,
-                                           gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2}[gemm], use_dropout=int(args.dropout > 0 and not kw.get("cv_update")),
+                                           gemm_precision={"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}[gemm], use_dropout=int(args.dropout > 0 and not kw.get("cv_update")),
                                            **kw)
         self.net = pkg.trainer.ChainNet(self.cfg)
         if args.dropout > 0 and not kw.get("cv_update"):
@@ -351,7 +351,7 @@ def main():
     ap.add_argument("--bn-choices", default="reference", choices=["reference", "baseline"],
                     help="bottleneck supernet candidates: reference = 25,50,80,100,120,160,200,240 (the recipe's 8); baseline = 80,160,240,320 "
                          "(BASELINE configs[4])")
-    ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3", "bf16x6"],
+    ap.add_argument("--gemm", default="f32", choices=["f32", "bf16x3", "bf16x6", "f16x3"],
                     help="GEMM arithmetic: f32 = exact v_mfma_f32_32x32x2_f32 (default, the reference's BaseFloat); bf16x3 = split-bf16 "
                          "(three bf16 MFMAs per product, f32 accumulate; 16 operand bits); bf16x6 = three planes, six MFMAs "
                          "(24 operand bits, f32-equivalent)")
@@ -474,7 +474,9 @@ def main():
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, 2 planes / 3 products, f32 accumulate)",
-                                          "bf16x6": "bf16x6 (split-bf16 MFMA, 3 planes / 6 products, f32 accumulate; f32-equivalent)"}[args.gemm], "data": "synthetic",
+                                          "bf16x6": "bf16x6 (split-bf16 MFMA, 3 planes / 6 products, f32 accumulate; f32-equivalent)",
+                                          "f16x3": "f16x3 (operands pre-split into 2 scaled f16 planes, 3 products on the f16 MFMA, f32 accumulate; f32-equivalent)"}[args.gemm],
+            "data": "synthetic",
             "config": {"workload": workload_text(args),
                        "frames_per_chunk": args.chunk, "sequences_per_gpu": seqs, "global_batch": world * seqs,
                        "den_graph": {"states": args.den_states, "arcs": den_arcs},

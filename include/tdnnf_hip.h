@@ -391,7 +391,12 @@ typedef struct {
      v_mfma_f32_32x32x16_bf16 with f32 accumulation (products to ~2^-16 relative; BASELINE configs[4] names
      "fp32 objf / bf16 MFMA GEMM").  The objective, BatchNorm, the optimizer step and all reductions stay f32 / f64.
      2: the same with three bf16 planes per operand and the six products a_i b_j, i + j <= 2 (24 mantissa bits per
-     operand, products to ~2^-24 relative: f32-equivalent results from the bf16 matrix cores). */
+     operand, products to ~2^-24 relative: f32-equivalent results from the bf16 matrix cores).  With option "planes" (default) and
+     a minibatch large enough to run on one stream, operands are split ONCE into planes in HBM (tdnnf_planes_*) instead of in the kernels.
+     3: "f16x3": every GEMM operand is split once into two f16 planes after scaling by the power of two its Frobenius norm allows
+     (no element can overflow), a b ~ h h' + h l' + l h' on v_mfma_f32_32x32x16_f16 with f32 accumulation: 22-23 operand bits,
+     f32-equivalent results in norm (tests/test_gpu_planes_gemm.py) at 3/16 of the f32 MFMA's cycles and 4 bytes per operand element;
+     GEMMs the planes do not cover (tap coefficients, row strides, small minibatches) run exact f32. */
   int gemm_precision;
   /* Derived child networks (local/chain_NAS/scripts/generate_top_list.py:97-141, generate_optimal_stride.py): when
      use_layer_offsets != 0, layer l's X.linear has time-offsets {-offset_left[l], 0} and its X.affine {0, offset_right[l]}

@@ -12,6 +12,7 @@
 
 #include "common.h"
 #include "gemm_f32.h"
+#include "planes_gemm.h"
 
 namespace tdnnf {
 
@@ -201,7 +202,7 @@ int tdnn_backprop_data_impl(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *out_d
     a.ldb = ldw;
     // split-bf16 default arithmetic with a transposed copy of W registered (the trainer): B becomes k-contiguous,
     // B[n = i][k = o] = WT[(tap Di + i) Do + o]
-    const float *WT = ldw == K * Di ? transposed_weights(W) : nullptr;
+    const float *WT = (ldw == K * Di && !planes_hint_b()) ? transposed_weights(W) : nullptr;  // (pre-split planes hold both orientations)
     if (WT) {
       a.B = WT;
       a.ldb = Do;
@@ -324,7 +325,7 @@ int tdnnf_affine_backprop(const tdnnf_mat *out_deriv, const float *W, int ldw, i
   a.lda = out_deriv->stride;
   a.B = W;
   a.ldb = ldw;
-  const float *WT = ldw == Di ? transposed_weights(W) : nullptr;  // (see tdnn_backprop_data_impl)
+  const float *WT = (ldw == Di && !planes_hint_b()) ? transposed_weights(W) : nullptr;  // (see tdnn_backprop_data_impl)
   if (WT) {
     a.B = WT;
     a.ldb = out_deriv->cols;

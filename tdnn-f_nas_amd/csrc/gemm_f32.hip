@@ -17,6 +17,7 @@
 // K-step); LDS rows are padded by 4 floats so the ds_read_b128 fragment reads are
 // bank-conflict free (stride 36 / 20 dwords).
 #include "gemm_f32.h"
+#include "planes_gemm.h"
 #include "gemm_ring.h"
 
 #include "common.h"
@@ -24,6 +25,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "tdnnf_hip.h"
@@ -1208,6 +1210,72 @@ hipError_t launch_rows_sumsq(const RowsGemmArgs &a, bool b_kc, bool vec, hipStre
 
 }  // namespace
 
+// floor division / modulus for element offsets that may be negative (row shifts of the backward-data gather)
+static inline long long floordiv(long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+// The rows GEMM on the pre-split plane kernels (planes_gemm.hip) when the caller's hint describes these operands.  Everything is
+// checked against the hint (base pointers, leading dimensions, 16-column alignment of the K segments, zero rows wherever a segment's
+// view leaves [m_lo, m_hi)); false = not applicable, nothing launched.
+static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flops, hipStream_t s, hipError_t *err) {
+  const PlanesOperand *ha = planes_hint_a(), *hb = planes_hint_b();
+  if (!ha || !hb || ha->np != np || hb->np != np || !ha->P || a.coef || a.sumsq || a.ksplit > 1 || a.nseg > 16) return false;
+  if (a.lda != ha->ld || a.A < ha->base || (a.A - ha->base) % ha->ld != 0) return false;
+  const long long arow0 = (a.A - ha->base) / ha->ld;
+  const int BM = planes_gemm_tile_rows(a.N), BN = planes_gemm_tile_cols(a.N);
+  const long long m_pad = (long long)((a.M + BM - 1) / BM) * BM, n_pad = (long long)((a.N + BN - 1) / BN) * BN;
+  PlanesGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.np = np;
+  g.A = ha->P; g.RA = ha->R; g.scale_a = ha->scale; g.scale_b = hb->scale;
+  if (a.ldb != hb->ld || a.B < hb->base) return false;
+  const long long boff0 = a.B - hb->base;
+  if (b_kc) {
+    if (!hb->P) return false;
+    g.B = hb->P; g.RB = hb->R;
+  } else {
+    if (!hb->PT) return false;
+    g.B = hb->PT; g.RB = hb->Rt;
+  }
+  for (int i = 0; i < a.nseg; i++) {
+    const GemmSeg &sg = a.seg[i];
+    // A_s[m][k] = base[(arow0 + shift + m) * ld + c0 + k]
+    const long long shift = floordiv(sg.a_off, ha->ld), c0 = sg.a_off - shift * ha->ld;
+    if (c0 % 16 != 0 || c0 + sg.klen > ha->cols || sg.klen <= 0) return false;
+    const long long first = arow0 + shift;  // matrix row of output row 0
+    const int lo = sg.m_lo > 0 ? sg.m_lo : 0, hi = sg.m_hi < a.M ? sg.m_hi : a.M;
+    if (hi <= lo) return false;
+    if (first + lo < 0 || first + hi > ha->rows) return false;       // rows that count must be the matrix's
+    if (lo > 0 && first + lo != 0) return false;                      // rows below m_lo must fall into the lead zeros ...
+    if (hi < a.M && first + hi != ha->rows) return false;             // ... and rows from m_hi on into the tail zeros
+    if (ha->lead + first < 0 || ha->lead + first + m_pad > ha->R) return false;
+    g.seg[i].a_row = ha->lead + first;
+    g.seg[i].a_kb0 = (int)(c0 / 16);
+    g.seg[i].nkb = (sg.klen + 15) / 16;
+    if (sg.klen % 16 != 0 && c0 + sg.klen != ha->cols) return false;  // a ragged K block is zero-padded only at the matrix's end
+    const long long bo = boff0 + sg.b_off;
+    if (b_kc) {  // B[n][k] at base[(brow + n) * ld + bc0 + k]: the row-major planes of the hinted matrix
+      const long long brow = bo / hb->ld, bc0 = bo % hb->ld;
+      if (bo < 0 || bc0 % 16 != 0 || bc0 + sg.klen > hb->cols || brow + a.N > hb->rows || brow + n_pad > hb->R) return false;
+      if (sg.klen % 16 != 0 && bc0 + sg.klen != hb->cols) return false;
+      g.seg[i].b_row = brow;
+      g.seg[i].b_kb0 = (int)(bc0 / 16);
+    } else {     // B[k][n] at base[(krow + k) * ld + ncol + n]: the transposed planes (k = row of the hinted matrix)
+      const long long krow = bo / hb->ld, ncol = bo % hb->ld;
+      if (bo < 0 || krow % 16 != 0 || krow + sg.klen > hb->rows || ncol + a.N > hb->cols || ncol + n_pad > hb->Rt) return false;
+      if (sg.klen % 16 != 0 && krow + sg.klen != hb->rows) return false;
+      g.seg[i].b_row = ncol;
+      g.seg[i].b_kb0 = (int)(krow / 16);
+    }
+  }
+  g.nseg = a.nseg;
+  g.C = a.C; g.ldc = a.ldc; g.M = a.M; g.N = a.N;
+  g.bias = a.bias; g.init_mode = a.init_mode; g.relu = a.relu;
+  g.add = a.add; g.ldadd = a.ldadd; g.add_scale = a.add_scale; g.add_lo = a.add_lo; g.add_hi = a.add_hi;
+  ProfScope ps(BN == 160 ? 1 : 0, flops, s);
+  *err = planes_gemm(g, s);
+  return true;
+}
+
 hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   if (a_in.M <= 0 || a_in.N <= 0 || a_in.nseg <= 0) return hipSuccess;
   RowsGemmArgs a = a_in;
@@ -1250,6 +1318,11 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
   a.serial_epilogue = 0;
   if (a.prec == 0) a.prec = g_gemm_prec;
   if (a.prec == 2) a.prec = 0;  // 2 = exact f32 regardless of the default
+  if (a.prec == 4 || (a.prec == 3 && options().planes)) {  // pre-split planes (f16x3 / bf16x6) when the caller hinted them for these operands
+    hipError_t pe = hipSuccess;
+    if (planes_try_rows(a, b_kc, a.prec == 4 ? 2 : 3, flops, s, &pe)) return pe;
+    if (a.prec == 4) a.prec = 0;  // no planes for this call: exact f32
+  }
   if (!(b_kc && vec)) a.prec = 0;  // the split-bf16 kernels need a k-contiguous B and 16-byte alignment
   if (a.colstats_rows) *a.colstats_rows = 0;
   if (!a.colstats_rows || a.prec != 0 || a.sumsq || a.N <= 32 || waste160 < waste128 || a.ksplit > 1) a.colstats = nullptr;
@@ -1724,7 +1797,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_x3_kernel(const WgradArgs p, int
 
 // G[o][c] (+)= scale * coef[tap(c)] * sum_split partial[split][o][c]
 __global__ void wgrad_reduce_kernel(const float *partial, int splits, int Do, int KDi, int Di, const float *coef,
-                                    float scale, float *G, long long ldg, int accumulate) {
+                                    float scale, float *G, long long ldg, int accumulate, const float *ds1 = nullptr, const float *ds2 = nullptr) {
+  if (ds1) scale *= ds1[1] * ds2[1];  // plane operands: the reciprocals of the scales they were split with
   const long long total = (long long)Do * KDi;
   for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
        e += (long long)gridDim.x * blockDim.x) {
@@ -1871,6 +1945,75 @@ size_t wgrad_workspace_bytes(int Do, int Di, int K, int N) {
   return sizeof(float) * (max_splits * Do * K * Di) + colreduce_bytes(N, Do) + 64;
 }
 
+static hipError_t wgrad_finish(const WgradArgs &a, const float *partial, int splits, float *cs_partial, const float *ds1, const float *ds2, hipStream_t s);
+
+// The weight gradient on the pre-split plane kernels: G = dY^T X_tap reduces over ROWS, so its operands are the transposed planes of
+// dY and X (k = row); the taps are K-block offsets of X.  The operand with more columns gives the tile rows (Do < Di: the transposed
+// product, stored through strides), the rows are split over the CUs into slabs that wgrad_finish() adds.  false = not applicable.
+static bool planes_try_wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, int np, hipStream_t s, hipError_t *err) {
+  const PlanesOperand *hy = planes_hint_a(), *hx = planes_hint_b();
+  if (!hy || !hx || hy->np != np || hx->np != np || !hy->PT || !hx->PT) return false;
+  if (a.coef || a.active || a.row_stride != 1 || a.K > 16 || a.K < 1) return false;
+  if (a.dY != hy->base || a.lddy != hy->ld || a.N != hy->rows || a.Do != hy->cols) return false;
+  if (a.ldx != hx->ld || a.X < hx->base || (a.X - hx->base) % hx->ld != 0 || a.Di != hx->cols) return false;
+  const long long xrow0 = (a.X - hx->base) / hx->ld;
+  const int nkb = (a.N + 15) / 16;
+  if (nkb < 16) return false;  // (too few rows to split over the chip: the f32 kernels)
+  const bool normal = a.Do >= a.Di;
+  const int M = normal ? a.Do : a.Di, Nn = normal ? a.Di : a.Do;
+  const int BM = planes_gemm_tile_rows(Nn), BN = planes_gemm_tile_cols(Nn);
+  const int ntm = (M + BM - 1) / BM, ntn = (Nn + BN - 1) / BN;
+  const PlanesOperand *hm = normal ? hy : hx, *hn = normal ? hx : hy;  // operands giving the tile rows / columns
+  if ((long long)ntm * BM > hm->Rt || (long long)ntn * BN > hn->Rt) return false;
+  PlanesGemmArgs g;
+  memset(&g, 0, sizeof(g));
+  for (int i = 0; i < a.K; i++) {
+    const long long off = xrow0 + a.row_offsets[i];
+    if (off < 0 || off % 16 != 0 || off + a.N > hx->rows) return false;
+    (normal ? g.tap_b_kb : g.tap_a_kb)[i] = (int)(off / 16);
+  }
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+    (void)hipGetLastError();
+  }
+  const int tiles = ntm * ntn * a.K;
+  const size_t slab = (size_t)a.Do * a.K * a.Di;
+  int splits = std::max(2, (2 * cus) / tiles);  // two rounds of one block per CU
+  splits = std::min(splits, nkb / 8);
+  splits = (int)std::min<size_t>((size_t)splits, workspace_bytes / sizeof(float) / slab);
+  if (splits < 2) return false;
+  const int kbps = (nkb + splits - 1) / splits;
+  splits = (nkb + kbps - 1) / kbps;
+  if (splits < 2) return false;
+  if (sizeof(float) * slab * splits + colreduce_bytes(a.N, a.Do) > workspace_bytes) return false;
+  g.np = np;
+  g.A = hm->PT; g.RA = hm->Rt; g.B = hn->PT; g.RB = hn->Rt;
+  g.M = M; g.N = Nn;
+  g.nseg = 1;
+  g.seg[0].nkb = nkb;
+  g.ntap = a.K;
+  g.ksplit = splits; g.kb_per_split = kbps;
+  g.partial = reinterpret_cast<float *>(workspace);
+  g.partial_stride = (long long)slab;
+  g.tap_off_p = a.Di;
+  if (normal) { g.ldp_m = (long long)a.K * a.Di; g.ldp_n = 1; }
+  else { g.ldp_m = 1; g.ldp_n = (long long)a.K * a.Di; }
+  {
+    if (g_prof_on) {
+      g_prof_next_flops = 2.0 * a.N * a.Do * a.K * a.Di;
+      g_prof_next_bytes = 4.0 * ((double)a.N * a.Do + ((double)a.N + a.row_offsets[a.K - 1] - a.row_offsets[0]) * a.Di + (double)a.Do * a.K * a.Di * (a.accumulate ? 2.0 : 1.0));
+    }
+    ProfScope ps(2, 2.0 * a.N * a.Do * a.K * a.Di, s);
+    *err = planes_gemm(g, s);
+  }
+  if (*err != hipSuccess) return true;
+  *err = wgrad_finish(a, g.partial, splits, g.partial + slab * splits, hy->scale, hx->scale, s);
+  return true;
+}
+
 hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hipStream_t s) {
   if (a.N <= 0 || a.Do <= 0 || a.Di <= 0) return hipSuccess;
   if (workspace_bytes < wgrad_workspace_bytes(a.Do, a.Di, a.K, a.N)) return hipErrorInvalidValue;
@@ -1878,6 +2021,10 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   {
     int prec = a.prec;
     if (prec == 0) prec = g_gemm_prec;
+    if (prec == 4 || (prec == 3 && options().planes)) {  // pre-split planes when the caller hinted them for these operands
+      hipError_t pe = hipSuccess;
+      if (planes_try_wgrad(a, workspace, workspace_bytes, prec == 4 ? 2 : 3, s, &pe)) return pe;
+    }
     planes = prec == 1 ? 2 : prec == 3 ? 3 : 0;
   }
   const bool use_x3 = planes != 0;
@@ -1951,15 +2098,22 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  return wgrad_finish(a, partial, pl.splits, cs_partial, nullptr, nullptr, s);
+}
+
+// sum of the split slabs into G (scaled, accumulated) and the bias column sums
+static hipError_t wgrad_finish(const WgradArgs &a, const float *partial, int splits, float *cs_partial, const float *ds1, const float *ds2, hipStream_t s) {
+  hipError_t e;
+  struct { int splits; } pl{splits};
   const long long total = (long long)a.Do * a.K * a.Di;
   int rb = (int)((total + 255) / 256);
   if (rb > 2048) rb = 2048;
-  if (total <= 32768 && pl.splits >= 8)
+  if (total <= 32768 && pl.splits >= 8 && !ds1)
     hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, s, partial, pl.splits, a.Do, a.K * a.Di,
                        a.Di, a.coef, a.scale, a.G, a.ldg, a.accumulate);
   else
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rb), dim3(256), 0, s, partial, pl.splits, a.Do, a.K * a.Di, a.Di, a.coef,
-                       a.scale, a.G, a.ldg, a.accumulate);
+                       a.scale, a.G, a.ldg, a.accumulate, ds1, ds2);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   if (a.bias_acc) {

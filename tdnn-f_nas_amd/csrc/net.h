@@ -6,7 +6,10 @@
 #include <utility>
 #include <vector>
 
+#include <map>
+
 #include "common.h"
+#include "planes_gemm.h"
 #include "tdnnf_hip.h"
 
 namespace tdnnf {
@@ -68,7 +71,20 @@ struct tdnnf_net {
   std::vector<tdnnf::CompDesc> comps;
   long long num_params;
   float *params, *grads;
-  float *paramsT;      // gemm_precision 1: per component, the transpose of its weight matrix at the same offset (backward-data GEMMs)
+  float *paramsT;      // gemm_precision 1 / 2: per component, the transpose of its weight matrix at the same offset (backward-data GEMMs)
+  // Pre-split plane operands (planes_gemm.h; gemm_precision 3 "f16x3", or 2 "bf16x6" with option planes): 0 = off, else planes per element.
+  // Every matrix that is a GEMM operand has a slot (storage for its row-major and transposed planes and its scale), keyed by the
+  // matrix's base pointer; a slot's CONTENT is only what the last split put there -- forward_backward() splits an operand where it is
+  // produced and hands the description to the GEMM as a hint.  pw: the weight matrices' planes, re-split at the start of every step.
+  int planes_np = 0;
+  struct PlaneSlot {
+    void *P = nullptr, *PT = nullptr;
+    size_t bytesP = 0, bytesPT = 0;
+    float *scale = nullptr;
+  };
+  std::map<const float *, PlaneSlot> plane_slots;
+  std::vector<tdnnf::PlanesOperand> pw;  // by component
+  void *planes_ws = nullptr;
   int B, T, Tout;
   // graph
   tdnnf::Grid g_lda, g_feat;

@@ -394,7 +394,62 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->gtmp = A.take<float>((size_t)n->num_params + 16);
   // transposed copy of every weight matrix for the split-bf16 backward-data GEMMs (k-contiguous B operand).  (Measured for exact
   // f32 too, twice: no gain -- docs/experiments.md.)
-  n->paramsT = n->cfg.gemm_precision != 0 ? A.take<float>((size_t)n->num_params + 16) : nullptr;
+  n->paramsT = (n->cfg.gemm_precision == 1 || n->cfg.gemm_precision == 2) ? A.take<float>((size_t)n->num_params + 16) : nullptr;
+  // ---- pre-split plane operands (net.h): a slot per GEMM operand matrix, keyed by its base pointer
+  n->planes_np = n->cfg.gemm_precision == 3 ? 2 : (n->cfg.gemm_precision == 2 && options().planes ? 3 : 0);
+  n->plane_slots.clear();
+  n->pw.assign(n->comps.size(), PlanesOperand());
+  n->planes_ws = nullptr;
+  if (n->planes_np) {
+    const int np = n->planes_np;
+    int lead_cap = 0;  // the largest row shift of a backward-data view (taps of rho == 1 layers)
+    for (auto &L : n->layers)
+      for (const Tdnn *td : {&L.lin, &L.aff})
+        for (int i = 0; i < td->K; i++) lead_cap = std::max(lead_cap, td->ix.row_offsets[i]);
+    auto slot = [&](const float *key, int rows, int cols, bool with_lead) {
+      const long long R = planes_rows_padded((long long)(with_lead ? 2 * lead_cap : 0) + rows + 256);
+      const long long Rt = planes_rows_padded(((cols + 255) / 256) * 256LL);
+      tdnnf_net::PlaneSlot ps;
+      ps.bytesP = planes_bytes(np, R, planes_kblocks(cols));
+      ps.bytesPT = planes_bytes(np, Rt, planes_t_kblocks(rows));
+      ps.P = A.take<char>(ps.bytesP + 64);
+      ps.PT = A.take<char>(ps.bytesPT + 64);
+      ps.scale = A.take<float>(4);
+      if (A.base) n->plane_slots[key] = ps;
+    };
+    const int big_rows = std::max(max_rows, std::max(N0, No)), small_rows = std::max(max_lin_rows, No), small_cols = std::max(S, 512);
+    slot(n->lda_out, N0, lda_dim, false);
+    slot(n->t1_bn, N0, Hd, false);
+    for (auto &L : n->layers) {
+      slot(L.noop_out, N_of(L.gout, B), Hd, false);
+      slot(L.lin_out, N_of(L.lin.out, B), L.bn, false);
+    }
+    slot(n->prefinal_l_out, No, S, false);
+    for (int h = 0; h < 2; h++) {
+      slot(n->head[h].bn1_out, No, Hd, false);
+      slot(n->head[h].bn2_out, No, S, false);
+    }
+    slot(n->d_y, No, P, false);
+    slot(n->d_xent, No, P, false);
+    slot(n->dA, big_rows, Hd, true);
+    slot(n->dB, big_rows, Hd, true);
+    slot(n->dC, big_rows, Hd, true);
+    slot(n->d_small, small_rows, small_cols, true);
+    slot(n->d_small2, small_rows, small_cols, true);
+    n->planes_ws = A.take<char>(planes_sumsq_ws_bytes() + 64);
+    // the weight matrices: row-major planes (forward: one row per output, k contiguous) and transposed planes (backward-data)
+    for (size_t i = 0; i < n->comps.size(); i++) {
+      const CompDesc &cd = n->comps[i];
+      if (cd.plain || cd.rows < 2 || (int)i == n->c_lda) continue;
+      PlanesOperand &o = n->pw[i];
+      o.rows = cd.rows; o.cols = cd.cols; o.ld = cd.cols; o.np = np; o.lead = 0;
+      o.R = planes_rows_padded(((cd.rows + 255) / 256) * 256LL);
+      o.Rt = planes_rows_padded(((cd.cols + 255) / 256) * 256LL);
+      o.P = A.take<char>(planes_bytes(np, o.R, planes_kblocks(cd.cols)) + 64);
+      o.PT = A.take<char>(planes_bytes(np, o.Rt, planes_t_kblocks(cd.rows)) + 64);
+      o.scale = A.take<float>(4);
+    }
+  }
   n->s3_scratch = nullptr;
   n->s3_scratch_bytes = 0;
   n->ng_grouped = options().ng_grouped != 0;  // 0: the per-object side chain for every component
@@ -624,7 +679,8 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
     for (int l = 0; l < c.num_layers; l++)
       TDNNF_REQUIRE(c.bottleneck_dim[l] == sum, "net_create: bottleneck_dim[%d] = %d but the choice blocks sum to %d", l, c.bottleneck_dim[l], sum);
   }
-  TDNNF_REQUIRE(c.gemm_precision >= 0 && c.gemm_precision <= 2, "net_create: gemm_precision must be 0 (f32), 1 (split-bf16, 3 products) or 2 (split-bf16, 6 products)");
+  TDNNF_REQUIRE(c.gemm_precision >= 0 && c.gemm_precision <= 3,
+                "net_create: gemm_precision must be 0 (f32), 1 (split-bf16, 3 products), 2 (split-bf16, 6 products) or 3 (pre-split scaled f16 pairs, 3 products)");
   TDNNF_REQUIRE(c.darts_num_offsets == 0 || !(c.darts_flags & TDNNF_DARTS_USE_GUMBEL) || c.darts_temp_proportion > 0,
                 "net_create: gumbel mode needs temp-proportion > 0");
   TDNNF_REQUIRE(c.frame_subsampling >= 1 && c.frames_per_chunk > 0 && c.frames_per_chunk % c.frame_subsampling == 0 && c.num_sequences > 0,
@@ -1221,7 +1277,48 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   BnSyncScope bn_sync_scope(n->bn_sync.fn && !c.cv_update ? &n->bn_sync : nullptr);  // synchronised BatchNorm (data-parallel callers)
-  GemmPrecisionScope gemm_arith(c.gemm_precision == 2 ? 3 : c.gemm_precision);  // scope values: 1 two planes, 3 three planes
+  // scope values: 1 two bf16 planes split in the kernel, 3 three; 4 pre-split f16 pairs (exact f32 where no planes are hinted)
+  GemmPrecisionScope gemm_arith(c.gemm_precision == 2 ? 3 : c.gemm_precision == 3 ? 4 : c.gemm_precision);
+  const int np = n->planes_np;
+  if (np && n->wg_on) {
+    // (the weight-gradient stream reads operands while the caller's stream moves on: plane slots are reused per layer -- small minibatches keep the f32 kernels)
+  }
+  const bool pl_on = np != 0 && !n->wg_on;
+  // plane operands: split a matrix into its slot and describe it
+  enum { kP = 1, kT = 2 };
+  auto split = [&](const tdnnf_mat &m, int lead, int want, PlanesOperand *o, hipStream_t st) -> int {
+    *o = PlanesOperand();
+    if (!pl_on) return TDNNF_OK;
+    auto it = n->plane_slots.find(m.data);
+    if (it == n->plane_slots.end() || m.rows <= 0) return TDNNF_OK;  // (no slot: the GEMM runs its own kernels)
+    const tdnnf_net::PlaneSlot &ps = it->second;
+    PlanesSplitArgs a;
+    a.np = np; a.x = view(&m); a.lead = lead; a.scale = ps.scale; a.sumsq_ws = n->planes_ws;
+    a.R = planes_rows_padded((long long)2 * lead + m.rows + 256);
+    a.Rt = planes_rows_padded(((m.cols + 255) / 256) * 256LL);
+    a.P = (want & kP) ? ps.P : nullptr;
+    a.PT = (want & kT) ? ps.PT : nullptr;
+    TDNNF_REQUIRE(planes_bytes(np, a.R, planes_kblocks(m.cols)) <= ps.bytesP && planes_bytes(np, a.Rt, planes_t_kblocks(m.rows)) <= ps.bytesPT,
+                  "net_forward_backward: plane slot too small for a %d x %d matrix", m.rows, m.cols);
+    TDNNF_HIP(planes_split(a, st));
+    o->base = m.data; o->rows = m.rows; o->cols = m.cols; o->ld = m.stride; o->np = np;
+    o->P = a.P; o->R = a.R; o->lead = lead; o->PT = a.PT; o->Rt = a.Rt; o->scale = np == 2 ? ps.scale : nullptr;
+    return TDNNF_OK;
+  };
+  auto hint_of = [&](const PlanesOperand &o) -> const PlanesOperand * { return o.base ? &o : nullptr; };
+  if (pl_on) {  // this step's weights as planes
+    for (size_t i = 0; i < n->comps.size(); i++) {
+      PlanesOperand &o = n->pw[i];
+      if (!o.P) continue;
+      o.base = Wp(n, (int)i);
+      PlanesSplitArgs a;
+      a.np = np; a.x = MatView{Wp(n, (int)i), o.rows, o.cols, o.cols}; a.lead = 0; a.R = o.R; a.P = const_cast<void *>(o.P); a.Rt = o.Rt;
+      a.PT = const_cast<void *>(o.PT); a.scale = const_cast<float *>(o.scale); a.sumsq_ws = n->planes_ws;
+      if (np != 2) o.scale = nullptr;
+      TDNNF_HIP(planes_split(a, s));
+    }
+  }
+  auto wplanes = [&](int comp) -> const PlanesOperand * { return pl_on && n->pw[comp].P ? &n->pw[comp] : nullptr; };
   TransposedWeightsScope gemm_wt(n->params, n->paramsT, n->paramsT ? n->num_params : 0);
   if (n->paramsT) {  // split-bf16 backward-data GEMMs read W^T (k-contiguous B operand)
     TransTable tb;
@@ -1261,7 +1358,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   auto mask_of = [&](int m) -> const float * { return drop ? n->dropout_masks + (size_t)m * B * Hd : nullptr; };
   // tdnn1: affine (+bias, ReLU in the GEMM epilogue) -> BatchNorm
-  CK(affine_relu_bn_stats(n, &ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, &t1r, n->t1_bn_memo, n->t1_bn_stats, s));
+  // plane operands of this step, by role (empty = the GEMM runs its own kernels)
+  std::vector<PlanesOperand> po_in(n->layers.size()), po_lin(n->layers.size());
+  PlanesOperand po_lda, po_top, po_pl, po_b1[2], po_b2[2];
+  CK(split(lda_out, 0, kP | kT, &po_lda, s));
+  {
+    PlanesHintScope ph(hint_of(po_lda), wplanes(n->tdnn1.comp));
+    CK(affine_relu_bn_stats(n, &ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, &t1r, n->t1_bn_memo, n->t1_bn_stats, s));
+  }
   TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, ldpad(Hd), none, 0.f, view(&t1b), s, mask_of(0), B));
   float *prev = n->t1_bn;
   int layer_no = 0;
@@ -1285,7 +1389,12 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // uniform-sample mode runs at most two taps of K (share + sampled): tell the FLOP accounting of the profiler
     ProfFlopsScale taps_active(L.lin.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && L.lin.K > 2 ? 2.0 / L.lin.K : 1.0);
     // (DARTS .linear: bias present but offsets[1] < 0 -> out is zeroed and the bias never added, :237-240)
-    CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, lin_eff, 2, &lin, s));
+    const bool use_pl = pl_on && !L.lin.darts;  // (tap coefficients: the f32 kernels)
+    if (use_pl) CK(split(in, 0, kP | kT, &po_in[layer_no - 1], s));  // row-major planes now, the transposed ones for the weight gradient
+    {
+      PlanesHintScope ph(hint_of(po_in[layer_no - 1]), wplanes(L.lin.comp));
+      CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, lin_eff, 2, &lin, s));
+    }
     tdnnf_mat aff_in = lin;
     if (L.c_arch >= 0) {  // bottleneck supernet: column blocks of the linear output times CopyN(Sum(p_k..))
       TDNNF_REQUIRE(n->draws || c.bn_mode == 1, "net_forward_backward: the bottleneck supernet needs net_set_random_draws before every step");
@@ -1300,7 +1409,11 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_reorder_rows(&src, B, L.aff.ix.row_stride, 1, &aff_in, s));
     }
     tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
-    CK(affine_relu_bn_stats(n, &L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, &relu, L.bn_memo, L.bn_stats, s));
+    if (use_pl && !L.perm && L.c_arch < 0) CK(split(lin, 0, kP | kT, &po_lin[layer_no - 1], s));
+    {
+      PlanesHintScope ph(hint_of(po_lin[layer_no - 1]), wplanes(L.aff.comp));
+      CK(affine_relu_bn_stats(n, &L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, &relu, L.bn_memo, L.bn_stats, s));
+    }
     // noop = Sum(Scale(bypass, input), dropout(batchnorm(relu)))  in one pass
     tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
     tdnnf_mat x = relu, out = M(L.noop_out, L.aff.rows_out, Hd);
@@ -1313,17 +1426,33 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   const int No = n->Tout * B;
   tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
-  CK(tdnnf_affine_propagate(&top, Wp(n, n->c_prefinal_l), Hd, nullptr, S, &pl, s));
+  CK(split(top, 0, kP | kT, &po_top, s));
+  {
+    PlanesHintScope ph(hint_of(po_top), wplanes(n->c_prefinal_l));
+    CK(tdnnf_affine_propagate(&top, Wp(n, n->c_prefinal_l), Hd, nullptr, S, &pl, s));
+  }
+  CK(split(pl, 0, kP | kT, &po_pl, s));
   tdnnf_mat y = M(n->head[0].y, No, P), dy = M(n->d_y, No, P), dx = M(n->d_xent, No, P);
   tdnnf_mat lsm = M(n->xent_logsoftmax, No, P);
   for (int h = 0; h < 2; h++) {
     auto &H = n->head[h];
     tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), yh = M(H.y, No, P);
-    CK(affine_relu_bn_stats(n, &ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, &ar, H.bn1_memo, H.bn1_stats, s));
+    {
+      PlanesHintScope ph(hint_of(po_pl), wplanes(H.c_affine));
+      CK(affine_relu_bn_stats(n, &ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, &ar, H.bn1_memo, H.bn1_stats, s));
+    }
     TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, ldpad(Hd), none, 0.f, view(&b1), s));
-    CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
+    CK(split(b1, 0, kP | kT, &po_b1[h], s));
+    {
+      PlanesHintScope ph(hint_of(po_b1[h]), wplanes(H.c_linear));
+      CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
+    }
     CK(bn_fwd(n, H.lin_out, H.bn2_out, No, S, H.bn2_memo, H.bn2_stats, s));
-    CK(tdnnf_affine_propagate(&b2, Wp(n, H.c_output), S, Bp(n, H.c_output), P, &yh, s));
+    CK(split(b2, 0, kP | kT, &po_b2[h], s));
+    {
+      PlanesHintScope ph(hint_of(po_b2[h]), wplanes(H.c_output));
+      CK(tdnnf_affine_propagate(&b2, Wp(n, H.c_output), S, Bp(n, H.c_output), P, &yh, s));
+    }
     if (h == 0) {
       // ====================================================== objective, part 1 (second stream)
       // The denominator forward-backward (one workgroup per sequence) only needs the chain head's output: it
@@ -1659,18 +1788,38 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
     const std::string hname = h == 0 ? "prefinal-chain" : "prefinal-xent";
     if (h == 1) CK(capture("output-xent.deriv", dout));
-    CK(param_grad(H.c_output, ix1, 1, S, P, &b2, &dout, nullptr, false, nullptr, 0, false));
-    CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
+    PlanesOperand po_d;  // the derivative matrix being propagated: planes where a GEMM reads it
+    CK(split(dout, 0, kP | kT, &po_d, s));
+    {
+      PlanesHintScope ph(hint_of(po_d), hint_of(po_b2[h]));
+      CK(param_grad(H.c_output, ix1, 1, S, P, &b2, &dout, nullptr, false, nullptr, 0, false));
+    }
+    {
+      PlanesHintScope ph(hint_of(po_d), wplanes(H.c_output));
+      CK(tdnnf_affine_backprop(&dout, Wp(n, H.c_output), S, S, &d_b2, s));
+    }
     CK(capture(hname + ".batchnorm2.deriv", d_b2));
     if (cv) CK(tdnnf_batchnorm_test_backprop(&d_b2, H.bn2_memo + 2 * S, &d_b2, s));
     else CK(tdnnf_batchnorm_backprop(&b2, &d_b2, 1.0f, H.bn2_memo, &d_b2, n->ws, n->ws_bytes, s));  // -> d lin_out
     CK(capture(hname + ".linear.deriv", d_b2));
-    CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0, false));
-    CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
+    CK(split(d_b2, 0, kP | kT, &po_d, s));
+    {
+      PlanesHintScope ph(hint_of(po_d), hint_of(po_b1[h]));
+      CK(param_grad(H.c_linear, ix1, 1, Hd, S, &b1, &d_b2, nullptr, false, nullptr, 0, false));
+    }
+    {
+      PlanesHintScope ph(hint_of(po_d), wplanes(H.c_linear));
+      CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
+    }
     CK(capture(hname + ".batchnorm1.deriv", d_b1));
     CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h));  // dA -> d affine out
     CK(capture(hname + ".affine.deriv", d_b1));
-    CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
+    CK(split(d_b1, 0, kP | kT, &po_d, s));
+    {
+      PlanesHintScope ph(hint_of(po_d), hint_of(po_pl));
+      CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
+    }
+    PlanesHintScope ph_bp(hint_of(po_d), wplanes(H.c_affine));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
       if (early_after_xent) CK(launch_early_in());
@@ -1681,11 +1830,17 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   CK(capture("prefinal-l.deriv", d_pl));
-  CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0, false));
+  PlanesOperand po_dpl;
+  CK(split(d_pl, 0, kP | kT, &po_dpl, s));
+  {
+    PlanesHintScope ph(hint_of(po_dpl), hint_of(po_top));
+    CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0, false));
+  }
   CK(close_bucket(-2));
   float *d_cur = n->dA, *d_next = n->dB;  // d_cur: deriv w.r.t. the current layer's output (noop)
   {
     tdnnf_mat d_top = M(d_cur, No, Hd);
+    PlanesHintScope ph(hint_of(po_dpl), wplanes(n->c_prefinal_l));
     CK(tdnnf_affine_backprop(&d_pl, Wp(n, n->c_prefinal_l), Hd, Hd, &d_top, s));
   }
   for (int l = c.num_layers - 1; l >= 0; l--) {
@@ -1737,7 +1892,19 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const bool compact = td.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && td.K > 2;
       return param_grad(td.comp, td.ix, td.K, td.Di, td.Do, x, dyv, eff, bias_done, compact ? td.active : nullptr, compact ? 2 : 0, tap_ready);
     };
-    CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff, true));
+    const bool use_pl = pl_on && !L.lin.darts;
+    auto max_off = [](const Tdnn &td) {
+      int m = 0;
+      for (int i = 0; i < td.K; i++) m = std::max(m, td.ix.row_offsets[i]);
+      return m;
+    };
+    PlanesOperand po_daff, po_dlin;
+    if (use_pl) CK(split(d_aff, max_off(L.aff), kP | kT, &po_daff, s));
+    {
+      PlanesHintScope ph(hint_of(po_daff), hint_of(po_lin[l]));
+      CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff, true));
+    }
+    PlanesHintScope ph_aff_bp(hint_of(po_daff), wplanes(L.aff.comp));  // (for the backward-data GEMM of the affine, either branch below)
     tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
     if (L.perm) {  // rho > 1: some row classes receive no tap -> zero first, then add; un-permute afterwards
       TDNNF_HIP(hipMemsetAsync(d_lin.data, 0, sizeof(float) * (size_t)nl * d_lin.stride, s));
@@ -1759,8 +1926,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(capture(lname + ".linear.deriv", d_lin));
     tdnnf_mat in = M(in_act, ni, Hd);
     // (the never-added bias of a DARTS .linear is still updated by the reference, :614 -- Bg() is null for plain layers)
-    CK(tdnn_wgrad(L.lin, &in, &d_lin, lin_eff, false));
+    if (use_pl) CK(split(d_lin, max_off(L.lin), kP | kT, &po_dlin, s));
+    {
+      PlanesHintScope ph(hint_of(po_dlin), hint_of(po_in[l]));
+      CK(tdnn_wgrad(L.lin, &in, &d_lin, lin_eff, false));
+    }
     CK(close_bucket(l));
+    PlanesHintScope ph_lin_bp(hint_of(po_dlin), wplanes(L.lin.comp));  // (the backward-data GEMM of the linear below)
     // deriv w.r.t. the layer input = linear backprop (overwrites) + bypass_scale * d_out on the output-grid rows
     tdnnf_mat d_in = M(d_next, ni, Hd);
     tdnnf_mat d_byp = sub_grid_view(d_next, L.gin, L.gout, B, Hd);
@@ -1778,6 +1950,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
     CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, 0, mask_of(0)));
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
+    PlanesOperand po_d;
+    CK(split(d_aff, 0, kT, &po_d, s));
+    PlanesHintScope ph(hint_of(po_d), hint_of(po_lda));
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }
   CK(close_bucket(-1));

@@ -82,6 +82,30 @@ struct PlanesSplitArgs {
 size_t planes_sumsq_ws_bytes();
 hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s);
 // tile shape the GEMM uses for an N-column output: the A buffer needs tail >= tile rows beyond the last row read, the B buffer rows padded to the tile's columns
+// ---- routing of the f32 GEMM entry points (rows_gemm / wgrad, gemm_f32.h) onto the plane kernels.
+// The caller that owns the matrices (net.hip) splits an operand, describes the result in a PlanesOperand and installs it as a hint
+// around the call; rows_gemm() / wgrad() check that the hinted planes really are those of their operands (base pointer, leading
+// dimension, row range, zero rows around the views) and run the plane kernels, else their own.
+struct PlanesOperand {
+  const float *base = nullptr;  // the f32 matrix the planes were split from: rows x cols, leading dimension ld
+  int rows = 0, cols = 0;
+  long long ld = 0;
+  int np = 0;
+  const void *P = nullptr;  // row-major planes (k = column), R rows of which `lead` zero rows in front
+  long long R = 0;
+  int lead = 0;
+  const void *PT = nullptr;  // planes of the transpose (k = row), Rt rows
+  long long Rt = 0;
+  const float *scale = nullptr;  // np == 2: [s, 1 / s] on the device
+};
+struct PlanesHintScope {
+  const PlanesOperand *prev_a, *prev_b;
+  PlanesHintScope(const PlanesOperand *a, const PlanesOperand *b);
+  ~PlanesHintScope();
+};
+const PlanesOperand *planes_hint_a();
+const PlanesOperand *planes_hint_b();
+
 int planes_gemm_tile_rows(int N);
 int planes_gemm_tile_cols(int N);
 hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s);

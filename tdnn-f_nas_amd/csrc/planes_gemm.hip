@@ -481,6 +481,18 @@ hipError_t launch(const PlanesGemmArgs &a, hipStream_t s) {
 
 }  // namespace
 
+static thread_local const PlanesOperand *g_hint_a = nullptr, *g_hint_b = nullptr;
+PlanesHintScope::PlanesHintScope(const PlanesOperand *a, const PlanesOperand *b) : prev_a(g_hint_a), prev_b(g_hint_b) {
+  g_hint_a = a;
+  g_hint_b = b;
+}
+PlanesHintScope::~PlanesHintScope() {
+  g_hint_a = prev_a;
+  g_hint_b = prev_b;
+}
+const PlanesOperand *planes_hint_a() { return g_hint_a; }
+const PlanesOperand *planes_hint_b() { return g_hint_b; }
+
 size_t planes_bytes(int np, long long rows_total, long long k_blocks) { return (size_t)(k_blocks * np * rows_total * 32); }
 size_t planes_sumsq_ws_bytes() { return sizeof(double) * kSumsqBlocks; }
 

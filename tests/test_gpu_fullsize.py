@@ -43,6 +43,12 @@ FULL = [
     ("7q-bf16x3", dict(gemm_precision=1)),
     ("7q-NG-bf16x3", dict(gemm_precision=1, use_natural_gradient=1)),
     ("bn-supernet-320-onehot-NG-bf16x3", dict(bn_choice_dims=[80, 80, 80, 80], bn_mode=0, use_natural_gradient=1, gemm_precision=1)),
+    # the pre-split plane kernels (planes_gemm.hip) at full width, on the one-stream schedule they need ("planes": see the test): two scaled
+    # f16 planes / three products and three bf16 planes / six products, both f32-equivalent -> the exact-f32 bars
+    ("7q-f16x3-planes", dict(gemm_precision=3, planes=1)),
+    ("7q-NG-f16x3-planes", dict(gemm_precision=3, use_natural_gradient=1, planes=1)),
+    ("manual-offset6-NG-f16x3-planes", dict(strides=[1, 1, 1, 0] + [6] * 10, use_natural_gradient=1, gemm_precision=3, planes=1)),
+    ("7q-NG-bf16x6-planes", dict(gemm_precision=2, use_natural_gradient=1, planes=1)),
 ]
 
 
@@ -66,9 +72,12 @@ def component_slice(c):
 
 @pytest.mark.parametrize("name,kw", FULL, ids=[c[0] for c in FULL])
 def test_full_width_net_step_matches_oracle(pkg, name, kw):
+    kw = dict(kw)
+    planes = kw.pop("planes", 0)
     cfg = pkg.trainer.make_config(frames_per_chunk=150, num_sequences=8, **kw)
     assert cfg.hidden_dim == 1536 and cfg.num_pdfs == 6034 and cfg.num_layers == 14
-    net = pkg.trainer.ChainNet(cfg)
+    with pkg.hipabi.option("wgrad_stream", 0 if planes else -1):  # (read by tdnnf_net_create)
+        net = pkg.trainer.ChainNet(cfg)
     # the oracle's own component table (derived from the config alone) is the library's
     table, num_params = component_table(cfg)
     assert num_params == net.num_params
@@ -288,8 +297,11 @@ def test_bench_shape_fused_statistics_against_separate_passes(pkg, bench_egs):
     assert any(not torch.equal(ga, gb) for (_, ga), (_, gb) in zip(fus[1:], sep[1:]))  # the switch did switch
 
 
-def test_bench_shape_split_bf16_six_products_against_f32(pkg, bench_egs):
-    """gemm_precision 2 (three bf16 planes, six products) against exact f32 at the bench shape.  Forward values agree to f32
+@pytest.mark.parametrize("arith", ["bf16x6-planes", "f16x3-planes", "bf16x6-in-kernel"])
+def test_bench_shape_split_bf16_six_products_against_f32(pkg, bench_egs, arith):
+    """The f32-equivalent GEMM arithmetics on the 16-bit matrix cores -- gemm_precision 2 (three bf16 planes, six products) on the
+    pre-split plane kernels and with the in-kernel split, gemm_precision 3 (two scaled f16 planes, three products, pre-split) --
+    against exact f32 at the bench shape.  Forward values agree to f32
     rounding; but with 295 million ReLU elements per full-rate layer, ~1e-7 differences in the pre-activations flip the
     derivative mask of the few hundred elements that sit within rounding of zero, and each flip is a typical-size element of
     the derivative (tools/fullsize_diag.py: ONE flip among 614 000 elements = 4.7e-4 of that matrix's norm).  So: the masks
@@ -297,7 +309,8 @@ def test_bench_shape_split_bf16_six_products_against_f32(pkg, bench_egs):
     1e-3 bar; the whole gradient to the size of that tie noise."""
     keep = ["tdnnf2.relu", "tdnnf9.relu", "tdnnf15.relu", "prefinal-chain.relu"]
     f32, ef = run_bench_shape(pkg, bench_egs, 1, keep=keep)
-    x6, ex = run_bench_shape(pkg, bench_egs, 1, keep=keep, gemm_precision=2)
+    with pkg.hipabi.option("planes", 0 if arith == "bf16x6-in-kernel" else 1):
+        x6, ex = run_bench_shape(pkg, bench_egs, 1, keep=keep, gemm_precision=3 if arith == "f16x3-planes" else 2)
     (ra, ga), (rb, gb) = x6[0], f32[0]
     assert abs(ra[0] - rb[0]) < 1e-4 * abs(rb[0]), (ra[0], rb[0])
     for k in keep:

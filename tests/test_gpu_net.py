@@ -93,6 +93,20 @@ CASES += [
     ("7q-shape-small-NG-bf16x6", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=24, feat_dim=40,
                                       ivector_dim=100, num_pdfs=150, hidden_dim=96, small_dim=48, use_natural_gradient=1, gemm_precision=2), 60),
 ]
+# gemm_precision 3 (two scaled f16 planes, three products) and gemm_precision 2 on the PRE-SPLIT plane kernels (planes_gemm.hip): the
+# trainer only takes them on one stream, so the tiny nets here switch the weight-gradient stream off ("planes": forced in the test below).
+# Held to the SAME tolerances as exact f32.
+CASES += [
+    ("7q-shape-small-f16x3-planes", dict(CASES[1][1], gemm_precision=3, planes=1), 60),
+    ("manual-offset6-f16x3-planes", dict(CASES[2][1], gemm_precision=3, planes=1), 40),
+    ("7q-shape-small-NG-f16x3-planes", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=24, feat_dim=40,
+                                            ivector_dim=100, num_pdfs=150, hidden_dim=96, small_dim=48, use_natural_gradient=1, gemm_precision=3, planes=1), 60),
+    ("bn-supernet-softmax-flops-f16x3-planes", dict(_B, bn_choice_dims=[8, 8, 16, 32], bn_mode=1, bn_flops_scale=2.0, gemm_precision=3, planes=1), 40),
+    ("darts-k7-uniform-f16x3-planes", dict(_D, darts_num_offsets=7, darts_flags=4, gemm_precision=3, planes=1), 40),
+    ("7q-shape-small-bf16x6-planes", dict(CASES[1][1], gemm_precision=2, planes=1), 60),
+    ("7q-shape-small-NG-bf16x6-planes", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=24, feat_dim=40,
+                                             ivector_dim=100, num_pdfs=150, hidden_dim=96, small_dim=48, use_natural_gradient=1, gemm_precision=2, planes=1), 60),
+]
 # hidden_dim 160: output-side rank 80, the three-tile form of the fused BatchNorm/ReLU-backward + statistic sweep (step 1)
 CASES += [
     ("7q-shape-small-NG-rank80", dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 0, 3], bottleneck=24, feat_dim=40, ivector_dim=100,
@@ -104,9 +118,11 @@ CASES += [
 def test_net_step_matches_oracle(pkg, name, kw, H):
     kw = dict(kw)
     dropout_p = kw.pop("dropout_proportion", 0.0)
+    planes = kw.pop("planes", 0)
     cfg = pkg.trainer.make_config(**kw)
-    x3 = cfg.gemm_precision == 1  # 16-bit operands; gemm_precision 2 is f32-equivalent and gets the f32 tolerances
-    net = pkg.trainer.ChainNet(cfg)
+    x3 = cfg.gemm_precision == 1  # 16-bit operands; gemm_precision 2 / 3 are f32-equivalent and get the f32 tolerances
+    with pkg.hipabi.option("wgrad_stream", 0 if planes else -1):  # (read by tdnnf_net_create; plane operands need the one-stream schedule)
+        net = pkg.trainer.ChainNet(cfg)
     params = net.init_params_numpy(seed=3, output_stddev=0.3)
     if cfg.darts_num_offsets:  # non-trivial architecture logits
         rng = np.random.default_rng(17)
