@@ -231,8 +231,17 @@ class Job:
         # strong scaling shards ONE minibatch: train-mode BatchNorm statistics are all-reduced so that it normalises as the whole
         # minibatch does on one GPU (--sync-batchnorm auto); weak scaling = independent jobs, statistics per job as in Kaldi
         self.sync_bn = world > 1 and (args.sync_batchnorm == "on" or (args.sync_batchnorm == "auto" and scaling == "strong"))
-        if self.sync_bn:
-            self.net.set_batchnorm_sync(True)
+        # the exchanges are issued by the library itself on RCCL (csrc/rccl_sync.hip) unless the group is the gloo rehearsal
+        import torch.distributed as dist
+        self.rccl = None
+        if (world > 1 and dist.get_backend() != "gloo") or (world == 1 and args.sync_batchnorm == "on"):
+            self.rccl = pkg.trainer.RcclComm(single=world == 1)
+        if self.sync_bn or (world == 1 and args.sync_batchnorm == "on"):
+            if self.rccl is not None:
+                self.net.set_batchnorm_sync_rccl(self.rccl)
+                self.sync_bn = True
+            else:
+                self.net.set_batchnorm_sync(True)
         self.gen = torch.Generator(device="cuda")
         self.gen.manual_seed(1234)  # same architecture sample on every rank (seed-shared draws)
         self.comm = torch.cuda.Stream() if world > 1 and not args.no_overlap else None
@@ -271,7 +280,9 @@ class Job:
             self.net.forward_backward(f, v, self.dg, sp, step=self.i)
         else:
             self.net.forward_backward(self.fd, self.ivd, self.dg, self.ds, step=self.i)
-        if self.comm is not None:  # one collective per gradient bucket, each behind its "bucket final" event: overlaps the backward pass
+        if self.comm is not None and self.rccl is not None and self.world > 1:  # ... issued from C++ (tdnnf_net_allreduce_grads_rccl)
+            self.net.allreduce_grads_rccl(self.rccl, self.comm)
+        elif self.comm is not None:  # one collective per gradient bucket, each behind its "bucket final" event: overlaps the backward pass
             self.net.allreduce_grads_overlapped(self.comm)
         else:
             self.net.allreduce_grads()

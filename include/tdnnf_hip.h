@@ -517,6 +517,8 @@ int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
    init_mode 0: C += , 1: C = bias + , 2: C = . */
 size_t tdnnf_planes_bytes(int num_planes, long long rows_total, long long k_blocks);
 size_t tdnnf_planes_split_workspace_bytes(void);
+/* how many GEMMs / weight gradients of the trainer ran on the plane kernels so far in this process (either pointer may be NULL) */
+void tdnnf_planes_routed(long long *rows_gemms, long long *weight_gradients);
 int tdnnf_planes_split(int num_planes, const tdnnf_mat *x, int lead_rows, long long rows_total, void *planes, long long t_rows_total, void *planes_t,
                        float *scale_dev, void *workspace_dev, tdnnf_stream);
 int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
@@ -533,6 +535,23 @@ int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_tot
    The typedef is spelled in capitals on purpose (not an exported symbol). */
 typedef int TDNNF_ALLREDUCE_FN(void *ctx, double *buf, long long count, tdnnf_stream stream);
 int tdnnf_net_set_batchnorm_sync(tdnnf_net *, TDNNF_ALLREDUCE_FN *allreduce, void *ctx, int world_size);
+
+/* ---- The data-parallel exchanges on RCCL, issued from C++ on the library's streams (csrc/rccl_sync.hip).
+   librccl.so is resolved with dlopen on first use (no link-time dependency).  One process per GPU: rank 0 takes a unique id
+   (128 bytes), the launcher's own channel distributes it (e.g. a torch.distributed broadcast), every rank creates its communicator
+   on its current device.
+   tdnnf_net_set_batchnorm_sync_rccl: the synchronised BatchNorm above with ncclAllReduce (doubles, in place) on the compute stream
+     as the collective -- nothing host-side between the two finalize launches; comm NULL switches it off.
+   tdnnf_net_allreduce_grads_rccl: the gradient exchange of one minibatch, call right after tdnnf_net_forward_backward: one
+     ncclAllReduce (sum, f32) per gradient bucket (tdnnf_net_grad_bucket) on comm_stream, each behind the event recorded when that
+     bucket became final, so the upper layers' reductions run under the lower layers' backward pass; `stream` then waits for the last. */
+int tdnnf_rccl_available(void);
+int tdnnf_rccl_unique_id(void *out_128_bytes);
+int tdnnf_rccl_comm_create(const void *id_128_bytes, int world_size, int rank, void **comm_out);
+void tdnnf_rccl_comm_destroy(void *comm);
+int tdnnf_rccl_allreduce_sum(void *comm, void *buf_dev, long long count, int is_double, tdnnf_stream stream);
+int tdnnf_net_set_batchnorm_sync_rccl(tdnnf_net *, void *comm, int world_size);
+int tdnnf_net_allreduce_grads_rccl(tdnnf_net *, void *comm, tdnnf_stream comm_stream, tdnnf_stream stream);
 /* The nnet edit "set-learning-rate-factor name=<pattern> learning-rate-factor=f" (ReadEditConfig,
    /root/reference/src/nnet3/nnet-utils.cc:1232-1256): SetLearningRateFactor(f) on every UPDATABLE component whose name matches
    the pattern ('*' matches any run of characters, as NameMatchesPattern; the fixed lda layer is not updatable).  The cv-update

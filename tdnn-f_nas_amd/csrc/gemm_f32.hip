@@ -1273,6 +1273,7 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
   g.add = a.add; g.ldadd = a.ldadd; g.add_scale = a.add_scale; g.add_lo = a.add_lo; g.add_hi = a.add_hi;
   ProfScope ps(BN == 160 ? 1 : 0, flops, s);
   *err = planes_gemm(g, s);
+  g_planes_routed_rows++;
   return true;
 }
 
@@ -2011,6 +2012,7 @@ static bool planes_try_wgrad(const WgradArgs &a, void *workspace, size_t workspa
   }
   if (*err != hipSuccess) return true;
   *err = wgrad_finish(a, g.partial, splits, g.partial + slab * splits, hy->scale, hx->scale, s);
+  g_planes_routed_wgrad++;
   return true;
 }
 

@@ -176,6 +176,7 @@ struct tdnnf_net {
   tdnnf::BnSync bn_sync{nullptr, nullptr, nullptr, 1};  // tdnnf_net_set_batchnorm_sync; buf lives in the arena
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done
+  hipEvent_t ev_comm = nullptr;        // tdnnf_net_allreduce_grads_rccl: the last bucket's collective
   int num_draws;
   bool owns_ng = true;    // false: created by tdnnf_net_create_shared, the preconditioners belong to the primary net
   int dropout_draw0;      // first of the (num_layers + 1) * B * hidden_dim dropout draws (cfg.use_dropout)

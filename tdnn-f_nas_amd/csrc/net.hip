@@ -968,7 +968,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->ev_fin0) hipEventDestroy(n->ev_fin0);
   if (n->ev_fin) hipEventDestroy(n->ev_fin);
   if (n->s3) hipStreamDestroy(n->s3);
-  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg_in, n->ev_early_in, n->ev_early})
+  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg_in, n->ev_early_in, n->ev_early, n->ev_comm})
     if (e) hipEventDestroy(e);
   if (n->s4) hipStreamDestroy(n->s4);
   delete n;

@@ -103,6 +103,8 @@ struct PlanesHintScope {
   PlanesHintScope(const PlanesOperand *a, const PlanesOperand *b);
   ~PlanesHintScope();
 };
+// how many rows GEMMs / weight gradients ran on the plane kernels so far in this process (tests: the routing did route)
+extern long long g_planes_routed_rows, g_planes_routed_wgrad;
 const PlanesOperand *planes_hint_a();
 const PlanesOperand *planes_hint_b();
 

@@ -481,6 +481,7 @@ hipError_t launch(const PlanesGemmArgs &a, hipStream_t s) {
 
 }  // namespace
 
+long long g_planes_routed_rows = 0, g_planes_routed_wgrad = 0;
 static thread_local const PlanesOperand *g_hint_a = nullptr, *g_hint_b = nullptr;
 PlanesHintScope::PlanesHintScope(const PlanesOperand *a, const PlanesOperand *b) : prev_a(g_hint_a), prev_b(g_hint_b) {
   g_hint_a = a;
@@ -559,6 +560,10 @@ size_t tdnnf_planes_bytes(int num_planes, long long rows_total, long long k_bloc
   return planes_bytes(num_planes, rows_total, k_blocks);
 }
 size_t tdnnf_planes_split_workspace_bytes(void) { return planes_sumsq_ws_bytes(); }
+void tdnnf_planes_routed(long long *rows_gemms, long long *weight_gradients) {
+  if (rows_gemms) *rows_gemms = g_planes_routed_rows;
+  if (weight_gradients) *weight_gradients = g_planes_routed_wgrad;
+}
 
 int tdnnf_planes_split(int num_planes, const tdnnf_mat *x, int lead_rows, long long rows_total, void *planes, long long t_rows_total, void *planes_t,
                        float *scale_dev, void *workspace_dev, tdnnf_stream stream) {

@@ -296,6 +296,21 @@ class ChainNet:
         return out
 
     # ------------------------------------------------------------ data-parallel step
+    def set_batchnorm_sync_rccl(self, comm):
+        """Synchronised BatchNorm with the collective issued by the library itself (tdnnf_net_set_batchnorm_sync_rccl: ncclAllReduce
+        on the compute stream between the two finalize launches, no host code in between).  comm: an RcclComm, or None = off."""
+        if comm is not None:
+            _require_equal_shards(self.cfg.num_sequences, comm.group, comm.world)
+        hipabi.check(self.lib.tdnnf_net_set_batchnorm_sync_rccl(self.h, comm.h if comm is not None else None, comm.world if comm is not None else 1))
+        self._bn_sync_cb = None
+        return comm is not None
+
+    def allreduce_grads_rccl(self, comm, comm_stream):
+        """The gradient exchange of one minibatch issued by the library (tdnnf_net_allreduce_grads_rccl): one ncclAllReduce per gradient
+        bucket on `comm_stream`, each behind the event recorded when the bucket became final; the current stream waits for the last."""
+        import torch
+        hipabi.check(self.lib.tdnnf_net_allreduce_grads_rccl(self.h, comm.h, C.c_void_p(comm_stream.cuda_stream), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
     def set_batchnorm_sync(self, on=True, group=None, min_world=2):
         """Synchronised BatchNorm (tdnnf_net_set_batchnorm_sync): every train-mode BatchNorm all-reduces its column sums over the
         ranks of `group` on the compute stream, so that a minibatch sharded over the ranks (bench.py --scaling strong) normalises
@@ -309,6 +324,7 @@ class ChainNet:
             self._bn_sync_cb = None
             return False
         world = dist.get_world_size(group)
+        _require_equal_shards(self.cfg.num_sequences, group, world)
 
         class _DevDoubles:  # zero-copy view of `count` doubles at a raw device pointer
             def __init__(self, ptr, count):
@@ -371,6 +387,65 @@ class ChainNet:
         for w in works:
             w.wait()  # the current stream waits for the collective's stream
         torch.cuda.current_stream().wait_stream(comm_stream)
+
+
+def _require_equal_shards(num_sequences, group, world):
+    """Synchronised BatchNorm forms its global row count as rows x world_size: every rank must hold the same number of sequences."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        return
+    mine = torch.tensor([int(num_sequences)], dtype=torch.int64)
+    if dist.get_backend(group) != "gloo":
+        mine = mine.cuda()
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine, group=group)
+    counts = [int(t.item()) for t in every]
+    if len(set(counts)) != 1:
+        raise ValueError("synchronised BatchNorm needs the same number of sequences on every rank, got %r (shard a minibatch that divides "
+                         "by the world size)" % (counts,))
+
+
+class RcclComm:
+    """A RCCL communicator owned by the library (csrc/rccl_sync.hip) for the exchanges it issues itself from C++: rank 0 takes the
+    unique id, torch.distributed's group (whatever its backend) carries the 128 bytes to the other ranks, every rank joins on its
+    current device.  single=True: a one-rank communicator without any process group (tests, rehearsals on one GPU)."""
+
+    def __init__(self, group=None, single=False):
+        import torch.distributed as dist
+        self.lib = hipabi.load()
+        if not self.lib.tdnnf_rccl_available():
+            raise RuntimeError("librccl.so is not available")
+        self.group = group
+        self.world, self.rank = (1, 0) if single else (dist.get_world_size(group), dist.get_rank(group))
+        ident = None
+        if self.rank == 0:
+            buf = (C.c_char * 128)()
+            hipabi.check(self.lib.tdnnf_rccl_unique_id(buf))
+            ident = bytes(buf)
+        if self.world > 1:
+            box = [ident]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = box[0]
+        self.h = C.c_void_p()
+        hipabi.check(self.lib.tdnnf_rccl_comm_create(ident, self.world, self.rank, C.byref(self.h)))
+
+    def allreduce_sum(self, tensor, stream=None):
+        """In-place sum of a contiguous float32 / float64 device tensor over the ranks, on `stream` (default: the current one)."""
+        import torch
+        assert tensor.is_cuda and tensor.is_contiguous() and tensor.dtype in (torch.float32, torch.float64)
+        st = stream if stream is not None else torch.cuda.current_stream()
+        hipabi.check(self.lib.tdnnf_rccl_allreduce_sum(self.h, C.c_void_p(tensor.data_ptr()), tensor.numel(), int(tensor.dtype == torch.float64),
+                                                       C.c_void_p(st.cuda_stream)))
+        return tensor
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.tdnnf_rccl_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def allreduce_flat(flat, group=None, min_world=2):

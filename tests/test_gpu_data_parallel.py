@@ -273,3 +273,73 @@ def test_rccl_runs_the_batchnorm_sync_collectives(pkg, tmp_path):
     mp.spawn(_rccl_bn_sync_main, args=(port, str(tmp_path)), nprocs=1, join=True)
     o = np.load(tmp_path / "rccl_bn.npz")
     assert np.linalg.norm(o["before"]) > 0 and rel_l2(o["after"], o["before"]) < 1e-6
+
+
+def _native_rccl_main(rank, out_dir):
+    """One process = one rank = one GPU; the library creates the communicator itself (csrc/rccl_sync.hip), no torch process group."""
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    torch.cuda.set_device(0)
+    comm = pkg.trainer.RcclComm(single=True)
+    try:
+        x = torch.randn(1000, device="cuda", dtype=torch.float64)
+        x0 = x.clone()
+        comm.allreduce_sum(x)
+        y = torch.randn(777, device="cuda")
+        y0 = y.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        comm.allreduce_sum(y, stream=side)
+        side.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(x, x0) and torch.equal(y, y0)  # one rank: sums unchanged
+        net, feats, iv, den, sup = _bn_problem(pkg, KW_BN["num_sequences"])
+        fd, ivd, dg, ds = dev(feats), dev(iv), pkg.hipabi.DenGraph(den), pkg.hipabi.Supervision(sup)
+        net.forward_backward(fd, ivd, dg, ds, step=0)
+        before = host(net.grads).copy()
+        net.grads.zero_()
+        assert net.set_batchnorm_sync_rccl(comm)  # every train-mode BatchNorm: ncclAllReduce of its column sums, issued from C++ on the compute stream
+        cs = torch.cuda.Stream()
+        with torch.cuda.stream(side):  # (also when the compute stream is not torch's default stream)
+            side.wait_stream(torch.cuda.default_stream())
+            net.forward_backward(fd, ivd, dg, ds, step=0)
+            net.allreduce_grads_rccl(comm, cs)  # the gradient buckets on their own stream behind the bucket events; `side` waits for them
+            after = net.grads.clone()
+        side.synchronize()
+        net.set_batchnorm_sync_rccl(None)
+        net.grads.zero_()
+        net.forward_backward(fd, ivd, dg, ds, step=0)
+        torch.cuda.synchronize()
+        np.savez(os.path.join(out_dir, "native.npz"), before=before, after=host(after), off_again=host(net.grads).copy())
+        net.close()
+    finally:
+        comm.close()
+
+
+def test_library_issued_rccl_exchanges_with_a_one_rank_communicator(pkg, tmp_path):
+    """The exchanges the library issues itself (tdnnf_rccl_*, tdnnf_net_set_batchnorm_sync_rccl, tdnnf_net_allreduce_grads_rccl): librccl
+    loaded with dlopen, a communicator created from a unique id, ncclAllReduce of doubles on the compute stream inside
+    tdnnf_net_forward_backward and of the gradient buckets on a communication stream.  A one-GPU box can only run one rank: the
+    sums must come back unchanged and the step must equal the unsynchronised one bit for bit."""
+    import torch.multiprocessing as mp
+    mp.spawn(_native_rccl_main, args=(str(tmp_path),), nprocs=1, join=True)  # (its own process: RCCL initialises its own GPU context state)
+    o = np.load(tmp_path / "native.npz")
+    assert np.linalg.norm(o["before"]) > 0
+    assert np.array_equal(o["after"], o["before"]) and np.array_equal(o["off_again"], o["before"])
+
+
+def test_unequal_shards_are_refused_by_synchronised_batchnorm(pkg):
+    """rows x world_size is the global row count synchronised BatchNorm divides by: ranks with different sequence counts are an error
+    (trainer._require_equal_shards), checked on the host with a fake two-rank gather."""
+    import unittest.mock as mock
+    import torch.distributed as dist
+    T = pkg.trainer
+
+    def fake_all_gather(out, mine, group=None):
+        out[0].copy_(mine)
+        out[1].copy_(mine + 1)
+
+    with mock.patch.object(dist, "is_available", return_value=True), mock.patch.object(dist, "is_initialized", return_value=True), \
+            mock.patch.object(dist, "get_backend", return_value="gloo"), mock.patch.object(dist, "all_gather", side_effect=fake_all_gather):
+        with pytest.raises(ValueError, match="same number of sequences"):
+            T._require_equal_shards(8, None, 2)

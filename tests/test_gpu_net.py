@@ -114,6 +114,12 @@ CASES += [
 ]
 
 
+def _planes_routed(pkg):
+    a, b = C.c_longlong(), C.c_longlong()
+    pkg.hipabi.load().tdnnf_planes_routed(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
 @pytest.mark.parametrize("name,kw,H", CASES, ids=[c[0] for c in CASES])
 def test_net_step_matches_oracle(pkg, name, kw, H):
     kw = dict(kw)
@@ -123,6 +129,7 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
     x3 = cfg.gemm_precision == 1  # 16-bit operands; gemm_precision 2 / 3 are f32-equivalent and get the f32 tolerances
     with pkg.hipabi.option("wgrad_stream", 0 if planes else -1):  # (read by tdnnf_net_create; plane operands need the one-stream schedule)
         net = pkg.trainer.ChainNet(cfg)
+    routed0 = _planes_routed(pkg)
     params = net.init_params_numpy(seed=3, output_stddev=0.3)
     if cfg.darts_num_offsets:  # non-trivial architecture logits
         rng = np.random.default_rng(17)
@@ -187,6 +194,11 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
         params = p_ref
         net.set_params(params)
     net.close()
+    if planes:  # the plane kernels did run: forward / backward-data GEMMs of every plain layer, and the weight gradients where the rows suffice
+        routed = _planes_routed(pkg)
+        assert routed[0] - routed0[0] >= 2 * 2 * (cfg.num_layers if not cfg.darts_num_offsets else 1), (routed0, routed)
+        if cfg.frames_per_chunk * cfg.num_sequences >= 300 and not cfg.darts_num_offsets:
+            assert routed[1] > routed0[1], (routed0, routed)
 
 
 def test_net_gradients_accumulate_and_are_reproducible(pkg):
