@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_f32.h"
 
 struct tdnnf_den_graph {
   int H, A, P;
@@ -1395,6 +1396,9 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
   ChainBufs b = chain_bufs(g, B, T, ws);
   DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
   MatView yv = view(y), dv = view(deriv);
+  // algorithmic bytes per (frame, sequence): the arcs once per recursion (8 bytes each forward, twice that backward: two arrays), the
+  // output row read by both recursions and the derivative row written; the range covers both streams (fork .. join)
+  ProfHbmRange prof(6, (double)B * T * (24.0 * g->A + 12.0 * g->P), s);
   if (b.p.wide) {
     const int Hs = b.p.Hs, P = g->P;
     const WideDims d{B, b.p.NG, b.p.SG};

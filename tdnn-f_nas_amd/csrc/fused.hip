@@ -15,6 +15,7 @@
 
 #include "common.h"
 #include "fused.h"
+#include "gemm_f32.h"
 
 namespace tdnnf {
 namespace {
@@ -426,6 +427,7 @@ hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatV
   const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0 &&
                    (!mask || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
   const long long work = (long long)x.rows * (vec ? x.cols / 4 : x.cols);
+  ProfHbmRange prof(4, 4.0 * x.rows * x.cols * (prev.data ? 3.0 : 2.0), s);  // reads x [and the bypass rows], writes out
   if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
   else hipLaunchKernelGGL((bn_apply_bypass_kernel<1>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
   return hipGetLastError();
@@ -466,6 +468,7 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
   if (ng && (!bn_relu_bwd_ng_ok(x, dz, d_aff, ng->Rp) || (reinterpret_cast<uintptr_t>(memo) & 15) || (reinterpret_cast<uintptr_t>(ng->W) & 15) || ng->ldw % 4))
     return hipErrorInvalidValue;
   const int D = x.cols;
+  ProfHbmRange prof(5, 4.0 * x.rows * x.cols * 5.0, s);  // two stages: (x, dz) read twice, d_aff written
   ColReducePlan pl = colreduce_plan(x.rows, D);
   const bool vec = vec4_ok(x) && vec4_ok(dz) && vec4_ok(d_aff);
   const int per = vec ? 256 : 64;

@@ -68,6 +68,15 @@ struct ProfClassOverride {
   ~ProfClassOverride();
 };
 
+// Event timing of an HBM-bound pass while tdnnf_profile_enable is on: class 4 bn_apply_bypass, 5 bn_relu_bwd (both stages),
+// 6 denominator (forward + backward recursions), 7 planes_split; `bytes` = the pass's algorithmic HBM bytes (every element once).
+struct ProfHbmRange {
+  void *c;
+  hipStream_t s;
+  ProfHbmRange(int cls, double bytes, hipStream_t stream);
+  ~ProfHbmRange();
+};
+
 // Scales the algorithmic FLOPs recorded for the launches made while alive: the host cannot see device-side tap
 // coefficients, so a caller that knows only `active` of K taps are non-zero (DARTS uniform-sample mode) says so.
 struct ProfFlopsScale {

@@ -40,7 +40,9 @@ struct ProfClass {
   double flops = 0;
   double bytes = 0;  // algorithmic HBM bytes: every operand element touched once
 };
-static ProfClass g_prof[4] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32"}, {"ng_skinny_gemm_f32"}};
+constexpr int kProfClasses = 8;
+static ProfClass g_prof[kProfClasses] = {{"rows_gemm_f32_128x128"}, {"rows_gemm_f32_128x160"}, {"wgrad_f32"}, {"ng_skinny_gemm_f32"},
+                                         {"bn_apply_bypass"}, {"bn_relu_bwd"}, {"denominator"}, {"planes_split"}};
 static bool g_prof_on = false;
 static int g_prof_override = -1;
 static double g_prof_flops_scale = 1.0;
@@ -102,6 +104,22 @@ struct ProfScope {
     c->used += 2;
   }
 };
+
+// event pair around the launches of an HBM-bound pass (classes 4..7) with its algorithmic bytes
+ProfHbmRange::ProfHbmRange(int cls, double bytes, hipStream_t stream) : c(nullptr), s(stream) {
+  if (!g_prof_on || cls < 4 || cls >= kProfClasses) return;
+  ProfClass &p = g_prof[cls];
+  if (p.used + 2 > p.ev.size()) return;
+  c = &p;
+  p.bytes += bytes;
+  hipEventRecord(p.ev[p.used], s);
+}
+ProfHbmRange::~ProfHbmRange() {
+  if (!c) return;
+  ProfClass *p = static_cast<ProfClass *>(c);
+  hipEventRecord(p->ev[p->used + 1], s);
+  p->used += 2;
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1953,26 +1971,39 @@ static hipError_t wgrad_finish(const WgradArgs &a, const float *partial, int spl
 // product, stored through strides), the rows are split over the CUs into slabs that wgrad_finish() adds.  false = not applicable.
 static bool planes_try_wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, int np, hipStream_t s, hipError_t *err) {
   const PlanesOperand *hy = planes_hint_a(), *hx = planes_hint_b();
-  if (!hy || !hx || hy->np != np || hx->np != np || !hy->PT || !hx->PT) return false;
+  if (!hy || !hx || hy->np != np || hx->np != np) return false;
   if (a.coef || a.active || a.row_stride != 1 || a.K > 16 || a.K < 1) return false;
   if (a.dY != hy->base || a.lddy != hy->ld || a.N != hy->rows || a.Do != hy->cols) return false;
   if (a.ldx != hx->ld || a.X < hx->base || (a.X - hx->base) % hx->ld != 0 || a.Di != hx->cols) return false;
   const long long xrow0 = (a.X - hx->base) / hx->ld;
   const int nkb = (a.N + 15) / 16;
   if (nkb < 16) return false;  // (too few rows to split over the chip: the f32 kernels)
-  const bool normal = a.Do >= a.Di;
+  const bool normal = a.Do >= a.Di;  // the operand with more columns gives the tile rows
   const int M = normal ? a.Do : a.Di, Nn = normal ? a.Di : a.Do;
   const int BM = planes_gemm_tile_rows(Nn), BN = planes_gemm_tile_cols(Nn);
   const int ntm = (M + BM - 1) / BM, ntn = (Nn + BN - 1) / BN;
   const PlanesOperand *hm = normal ? hy : hx, *hn = normal ? hx : hy;  // operands giving the tile rows / columns
-  if ((long long)ntm * BM > hm->Rt || (long long)ntn * BN > hn->Rt) return false;
+  if (!hn->PT || (long long)ntn * BN > hn->Rt) return false;
+  for (int i = 0; i < a.K; i++)
+    if (a.row_offsets[i] < 0 || a.row_offsets[i] % 16 != 0 || xrow0 + a.row_offsets[i] + a.N > hx->rows) return false;
   PlanesGemmArgs g;
   memset(&g, 0, sizeof(g));
-  for (int i = 0; i < a.K; i++) {
-    const long long off = xrow0 + a.row_offsets[i];
-    if (off < 0 || off % 16 != 0 || off + a.N > hx->rows) return false;
-    (normal ? g.tap_b_kb : g.tap_a_kb)[i] = (int)(off / 16);
+  // the tile-row operand: its row-major planes through transposing LDS reads when they are there (no planes of the transpose needed
+  // for the big matrix), else its transposed planes
+  const long long m_first = hm->lead + (normal ? 0 : xrow0);  // first matrix row of the K range in the row-major buffer
+  const bool atr = hm->P && m_first % 16 == 0 && (long long)ntm * (BM / 16) <= hm->kb_alloc && m_first + 16LL * nkb + (normal ? 0 : a.row_offsets[a.K - 1]) <= hm->R;
+  if (atr) {
+    g.A = hm->P; g.RA = hm->R; g.a_rows_as_k = 1;
+    g.seg[0].a_row = m_first;
+  } else {
+    if (!hm->PT || (long long)ntm * BM > hm->Rt || (!normal && xrow0 % 16 != 0)) return false;
+    g.A = hm->PT; g.RA = hm->Rt;
   }
+  for (int i = 0; i < a.K; i++) {
+    if (normal) g.tap_b_kb[i] = (int)((xrow0 + a.row_offsets[i]) / 16);
+    else g.tap_a_kb[i] = (int)((a.row_offsets[i] + (atr ? 0 : xrow0)) / 16);
+  }
+  if (normal && (xrow0 % 16 != 0)) return false;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -1991,7 +2022,7 @@ static bool planes_try_wgrad(const WgradArgs &a, void *workspace, size_t workspa
   if (splits < 2) return false;
   if (sizeof(float) * slab * splits + colreduce_bytes(a.N, a.Do) > workspace_bytes) return false;
   g.np = np;
-  g.A = hm->PT; g.RA = hm->Rt; g.B = hn->PT; g.RB = hn->Rt;
+  g.B = hn->PT; g.RB = hn->Rt;
   g.M = M; g.N = Nn;
   g.nseg = 1;
   g.seg[0].nkb = nkb;
@@ -2147,7 +2178,7 @@ int tdnnf_profile_enable(int on) {
 }
 int tdnnf_profile_read(int cls, double *launches, double *total_ms, double *total_flops) {
   using namespace tdnnf;
-  if (cls < 0 || cls > 3) return TDNNF_EINVAL;
+  if (cls < 0 || cls >= kProfClasses) return TDNNF_EINVAL;
   ProfClass &p = g_prof[cls];
   double ms = 0;
   for (size_t i = 0; i + 1 < p.used; i += 2) {
@@ -2162,9 +2193,9 @@ int tdnnf_profile_read(int cls, double *launches, double *total_ms, double *tota
   return TDNNF_OK;
 }
 int tdnnf_profile_read_bytes(int cls, double *algorithmic_bytes) {
-  if (cls < 0 || cls > 3 || !algorithmic_bytes) return TDNNF_EINVAL;
+  if (cls < 0 || cls >= tdnnf::kProfClasses || !algorithmic_bytes) return TDNNF_EINVAL;
   *algorithmic_bytes = tdnnf::g_prof[cls].bytes;
   return TDNNF_OK;
 }
-const char *tdnnf_profile_class_name(int cls) { return cls >= 0 && cls <= 3 ? tdnnf::g_prof[cls].name : ""; }
+const char *tdnnf_profile_class_name(int cls) { return cls >= 0 && cls < tdnnf::kProfClasses ? tdnnf::g_prof[cls].name : ""; }
 }

@@ -407,10 +407,10 @@ void layout_arena(tdnnf_net *n, Arena &A) {
       for (const Tdnn *td : {&L.lin, &L.aff})
         for (int i = 0; i < td->K; i++) lead_cap = std::max(lead_cap, td->ix.row_offsets[i]);
     auto slot = [&](const float *key, int rows, int cols, bool with_lead) {
-      const long long R = planes_rows_padded((long long)(with_lead ? 2 * lead_cap : 0) + rows + 256);
+      const long long R = planes_rows_padded((long long)(with_lead ? 2 * ((lead_cap + 15) & ~15) : 0) + rows + 256);
       const long long Rt = planes_rows_padded(((cols + 255) / 256) * 256LL);
       tdnnf_net::PlaneSlot ps;
-      ps.bytesP = planes_bytes(np, R, planes_kblocks(cols));
+      ps.bytesP = planes_bytes(np, R, (planes_kblocks(cols) + 15) / 16 * 16);  // (whole 256-column tiles of K blocks: the rows-as-K reads of a weight gradient)
       ps.bytesPT = planes_bytes(np, Rt, planes_t_kblocks(rows));
       ps.P = A.take<char>(ps.bytesP + 64);
       ps.PT = A.take<char>(ps.bytesPT + 64);
@@ -1292,17 +1292,23 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     auto it = n->plane_slots.find(m.data);
     if (it == n->plane_slots.end() || m.rows <= 0) return TDNNF_OK;  // (no slot: the GEMM runs its own kernels)
     const tdnnf_net::PlaneSlot &ps = it->second;
+    // a wide matrix (the 1536- / 6034-column activations and derivatives) is the tile-row operand of its weight gradient, which reads
+    // the ROW-MAJOR planes through transposing LDS loads: no planes of the transpose for those
+    if (m.cols >= 1024) want = kP;
     PlanesSplitArgs a;
     a.np = np; a.x = view(&m); a.lead = lead; a.scale = ps.scale; a.sumsq_ws = n->planes_ws;
+    lead = (lead + 15) & ~15;  // (a weight gradient reads the row-major planes in K steps of 16 rows: the matrix starts on one)
+    a.lead = lead;
     a.R = planes_rows_padded((long long)2 * lead + m.rows + 256);
     a.Rt = planes_rows_padded(((m.cols + 255) / 256) * 256LL);
     a.P = (want & kP) ? ps.P : nullptr;
     a.PT = (want & kT) ? ps.PT : nullptr;
-    TDNNF_REQUIRE(planes_bytes(np, a.R, planes_kblocks(m.cols)) <= ps.bytesP && planes_bytes(np, a.Rt, planes_t_kblocks(m.rows)) <= ps.bytesPT,
+    const long long kb_alloc = (planes_kblocks(m.cols) + 15) / 16 * 16;
+    TDNNF_REQUIRE(planes_bytes(np, a.R, kb_alloc) <= ps.bytesP && planes_bytes(np, a.Rt, planes_t_kblocks(m.rows)) <= ps.bytesPT,
                   "net_forward_backward: plane slot too small for a %d x %d matrix", m.rows, m.cols);
     TDNNF_HIP(planes_split(a, st));
     o->base = m.data; o->rows = m.rows; o->cols = m.cols; o->ld = m.stride; o->np = np;
-    o->P = a.P; o->R = a.R; o->lead = lead; o->PT = a.PT; o->Rt = a.Rt; o->scale = np == 2 ? ps.scale : nullptr;
+    o->P = a.P; o->R = a.R; o->lead = lead; o->kb_alloc = kb_alloc; o->PT = a.PT; o->Rt = a.Rt; o->scale = np == 2 ? ps.scale : nullptr;
     return TDNNF_OK;
   };
   auto hint_of = [&](const PlanesOperand &o) -> const PlanesOperand * { return o.base ? &o : nullptr; };

@@ -41,6 +41,11 @@ struct PlanesGemmArgs {
   int add_lo, add_hi;
   int nseg;
   PlanesSeg seg[16];
+  // != 0: A holds the ROW-MAJOR planes of a matrix whose COLUMNS are the tile rows and whose ROWS are the reduction index (a weight
+  // gradient's big operand, read with transposing LDS loads): RA = that buffer's rows, seg.a_row = the first matrix row of the K range
+  // (a multiple of 16, lead rows included), seg.a_kb0 / tap_a_kb count K steps of 16 rows; the buffer must hold whole 256-column tiles
+  // (K blocks padded to a multiple of 16).
+  int a_rows_as_k;
   // Tap mode (weight gradients, nseg == 1): `ntap` products per output tile position; product t runs with the A operand advanced by
   // tap_a_kb[t] K blocks and the B operand by tap_b_kb[t], and lands tap_off_c * t floats further in C (tap_off_p * t in a partial slab).
   // ntap <= 1: off.
@@ -94,6 +99,7 @@ struct PlanesOperand {
   const void *P = nullptr;  // row-major planes (k = column), R rows of which `lead` zero rows in front
   long long R = 0;
   int lead = 0;
+  long long kb_alloc = 0;   // K blocks the P buffer has room for (>= ceil(cols / 16); whole 256-column tiles for the rows-as-K reads)
   const void *PT = nullptr;  // planes of the transpose (k = row), Rt rows
   long long Rt = 0;
   const float *scale = nullptr;  // np == 2: [s, 1 / s] on the device

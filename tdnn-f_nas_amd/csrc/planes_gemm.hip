@@ -31,6 +31,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "gemm_f32.h"
 #include "planes_gemm.h"
 
 namespace tdnnf {
@@ -231,7 +232,13 @@ __global__ __launch_bounds__(256) void planes_pad_kernel(void *Pv, long long nch
 
 // ------------------------------------------------------------------------------------------------------ the GEMM
 // block = WM x WN waves, a wave owns TM x TN accumulator tiles of 32 x 32; BM = WM TM 32, BN = WN TN 32.
-template <int NP, int WM, int WN, int TM, int TN, bool DB>
+// ATR: the A operand is given by ROW-MAJOR planes of the matrix whose COLUMNS are the tile rows (a product that reduces over the
+// matrix's rows, i.e. a weight gradient, without planes of the transpose): a K step is 16 consecutive matrix rows, the tile's 256
+// columns are 16 K-block chunks of 16 x 32-byte row records, staged as [chunk pair][row 0..15][chunk parity][32 bytes] and read
+// with ds_read_b64_tr_b16 (gfx950's transposing LDS read: a 16-lane group fetches 4 rows x 16 columns and every lane receives one
+// column), two reads per operand register pair; rows of a 32-lane half cover 256 contiguous bytes: conflict-free.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+template <int NP, int WM, int WN, int TM, int TN, bool DB, bool ATR = false>
 __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGemmArgs p, int ntm, int ntn) {
   typedef typename Plane<NP>::V8 V8;
   constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
@@ -282,13 +289,17 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
     const int rowsb = isA[j] ? BM * 2 : BN * 2;            // pieces per plane chunk
     const int pl = w / rowsb, inner = w % rowsb;
     rel[j] = live[j] ? ((long long)pl * (isA[j] ? p.RA : p.RB)) * 32 + (long long)inner * 16 : 0;  // (surplus pieces re-read the tile's first 16 bytes)
+    if (ATR && isA[j] && live[j]) {  // piece `inner` of the image [chunk pair][row][parity][half]: K-block chunk 2 cp + parity, row record q
+      const int cp = inner >> 6, rem = inner & 63, q = rem >> 2, par = (rem >> 1) & 1, h16 = rem & 1;
+      rel[j] = ((long long)pl * p.RA + (long long)(2 * cp + par) * NP * p.RA + q) * 32 + h16 * 16;
+    }
   }
   // Requests: every piece keeps a running source pointer, advanced by its operand's K-block stride after each stage; the segment
   // table (kernel arguments) is only read when a segment ends.
   const char *srcp[PPT];
   long long kstride[PPT];
 #pragma unroll
-  for (int j = 0; j < PPT; j++) kstride[j] = (isA[j] ? p.RA : p.RB) * (32 * NP);
+  for (int j = 0; j < PPT; j++) kstride[j] = (ATR && isA[j]) ? 512 : (isA[j] ? p.RA : p.RB) * (32 * NP);  // (ATR: a K step is 16 rows of 32 bytes)
   int ld_seg = -1, ld_left = 0, ld_skip = g_begin;
   auto next_request_segment = [&]() {
     for (;;) {
@@ -300,7 +311,8 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
         continue;
       }
       ld_left = sg.nkb - ld_skip;
-      const char *ga = reinterpret_cast<const char *>(p.A) + ((long long)(sg.a_kb0 + tap_akb + ld_skip) * NP * p.RA + sg.a_row + m0) * 32;
+      const char *ga = ATR ? reinterpret_cast<const char *>(p.A) + ((long long)(m0 >> 4) * NP * p.RA + sg.a_row + 16LL * (sg.a_kb0 + tap_akb + ld_skip)) * 32
+                           : reinterpret_cast<const char *>(p.A) + ((long long)(sg.a_kb0 + tap_akb + ld_skip) * NP * p.RA + sg.a_row + m0) * 32;
       const char *gb = reinterpret_cast<const char *>(p.B) + ((long long)(sg.b_kb0 + tap_bkb + ld_skip) * NP * p.RB + sg.b_row + n0) * 32;
       ld_skip = 0;
 #pragma unroll
@@ -339,6 +351,10 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
       for (int i = 0; i < TM; i++) {
         const int row = wm * TM * 32 + i * 32 + li;
         a_off[i] = row * 32 + ((lh ^ (((row + arow0) >> 3) & 1)) << 4);
+        if (ATR) {  // lane = 16 G + 4 q + pp: group G reads chunk parity G & 1, rows 8 (G >> 1) + q (then + 4), columns 4 pp ..
+          const int G = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3, kg = G >> 1;
+          a_off[i] = (wm * TM + i) * 1024 + (8 * kg + q) * 64 + (G & 1) * 32 + ((((pp >> 1) ^ kg) & 1) << 4) + ((pp & 1) << 3);
+        }
       }
 #pragma unroll
       for (int j = 0; j < TN; j++) {
@@ -358,7 +374,19 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
 #pragma unroll
       for (int j = 0; j < TN; j++) b[q][j] = *reinterpret_cast<const V8 *>(st + q * BN * 32 + b_off[j]);
 #pragma unroll
-      for (int i = 0; i < TM; i++) a[q][i] = *reinterpret_cast<const V8 *>(st + q * BM * 32 + a_off[i]);
+      for (int i = 0; i < TM; i++) {
+        if constexpr (ATR) {
+          typedef __attribute__((address_space(3))) s16x4 *lds4;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(st + q * BM * 32 + a_off[i]));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(st + q * BM * 32 + a_off[i] + 256));
+          union { s16x4 h[2]; V8 v; } u;
+          u.h[0] = lo;
+          u.h[1] = hi;
+          a[q][i] = u.v;
+        } else {
+          a[q][i] = *reinterpret_cast<const V8 *>(st + q * BM * 32 + a_off[i]);
+        }
+      }
     }
     if (--cs_left == 0) next_compute_segment();  // (the NEXT read belongs to the next segment: its rows may swap other halves)
   };
@@ -462,20 +490,20 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
     }
 }
 
-template <int NP, int WM, int WN, int TM, int TN, bool DB = false>
+template <int NP, int WM, int WN, int TM, int TN, bool DB = false, bool ATR = false>
 hipError_t launch(const PlanesGemmArgs &a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int NT = WM * WN * 64, PIECES = (NP * BM * 32 + NP * BN * 32) / 16, PPT = (PIECES + NT - 1) / NT;
   constexpr size_t lds = (size_t)kStages * PPT * NT * 16;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void *)planes_gemm_kernel<NP, WM, WN, TM, TN, DB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)planes_gemm_kernel<NP, WM, WN, TM, TN, DB, ATR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     attr_done = true;
   }
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
   const int nblk = ntm * ntn * (a.ntap > 1 ? a.ntap : 1) * (a.ksplit > 1 ? a.ksplit : 1);
-  hipLaunchKernelGGL((planes_gemm_kernel<NP, WM, WN, TM, TN, DB>), dim3(nblk), dim3(WM * WN * 64), lds, s, a, ntm, ntn);
+  hipLaunchKernelGGL((planes_gemm_kernel<NP, WM, WN, TM, TN, DB, ATR>), dim3(nblk), dim3(WM * WN * 64), lds, s, a, ntm, ntn);
   return hipGetLastError();
 }
 
@@ -502,6 +530,7 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
   if (x.rows <= 0 || x.cols <= 0 || (!a.P && !a.PT)) return hipSuccess;
   if (a.np != 2 && a.np != 3) return hipErrorInvalidValue;
   const long long nkb = planes_kblocks(x.cols), nkbt = planes_t_kblocks(x.rows);
+  ProfHbmRange prof(7, (double)x.rows * x.cols * (4.0 + 2.0 * a.np * ((a.P ? 1 : 0) + (a.PT ? 1 : 0))), s);  // the matrix read once, each layout written once
   const bool vec4 = (reinterpret_cast<uintptr_t>(x.data) & 15) == 0 && x.stride % 4 == 0;
   if (a.np == 2) {
     if (!a.scale || !a.sumsq_ws) return hipErrorInvalidValue;
@@ -539,6 +568,16 @@ hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s) {
   //   256 x 128 tile, 4 x 2 waves of 64 x 64: 201 / 150.  Four waves of 64 rows x the tile's width: 194 / 121 (one wave per SIMD
   //   leaves every LDS / barrier wait exposed); fragments double-buffered in registers: no gain, spills on the wide tiles.
   const int bn = planes_gemm_tile_cols(a.N);
+  if (a.a_rows_as_k) {  // the A operand through transposing LDS reads (weight gradients from row-major planes)
+    if (a.np == 3) {
+      if (bn == 160) return launch<3, 8, 1, 1, 5, false, true>(a, s);
+      if (bn == 256) return launch<3, 4, 2, 2, 4, false, true>(a, s);
+      return launch<3, 4, 2, 2, 2, false, true>(a, s);
+    }
+    if (bn == 160) return launch<2, 8, 1, 1, 5, false, true>(a, s);
+    if (bn == 256) return launch<2, 4, 2, 2, 4, false, true>(a, s);
+    return launch<2, 4, 2, 2, 2, false, true>(a, s);
+  }
   if (a.np == 3) {
     if (bn == 160) return launch<3, 8, 1, 1, 5>(a, s);
     if (bn == 256) return launch<3, 4, 2, 2, 4>(a, s);
