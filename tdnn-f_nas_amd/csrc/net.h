@@ -81,6 +81,7 @@ struct tdnnf_net {
     void *P = nullptr, *PT = nullptr;
     size_t bytesP = 0, bytesPT = 0;
     float *scale = nullptr;
+    long long last[5] = {-1, -1, -1, -1, -1};  // (rows, cols, lead, R, layouts) of the last split: the same again leaves the zero rows as they are
   };
   std::map<const float *, PlaneSlot> plane_slots;
   std::vector<tdnnf::PlanesOperand> pw;  // by component

@@ -1291,7 +1291,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (!pl_on) return TDNNF_OK;
     auto it = n->plane_slots.find(m.data);
     if (it == n->plane_slots.end() || m.rows <= 0) return TDNNF_OK;  // (no slot: the GEMM runs its own kernels)
-    const tdnnf_net::PlaneSlot &ps = it->second;
+    tdnnf_net::PlaneSlot &ps = it->second;
     // a wide matrix (the 1536- / 6034-column activations and derivatives) is the tile-row operand of its weight gradient, which reads
     // the ROW-MAJOR planes through transposing LDS loads: no planes of the transpose for those
     if (m.cols >= 1024) want = kP;
@@ -1306,6 +1306,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const long long kb_alloc = (planes_kblocks(m.cols) + 15) / 16 * 16;
     TDNNF_REQUIRE(planes_bytes(np, a.R, kb_alloc) <= ps.bytesP && planes_bytes(np, a.Rt, planes_t_kblocks(m.rows)) <= ps.bytesPT,
                   "net_forward_backward: plane slot too small for a %d x %d matrix", m.rows, m.cols);
+    const long long cfg5[5] = {m.rows, m.cols, lead, a.R, want};
+    a.pads_done = memcmp(cfg5, ps.last, sizeof(cfg5)) == 0;
+    memcpy(ps.last, cfg5, sizeof(cfg5));
     TDNNF_HIP(planes_split(a, st));
     o->base = m.data; o->rows = m.rows; o->cols = m.cols; o->ld = m.stride; o->np = np;
     o->P = a.P; o->R = a.R; o->lead = lead; o->kb_alloc = kb_alloc; o->PT = a.PT; o->Rt = a.Rt; o->scale = np == 2 ? ps.scale : nullptr;
@@ -1321,6 +1324,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       a.np = np; a.x = MatView{Wp(n, (int)i), o.rows, o.cols, o.cols}; a.lead = 0; a.R = o.R; a.P = const_cast<void *>(o.P); a.Rt = o.Rt;
       a.PT = const_cast<void *>(o.PT); a.scale = const_cast<float *>(o.scale); a.sumsq_ws = n->planes_ws;
       if (np != 2) o.scale = nullptr;
+      a.pads_done = n->fb_count > 1;  // (fixed shapes: the zero rows written by the first step stay)
       TDNNF_HIP(planes_split(a, s));
     }
   }

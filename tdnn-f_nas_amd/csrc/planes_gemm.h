@@ -83,6 +83,9 @@ struct PlanesSplitArgs {
   // np == 2: [s, 1 / s] (device, 2 floats) receives the scale; `sumsq_ws` (device, planes_sumsq_ws_bytes()) is scratch of the norm pass
   float *scale;
   void *sumsq_ws;
+  // the zero rows around the matrix are in place already (the buffers were last split with exactly these dimensions, or were zeroed and
+  // never held another shape): skip the pad launches
+  bool pads_done = false;
 };
 size_t planes_sumsq_ws_bytes();
 hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s);

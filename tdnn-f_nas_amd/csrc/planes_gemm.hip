@@ -94,18 +94,23 @@ __global__ __launch_bounds__(256) void planes_sumsq_kernel(MatView x, double *pa
   __syncthreads();
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
-// the same with 16-byte reads (rows and base 16-byte aligned, cols % 4 == 0): a thread owns float4 columns
+// the same with 16-byte reads (rows and base 16-byte aligned): a thread owns float4 columns, a row's last few columns one by one
 __global__ __launch_bounds__(256) void planes_sumsq4_kernel(MatView x, double *partial) {
   __shared__ double red[4];
-  const int c4 = x.cols >> 2;
+  const int c4 = (x.cols + 3) >> 2;
   const long long total = (long long)x.rows * c4;
   double acc = 0;
   float run = 0.f;
   int cnt = 0;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int r = (int)(e / c4), c = (int)(e % c4);
-    const float4 v = *reinterpret_cast<const float4 *>(x.data + (long long)r * x.stride + 4 * c);
-    run += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    const float *src = x.data + (long long)r * x.stride + 4 * c;
+    if (4 * c + 3 < x.cols) {
+      const float4 v = *reinterpret_cast<const float4 *>(src);
+      run += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    } else {
+      for (int j = 0; 4 * c + j < x.cols; j++) run += src[j] * src[j];
+    }
     if (++cnt == 16) {
       acc += run;
       run = 0.f;
@@ -534,13 +539,13 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
   const bool vec4 = (reinterpret_cast<uintptr_t>(x.data) & 15) == 0 && x.stride % 4 == 0;
   if (a.np == 2) {
     if (!a.scale || !a.sumsq_ws) return hipErrorInvalidValue;
-    if (vec4 && x.cols % 4 == 0) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
+    if (vec4) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
     else hipLaunchKernelGGL(planes_sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
     hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)a.sumsq_ws, kSumsqBlocks, (double)x.rows * x.cols, a.scale);
   }
-  if (a.P && a.R > x.rows)
+  if (a.P && a.R > x.rows && !a.pads_done)
     hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(nkb * a.np * (a.R - x.rows) * 2, 256)), dim3(256), 0, s, a.P, nkb * a.np, a.R, a.lead, (long long)x.rows);
-  if (a.PT && a.Rt > x.cols)
+  if (a.PT && a.Rt > x.cols && !a.pads_done)
     hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(nkbt * a.np * (a.Rt - x.cols) * 2, 256)), dim3(256), 0, s, a.PT, nkbt * a.np, a.Rt, 0, (long long)x.cols);
   const dim3 grid((unsigned)((x.rows + 63) / 64), (unsigned)((x.cols + 63) / 64));
   if (a.np == 2)
