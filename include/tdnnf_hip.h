@@ -503,7 +503,7 @@ int tdnnf_net_set_temperature_proportion(tdnnf_net *, float proportion);
      num_planes 3 ("bf16x6", gemm_precision 2): x = p0 + p1 + p2, three bf16 planes, the six products p_i q_j with i + j <= 2;
      num_planes 2 ("f16x3",  gemm_precision 3): x s = h + l, two f16 planes of the operand scaled by the power of two s that its
        Frobenius norm allows (s ||X||_F <= 65504: no element can overflow, whatever the data), the three products h h', h l', l h';
-       the split writes [s, 1 / s] to scale_dev and the GEMM multiplies its result by 1 / (s s').
+       the split writes the record [s, 1 / s, ||X||_F] (room for 4 floats) to scale_dev and the GEMM multiplies its result by 1 / (s s').
    Both accumulate in f32.  tdnnf_planes_split writes the row-major planes (k = column; `planes`, rows_total = lead_rows + rows +
    zero tail rows) and / or the planes of the TRANSPOSE (k = row; `planes_t`, t_rows_total >= cols), for the products that reduce over
    the matrix's rows.  Sizes: tdnnf_planes_bytes(num_planes, rows_total, k_blocks) with k_blocks = ceil(cols / 16), resp.

@@ -144,6 +144,21 @@ struct BnSyncScope {
   ~BnSyncScope();
 };
 
+// While one of these is installed, the BatchNorm finalize launches of the calling thread -- the forward statistics (memo rows 0-2) and the
+// backward terms of the fused BatchNorm / ReLU sweep -- also write, per block of kFinCols columns, an UPPER BOUND of the squared Frobenius
+// norm of what the pass behind them produces (forward: z = (x - mean) scale, whose column sums of squares are N scale^2 var exactly;
+// backward: the ReLU's input derivative, bounded by the column sums of squares of its output derivative, which the finalize forms
+// anyway, plus the self-repair term).  planes_split takes its scale from such a bound instead of a pass over the matrix.
+// buf: >= finalize_grid(D) doubles; *blocks receives how many were written (0: none -- test-mode BatchNorm has no such bound).
+struct FroBoundScope {
+  double *prev_buf;
+  int *prev_blocks;
+  FroBoundScope(double *buf, int *blocks);
+  ~FroBoundScope();
+};
+double *fro_bound_buf();
+int *fro_bound_blocks();
+
 // two-stage deterministic column reduction (colreduce.hip)
 struct ColReducePlan {
   int chunks, rows_per_chunk;

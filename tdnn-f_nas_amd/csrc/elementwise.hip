@@ -132,32 +132,45 @@ namespace {
 // from there (all-reduced over the ranks) instead of from the partial rows, and N is the global row count.
 __global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(const float *partial, int chunks, int D, int N, float epsilon,
                                                                       float target_rms, float *memo, double *sums_out = nullptr,
-                                                                      const double *sums_in = nullptr, double *store = nullptr, int store_frames = 0) {
+                                                                      const double *sums_in = nullptr, double *store = nullptr, int store_frames = 0,
+                                                                      double *fro2 = nullptr) {
   __shared__ double red[2 * kFinLanes * (kFinCols + 1)];
   const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
   double q[2];
   if (!sums_in) finalize_sums<2, double>(partial, chunks, chunks, D, 2, q, red);
-  if (threadIdx.x >= kFinCols || d >= D) return;
+  const bool own = threadIdx.x < kFinCols && d < D;
   if (sums_out) {
-    sums_out[d] = q[0];
-    sums_out[D + d] = q[1];
+    if (own) {
+      sums_out[d] = q[0];
+      sums_out[D + d] = q[1];
+    }
     return;
   }
-  if (sums_in) {
-    q[0] = sums_in[d];
-    q[1] = sums_in[D + d];
+  double bound = 0;  // sum over rows of z^2 for this column: N scale^2 var (store_frames = this rank's rows)
+  if (own) {
+    if (sums_in) {
+      q[0] = sums_in[d];
+      q[1] = sums_in[D + d];
+    }
+    const float mean = (float)(q[0] / N), uvar = (float)(q[1] / N);
+    const float var_scale = 1.0f / (target_rms * target_rms);
+    float v = var_scale * uvar - var_scale * mean * mean;
+    v = floor_keep_nan(v, 0.f) + var_scale * epsilon;
+    memo[d] = mean;
+    memo[D + d] = uvar;
+    const float sc = 1.0f / sqrtf(v);
+    memo[2 * D + d] = sc;
+    const double var = (double)uvar - (double)mean * mean;
+    bound = (double)N * sc * sc * (var > 0 ? var : 0.0);
+    if (store) {  // BatchNormComponent::StoreStats (nnet-normalize-component.cc:551-589) in the same launch: count += I, sum += I mean, sumsq += I uvar
+      if (d == 0) store[0] += (double)store_frames;
+      store[1 + d] += (double)store_frames * mean;
+      store[1 + D + d] += (double)store_frames * uvar;
+    }
   }
-  const float mean = (float)(q[0] / N), uvar = (float)(q[1] / N);
-  const float var_scale = 1.0f / (target_rms * target_rms);
-  float v = var_scale * uvar - var_scale * mean * mean;
-  v = floor_keep_nan(v, 0.f) + var_scale * epsilon;
-  memo[d] = mean;
-  memo[D + d] = uvar;
-  memo[2 * D + d] = 1.0f / sqrtf(v);
-  if (store) {  // BatchNormComponent::StoreStats (nnet-normalize-component.cc:551-589) in the same launch: count += I, sum += I mean, sumsq += I uvar
-    if (d == 0) store[0] += (double)store_frames;
-    store[1 + d] += (double)store_frames * mean;
-    store[1 + D + d] += (double)store_frames * uvar;
+  if (fro2 && threadIdx.x < 64) {  // (kFinCols = 32 columns live in the first wave; the other lanes carry zeros)
+    for (int o = 16; o > 0; o >>= 1) bound += __shfl_xor(bound, o, 32);
+    if (threadIdx.x == 0) fro2[blockIdx.x] = bound;
   }
 }
 // memo rows 3 var_deriv_mod, 4 temp (:520-526)
@@ -712,6 +725,19 @@ __global__ void axpy_kernel(const float *x, float a, float *y, size_t n) {
 }  // namespace tdnnf
 
 namespace tdnnf {
+static thread_local double *g_fro_buf = nullptr;
+static thread_local int *g_fro_blocks = nullptr;
+FroBoundScope::FroBoundScope(double *buf, int *blocks) : prev_buf(g_fro_buf), prev_blocks(g_fro_blocks) {
+  g_fro_buf = buf;
+  g_fro_blocks = blocks;
+  if (blocks) *blocks = 0;
+}
+FroBoundScope::~FroBoundScope() {
+  g_fro_buf = prev_buf;
+  g_fro_blocks = prev_blocks;
+}
+double *fro_bound_buf() { return g_fro_buf; }
+int *fro_bound_blocks() { return g_fro_blocks; }
 static thread_local BnSync *g_bn_sync = nullptr;
 BnSync *bn_sync_current() { return g_bn_sync; }
 BnSyncScope::BnSyncScope(BnSync *b) : prev(g_bn_sync) { g_bn_sync = b; }
@@ -721,16 +747,18 @@ BnSyncScope::~BnSyncScope() { g_bn_sync = prev; }
 static hipError_t bn_fwd_finalize(const float *partial, int chunks, int rows, int cols, float epsilon, float target_rms, float *memo, hipStream_t s,
                                   double *store = nullptr) {
   BnSync *sy = bn_sync_current();
+  double *fro2 = fro_bound_buf();
+  if (fro2 && fro_bound_blocks()) *fro_bound_blocks() = (int)finalize_grid(cols);
   if (!sy) {
     hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo,
-                       (double *)nullptr, (const double *)nullptr, store, rows);
+                       (double *)nullptr, (const double *)nullptr, store, rows, fro2);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows, epsilon, target_rms, memo, sy->buf,
                      (const double *)nullptr);
   if (sy->fn(sy->ctx, sy->buf, 2LL * cols, (tdnnf_stream)s)) return hipErrorUnknown;
   hipLaunchKernelGGL(bn_fwd_finalize_kernel, dim3(finalize_grid(cols)), dim3(kFinThreads), 0, s, partial, chunks, cols, rows * sy->world, epsilon, target_rms, memo,
-                     (double *)nullptr, (const double *)sy->buf, store, rows);
+                     (double *)nullptr, (const double *)sy->buf, store, rows, fro2);  // (the bound then covers all ranks' rows: still an upper bound of this rank's)
   return hipGetLastError();
 }
 static hipError_t bn_bwd_finalize(const float *partial, int chunks, int rows, int D, float target_rms, float *memo, hipStream_t s) {

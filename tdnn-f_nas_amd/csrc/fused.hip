@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(MatView x, MatV
 // come from there (the first three all-reduced over the ranks), N is the GLOBAL row count and N_local this rank's (ReLU statistics).
 __global__ __launch_bounds__(kFinThreads) void bn_relu_bwd_finalize_kernel(const float *partial, int chunks, int D, int N, float target_rms,
                                                                            float *memo, double *relu_stats, int test_mode, double *oderiv,
-                                                                           double *sums_out = nullptr, const double *sums_in = nullptr, int N_local = 0) {
+                                                                           double *sums_out = nullptr, const double *sums_in = nullptr, int N_local = 0,
+                                                                           double *fro2 = nullptr, float repair_abs = 0.f) {
   __shared__ double red[5 * kFinLanes * (kFinCols + 1)];
   const int d = blockIdx.x * kFinCols + (threadIdx.x & (kFinCols - 1));
   double q[5];
@@ -138,27 +139,35 @@ __global__ __launch_bounds__(kFinThreads) void bn_relu_bwd_finalize_kernel(const
   }
   if (relu_stats && blockIdx.x == 0 && threadIdx.x == 0) relu_stats[0] += (double)(sums_in ? N_local : N);
   if (oderiv && blockIdx.x == 0 && threadIdx.x == 0) oderiv[0] += (double)N;
-  if (threadIdx.x >= kFinCols || d >= D) return;
-  if (sums_in)
-    for (int k = 0; k < nq; k++) q[k] = sums_in[(size_t)k * D + d];
-  const float coeff = -1.0f / (target_rms * target_rms * N);
-  // test mode (BatchNormTestComponent::Backprop, nnet-normalize-component.cc:879-922): in_deriv = out_deriv * scale
-  const float sc = memo[2 * D + d];
-  const float vdm = test_mode ? 0.f : (float)(coeff * q[0]) * sc;
-  memo[3 * D + d] = vdm;
-  memo[4 * D + d] = test_mode ? 0.f : (float)(-q[1] / N);
-  if (relu_stats) {
-    relu_stats[1 + d] += q[3];
-    relu_stats[1 + D + d] += q[4];
-  }
-  if (oderiv) {
-    const double sc2 = (double)sc * sc;
-    double v = sc2 * (test_mode ? q[2] : q[2] - q[1] * q[1] / N);
-    if (!test_mode) {
-      const double var = (double)memo[D + d] - (double)memo[d] * memo[d];  // uvar - mean^2 (memo rows 1, 0 of the forward pass)
-      v += 2.0 * vdm * sc * q[0] + (double)vdm * vdm * (double)N * (var > 0 ? var : 0.0) * sc2;
+  double bound = 0;  // upper bound of sum_r d_aff^2 for this column: d_aff = relu'(x) dr + repair, |relu'| <= 1
+  if (threadIdx.x < kFinCols && d < D) {
+    if (sums_in)
+      for (int k = 0; k < nq; k++) q[k] = sums_in[(size_t)k * D + d];
+    const float coeff = -1.0f / (target_rms * target_rms * N);
+    // test mode (BatchNormTestComponent::Backprop, nnet-normalize-component.cc:879-922): in_deriv = out_deriv * scale
+    const float sc = memo[2 * D + d];
+    const float vdm = test_mode ? 0.f : (float)(coeff * q[0]) * sc;
+    memo[3 * D + d] = vdm;
+    memo[4 * D + d] = test_mode ? 0.f : (float)(-q[1] / N);
+    if (relu_stats) {
+      relu_stats[1 + d] += q[3];
+      relu_stats[1 + D + d] += q[4];
     }
-    oderiv[1 + d] += v > 0 ? v : 0.0;
+    if (oderiv || fro2) {
+      const double sc2 = (double)sc * sc;
+      double v = sc2 * (test_mode ? q[2] : q[2] - q[1] * q[1] / N);
+      if (!test_mode) {
+        const double var = (double)memo[D + d] - (double)memo[d] * memo[d];  // uvar - mean^2 (memo rows 1, 0 of the forward pass)
+        v += 2.0 * vdm * sc * q[0] + (double)vdm * vdm * (double)N * (var > 0 ? var : 0.0) * sc2;
+      }
+      if (oderiv) oderiv[1 + d] += v > 0 ? v : 0.0;
+      const double nr = sqrt(v > 0 ? v : 0.0) * 1.0001 + sqrt((double)N) * repair_abs;  // (a hair of slack for the rounding of v itself)
+      bound = nr * nr;
+    }
+  }
+  if (fro2 && threadIdx.x < 64) {
+    for (int o = 16; o > 0; o >>= 1) bound += __shfl_xor(bound, o, 32);
+    if (threadIdx.x == 0) fro2[blockIdx.x] = bound;
   }
 }
 
@@ -484,16 +493,20 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     if (vec) hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<4, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
     else hipLaunchKernelGGL((bn_relu_bwd_reduce_kernel<1, false>), grid, block, 0, s, x, dz, memo, memo + 2 * D, pl.rows_per_chunk, pl.chunks, partial, mask, B);
   }
+  double *fro2 = fro_bound_buf();
+  if (fro2 && fro_bound_blocks()) *fro_bound_blocks() = (int)finalize_grid(D);
+  const float repair_abs = self_repair ? 2.0f * fabsf(self_repair_scale) : 0.f;  // |repair term| <= self_repair_scale / 0.5
   if (BnSync *sy = bn_test_mode ? nullptr : bn_sync_current()) {
     // [sum z dz, sum dz, sum dz^2] over all ranks' rows; the ReLU's value / derivative sums (rows 3, 4) stay this rank's
     hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
                        store_relu_stats ? relu_stats : (double *)nullptr, 0, (double *)nullptr, sy->buf, (const double *)nullptr, 0);
     if (sy->fn(sy->ctx, sy->buf, 3LL * D, (tdnnf_stream)s)) return hipErrorUnknown;
     hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows * sy->world, target_rms, memo,
-                       store_relu_stats ? relu_stats : (double *)nullptr, 0, oderiv_stats, (double *)nullptr, (const double *)sy->buf, x.rows);
+                       store_relu_stats ? relu_stats : (double *)nullptr, 0, oderiv_stats, (double *)nullptr, (const double *)sy->buf, x.rows, fro2, repair_abs);
   } else {
     hipLaunchKernelGGL(bn_relu_bwd_finalize_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, partial, pl.chunks, D, x.rows, target_rms, memo,
-                       store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0, oderiv_stats);
+                       store_relu_stats ? relu_stats : (double *)nullptr, bn_test_mode ? 1 : 0, oderiv_stats, (double *)nullptr, (const double *)nullptr, 0, fro2,
+                       repair_abs);
   }
   const double *rep = self_repair ? relu_stats : nullptr;
   if (ng) {

@@ -400,6 +400,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->plane_slots.clear();
   n->pw.assign(n->comps.size(), PlanesOperand());
   n->planes_ws = nullptr;
+  n->fro_buf = nullptr;
   if (n->planes_np) {
     const int np = n->planes_np;
     int lead_cap = 0;  // the largest row shift of a backward-data view (taps of rho == 1 layers)
@@ -437,6 +438,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     slot(n->d_small, small_rows, small_cols, true);
     slot(n->d_small2, small_rows, small_cols, true);
     n->planes_ws = A.take<char>(planes_sumsq_ws_bytes() + 64);
+    n->fro_buf = A.take<double>(finalize_grid(std::max(Hd, S)) + 8);
     // the weight matrices: row-major planes (forward: one row per output, k contiguous) and transposed planes (backward-data)
     for (size_t i = 0; i < n->comps.size(); i++) {
       const CompDesc &cd = n->comps[i];
@@ -1286,7 +1288,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   const bool pl_on = np != 0 && !n->wg_on;
   // plane operands: split a matrix into its slot and describe it
   enum { kP = 1, kT = 2 };
-  auto split = [&](const tdnnf_mat &m, int lead, int want, PlanesOperand *o, hipStream_t st) -> int {
+  // (optional) norm bound a BatchNorm finalize launch left in n->fro_buf: blocks > 0 -> the split takes its scale from it (planes_gemm.h)
+  struct FroBound {
+    int blocks = 0;
+    float mul = 1.0f, add_coef = 0.0f;
+    const float *add_rec = nullptr;
+  };
+  auto split = [&](const tdnnf_mat &m, int lead, int want, PlanesOperand *o, hipStream_t st, const FroBound &fb = FroBound()) -> int {
     *o = PlanesOperand();
     if (!pl_on) return TDNNF_OK;
     auto it = n->plane_slots.find(m.data);
@@ -1297,6 +1305,9 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (m.cols >= 1024) want = kP;
     PlanesSplitArgs a;
     a.np = np; a.x = view(&m); a.lead = lead; a.scale = ps.scale; a.sumsq_ws = n->planes_ws;
+    if (np == 2 && fb.blocks > 0 && (fb.add_coef == 0.f || fb.add_rec)) {
+      a.fro2_bound = n->fro_buf; a.fro2_blocks = fb.blocks; a.fro_mul = fb.mul; a.add_coef = fb.add_coef; a.add_rec = fb.add_rec;
+    }
     lead = (lead + 15) & ~15;  // (a weight gradient reads the row-major planes in K steps of 16 rows: the matrix starts on one)
     a.lead = lead;
     a.R = planes_rows_padded((long long)2 * lead + m.rows + 256);
@@ -1372,10 +1383,16 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   std::vector<PlanesOperand> po_in(n->layers.size()), po_lin(n->layers.size());
   PlanesOperand po_lda, po_top, po_pl, po_b1[2], po_b2[2];
   CK(split(lda_out, 0, kP | kT, &po_lda, s));
+  // the norm bound of the matrix the next bn_apply_bypass writes (= the next layer's input): from the BatchNorm finalize inside
+  // affine_relu_bn_stats; carried to the split at the top of the next layer
+  FroBound fb_next;
+  const float mask_max = drop ? 1.0f + 2.0f * n->dropout_proportion : 1.0f;
   {
     PlanesHintScope ph(hint_of(po_lda), wplanes(n->tdnn1.comp));
+    FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_next.blocks);
     CK(affine_relu_bn_stats(n, &ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, &t1r, n->t1_bn_memo, n->t1_bn_stats, s));
   }
+  fb_next.mul = mask_max;
   TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, ldpad(Hd), none, 0.f, view(&t1b), s, mask_of(0), B));
   float *prev = n->t1_bn;
   int layer_no = 0;
@@ -1400,7 +1417,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     ProfFlopsScale taps_active(L.lin.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && L.lin.K > 2 ? 2.0 / L.lin.K : 1.0);
     // (DARTS .linear: bias present but offsets[1] < 0 -> out is zeroed and the bias never added, :237-240)
     const bool use_pl = pl_on && !L.lin.darts;  // (tap coefficients: the f32 kernels)
-    if (use_pl) CK(split(in, 0, kP | kT, &po_in[layer_no - 1], s));  // row-major planes now, the transposed ones for the weight gradient
+    if (use_pl) CK(split(in, 0, kP | kT, &po_in[layer_no - 1], s, fb_next));  // (also the tile-row operand of this layer's weight gradient)
+    fb_next = FroBound();
     {
       PlanesHintScope ph(hint_of(po_in[layer_no - 1]), wplanes(L.lin.comp));
       CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, lin_eff, 2, &lin, s));
@@ -1422,8 +1440,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (use_pl && !L.perm && L.c_arch < 0) CK(split(lin, 0, kP | kT, &po_lin[layer_no - 1], s));
     {
       PlanesHintScope ph(hint_of(po_lin[layer_no - 1]), wplanes(L.aff.comp));
+      FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_next.blocks);
       CK(affine_relu_bn_stats(n, &L.aff.ix, &aff_in, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, Bp(n, L.aff.comp), aff_eff, &relu, L.bn_memo, L.bn_stats, s));
     }
+    // noop = mask * batchnorm(relu) + bypass_scale * (rows of the layer input): its norm bound from the two parts
+    fb_next.mul = mask_max;
+    fb_next.add_coef = c.bypass_scale;
+    fb_next.add_rec = po_in[layer_no - 1].base ? po_in[layer_no - 1].scale : nullptr;
+    if (c.bypass_scale != 0.f && !fb_next.add_rec) fb_next.blocks = 0;  // (the input was not split: no bound for the sum)
     // noop = Sum(Scale(bypass, input), dropout(batchnorm(relu)))  in one pass
     tdnnf_mat byp = sub_grid_view(prev, L.gin, L.gout, B, Hd);
     tdnnf_mat x = relu, out = M(L.noop_out, L.aff.rows_out, Hd);
@@ -1436,7 +1460,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   const int No = n->Tout * B;
   tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
-  CK(split(top, 0, kP | kT, &po_top, s));
+  CK(split(top, 0, kP | kT, &po_top, s, fb_next));
   {
     PlanesHintScope ph(hint_of(po_top), wplanes(n->c_prefinal_l));
     CK(tdnnf_affine_propagate(&top, Wp(n, n->c_prefinal_l), Hd, nullptr, S, &pl, s));
@@ -1447,12 +1471,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   for (int h = 0; h < 2; h++) {
     auto &H = n->head[h];
     tdnnf_mat ar = M(H.aff_relu, No, Hd), lo = M(H.lin_out, No, S), b1 = M(H.bn1_out, No, Hd), b2 = M(H.bn2_out, No, S), yh = M(H.y, No, P);
+    FroBound fb_b1;
     {
       PlanesHintScope ph(hint_of(po_pl), wplanes(H.c_affine));
+      FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_b1.blocks);
       CK(affine_relu_bn_stats(n, &ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, &ar, H.bn1_memo, H.bn1_stats, s));
     }
     TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, ldpad(Hd), none, 0.f, view(&b1), s));
-    CK(split(b1, 0, kP | kT, &po_b1[h], s));
+    CK(split(b1, 0, kP | kT, &po_b1[h], s, fb_b1));
     {
       PlanesHintScope ph(hint_of(po_b1[h]), wplanes(H.c_linear));
       CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));
@@ -1822,9 +1848,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_affine_backprop(&d_b2, Wp(n, H.c_linear), Hd, Hd, &d_b1, s));
     }
     CK(capture(hname + ".batchnorm1.deriv", d_b1));
-    CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h));  // dA -> d affine out
+    FroBound fb_d;
+    {
+      FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_d.blocks);
+      CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h));  // dA -> d affine out
+    }
     CK(capture(hname + ".affine.deriv", d_b1));
-    CK(split(d_b1, 0, kP | kT, &po_d, s));
+    CK(split(d_b1, 0, kP | kT, &po_d, s, fb_d));
     {
       PlanesHintScope ph(hint_of(po_d), hint_of(po_pl));
       CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
@@ -1862,6 +1892,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const std::string lname = "tdnnf" + std::to_string(l + 2);
     TraceRange trace_layer(("backward " + lname).c_str());
     CK(capture(lname + ".noop.deriv", d_out));
+    FroBound fb_daff;
     {
       const bool store = coin() || step == 0;
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
@@ -1869,6 +1900,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       NgFuse f;
       const int fuse = out_stats_fuse(L.aff.comp, view(&x), view(&d_out), view(&d_aff), f);
       if (fuse < 0) return TDNNF_EINVAL;
+      FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_daff.blocks);
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
                             view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr,
                             oderiv_of(L.relu_stats, 1 + l)));
@@ -1909,7 +1941,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       return m;
     };
     PlanesOperand po_daff, po_dlin;
-    if (use_pl) CK(split(d_aff, max_off(L.aff), kP | kT, &po_daff, s));
+    if (use_pl) CK(split(d_aff, max_off(L.aff), kP | kT, &po_daff, s, fb_daff));
     {
       PlanesHintScope ph(hint_of(po_daff), hint_of(po_lin[l]));
       CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff, true));
@@ -1958,10 +1990,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     std::swap(d_cur, d_next);
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
-    CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, 0, mask_of(0)));
+    FroBound fb_d;
+    {
+      FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_d.blocks);
+      CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, 0, mask_of(0)));
+    }
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
     PlanesOperand po_d;
-    CK(split(d_aff, 0, kT, &po_d, s));
+    CK(split(d_aff, 0, kT, &po_d, s, fb_d));
     PlanesHintScope ph(hint_of(po_d), hint_of(po_lda));
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }

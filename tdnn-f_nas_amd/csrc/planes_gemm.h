@@ -80,9 +80,16 @@ struct PlanesSplitArgs {
   // transposed planes (k = row), null to skip
   void *PT;
   long long Rt;
-  // np == 2: [s, 1 / s] (device, 2 floats) receives the scale; `sumsq_ws` (device, planes_sumsq_ws_bytes()) is scratch of the norm pass
+  // np == 2: [s, 1 / s, ||X||_F or its bound] (device, 3 floats) receives the scale record; `sumsq_ws` (device, planes_sumsq_ws_bytes()) is scratch of the norm pass
   float *scale;
   void *sumsq_ws;
+  // np == 2, optional: the scale from an UPPER BOUND of the matrix's Frobenius norm instead of a pass over it (common.h FroBoundScope):
+  //   ||X||_F <= fro_mul * sqrt(sum of fro2_bound[0 .. fro2_blocks)) + add_coef * add_rec[2]
+  // (add_rec: the scale record [s, 1 / s, norm bound] of a matrix added into this one with coefficient add_coef: the bypass sum).
+  const double *fro2_bound = nullptr;
+  int fro2_blocks = 0;
+  float fro_mul = 1.0f, add_coef = 0.0f;
+  const float *add_rec = nullptr;
   // the zero rows around the matrix are in place already (the buffers were last split with exactly these dimensions, or were zeroed and
   // never held another shape): skip the pad launches
   bool pads_done = false;

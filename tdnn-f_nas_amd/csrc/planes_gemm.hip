@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256) void planes_sumsq4_kernel(MatView x, double *p
   if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 // scale[0] = s = 2^e, the largest power of two with s ||X||_F <= 65504 (every |x| <= ||X||_F: nothing overflows) and s rms(X) <= 64;
-// scale[1] = 1 / s.  An all-zero matrix gets s = 1; a NaN / Inf norm gives a NaN scale (the product is then NaN, as in f32).
-__global__ void planes_scale_kernel(const double *partial, int nb, double numel, float *scale) {
+// scale[1] = 1 / s; scale[2] = the norm (or the upper bound it was taken from).  An all-zero matrix gets s = 1; a NaN / Inf norm gives a
+// NaN scale (the product is then NaN, as in f32).  With `mul` / `add_rec`: sqrt(sum) is only part of a bound, mul sqrt(sum) + add_coef add_rec[2].
+__global__ void planes_scale_kernel(const double *partial, int nb, double numel, float *scale, float mul, float add_coef, const float *add_rec) {
   __shared__ double red[256];
   double a = 0;
   for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
@@ -137,11 +138,12 @@ __global__ void planes_scale_kernel(const double *partial, int nb, double numel,
   }
   if (threadIdx.x != 0) return;
   const double sum = red[0];
+  double fro = (double)mul * sqrt(sum) + (add_rec ? (double)add_coef * (double)add_rec[2] : 0.0);
   float s = 1.0f;
-  if (sum != sum || sum > 1.0e300) {
+  if (fro != fro || fro > 1.0e150) {
     s = __int_as_float(0x7fc00000);
-  } else if (sum > 0) {
-    const double fro = sqrt(sum), rms = sqrt(sum / numel);
+  } else if (fro > 0) {
+    const double rms = fro / sqrt(numel);
     int e = (int)floor(log2(65504.0 / fro));
     const int e2 = (int)floor(log2(64.0 / rms));
     if (e2 < e) e = e2;
@@ -151,6 +153,7 @@ __global__ void planes_scale_kernel(const double *partial, int nb, double numel,
   }
   scale[0] = s;
   scale[1] = 1.0f / s;
+  scale[2] = (float)(fro * 1.000001);  // (rounded up: the record may feed the bound of a matrix this one is added into)
 }
 
 // X (rows x cols, ld) -> P16 planes (k = column; `lead` zero rows in front) and / or the planes of the transpose (k = row).
@@ -539,9 +542,13 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
   const bool vec4 = (reinterpret_cast<uintptr_t>(x.data) & 15) == 0 && x.stride % 4 == 0;
   if (a.np == 2) {
     if (!a.scale || !a.sumsq_ws) return hipErrorInvalidValue;
-    if (vec4) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
-    else hipLaunchKernelGGL(planes_sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
-    hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)a.sumsq_ws, kSumsqBlocks, (double)x.rows * x.cols, a.scale);
+    if (a.fro2_bound && a.fro2_blocks > 0) {  // the producer's finalize launch left a bound: no pass over the matrix
+      hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, a.fro2_bound, a.fro2_blocks, (double)x.rows * x.cols, a.scale, a.fro_mul, a.add_coef, a.add_rec);
+    } else {
+      if (vec4) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
+      else hipLaunchKernelGGL(planes_sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
+      hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)a.sumsq_ws, kSumsqBlocks, (double)x.rows * x.cols, a.scale, 1.0f, 0.0f, (const float *)nullptr);
+    }
   }
   if (a.P && a.R > x.rows && !a.pads_done)
     hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(nkb * a.np * (a.R - x.rows) * 2, 256)), dim3(256), 0, s, a.P, nkb * a.np, a.R, a.lead, (long long)x.rows);

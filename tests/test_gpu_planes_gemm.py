@@ -29,7 +29,7 @@ def planes_of(pkg, np_, x, lead=0, tail=0, t_tail=None):
     if t_tail is not None:
         Rt = cols + t_tail
         PT = torch.full((lib.tdnnf_planes_bytes(np_, Rt, ((rows + 63) // 64) * 4) // 2,), float("nan"), dtype=ELEM[np_], device="cuda")
-    scale = torch.zeros(2, device="cuda")
+    scale = torch.zeros(4, device="cuda")
     ws = torch.zeros(lib.tdnnf_planes_split_workspace_bytes() // 4 + 4, device="cuda")
     abi.check(lib.tdnnf_planes_split(np_, abi.pmat(x), lead, R, abi.ptr(P), Rt, abi.ptr(PT) if PT is not None else None, abi.ptr(scale), abi.ptr(ws), abi.stream()))
     return P, R, PT, Rt, scale
@@ -142,10 +142,10 @@ def test_planes_split_layout_and_transposed_planes(pkg):
 
     for np_, tol in ((3, 2.0 ** -23), (2, 2.0 ** -21)):
         P, R, PT, Rt, scale = planes_of(pkg, np_, dev(X), lead, tail, t_tail)
-        s, inv = host(scale)
+        s, inv, fro_rec = host(scale)[:3]
         if np_ == 2:
             fro = np.sqrt((X.astype(np.float64) ** 2).sum())
-            assert s == 2.0 ** np.floor(np.log2(min(65504.0 / fro, 64.0 / (fro / np.sqrt(X.size))))) and inv == 1.0 / s
+            assert s == 2.0 ** np.floor(np.log2(min(65504.0 / fro, 64.0 / (fro / np.sqrt(X.size))))) and inv == 1.0 / s and fro <= fro_rec <= fro * 1.00001
         else:
             s = 1.0
         nkb = (cols + 15) // 16

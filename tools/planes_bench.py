@@ -35,7 +35,7 @@ ELEM = {3: torch.bfloat16, 2: torch.float16}
 def planes(np_, x, lead, R, t_rows=0):
     P = torch.zeros(lib.tdnnf_planes_bytes(np_, R, (x.shape[1] + 15) // 16) // 2, dtype=ELEM[np_], device="cuda")
     PT = torch.zeros(lib.tdnnf_planes_bytes(np_, t_rows, ((x.shape[0] + 63) // 64) * 4) // 2, dtype=ELEM[np_], device="cuda") if t_rows else None
-    scale = torch.zeros(2, device="cuda")
+    scale = torch.zeros(4, device="cuda")
     ws = torch.zeros(lib.tdnnf_planes_split_workspace_bytes() // 4 + 4, device="cuda")
     s = abi.stream()
     fn = lambda: abi.check(lib.tdnnf_planes_split(np_, abi.pmat(x), lead, R, abi.ptr(P), t_rows, abi.ptr(PT) if PT is not None else None, abi.ptr(scale), abi.ptr(ws), s))
