@@ -8,8 +8,16 @@ namespace tdnnf {
 // x / prev / out may be "super row" views (cols > D): runs of D-column rows, each `period` elements apart.
 // mask (may be null): B x D GeneralDropoutComponent mask between the BatchNorm and the bypass sum; row r of a plain view belongs to
 // sequence r % B.
+// planes (may be null): the pass also writes `out` as two scaled f16 planes in the row-major P16 layout of planes_gemm.h (no lead rows;
+// R rows per chunk), with the scale record a bound-based planes_scale_bound() left in `rec` -- the GEMM that reads `out` next then
+// needs no split pass over it.  Plain views only (cols == D, 16-byte aligned).
+struct PlanesSink {
+  void *P;
+  long long R;
+  const float *rec;  // [s, 1 / s, bound] on the device, written before this launch
+};
 hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s,
-                           const float *mask = nullptr, int B = 1);
+                           const float *mask = nullptr, int B = 1, const PlanesSink *planes = nullptr);
 
 // Natural-gradient statistic of the component that produced x, formed by the same sweep (ng.h, ng_external_begin):
 // H (rows x Rp) = d_aff W^T and the per-128-row-block sums of squares of d_aff (`part`, part_cap doubles, unused tail zeroed).

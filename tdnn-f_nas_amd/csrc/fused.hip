@@ -35,11 +35,12 @@ __device__ __forceinline__ void st(float *p, const float (&v)[4], bool vec) {
 
 // out = (x - mean) * scale + bypass * prev   (prev.data may be null).  Views may be "super rows"
 // (cols = k * D): the column parameters repeat with period D.
-template <int VEC>
+template <int VEC, bool PLANES>
 __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const float *mean, const float *scale, int D, int period,
-                                                              MatView prev, float bypass, MatView out, const float *mask, int B) {
+                                                              MatView prev, float bypass, MatView out, const float *mask, int B, PlanesSink pk) {
   const int cv = x.cols / VEC;
   const long long total = (long long)x.rows * cv;
+  const float ps = PLANES ? pk.rec[0] : 1.0f;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
     const int r = (int)(e / cv), c = (int)(e % cv) * VEC, cd = c % period;
     if (cd >= D) continue;  // row padding inside a super row
@@ -56,6 +57,22 @@ __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const f
 #pragma unroll
     for (int j = 0; j < VEC; j++) o[j] = (xv[j] - mu[j]) * sc[j] * mv[j] + bypass * pv[j];
     st(out.data + (long long)r * out.stride + c, o, VEC == 4);
+    if constexpr (PLANES && VEC == 4) {
+      // the same four values as two f16 planes of o * s: columns c .. c + 3 of row r sit in K block c / 16 at k = c % 16 of the row's
+      // 32-byte record, whose halves are swapped when bit 3 of the row is set (planes_gemm.h)
+      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+      h4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float v = o[j] * ps;
+        hi[j] = (_Float16)v;
+        lo[j] = (_Float16)(v - (float)hi[j]);
+      }
+      const int kb = c >> 4, k = c & 15, half = (k >> 3) ^ ((r >> 3) & 1);
+      _Float16 *dst = reinterpret_cast<_Float16 *>(pk.P) + (((long long)kb * 2) * pk.R + r) * 16 + half * 8 + (k & 7);
+      *reinterpret_cast<h4 *>(dst) = hi;
+      *reinterpret_cast<h4 *>(dst + pk.R * 16) = lo;
+    }
   }
 }
 
@@ -430,15 +447,19 @@ __global__ __launch_bounds__(kFinThreads) void colsum_add_kernel(const float *pa
 
 }  // namespace
 
-hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s, const float *mask, int B) {
+hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s, const float *mask, int B,
+                           const PlanesSink *planes) {
   if (x.rows == 0) return hipSuccess;
   // period: a super row (cols > D) is a run of rows of D values, each padded to `period` (the plain rows' stride)
   const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0 &&
                    (!mask || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
   const long long work = (long long)x.rows * (vec ? x.cols / 4 : x.cols);
-  ProfHbmRange prof(4, 4.0 * x.rows * x.cols * (prev.data ? 3.0 : 2.0), s);  // reads x [and the bypass rows], writes out
-  if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
-  else hipLaunchKernelGGL((bn_apply_bypass_kernel<1>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B);
+  if (planes && !(vec && x.cols == D && planes->P && planes->rec)) return hipErrorInvalidValue;
+  ProfHbmRange prof(4, 4.0 * x.rows * x.cols * ((prev.data ? 3.0 : 2.0) + (planes ? 1.0 : 0.0)), s);  // reads x [and the bypass rows], writes out [and its planes]
+  const PlanesSink none{nullptr, 0, nullptr};
+  if (planes) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, true>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, *planes);
+  else if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none);
+  else hipLaunchKernelGGL((bn_apply_bypass_kernel<1, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none);
   return hipGetLastError();
 }
 

@@ -1340,6 +1340,33 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   auto wplanes = [&](int comp) -> const PlanesOperand * { return pl_on && n->pw[comp].P ? &n->pw[comp] : nullptr; };
+  // bn_apply_bypass that ALSO writes its output as f16 planes when the BatchNorm finalize left a norm bound (f16x3, plain views): the
+  // scale record first (from the bound), then one pass writes the f32 matrix and its row-major planes -- the GEMM that reads `out`
+  // next needs no split pass.  *po describes the planes (empty: not fused, the consumer splits).
+  auto bn_apply_planes = [&](const tdnnf_mat &x, const float *memo, const MatView &byp, float bypass, const tdnnf_mat &out, const float *mask, const FroBound &fb,
+                             PlanesOperand *po) -> int {
+    *po = PlanesOperand();
+    auto it = (pl_on && np == 2 && fb.blocks > 0 && (fb.add_coef == 0.f || fb.add_rec) && out.cols == Hd && out.stride == ldpad(Hd)) ? n->plane_slots.find(out.data)
+                                                                                                                                         : n->plane_slots.end();
+    if (it == n->plane_slots.end()) {
+      TDNNF_HIP(bn_apply_bypass(view(&x), memo, Hd, ldpad(Hd), byp, bypass, view(&out), s, mask, B));
+      return TDNNF_OK;
+    }
+    tdnnf_net::PlaneSlot &ps = it->second;
+    const long long R = planes_rows_padded((long long)out.rows + 256), kb_alloc = (planes_kblocks(out.cols) + 15) / 16 * 16;
+    TDNNF_REQUIRE(planes_bytes(np, R, kb_alloc) <= ps.bytesP, "net_forward_backward: plane slot too small for a %d x %d matrix", out.rows, out.cols);
+    TDNNF_HIP(planes_scale_bound(n->fro_buf, fb.blocks, (double)out.rows * out.cols, fb.mul, fb.add_coef, fb.add_rec, ps.scale, s));
+    const long long cfg5[5] = {out.rows, out.cols, 0, R, kP};
+    if (memcmp(cfg5, ps.last, sizeof(cfg5)) != 0 && ps.last[0] >= 0) {  // (the slot last held another shape: zero rows behind the matrix again)
+      TDNNF_HIP(hipMemsetAsync(ps.P, 0, planes_bytes(np, R, kb_alloc), s));
+    }
+    memcpy(ps.last, cfg5, sizeof(cfg5));
+    const PlanesSink sink{ps.P, R, ps.scale};
+    TDNNF_HIP(bn_apply_bypass(view(&x), memo, Hd, ldpad(Hd), byp, bypass, view(&out), s, mask, B, &sink));
+    po->base = out.data; po->rows = out.rows; po->cols = out.cols; po->ld = out.stride; po->np = np;
+    po->P = ps.P; po->R = R; po->lead = 0; po->kb_alloc = kb_alloc; po->scale = ps.scale;
+    return TDNNF_OK;
+  };
   TransposedWeightsScope gemm_wt(n->params, n->paramsT, n->paramsT ? n->num_params : 0);
   if (n->paramsT) {  // split-bf16 backward-data GEMMs read W^T (k-contiguous B operand)
     TransTable tb;
@@ -1393,7 +1420,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(affine_relu_bn_stats(n, &ix1, &lda_out, Wp(n, n->tdnn1.comp), lda_dim, Hd, lda_dim, Bp(n, n->tdnn1.comp), nullptr, &t1r, n->t1_bn_memo, n->t1_bn_stats, s));
   }
   fb_next.mul = mask_max;
-  TDNNF_HIP(bn_apply_bypass(view(&t1r), n->t1_bn_memo, Hd, ldpad(Hd), none, 0.f, view(&t1b), s, mask_of(0), B));
+  PlanesOperand po_next;  // planes of the matrix just written by bn_apply_planes (= the next layer's input), when it wrote them itself
+  CK(bn_apply_planes(t1r, n->t1_bn_memo, none, 0.f, t1b, mask_of(0), fb_next, &po_next));
   float *prev = n->t1_bn;
   int layer_no = 0;
   for (auto &L : n->layers) {
@@ -1417,8 +1445,12 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     ProfFlopsScale taps_active(L.lin.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && L.lin.K > 2 ? 2.0 / L.lin.K : 1.0);
     // (DARTS .linear: bias present but offsets[1] < 0 -> out is zeroed and the bias never added, :237-240)
     const bool use_pl = pl_on && !L.lin.darts;  // (tap coefficients: the f32 kernels)
-    if (use_pl) CK(split(in, 0, kP | kT, &po_in[layer_no - 1], s, fb_next));  // (also the tile-row operand of this layer's weight gradient)
+    if (use_pl) {  // (the planes are also the tile-row operand of this layer's weight gradient)
+      if (po_next.base == in.data && po_next.rows == in.rows) po_in[layer_no - 1] = po_next;
+      else CK(split(in, 0, kP | kT, &po_in[layer_no - 1], s, fb_next));
+    }
     fb_next = FroBound();
+    po_next = PlanesOperand();
     {
       PlanesHintScope ph(hint_of(po_in[layer_no - 1]), wplanes(L.lin.comp));
       CK(tdnnf_tdnn_propagate(&L.lin.ix, &in, Wp(n, L.lin.comp), L.lin.K * Hd, L.bn, Hd, nullptr, lin_eff, 2, &lin, s));
@@ -1455,12 +1487,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       x = tdnnf_mat{L.relu_out, L.gout.n, byp.cols, B * ldpad(Hd)};
       out = tdnnf_mat{L.noop_out, L.gout.n, byp.cols, B * ldpad(Hd)};
     }
-    TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, ldpad(Hd), view(&byp), c.bypass_scale, view(&out), s, mask_of(layer_no), B));
+    if (byp.rows == relu.rows) CK(bn_apply_planes(x, L.bn_memo, view(&byp), c.bypass_scale, out, mask_of(layer_no), fb_next, &po_next));
+    else TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, ldpad(Hd), view(&byp), c.bypass_scale, view(&out), s, mask_of(layer_no), B));
     prev = L.noop_out;
   }
   const int No = n->Tout * B;
   tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
-  CK(split(top, 0, kP | kT, &po_top, s, fb_next));
+  if (po_next.base == top.data && po_next.rows == top.rows) po_top = po_next;
+  else CK(split(top, 0, kP | kT, &po_top, s, fb_next));
   {
     PlanesHintScope ph(hint_of(po_top), wplanes(n->c_prefinal_l));
     CK(tdnnf_affine_propagate(&top, Wp(n, n->c_prefinal_l), Hd, nullptr, S, &pl, s));
@@ -1477,8 +1511,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_b1.blocks);
       CK(affine_relu_bn_stats(n, &ix1, &pl, Wp(n, H.c_affine), S, Hd, S, Bp(n, H.c_affine), nullptr, &ar, H.bn1_memo, H.bn1_stats, s));
     }
-    TDNNF_HIP(bn_apply_bypass(view(&ar), H.bn1_memo, Hd, ldpad(Hd), none, 0.f, view(&b1), s));
-    CK(split(b1, 0, kP | kT, &po_b1[h], s, fb_b1));
+    CK(bn_apply_planes(ar, H.bn1_memo, none, 0.f, b1, nullptr, fb_b1, &po_b1[h]));
+    if (!po_b1[h].base) CK(split(b1, 0, kP | kT, &po_b1[h], s, fb_b1));
     {
       PlanesHintScope ph(hint_of(po_b1[h]), wplanes(H.c_linear));
       CK(tdnnf_affine_propagate(&b1, Wp(n, H.c_linear), Hd, nullptr, S, &lo, s));

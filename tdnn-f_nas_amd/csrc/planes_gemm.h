@@ -95,6 +95,9 @@ struct PlanesSplitArgs {
   bool pads_done = false;
 };
 size_t planes_sumsq_ws_bytes();
+// the scale record [s, 1 / s, bound] of a matrix of `numel` elements from a norm bound alone (PlanesSplitArgs::fro2_bound): for a producer that
+// writes the planes itself (fused.h PlanesSink)
+hipError_t planes_scale_bound(const double *fro2_bound, int blocks, double numel, float mul, float add_coef, const float *add_rec, float *rec, hipStream_t s);
 hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s);
 // tile shape the GEMM uses for an N-column output: the A buffer needs tail >= tile rows beyond the last row read, the B buffer rows padded to the tile's columns
 // ---- routing of the f32 GEMM entry points (rows_gemm / wgrad, gemm_f32.h) onto the plane kernels.

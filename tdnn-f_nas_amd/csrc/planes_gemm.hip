@@ -533,6 +533,11 @@ const PlanesOperand *planes_hint_b() { return g_hint_b; }
 size_t planes_bytes(int np, long long rows_total, long long k_blocks) { return (size_t)(k_blocks * np * rows_total * 32); }
 size_t planes_sumsq_ws_bytes() { return sizeof(double) * kSumsqBlocks; }
 
+hipError_t planes_scale_bound(const double *fro2_bound, int blocks, double numel, float mul, float add_coef, const float *add_rec, float *rec, hipStream_t s) {
+  hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, fro2_bound, blocks, numel, rec, mul, add_coef, add_rec);
+  return hipGetLastError();
+}
+
 hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
   const MatView &x = a.x;
   if (x.rows <= 0 || x.cols <= 0 || (!a.P && !a.PT)) return hipSuccess;
