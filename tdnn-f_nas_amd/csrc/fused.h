@@ -19,6 +19,15 @@ struct PlanesSink {
 hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatView prev, float bypass, MatView out, hipStream_t s,
                            const float *mask = nullptr, int B = 1, const PlanesSink *planes = nullptr);
 
+// where bn_relu_bwd writes the f16 planes of d_aff: the row-major P16 buffer (R rows per chunk, `lead` zero rows in front) and the
+// scale record it fills from the finalize launch's norm bound
+struct BwdPlanes {
+  void *P;
+  long long R;
+  int lead;
+  float *rec;
+};
+
 // Natural-gradient statistic of the component that produced x, formed by the same sweep (ng.h, ng_external_begin):
 // H (rows x Rp) = d_aff W^T and the per-128-row-block sums of squares of d_aff (`part`, part_cap doubles, unused tail zeroed).
 struct NgFuse {
@@ -41,6 +50,8 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
                        // NonlinearComponent::StoreBackpropStats (nnet-component-itf.cc:461-480) for the ReLU: [oderiv_count,
                        // oderiv_sumsq[D]] doubles to add this minibatch's count and column sums of squares of the ReLU's
                        // out_deriv to; null = not this minibatch
-                       double *oderiv_stats = nullptr);
+                       double *oderiv_stats = nullptr,
+                       // d_aff also as two scaled f16 planes (planes_gemm.h), written by the apply pass; needs a FroBoundScope (common.h) around the call
+                       const BwdPlanes *planes = nullptr);
 
 }  // namespace tdnnf

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "fused.h"
 #include "gemm_f32.h"
+#include "planes_gemm.h"
 
 namespace tdnnf {
 namespace {
@@ -31,6 +32,23 @@ __device__ __forceinline__ void ld(const float *p, float (&v)[4], bool vec) {
 __device__ __forceinline__ void st(float *p, const float (&v)[4], bool vec) {
   if (vec) *reinterpret_cast<float4 *>(p) = make_float4(v[0], v[1], v[2], v[3]);
   else p[0] = v[0];
+}
+
+// four consecutive columns c .. c + 3 (c % 4 == 0) of row `ra` of a matrix as two f16 planes of v * s in the P16 layout (planes_gemm.h):
+// K block c / 16, k = c % 16 of the row's 32-byte record, halves swapped when bit 3 of the row is set; `R` rows per chunk
+__device__ __forceinline__ void store_planes4(const PlanesSink &pk, float ps, long long ra, int c, const float (&v)[4]) {
+  typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+  h4 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const float w = v[j] * ps;
+    hi[j] = (_Float16)w;
+    lo[j] = (_Float16)(w - (float)hi[j]);
+  }
+  const int kb = c >> 4, k = c & 15, half = (k >> 3) ^ (int)((ra >> 3) & 1);
+  _Float16 *dst = reinterpret_cast<_Float16 *>(pk.P) + (((long long)kb * 2) * pk.R + ra) * 16 + half * 8 + (k & 7);
+  *reinterpret_cast<h4 *>(dst) = hi;
+  *reinterpret_cast<h4 *>(dst + pk.R * 16) = lo;
 }
 
 // out = (x - mean) * scale + bypass * prev   (prev.data may be null).  Views may be "super rows"
@@ -57,22 +75,7 @@ __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const f
 #pragma unroll
     for (int j = 0; j < VEC; j++) o[j] = (xv[j] - mu[j]) * sc[j] * mv[j] + bypass * pv[j];
     st(out.data + (long long)r * out.stride + c, o, VEC == 4);
-    if constexpr (PLANES && VEC == 4) {
-      // the same four values as two f16 planes of o * s: columns c .. c + 3 of row r sit in K block c / 16 at k = c % 16 of the row's
-      // 32-byte record, whose halves are swapped when bit 3 of the row is set (planes_gemm.h)
-      typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-      h4 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const float v = o[j] * ps;
-        hi[j] = (_Float16)v;
-        lo[j] = (_Float16)(v - (float)hi[j]);
-      }
-      const int kb = c >> 4, k = c & 15, half = (k >> 3) ^ ((r >> 3) & 1);
-      _Float16 *dst = reinterpret_cast<_Float16 *>(pk.P) + (((long long)kb * 2) * pk.R + r) * 16 + half * 8 + (k & 7);
-      *reinterpret_cast<h4 *>(dst) = hi;
-      *reinterpret_cast<h4 *>(dst + pk.R * 16) = lo;
-    }
+    if constexpr (PLANES && VEC == 4) store_planes4(pk, ps, r, c, o);  // the same four values as two f16 planes of o * s (no lead rows)
   }
 }
 
@@ -190,10 +193,12 @@ __global__ __launch_bounds__(kFinThreads) void bn_relu_bwd_finalize_kernel(const
 
 // d_aff = relu'(x) * [ (dz + temp) * scale + z * vdm ] + repair[col];  partial[chunk][col] = column sums of d_aff.
 // repair_stats (may be null): ReLU statistics deciding the self-repair term (nnet-simple-component.cc:1028-1073).
-template <int VEC>
+template <int VEC, bool PLANES>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatView dz, const float *memo, int D,
                                                                 const double *repair_stats, float self_repair_scale,
-                                                                int rows_per_chunk, int chunks, MatView d_aff, float *partial, const float *mask, int B) {
+                                                                int rows_per_chunk, int chunks, MatView d_aff, float *partial, const float *mask, int B,
+                                                                PlanesSink pk, int pk_lead) {
+  const float pks = PLANES ? pk.rec[0] : 1.0f;
   __shared__ float red[4][64 * 4 + 4];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + tc) * VEC;
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
         s[j] += v;
       }
       st(d_aff.data + (long long)r * d_aff.stride + col, o, VEC == 4);
+      if constexpr (PLANES && VEC == 4) store_planes4(pk, pks, (long long)pk_lead + r, col, o);
     };
     int r = r0 + tr;
     for (; r + 12 < r1; r += 16) {  // four rows requested together (d_aff may be dz itself: a row is read before it is written)
@@ -275,10 +281,11 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
 // step made four trips to HBM in a row (11 us per step of a kernel whose step has 1.3 us of MFMAs; found in the ISA).
 // FULL: every row of the block exists (the per-row `if (r < rows)` around the loads made the compiler wait for ALL outstanding memory
 // operations -- the previous row's store among them -- at each of them: four trips to HBM in a row per step)
-template <int NT, bool MASK, bool FULL>
+template <int NT, bool MASK, bool FULL, bool PLANES>
 __device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
                                                                    float self_repair_scale, MatView d_aff, float *partial, const float *mask, int B,
-                                                                   NgFuse ng) {
+                                                                   NgFuse ng, PlanesSink pk, int pk_lead) {
+  const float pks = PLANES ? pk.rec[0] : 1.0f;
   constexpr int BM = 128, BK = 32, LD = BK + 4;
   __shared__ __attribute__((aligned(16))) float As[BM * LD];
   __shared__ __attribute__((aligned(16))) float Bs[NT * 32 * LD];
@@ -380,7 +387,10 @@ __device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz,
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       const int r = r0 + rr + 32 * i;
-      if (FULL || r < x.rows) st(d_aff.data + (long long)r * d_aff.stride + col, o[i], true);
+      if (FULL || r < x.rows) {
+        st(d_aff.data + (long long)r * d_aff.stride + col, o[i], true);
+        if constexpr (PLANES) store_planes4(pk, pks, (long long)pk_lead + r, col, o[i]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 4; j++) {  // column sums over the wave's 8 row groups (lanes 8 apart hold the same columns)
@@ -429,12 +439,13 @@ __device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz,
     for (int i = gridDim.x + t; i < ng.part_cap; i += 256) ng.part[i] = 0.0;
 }
 
-template <int NT, bool MASK>
+template <int NT, bool MASK, bool PLANES>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
                                                                    float self_repair_scale, MatView d_aff, float *partial, const float *mask, int B,
-                                                                   NgFuse ng) {
-  if ((int)blockIdx.x * 128 + 128 <= x.rows) bn_relu_bwd_apply_ng_body<NT, MASK, true>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng);
-  else bn_relu_bwd_apply_ng_body<NT, MASK, false>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng);
+                                                                   NgFuse ng, PlanesSink pk, int pk_lead) {
+  if ((int)blockIdx.x * 128 + 128 <= x.rows)
+    bn_relu_bwd_apply_ng_body<NT, MASK, true, PLANES>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng, pk, pk_lead);
+  else bn_relu_bwd_apply_ng_body<NT, MASK, false, PLANES>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng, pk, pk_lead);
 }
 
 __global__ __launch_bounds__(kFinThreads) void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
@@ -492,7 +503,7 @@ size_t bn_relu_bwd_workspace_bytes(int rows, int cols) {
 // valid).  Writes d_aff (may alias dz) and adds lr_scale * colsum(d_aff) into bias_acc (may be null).
 hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, bool bn_test_mode, double *relu_stats, bool store_relu_stats,
                        bool self_repair, float self_repair_scale, MatView d_aff, float *bias_acc, float bias_scale,
-                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask, int B, const NgFuse *ng, double *oderiv_stats) {
+                       void *ws, size_t ws_bytes, hipStream_t s, const float *mask, int B, const NgFuse *ng, double *oderiv_stats, const BwdPlanes *planes) {
   if (x.rows == 0) return hipSuccess;
   if (ws_bytes < bn_relu_bwd_workspace_bytes(x.rows, x.cols)) return hipErrorInvalidValue;
   if (ng && (!bn_relu_bwd_ng_ok(x, dz, d_aff, ng->Rp) || (reinterpret_cast<uintptr_t>(memo) & 15) || (reinterpret_cast<uintptr_t>(ng->W) & 15) || ng->ldw % 4))
@@ -530,12 +541,24 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
                        repair_abs);
   }
   const double *rep = self_repair ? relu_stats : nullptr;
+  // planes of d_aff written by the apply pass itself: the scale record first, from the bound the finalize launch just left (common.h FroBoundScope)
+  PlanesSink pk{nullptr, 0, nullptr};
+  int pk_lead = 0;
+  if (planes && planes->P) {
+    if (!(fro2 && vec && x.cols % 16 == 0)) return hipErrorInvalidValue;  // (the caller already counts on the planes)
+    hipError_t e = planes_scale_bound(fro2, (int)finalize_grid(D), (double)x.rows * D, 1.0f, 0.0f, nullptr, planes->rec, s);
+    if (e != hipSuccess) return e;
+    pk = PlanesSink{planes->P, planes->R, planes->rec};
+    pk_lead = planes->lead;
+  }
   if (ng) {
     const int blocks = (x.rows + 127) / 128;
 #define APPLY_NG(NT)                                                                                                                                     \
   do {                                                                                                                                               \
-    if (mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng); \
-    else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng);    \
+    if (pk.P && mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead); \
+    else if (pk.P) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead); \
+    else if (mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead); \
+    else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead);    \
   } while (0)
     if (ng->Rp <= 32) APPLY_NG(1);
     else if (ng->Rp <= 64) APPLY_NG(2);
@@ -544,8 +567,9 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, bias_partial, blocks, D, bias_scale, bias_acc);
     return hipGetLastError();
   }
-  if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
-  else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B);
+  if (pk.P) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4, true>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead);
+  else if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4, false>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead);
+  else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1, false>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead);
   if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
   return hipGetLastError();
 }

@@ -1340,6 +1340,26 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
   }
   auto wplanes = [&](int comp) -> const PlanesOperand * { return pl_on && n->pw[comp].P ? &n->pw[comp] : nullptr; };
+  // where the fused BatchNorm / ReLU backward sweep may write the f16 planes of the derivative matrix `d` it produces (f16x3, 1536-wide
+  // matrices with a slot): fills *bp for bn_relu_bwd and *po for the GEMMs that read `d` next; bp->P == null: not fused, split afterwards
+  auto bwd_planes = [&](const tdnnf_mat &d, int lead, BwdPlanes *bp, PlanesOperand *po) -> int {
+    *bp = BwdPlanes{nullptr, 0, 0, nullptr};
+    *po = PlanesOperand();
+    if (!(pl_on && np == 2 && d.cols % 16 == 0 && d.cols >= 1024)) return TDNNF_OK;
+    auto it = n->plane_slots.find(d.data);
+    if (it == n->plane_slots.end()) return TDNNF_OK;
+    tdnnf_net::PlaneSlot &ps = it->second;
+    lead = (lead + 15) & ~15;
+    const long long R = planes_rows_padded((long long)2 * lead + d.rows + 256), kb_alloc = (planes_kblocks(d.cols) + 15) / 16 * 16;
+    TDNNF_REQUIRE(planes_bytes(np, R, kb_alloc) <= ps.bytesP, "net_forward_backward: plane slot too small for a %d x %d matrix", d.rows, d.cols);
+    const long long cfg5[5] = {d.rows, d.cols, lead, R, kP};
+    if (memcmp(cfg5, ps.last, sizeof(cfg5)) != 0) TDNNF_HIP(planes_pad(np, ps.P, planes_kblocks(d.cols), R, lead, d.rows, s));
+    memcpy(ps.last, cfg5, sizeof(cfg5));
+    *bp = BwdPlanes{ps.P, R, lead, ps.scale};
+    po->base = d.data; po->rows = d.rows; po->cols = d.cols; po->ld = d.stride; po->np = np;
+    po->P = ps.P; po->R = R; po->lead = lead; po->kb_alloc = kb_alloc; po->scale = ps.scale;
+    return TDNNF_OK;
+  };
   // bn_apply_bypass that ALSO writes its output as f16 planes when the BatchNorm finalize left a norm bound (f16x3, plain views): the
   // scale record first (from the bound), then one pass writes the f32 matrix and its row-major planes -- the GEMM that reads `out`
   // next needs no split pass.  *po describes the planes (empty: not fused, the consumer splits).
@@ -1358,7 +1378,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(planes_scale_bound(n->fro_buf, fb.blocks, (double)out.rows * out.cols, fb.mul, fb.add_coef, fb.add_rec, ps.scale, s));
     const long long cfg5[5] = {out.rows, out.cols, 0, R, kP};
     if (memcmp(cfg5, ps.last, sizeof(cfg5)) != 0 && ps.last[0] >= 0) {  // (the slot last held another shape: zero rows behind the matrix again)
-      TDNNF_HIP(hipMemsetAsync(ps.P, 0, planes_bytes(np, R, kb_alloc), s));
+      TDNNF_HIP(planes_pad(np, ps.P, planes_kblocks(out.cols), R, 0, out.rows, s));
     }
     memcpy(ps.last, cfg5, sizeof(cfg5));
     const PlanesSink sink{ps.P, R, ps.scale};
@@ -1606,16 +1626,22 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (!skip) nz[relu_index] = 1;
     return skip ? nullptr : relu_stats + 1 + 2 * Hd;
   };
+  // po (may be null): receives the plane operand of the derivative when the sweep wrote its f16 planes itself (bwd_planes; the caller
+  // has a FroBoundScope installed), else stays empty and the caller splits
   auto bn_relu_backward = [&](float *relu_out, float *d_io, int rows, float *memo, double *relu_stats, float *bias_acc, int comp, int relu_index,
-                              const float *mask = nullptr) -> int {
+                              const float *mask = nullptr, PlanesOperand *po = nullptr) -> int {
     const bool store = coin() || step == 0;
     const bool repair = c.relu_self_repair_scale > 0.f && coin();
     tdnnf_mat x = M(relu_out, rows, Hd), d = M(d_io, rows, Hd);
     NgFuse f;
     const int fuse = out_stats_fuse(comp, view(&x), view(&d), view(&d), f);
     if (fuse < 0) return TDNNF_EINVAL;
+    BwdPlanes bp{nullptr, 0, 0, nullptr};
+    PlanesOperand tmp;
+    if (po && fro_bound_buf()) CK(bwd_planes(d, 0, &bp, &tmp));
     TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, cv, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
-                          n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr, oderiv_of(relu_stats, relu_index)));
+                          n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr, oderiv_of(relu_stats, relu_index), bp.P ? &bp : nullptr));
+    if (po && bp.P) *po = tmp;
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
@@ -1885,10 +1911,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     FroBound fb_d;
     {
       FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_d.blocks);
-      CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h));  // dA -> d affine out
+      CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h, nullptr, &po_d));  // dA -> d affine out
     }
     CK(capture(hname + ".affine.deriv", d_b1));
-    CK(split(d_b1, 0, kP | kT, &po_d, s, fb_d));
+    if (!po_d.base || po_d.base != d_b1.data) CK(split(d_b1, 0, kP | kT, &po_d, s, fb_d));
     {
       PlanesHintScope ph(hint_of(po_d), hint_of(po_pl));
       CK(param_grad(H.c_affine, ix1, 1, S, Hd, &pl, &d_b1, nullptr, true, nullptr, 0, false));
@@ -1927,6 +1953,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TraceRange trace_layer(("backward " + lname).c_str());
     CK(capture(lname + ".noop.deriv", d_out));
     FroBound fb_daff;
+    auto max_off = [](const Tdnn &td) {
+      int m = 0;
+      for (int i = 0; i < td.K; i++) m = std::max(m, td.ix.row_offsets[i]);
+      return m;
+    };
+    const bool use_pl = pl_on && !L.lin.darts;
+    PlanesOperand po_daff, po_dlin;
+    BwdPlanes bp_daff{nullptr, 0, 0, nullptr};
     {
       const bool store = coin() || step == 0;
       const bool repair = c.relu_self_repair_scale > 0.f && coin();
@@ -1935,9 +1969,12 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const int fuse = out_stats_fuse(L.aff.comp, view(&x), view(&d_out), view(&d_aff), f);
       if (fuse < 0) return TDNNF_EINVAL;
       FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_daff.blocks);
+      PlanesOperand tmp;
+      if (use_pl) CK(bwd_planes(d_aff, max_off(L.aff), &bp_daff, &tmp));
       TDNNF_HIP(bn_relu_bwd(view(&x), view(&d_out), L.bn_memo, 1.0f, cv, L.relu_stats, store, repair, c.relu_self_repair_scale,
                             view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr,
-                            oderiv_of(L.relu_stats, 1 + l)));
+                            oderiv_of(L.relu_stats, 1 + l), bp_daff.P ? &bp_daff : nullptr));
+      if (bp_daff.P) po_daff = tmp;
     }
     CK(capture(lname + ".affine.deriv", d_aff));
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);
@@ -1968,14 +2005,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       const bool compact = td.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && td.K > 2;
       return param_grad(td.comp, td.ix, td.K, td.Di, td.Do, x, dyv, eff, bias_done, compact ? td.active : nullptr, compact ? 2 : 0, tap_ready);
     };
-    const bool use_pl = pl_on && !L.lin.darts;
-    auto max_off = [](const Tdnn &td) {
-      int m = 0;
-      for (int i = 0; i < td.K; i++) m = std::max(m, td.ix.row_offsets[i]);
-      return m;
-    };
-    PlanesOperand po_daff, po_dlin;
-    if (use_pl) CK(split(d_aff, max_off(L.aff), kP | kT, &po_daff, s, fb_daff));
+    if (use_pl && !po_daff.base) CK(split(d_aff, max_off(L.aff), kP | kT, &po_daff, s, fb_daff));
     {
       PlanesHintScope ph(hint_of(po_daff), hint_of(po_lin[l]));
       CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff, true));
@@ -2025,13 +2055,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   {  // tdnn1: batchnorm -> relu -> affine (the lda layer is fixed: no input derivative needed)
     FroBound fb_d;
+    PlanesOperand po_d;
     {
       FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_d.blocks);
-      CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, 0, mask_of(0)));
+      CK(bn_relu_backward(n->t1_relu, d_cur, N0, n->t1_bn_memo, n->t1_relu_stats, bias_target(n->tdnn1.comp), n->tdnn1.comp, 0, mask_of(0), &po_d));
     }
     tdnnf_mat d_aff = M(d_cur, N0, Hd);
-    PlanesOperand po_d;
-    CK(split(d_aff, 0, kT, &po_d, s, fb_d));
+    if (!po_d.base) CK(split(d_aff, 0, kT, &po_d, s, fb_d));
     PlanesHintScope ph(hint_of(po_d), hint_of(po_lda));
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }

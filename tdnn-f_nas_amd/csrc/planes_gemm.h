@@ -99,6 +99,8 @@ size_t planes_sumsq_ws_bytes();
 // writes the planes itself (fused.h PlanesSink)
 hipError_t planes_scale_bound(const double *fro2_bound, int blocks, double numel, float mul, float add_coef, const float *add_rec, float *rec, hipStream_t s);
 hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s);
+// zero the rows [0, lead) and [lead + rows, R) of every (K block, plane) chunk of a row-major plane buffer (a producer that writes the data rows itself)
+hipError_t planes_pad(int np, void *P, long long k_blocks, long long R, int lead, long long rows, hipStream_t s);
 // tile shape the GEMM uses for an N-column output: the A buffer needs tail >= tile rows beyond the last row read, the B buffer rows padded to the tile's columns
 // ---- routing of the f32 GEMM entry points (rows_gemm / wgrad, gemm_f32.h) onto the plane kernels.
 // The caller that owns the matrices (net.hip) splits an operand, describes the result in a PlanesOperand and installs it as a hint

@@ -533,6 +533,12 @@ const PlanesOperand *planes_hint_b() { return g_hint_b; }
 size_t planes_bytes(int np, long long rows_total, long long k_blocks) { return (size_t)(k_blocks * np * rows_total * 32); }
 size_t planes_sumsq_ws_bytes() { return sizeof(double) * kSumsqBlocks; }
 
+hipError_t planes_pad(int np, void *P, long long k_blocks, long long R, int lead, long long rows, hipStream_t s) {
+  if (!P || R <= rows) return hipSuccess;
+  hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(k_blocks * np * (R - rows) * 2, 256)), dim3(256), 0, s, P, k_blocks * np, R, lead, rows);
+  return hipGetLastError();
+}
+
 hipError_t planes_scale_bound(const double *fro2_bound, int blocks, double numel, float mul, float add_coef, const float *add_rec, float *rec, hipStream_t s) {
   hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, fro2_bound, blocks, numel, rec, mul, add_coef, add_rec);
   return hipGetLastError();
