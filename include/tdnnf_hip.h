@@ -56,7 +56,9 @@ int tdnnf_abi_version(void);
      "ng_early_in"   1 (default) input-side statistics ahead of the backward pass, 0 with the component's backward call [tdnnf_net_create]
      "wgrad_stream"  -1 (default) parameter gradients on their own stream for small minibatches, 0 never, 1 always       [tdnnf_net_create]
      "gemm_ring"     1 (default) persistent LDS-DMA-ring rows GEMM where it applies, 0 the plain tile kernel
-     "planes"        1 (default) gemm_precision 2 runs the pre-split bf16-plane GEMMs where they apply, 0 the in-kernel split */
+     "planes"        1 (default) gemm_precision 2 runs the pre-split bf16-plane GEMMs where they apply, 0 the in-kernel split
+     "den_split"     -1 (default) the trainer runs the denominator's two recursions side by side for <= 96 sequences, 0 never, 1 always
+                     (set before the first tdnnf_net_forward_backward of a net: it sizes the chain workspace) */
 int tdnnf_set_option(const char *name, int value);
 int tdnnf_get_option(const char *name, int *value_out);
 

@@ -87,14 +87,14 @@ static int *option_slot(const char *name) {
   Options &o = options();
   if (!name) return nullptr;
   const struct { const char *n; int *p; } table[] = {{"ng_grouped", &o.ng_grouped}, {"ng_fuse", &o.ng_fuse}, {"ng_early_in", &o.ng_early_in},
-                                                     {"wgrad_stream", &o.wgrad_stream}, {"gemm_ring", &o.gemm_ring}, {"planes", &o.planes}};
+                                                     {"wgrad_stream", &o.wgrad_stream}, {"gemm_ring", &o.gemm_ring}, {"planes", &o.planes}, {"den_split", &o.den_split}};
   for (auto &e : table)
     if (strcmp(e.n, name) == 0) return e.p;
   return nullptr;
 }
 int tdnnf_set_option(const char *name, int value) {
   int *p = option_slot(name);
-  TDNNF_REQUIRE(p, "set_option: unknown option '%s' (ng_grouped, ng_fuse, ng_early_in, wgrad_stream, gemm_ring, planes)", name ? name : "(null)");
+  TDNNF_REQUIRE(p, "set_option: unknown option '%s' (ng_grouped, ng_fuse, ng_early_in, wgrad_stream, gemm_ring, planes, den_split)", name ? name : "(null)");
   *p = value;
   return TDNNF_OK;
 }

@@ -51,6 +51,7 @@ struct Options {
   int wgrad_stream = -1;  // parameter gradients on a stream of their own: -1 by minibatch size, 0 off, 1 on (read by tdnnf_net_create)
   int gemm_ring = 1;      // the persistent LDS-DMA-ring form of the rows GEMM where it applies
   int planes = 1;         // gemm_precision 2: the pre-split bf16-plane GEMMs where they apply (0: the in-kernel split everywhere)
+  int den_split = -1;     // trainer: the denominator's two recursions side by side (then the occupancies of all frames at once): -1 by minibatch size, 0 / 1
 };
 Options &options();
 

@@ -57,10 +57,23 @@ template <int VEC, bool PLANES>
 __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const float *mean, const float *scale, int D, int period,
                                                               MatView prev, float bypass, MatView out, const float *mask, int B, PlanesSink pk) {
   const int cv = x.cols / VEC;
-  const long long total = (long long)x.rows * cv;
   const float ps = PLANES ? pk.rec[0] : 1.0f;
+  // PLANES: a wave covers 8 rows x 32 columns (not 1 row x 256): its plane stores are then two runs of 8 consecutive 32-byte row records per
+  // plane (256 contiguous bytes) instead of 32 scattered records, and the f32 accesses are still whole 128-byte lines
+  const int ncb = PLANES ? cv / 8 : 1;
+  const long long total = PLANES ? (long long)((x.rows + 7) / 8) * 8 * cv : (long long)x.rows * cv;
   for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
-    const int r = (int)(e / cv), c = (int)(e % cv) * VEC, cd = c % period;
+    int r, c;
+    if (PLANES) {
+      const long long blk = e >> 6;
+      r = (int)(blk / ncb) * 8 + (int)((e >> 3) & 7);
+      c = ((int)(blk % ncb) * 8 + (int)(e & 7)) * VEC;
+      if (r >= x.rows) continue;
+    } else {
+      r = (int)(e / cv);
+      c = (int)(e % cv) * VEC;
+    }
+    const int cd = c % period;
     if (cd >= D) continue;  // row padding inside a super row
     float xv[4], pv[4] = {0, 0, 0, 0}, o[4];
     ld(x.data + (long long)r * x.stride + c, xv, VEC == 4);
@@ -465,10 +478,10 @@ hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatV
   const bool vec = vec4_ok(x) && vec4_ok(out) && (!prev.data || vec4_ok(prev)) && D % 4 == 0 && (reinterpret_cast<uintptr_t>(memo) & 15) == 0 &&
                    (!mask || (reinterpret_cast<uintptr_t>(mask) & 15) == 0);
   const long long work = (long long)x.rows * (vec ? x.cols / 4 : x.cols);
-  if (planes && !(vec && x.cols == D && planes->P && planes->rec)) return hipErrorInvalidValue;
+  if (planes && !(vec && x.cols == D && D % 32 == 0 && planes->P && planes->rec)) return hipErrorInvalidValue;
   ProfHbmRange prof(4, 4.0 * x.rows * x.cols * ((prev.data ? 3.0 : 2.0) + (planes ? 1.0 : 0.0)), s);  // reads x [and the bypass rows], writes out [and its planes]
   const PlanesSink none{nullptr, 0, nullptr};
-  if (planes) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, true>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, *planes);
+  if (planes) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, true>), dim3(grid_for((long long)((x.rows + 7) / 8) * 8 * (x.cols / 4), 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, *planes);
   else if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none);
   else hipLaunchKernelGGL((bn_apply_bypass_kernel<1, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none);
   return hipGetLastError();

@@ -1196,7 +1196,9 @@ namespace {
 // 37.3 -> 28.5, x 32 53.1 -> 45.3, x 64 80.9 -> 75.2, x 128 127.6 -> 128.2; 150 x 64 14.2 -> 13.8.  The second recursion runs on the
 // weight-gradient stream (or the natural-gradient side stream), idle until the backward pass (on a stream of its own -- a fifth in flight -- the
 // step at 150 x 64 took 20.0 ms: they then share hardware queues).
-bool den_uses_split(int B) { return B <= 96; }
+// [r4] with the pre-split plane GEMMs (planes = true) the xent head no longer covers a 25 ms denominator at 128 sequences: side by side there too
+// (same box, ms per step: f16x3 103.8 / 105.2 -> 102.1 / 102.4; exact f32 124.4 / 124.6 -> 125.4 / 125.0, so f32 keeps the one-kernel backward pass)
+bool den_uses_split(int B, bool planes) { return options().den_split >= 0 ? options().den_split != 0 : (B <= 96 || planes); }
 }  // namespace
 
 int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *den,
@@ -1211,7 +1213,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   hipStream_t s = (hipStream_t)stream;
   const bool cv = c.cv_update != 0;  // BatchNorm components are BatchNormTestComponents
   if (!n->chain_ws) {
-    n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B) ? 0 : chain_split_region_bytes(den, B, n->Tout));
+    n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B, n->planes_np != 0 && !n->wg_on) ? 0 : chain_split_region_bytes(den, B, n->Tout));
     TDNNF_HIP(hipMalloc(&n->chain_ws, n->chain_ws_bytes));
     TDNNF_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
@@ -1399,7 +1401,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
     hipLaunchKernelGGL(transpose_weights_kernel, dim3(256, nc), dim3(256), 0, s, n->params, n->paramsT, tb);
   }
-  TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B) ? 0 : chain_split_region_bytes(den, B, n->Tout)),
+  TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B, n->planes_np != 0 && !n->wg_on) ? 0 : chain_split_region_bytes(den, B, n->Tout)),
                 "net_forward_backward: denominator graph changed size");
   // the reference's RandInt()/RandUniform() coin flips, made reproducible: k-th decision of this minibatch
   unsigned long long coin_k = 0;
@@ -1552,7 +1554,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
       // few sequences leave most CUs idle while one workgroup per sequence walks the frames: there the backward recursion runs
       // beside the forward one (den_beta_kernel on a further stream) and the occupancies of all frames at once
-      const bool den_split = den_uses_split(B);
+      const bool den_split = den_uses_split(B, n->planes_np != 0 && !n->wg_on);
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fork, 0));
       CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, !den_split, n->s3));
       TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));
