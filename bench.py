@@ -460,11 +460,12 @@ def main():
 
     # live roofline of the dominant kernel class (HIP events recorded on the launch stream)
     classes = []
-    for k in range(4):
+    for k in range(8):  # 0..3 the GEMM classes, 4..7 the HBM-bound passes (bn_apply_bypass, bn_relu_bwd, denominator, planes_split)
         n, ms, fl, by = C.c_double(), C.c_double(), C.c_double(), C.c_double()
         pkg.hipabi.check(lib.tdnnf_profile_read(k, C.byref(n), C.byref(ms), C.byref(fl)))
         pkg.hipabi.check(lib.tdnnf_profile_read_bytes(k, C.byref(by)))
         classes.append(dict(name=lib.tdnnf_profile_class_name(k).decode(), launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value))
+    hbm_classes, classes = classes[4:], classes[:4]
     # "dominant" = the TDNN-F factored GEMM class with the most time (north_star's kernel); the natural-gradient class (HBM-bound
     # passes over the layer inputs / output derivatives) is reported beside it as roofline_secondary
     dom = max(classes[:3], key=lambda c: c["ms"])
@@ -532,6 +533,28 @@ def main():
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "tflops": round(ngc["flops"] / (ngc["ms"] * 1e-3) / 1e12, 2),
                                          "launches": int(ngc["launches"]), "ms_per_step": round(ngc["ms"] / job.event_steps_, 3), "traffic": None}
 
+        # "fraction of HBM roofline on elementwise / denominator work" -- the HBM-bound passes of the step, each timed live
+        # with HIP events on its launch stream over the same event steps: algorithmic bytes (every element the pass must touch, once per
+        # stage) / event time against the 8 TB/s peak; the measured PMC traffic of the same kernels is in profiles/ (make_profiles.py)
+        what = {"bn_apply_bypass": "BatchNorm apply + dropout mask + Sum(Scale(0.66, bypass), .): reads x [and the bypass rows], writes the layer output [and, "
+                                   "--gemm f16x3, its f16 planes]",
+                "bn_relu_bwd": "BatchNorm backward + ReLU backward + self-repair + ReLU statistics + bias column sums, two stages: (x, dz) read twice, d_aff written",
+                "denominator": "chain denominator forward-backward, both recursions (fork .. join): per (frame, sequence) the arcs once per recursion "
+                               "(8 B forward, 16 B backward), the output row read twice, the derivative row written; L2 gather + latency bound, not HBM",
+                "planes_split": "operand split into 16-bit planes (--gemm f16x3 / bf16x6): the matrix read once, each plane layout written once"}
+        out["roofline_hbm"] = []
+        for hc in hbm_classes:
+            if hc["ms"] <= 0:
+                continue
+            gbs = hc["bytes"] / (hc["ms"] * 1e-3) / 1e9
+            ent = {"bound": "hbm", "kernel": hc["name"], "what": what.get(hc["name"], ""), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": int(hc["launches"]), "ms_per_step": round(hc["ms"] / job.event_steps_, 3),
+                   "algorithmic_bytes_per_step": round(hc["bytes"] / job.event_steps_, 1), "traffic": None}
+            if hc["name"] == "denominator":
+                ent["us_per_frame_step"] = round(1e3 * hc["ms"] / max(hc["launches"], 1) / (args.chunk // 3), 2)
+                ent["note"] = "one persistent workgroup per sequence walks the frames of both recursions (128 CUs at 128 sequences) beside the xent head on another stream"
+            out["roofline_hbm"].append(ent)
+
         if strong is not None:
             out["strong"] = strong
 
@@ -591,6 +614,7 @@ def main():
             shard = line_item("the per-GPU shard of a 128-sequence minibatch at 8 GPUs, --scaling strong (--chunk 1500 --minibatch 16)", args.chunk, 16, args.den_states,
                               steps=16)
             shard["vs_one_eighth_of_the_headline_step"] = round(shard["ms_per_step"] / (1e3 * dt / args.steps / 8.0), 3)
+            shard["ideal_speedup_at_8_gpus_before_any_collective"] = round(8.0 / shard["vs_one_eighth_of_the_headline_step"], 2)
             out["also"] = [recipe, shard,
                            line_item("10 000-state denominator graph (--den-states 10000)", args.chunk, seqs, 10000, steps=4),
                            line_item("30 000-state denominator graph (--den-states 30000)", args.chunk, seqs, 30000, steps=4)]
@@ -607,12 +631,20 @@ def main():
                 out["also"].append(pre)
                 out["also"].append(line_item("DARTS offset supernet, cv-update: Gumbel over all %d taps, BatchNormTest (--workload darts-offset-cvupdate)" % args.darts_offsets,
                                              args.chunk, seqs, args.den_states, steps=6, workload="darts-offset-cvupdate", stats=stats))
-                out["also"].append(line_item("bottleneck-dimension supernet, Onehot pretrain (--workload bn-supernet)", args.chunk, seqs, args.den_states, steps=6,
-                                             workload="bn-supernet"))
-                if not args.no_alt:  # configs[4] as BASELINE.json words it: "fp32 objf / bf16 MFMA GEMM"
-                    out["also"].append(line_item("bottleneck-dimension supernet with the split-bf16 GEMM arithmetic (--workload bn-supernet --gemm bf16x3: "
-                                                 "BASELINE configs[4], fp32 objective / bf16 MFMA GEMMs)", args.chunk, seqs, args.den_states, steps=6,
-                                                 workload="bn-supernet", gemm="bf16x3"))
+                bnsup = line_item("bottleneck-dimension supernet, Onehot pretrain (--workload bn-supernet)", args.chunk, seqs, args.den_states, steps=6, workload="bn-supernet")
+                out["also"].append(bnsup)
+                # north_star quotes the >= 6x scaling target "on the SWBD 7q DARTS supernet": the per-GPU shards of the two supernets at 8 GPUs
+                # (strong scaling of the 128-sequence minibatch), against an eighth of their own one-GPU step
+                for nm, wl, full in (("DARTS offset supernet, pretrain", "darts-offset", pre), ("bottleneck-dimension supernet, Onehot pretrain", "bn-supernet", bnsup)):
+                    it = line_item(nm + ": the per-GPU shard of a 128-sequence minibatch at 8 GPUs (--workload %s --chunk 1500 --minibatch 16)" % wl, args.chunk, 16,
+                                   args.den_states, steps=12, workload=wl)
+                    it["vs_one_eighth_of_its_128_sequence_step"] = round(it["ms_per_step"] / (full["ms_per_step"] / 8.0), 3)
+                    it["ideal_speedup_at_8_gpus_before_any_collective"] = round(8.0 / it["vs_one_eighth_of_its_128_sequence_step"], 2)
+                    out["also"].append(it)
+                if not args.no_alt:  # configs[4] as BASELINE.json words it: "fp32 objf / bf16 MFMA GEMM" -- the 16-bit matrix cores with an f32 objective
+                    out["also"].append(line_item("bottleneck-dimension supernet with the f32-equivalent 16-bit matrix-core arithmetic (--workload bn-supernet --gemm f16x3: "
+                                                 "BASELINE configs[4], fp32 objective / 16-bit MFMA GEMMs)", args.chunk, seqs, args.den_states, steps=6,
+                                                 workload="bn-supernet", gemm="f16x3"))
             # archive-fed: every minibatch read from a cegs archive, decompressed, merged and copied to the device inside the timed loop
             for (ch, sq, st, resident) in ((args.chunk, seqs, 8, 1e3 * dt / args.steps), (150, 64, 40, recipe["ms_per_step"])):
                 it = line_item("archive-fed (egs.minibatches(prefetch=2): read + decompress + merge on a worker thread, H2D included), --chunk %d --minibatch %d" % (ch, sq),

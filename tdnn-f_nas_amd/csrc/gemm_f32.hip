@@ -1290,8 +1290,79 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
   g.bias = a.bias; g.init_mode = a.init_mode; g.relu = a.relu;
   g.add = a.add; g.ldadd = a.ldadd; g.add_scale = a.add_scale; g.add_lo = a.add_lo; g.add_hi = a.add_hi;
   ProfScope ps(BN == 160 ? 1 : 0, flops, s);
-  *err = planes_gemm(g, s);
   g_planes_routed_rows++;
+  // One block per CU, equal block durations: a launch of q * CUs + r tiles costs q + 1 rounds.  When the last round would be less than
+  // half full, the whole rounds run as one launch and the r tail tiles as a second one that splits K over the idle CUs (slabs in the
+  // split-K scratch, then the epilogue): 260 row tiles of the 1/3-rate .linear layers on 256 CUs = 1.02 rounds instead of 2.
+  {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
+      (void)hipGetLastError();
+    }
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, tiles = ntm * ntn, q = tiles / cus, r = tiles % cus;
+    int nkb = 0;
+    for (int i = 0; i < g.nseg; i++) nkb += g.seg[i].nkb;
+    const int main_mt = (q * cus) / ntn;  // whole row tiles inside the full rounds
+    // BatchNorm statistics of the stored output from the epilogue (RowsGemmArgs::colstats): one partial row per row tile
+    const bool stats = a.colstats && a.colstats_rows && g.init_mode != 0;
+    if (stats) {
+      g.colstats = a.colstats;
+      g.colstats_stride = ntm;
+      *a.colstats_rows = ntm;
+    }
+    size_t scratch_bytes = 0;
+    float *scratch = nullptr;
+    if (q >= 1 && r > 0 && 2 * r <= cus && main_mt > 0 && main_mt < ntm && nkb >= 16 && (scratch = splitk_scratch(&scratch_bytes))) {
+      const int m_main = main_mt * BM, tail_rows = a.M - m_main, tail_tiles = ((tail_rows + BM - 1) / BM) * ntn;
+      int S = std::min(cus / tail_tiles, nkb / 4);
+      const long long ldp = (a.N + 3) & ~3;
+      if (S >= 2 && sizeof(float) * (size_t)S * tail_rows * ldp <= scratch_bytes) {
+        PlanesGemmArgs gm = g;
+        gm.M = m_main;
+        const ColReducePlan tail_plan = colreduce_plan(tail_rows, a.N);
+        if (stats) {  // the main launch's row tiles, then the chunks of a column-reduction pass over the finished tail rows
+          gm.colstats_stride = main_mt + tail_plan.chunks;
+          *a.colstats_rows = gm.colstats_stride;
+        }
+        *err = planes_gemm(gm, s);
+        if (*err != hipSuccess) return true;
+        PlanesGemmArgs gt = g;
+        gt.colstats = nullptr;
+        gt.M = tail_rows;
+        gt.C = g.C + (long long)m_main * g.ldc;
+        for (int i = 0; i < gt.nseg; i++) gt.seg[i].a_row += m_main;
+        if (gt.add) {  // (addend rows are relative to the launch's first output row)
+          gt.add_lo = g.add_lo - m_main;
+          gt.add_hi = g.add_hi - m_main;
+          gt.add = g.add;
+        }
+        const int kbps = (nkb + S - 1) / S;
+        gt.ksplit = (nkb + kbps - 1) / kbps;
+        gt.kb_per_split = kbps;
+        gt.partial = scratch;
+        gt.partial_stride = (long long)tail_rows * ldp;
+        gt.ldp_m = ldp;
+        gt.ldp_n = 1;
+        if (gt.ksplit >= 2) {
+          *err = planes_gemm(gt, s);
+          if (*err == hipSuccess) *err = planes_splitk_finish(gt, s);
+        } else {
+          gt.ksplit = 0;
+          gt.partial = nullptr;
+          *err = planes_gemm(gt, s);  // (a K range too short to split: the tail as a plain launch)
+        }
+        if (stats && *err == hipSuccess) {
+          MatView ct{gt.C, tail_rows, a.N, (int)gt.ldc};
+          *err = colreduce_partial_into(1, ct, ct, tail_plan.chunks, tail_plan.rows_per_chunk, gm.colstats_stride, a.colstats + (long long)main_mt * a.N, s);
+        }
+        return true;
+      }
+    }
+  }
+  *err = planes_gemm(g, s);
   return true;
 }
 

@@ -41,6 +41,11 @@ struct PlanesGemmArgs {
   int add_lo, add_hi;
   int nseg;
   PlanesSeg seg[16];
+  // optional (plain launches: ntap <= 1, ksplit <= 1): column sums and sums of squares of the STORED C values, one partial row per row tile --
+  // colstats[tile_m * N + n] and colstats[(colstats_stride + tile_m) * N + n] (the BatchNorm statistics of a layer output as a by-product
+  // of writing it, as RowsGemmArgs::colstats)
+  float *colstats;
+  int colstats_stride;
   // != 0: A holds the ROW-MAJOR planes of a matrix whose COLUMNS are the tile rows and whose ROWS are the reduction index (a weight
   // gradient's big operand, read with transposing LDS loads): RA = that buffer's rows, seg.a_row = the first matrix row of the K range
   // (a multiple of 16, lead rows included), seg.a_kb0 / tap_a_kb count K steps of 16 rows; the buffer must hold whole 256-column tiles
@@ -132,5 +137,8 @@ const PlanesOperand *planes_hint_b();
 int planes_gemm_tile_rows(int N);
 int planes_gemm_tile_cols(int N);
 hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s);
+// epilogue of a split-K launch whose slabs hold whole output rows (ksplit > 1, ntap <= 1, ldp_n == 1): C[m][n] = f(scale * sum_sp partial[sp][m][n])
+// with the launch's init / bias / addend / ReLU rules
+hipError_t planes_splitk_finish(const PlanesGemmArgs &a, hipStream_t s);
 
 }  // namespace tdnnf

@@ -477,6 +477,9 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
   }
   float sc = 1.0f;
   if (NP == 2) sc = (p.scale_a ? p.scale_a[1] : 1.0f) * (p.scale_b ? p.scale_b[1] : 1.0f);
+  float cs1[TN], cs2[TN];  // column sums / sums of squares of what this lane stores (p.colstats)
+#pragma unroll
+  for (int j = 0; j < TN; j++) cs1[j] = cs2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < TM; i++)
 #pragma unroll
@@ -494,8 +497,59 @@ __global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGe
         if (p.add && m >= p.add_lo && m < p.add_hi) v += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n];
         if (p.relu) v = floor_keep_nan(v, 0.f);
         *c = v;
+        cs1[j] += v;
+        cs2[j] += v * v;
       }
     }
+  if (p.colstats) {  // one partial row per row tile: lanes l and l + 32 hold the same columns, the WM wave rows go through LDS (fixed order)
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+      cs1[j] += __shfl_xor(cs1[j], 32, 64);
+      cs2[j] += __shfl_xor(cs2[j], 32, 64);
+    }
+    __syncthreads();  // (every wave is done with the stage buffers)
+    float *red = reinterpret_cast<float *>(smem);  // [wm][2][BN]
+    if (lh == 0) {
+#pragma unroll
+      for (int j = 0; j < TN; j++) {
+        const int nl = (wn * TN + j) * 32 + li;
+        red[(wm * 2 + 0) * BN + nl] = cs1[j];
+        red[(wm * 2 + 1) * BN + nl] = cs2[j];
+      }
+    }
+    __syncthreads();
+    for (int nl = t; nl < BN; nl += NT) {
+      const int n = n0 + nl;
+      if (n >= p.N) continue;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; w++) {
+        s1 += red[(w * 2 + 0) * BN + nl];
+        s2 += red[(w * 2 + 1) * BN + nl];
+      }
+      p.colstats[(long long)tile_m * p.N + n] = s1;
+      p.colstats[(long long)(p.colstats_stride + tile_m) * p.N + n] = s2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void planes_splitk_finish_kernel(const PlanesGemmArgs p) {
+  const long long total = (long long)p.M * p.N;
+  float sc = 1.0f;
+  if (p.np == 2) sc = (p.scale_a ? p.scale_a[1] : 1.0f) * (p.scale_b ? p.scale_b[1] : 1.0f);
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int m = (int)(e / p.N), n = (int)(e % p.N);
+    float v = 0.f;
+#pragma unroll 4
+    for (int sp = 0; sp < p.ksplit; sp++) v += p.partial[(long long)sp * p.partial_stride + (long long)m * p.ldp_m + n];
+    v *= sc;
+    float *c = p.C + (long long)m * p.ldc + n;
+    if (p.init_mode == 1) v += p.bias[n];
+    else if (p.init_mode == 0) v += *c;
+    if (p.add && m >= p.add_lo && m < p.add_hi) v += p.add_scale * p.add[(long long)(m - p.add_lo) * p.ldadd + n];
+    if (p.relu) v = floor_keep_nan(v, 0.f);
+    *c = v;
+  }
 }
 
 template <int NP, int WM, int WN, int TM, int TN, bool DB = false, bool ATR = false>
@@ -570,6 +624,13 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(planes_split_kernel<2>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)a.scale, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0);
   else
     hipLaunchKernelGGL(planes_split_kernel<3>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)nullptr, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0);
+  return hipGetLastError();
+}
+
+hipError_t planes_splitk_finish(const PlanesGemmArgs &a, hipStream_t s) {
+  if (a.ksplit < 2 || a.ntap > 1 || a.ldp_n != 1 || !a.partial) return hipErrorInvalidValue;
+  const long long total = (long long)a.M * a.N;
+  hipLaunchKernelGGL(planes_splitk_finish_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 2048)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
