@@ -1315,7 +1315,8 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
     }
     size_t scratch_bytes = 0;
     float *scratch = nullptr;
-    if (q >= 1 && r > 0 && 2 * r <= cus && main_mt > 0 && main_mt < ntm && nkb >= 16 && (scratch = splitk_scratch(&scratch_bytes))) {
+    // (a long K range only: with K = 320 the round that is saved is as short as the tail's two extra launches)
+    if (q >= 1 && r > 0 && 2 * r <= cus && main_mt > 0 && main_mt < ntm && nkb >= 48 && (scratch = splitk_scratch(&scratch_bytes))) {
       const int m_main = main_mt * BM, tail_rows = a.M - m_main, tail_tiles = ((tail_rows + BM - 1) / BM) * ntn;
       int S = std::min(cus / tail_tiles, nkb / 4);
       const long long ldp = (a.N + 3) & ~3;

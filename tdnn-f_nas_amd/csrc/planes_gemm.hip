@@ -126,8 +126,9 @@ __global__ __launch_bounds__(256) void planes_sumsq4_kernel(MatView x, double *p
 // scale[0] = s = 2^e, the largest power of two with s ||X||_F <= 65504 (every |x| <= ||X||_F: nothing overflows) and s rms(X) <= 64;
 // scale[1] = 1 / s; scale[2] = the norm (or the upper bound it was taken from).  An all-zero matrix gets s = 1; a NaN / Inf norm gives a
 // NaN scale (the product is then NaN, as in f32).  With `mul` / `add_rec`: sqrt(sum) is only part of a bound, mul sqrt(sum) + add_coef add_rec[2].
-__global__ void planes_scale_kernel(const double *partial, int nb, double numel, float *scale, float mul, float add_coef, const float *add_rec) {
-  __shared__ double red[256];
+// (all 256 threads of a block; every block that calls it with the same partials gets the same s: fixed summation order)
+__device__ __forceinline__ float planes_scale_of(const double *partial, int nb, double numel, float mul, float add_coef, const float *add_rec, double *red,
+                                                 double *fro_out) {
   double a = 0;
   for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
   red[threadIdx.x] = a;
@@ -136,9 +137,8 @@ __global__ void planes_scale_kernel(const double *partial, int nb, double numel,
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x != 0) return;
   const double sum = red[0];
-  double fro = (double)mul * sqrt(sum) + (add_rec ? (double)add_coef * (double)add_rec[2] : 0.0);
+  const double fro = (double)mul * sqrt(sum) + (add_rec ? (double)add_coef * (double)add_rec[2] : 0.0);
   float s = 1.0f;
   if (fro != fro || fro > 1.0e150) {
     s = __int_as_float(0x7fc00000);
@@ -151,6 +151,15 @@ __global__ void planes_scale_kernel(const double *partial, int nb, double numel,
     if (e < -120) e = -120;
     s = ldexpf(1.0f, e);
   }
+  *fro_out = fro;
+  __syncthreads();  // (red is reused by the caller)
+  return s;
+}
+__global__ void planes_scale_kernel(const double *partial, int nb, double numel, float *scale, float mul, float add_coef, const float *add_rec) {
+  __shared__ double red[256];
+  double fro;
+  const float s = planes_scale_of(partial, nb, numel, mul, add_coef, add_rec, red, &fro);
+  if (threadIdx.x != 0) return;
   scale[0] = s;
   scale[1] = 1.0f / s;
   scale[2] = (float)(fro * 1.000001);  // (rounded up: the record may feed the bound of a matrix this one is added into)
@@ -159,15 +168,26 @@ __global__ void planes_scale_kernel(const double *partial, int nb, double numel,
 // X (rows x cols, ld) -> P16 planes (k = column; `lead` zero rows in front) and / or the planes of the transpose (k = row).
 // A block: a 64 x 64 tile; thread t reads 16 consecutive floats of row t / 4 (one row record of P), the transposed records go
 // through LDS (thread t then owns column t % 64, rows 16 (t / 64) ..+15).
+// sq_partial != null (small matrices): the scale is formed here from the norm pass's partials -- by every block, identically -- and
+// block (0, 0) writes the record; saves the launch of planes_scale_kernel in front of every small split
 template <int NP>
 __global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long long ld, int rows, int cols, const float *scale, int lead, long long R, void *Pv,
-                                                           long long Rt, void *PTv, int vec_ok) {
+                                                           long long Rt, void *PTv, int vec_ok, const double *sq_partial, int sq_nb, float *scale_out) {
   typedef typename Plane<NP>::E E;
-  __shared__ E tile[NP][64][64 + 2];
+  __shared__ __attribute__((aligned(16))) E tile[NP][64][64 + 2];
   E *P = reinterpret_cast<E *>(Pv), *PT = reinterpret_cast<E *>(PTv);
   const int t = threadIdx.x, lr = t >> 2, cq = t & 3;
   const int r = blockIdx.x * 64 + lr, c0 = blockIdx.y * 64 + cq * 16;
-  const float s = scale ? scale[0] : 1.0f;
+  float s = scale ? scale[0] : 1.0f;
+  if (sq_partial) {
+    double fro;
+    s = planes_scale_of(sq_partial, sq_nb, (double)rows * cols, 1.0f, 0.0f, nullptr, reinterpret_cast<double *>(&tile[0][0][0]), &fro);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+      scale_out[0] = s;
+      scale_out[1] = 1.0f / s;
+      scale_out[2] = (float)(fro * 1.000001);
+    }
+  }
   float v[16];
 #pragma unroll
   for (int j = 0; j < 16; j++) v[j] = 0.f;
@@ -605,14 +625,20 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
   const long long nkb = planes_kblocks(x.cols), nkbt = planes_t_kblocks(x.rows);
   ProfHbmRange prof(7, (double)x.rows * x.cols * (4.0 + 2.0 * a.np * ((a.P ? 1 : 0) + (a.PT ? 1 : 0))), s);  // the matrix read once, each layout written once
   const bool vec4 = (reinterpret_cast<uintptr_t>(x.data) & 15) == 0 && x.stride % 4 == 0;
+  const bool small = (long long)x.rows * x.cols <= (4LL << 20);
+  const double *sq_partial = nullptr;
+  int sq_nb = 0;
   if (a.np == 2) {
     if (!a.scale || !a.sumsq_ws) return hipErrorInvalidValue;
     if (a.fro2_bound && a.fro2_blocks > 0) {  // the producer's finalize launch left a bound: no pass over the matrix
       hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, a.fro2_bound, a.fro2_blocks, (double)x.rows * x.cols, a.scale, a.fro_mul, a.add_coef, a.add_rec);
     } else {
-      if (vec4) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
-      else hipLaunchKernelGGL(planes_sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)a.sumsq_ws);
-      hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)a.sumsq_ws, kSumsqBlocks, (double)x.rows * x.cols, a.scale, 1.0f, 0.0f, (const float *)nullptr);
+      // (a small matrix gets as many norm-pass blocks as it has 16 K-element pieces, and its split forms the scale itself: two launches, not three)
+      sq_nb = small ? (int)std::max<long long>(1, std::min<long long>(kSumsqBlocks, ((long long)x.rows * x.cols + 16383) / 16384)) : kSumsqBlocks;
+      if (vec4) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(sq_nb), dim3(256), 0, s, x, (double *)a.sumsq_ws);
+      else hipLaunchKernelGGL(planes_sumsq_kernel, dim3(sq_nb), dim3(256), 0, s, x, (double *)a.sumsq_ws);
+      if (small) sq_partial = (const double *)a.sumsq_ws;
+      else hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, (const double *)a.sumsq_ws, sq_nb, (double)x.rows * x.cols, a.scale, 1.0f, 0.0f, (const float *)nullptr);
     }
   }
   if (a.P && a.R > x.rows && !a.pads_done)
@@ -621,9 +647,11 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(nkbt * a.np * (a.Rt - x.cols) * 2, 256)), dim3(256), 0, s, a.PT, nkbt * a.np, a.Rt, 0, (long long)x.cols);
   const dim3 grid((unsigned)((x.rows + 63) / 64), (unsigned)((x.cols + 63) / 64));
   if (a.np == 2)
-    hipLaunchKernelGGL(planes_split_kernel<2>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)a.scale, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0);
+    hipLaunchKernelGGL(planes_split_kernel<2>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)a.scale, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0,
+                       sq_partial, sq_nb, a.scale);
   else
-    hipLaunchKernelGGL(planes_split_kernel<3>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)nullptr, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0);
+    hipLaunchKernelGGL(planes_split_kernel<3>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)nullptr, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0,
+                       (const double *)nullptr, 0, (float *)nullptr);
   return hipGetLastError();
 }
 
