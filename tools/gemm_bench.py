@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the f32 MFMA GEMM kernels on the shapes of the 7q step (chunk 1500, 128 sequences).
-Usage (GPU box): python tools/gemm_bench.py [reps]"""
+Usage (GPU box): python tools/gemm_bench.py [reps [shape-filter [OPTION=VALUE ...]]]"""
 import ctypes as C
 import os
 import sys
@@ -15,6 +15,8 @@ abi = pkg.hipabi
 lib = abi.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 only = sys.argv[2] if len(sys.argv) > 2 else ""
+for spec in sys.argv[3:]:  # library options, NAME=VALUE (e.g. gemm_ring=0)
+    abi.check(lib.tdnnf_set_option(spec.split("=")[0].encode(), int(spec.split("=")[1])))
 
 
 def timed(fn):

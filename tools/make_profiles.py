@@ -36,6 +36,17 @@ def klass(nm):
         return "rows_gemm_f32_128x160"
     if s.startswith("wgrad_kernel"):
         return "wgrad_f32"
+    # the pre-split plane kernels: <planes, WM, WN, TM, TN, DB, ATR> -- by arithmetic, tile width, and the rows-as-K form of the weight gradients
+    m = re.match(r"planes_gemm_kernel<(\d), (\d), (\d), (\d), (\d), (\w+), (\w+)>", s)
+    if m:
+        arith = {"2": "f16x3", "3": "bf16x6"}[m.group(1)]
+        if m.group(7) == "true":
+            return "planes_gemm_%s_wgrad" % arith
+        return "planes_gemm_%s_256x%d" % (arith, int(m.group(3)) * int(m.group(5)) * 32)
+    if s.startswith(("planes_split_kernel", "planes_sumsq", "planes_scale_kernel", "planes_pad_kernel")):
+        return "planes_split"
+    if s.startswith("planes_splitk_finish"):
+        return "planes_gemm_splitk_finish"
     return s
 
 
