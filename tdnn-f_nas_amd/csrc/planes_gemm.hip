@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void planes_pad_kernel(void *Pv, long long nch
 // column), two reads per operand register pair; rows of a 32-lane half cover 256 contiguous bytes: conflict-free.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 template <int NP, int WM, int WN, int TM, int TN, bool DB, bool ATR = false>
-__global__ __launch_bounds__(WM *WN * 64) void planes_gemm_kernel(const PlanesGemmArgs p, int ntm, int ntn) {
+__global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void planes_gemm_kernel(const PlanesGemmArgs p, int ntm, int ntn) {
   typedef typename Plane<NP>::V8 V8;
   constexpr int NT = WM * WN * 64, BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, STAGE = A_BYTES + B_BYTES;
@@ -696,7 +696,15 @@ hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s) {
     return launch<3, 4, 2, 2, 2>(a, s);
   }
   if (bn == 160) return launch<2, 8, 1, 1, 5>(a, s);
-  if (bn == 256) return launch<2, 4, 2, 2, 4>(a, s);
+  if (bn == 256) {
+    // Short reductions (K = 320: the .affine forward and .linear backward-data GEMMs, 1536 columns out): a tile's 256 KB of output and
+    // its 20 K steps of loads both run at what ONE CU can move (~20-50 GB/s), one after the other when the CU holds a single block.
+    // 128 x 256 tiles of four waves take 72 KB of LDS: two blocks per CU, one storing while the other multiplies.
+    int nkb = 0;
+    for (int i = 0; i < a.nseg; i++) nkb += a.seg[i].nkb;
+    if (nkb <= 40 && a.ntap <= 1 && a.ksplit <= 1 && a.M > 4096) return launch<2, 2, 2, 2, 4>(a, s);
+    return launch<2, 4, 2, 2, 4>(a, s);
+  }
   return launch<2, 4, 2, 2, 2>(a, s);
 }
 

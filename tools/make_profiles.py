@@ -14,6 +14,7 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 stats_dir = sys.argv[2] if len(sys.argv) > 2 else "prof4"
+pmc_prefix = sys.argv[3] if len(sys.argv) > 3 else "pmc"  # gpurun_out/<pmc_prefix>_fetch, _write
 
 
 def short(nm):
@@ -72,11 +73,11 @@ def load(d):
 
 
 traffic = collections.defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0))
-for r in load("pmc_fetch"):
+for r in load(pmc_prefix + "_fetch"):
     t = traffic[klass(r["Kernel_Name"])]
     t["launches"] += 1
     t["fetch_kb"] += float(r["Counter_Value"])
-for r in load("pmc_write"):
+for r in load(pmc_prefix + "_write"):
     traffic[klass(r["Kernel_Name"])]["write_kb"] += float(r["Counter_Value"])
 out = {}
 for k, t in traffic.items():
