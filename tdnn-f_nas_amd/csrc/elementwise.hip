@@ -688,13 +688,15 @@ __global__ __launch_bounds__(256) void tap_dots_kernel(const float *G, int ldg, 
 }
 __global__ void alpha_update_kernel(double *dots, int nslab, const float *coef, int K, int flags, int share, float temp,
                                     float lr, float *acc) {
-  if (threadIdx.x != 0) return;
-  if (nslab > 0)
+  // the slabs of a tap: one per lane, then a fixed shuffle tree (one wave; nslab <= 64) -- a serial chain of K x 64 dependent loads took 65 us
+  if (nslab > 0) {
     for (int i = 0; i < K; i++) {
-      double s = 0;
-      for (int j = 0; j < nslab; j++) s += dots[K + i * nslab + j];
-      dots[i] = s;
+      double s = (int)threadIdx.x < nslab ? dots[K + i * nslab + threadIdx.x] : 0.0;
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      if (threadIdx.x == 0) dots[i] = s;
     }
+  }
+  if (threadIdx.x != 0) return;
   if (!(flags & TDNNF_DARTS_UNIFORM_SAMPLE)) {
     for (int i = 0; i < K; i++) {
       const float si = (float)dots[i];

@@ -424,6 +424,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
     for (auto &L : n->layers) {
       slot(L.noop_out, N_of(L.gout, B), Hd, false);
       slot(L.lin_out, N_of(L.lin.out, B), L.bn, false);
+      if (L.c_arch >= 0) slot(L.lin_masked, N_of(L.lin.out, B), L.bn, false);  // (bottleneck supernet: the affine reads the masked blocks)
     }
     slot(n->prefinal_l_out, No, S, false);
     for (int h = 0; h < 2; h++) {
@@ -1491,7 +1492,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_reorder_rows(&src, B, L.aff.ix.row_stride, 1, &aff_in, s));
     }
     tdnnf_mat relu = M(L.relu_out, L.aff.rows_out, Hd);
-    if (use_pl && !L.perm && L.c_arch < 0) CK(split(lin, 0, kP | kT, &po_lin[layer_no - 1], s));
+    if (use_pl && !L.perm) CK(split(aff_in, 0, kP | kT, &po_lin[layer_no - 1], s));  // (the linear output, or its masked blocks in the bottleneck supernet)
     {
       PlanesHintScope ph(hint_of(po_lin[layer_no - 1]), wplanes(L.aff.comp));
       FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_next.blocks);
