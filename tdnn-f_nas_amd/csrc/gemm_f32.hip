@@ -1236,7 +1236,14 @@ static inline long long floordiv(long long a, long long b) { return a >= 0 ? a /
 // view leaves [m_lo, m_hi)); false = not applicable, nothing launched.
 static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flops, hipStream_t s, hipError_t *err) {
   const PlanesOperand *ha = planes_hint_a(), *hb = planes_hint_b();
-  if (!ha || !hb || ha->np != np || hb->np != np || !ha->P || a.coef || a.sumsq || a.ksplit > 1 || a.nseg > 16) return false;
+  if (!ha || !hb || ha->np != np || hb->np != np || !ha->P || a.sumsq || a.ksplit > 1 || a.nseg > 16) return false;
+  // tap coefficients: only when they are exactly the vector folded into the weight planes, segment s = tap s (then the product needs none)
+  if (ha->coef || (a.coef == nullptr) != (hb->coef == nullptr)) return false;
+  long long coef_t0 = 0;  // segment s carries the coefficient of tap coef_t0 + s: the planes must hold exactly that tap there
+  if (a.coef) {
+    coef_t0 = a.coef - hb->coef;
+    if (coef_t0 < 0 || coef_t0 >= 16 || hb->coef_period <= 0) return false;
+  }
   if (a.lda != ha->ld || a.A < ha->base || (a.A - ha->base) % ha->ld != 0) return false;
   const long long arow0 = (a.A - ha->base) / ha->ld;
   const int BM = planes_gemm_tile_rows(a.N), BN = planes_gemm_tile_cols(a.N);
@@ -1275,17 +1282,20 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
       const long long brow = bo / hb->ld, bc0 = bo % hb->ld;
       if (bo < 0 || bc0 % 16 != 0 || bc0 + sg.klen > hb->cols || brow + a.N > hb->rows || brow + n_pad > hb->R) return false;
       if (sg.klen % 16 != 0 && bc0 + sg.klen != hb->cols) return false;
+      if (a.coef && (bc0 % hb->coef_period != 0 || bc0 / hb->coef_period != coef_t0 + i || sg.klen > hb->coef_period)) return false;
       g.seg[i].b_row = brow;
       g.seg[i].b_kb0 = (int)(bc0 / 16);
     } else {     // B[k][n] at base[(krow + k) * ld + ncol + n]: the transposed planes (k = row of the hinted matrix)
       const long long krow = bo / hb->ld, ncol = bo % hb->ld;
       if (bo < 0 || krow % 16 != 0 || krow + sg.klen > hb->rows || ncol + a.N > hb->cols || ncol + n_pad > hb->Rt) return false;
       if (sg.klen % 16 != 0 && krow + sg.klen != hb->rows) return false;
+      if (a.coef && (ncol % hb->coef_period != 0 || ncol / hb->coef_period != coef_t0 + i || a.N > hb->coef_period)) return false;
       g.seg[i].b_row = ncol;
       g.seg[i].b_kb0 = (int)(krow / 16);
     }
   }
   g.nseg = a.nseg;
+  g.skip_coef = a.coef;
   g.C = a.C; g.ldc = a.ldc; g.M = a.M; g.N = a.N;
   g.bias = a.bias; g.init_mode = a.init_mode; g.relu = a.relu;
   g.add = a.add; g.ldadd = a.ldadd; g.add_scale = a.add_scale; g.add_lo = a.add_lo; g.add_hi = a.add_hi;
@@ -2044,7 +2054,7 @@ static hipError_t wgrad_finish(const WgradArgs &a, const float *partial, int spl
 static bool planes_try_wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, int np, hipStream_t s, hipError_t *err) {
   const PlanesOperand *hy = planes_hint_a(), *hx = planes_hint_b();
   if (!hy || !hx || hy->np != np || hx->np != np) return false;
-  if (a.coef || a.active || a.row_stride != 1 || a.K > 16 || a.K < 1) return false;
+  if (a.row_stride != 1 || a.K > 16 || a.K < 1) return false;  // (tap coefficients: applied by the reduce, zero ones skipped in the kernel -- the compacted tap list is not needed)
   if (a.dY != hy->base || a.lddy != hy->ld || a.N != hy->rows || a.Do != hy->cols) return false;
   if (a.ldx != hx->ld || a.X < hx->base || (a.X - hx->base) % hx->ld != 0 || a.Di != hx->cols) return false;
   const long long xrow0 = (a.X - hx->base) / hx->ld;
@@ -2103,6 +2113,7 @@ static bool planes_try_wgrad(const WgradArgs &a, void *workspace, size_t workspa
   g.partial = reinterpret_cast<float *>(workspace);
   g.partial_stride = (long long)slab;
   g.tap_off_p = a.Di;
+  g.skip_coef = a.coef;
   if (normal) { g.ldp_m = (long long)a.K * a.Di; g.ldp_n = 1; }
   else { g.ldp_m = 1; g.ldp_n = (long long)a.K * a.Di; }
   {

@@ -85,6 +85,7 @@ struct tdnnf_net {
   };
   std::map<const float *, PlaneSlot> plane_slots;
   std::vector<tdnnf::PlanesOperand> pw;  // by component
+  std::vector<float *> pw_scale;         // their scale records
   void *planes_ws = nullptr;
   double *fro_buf = nullptr;  // FroBoundScope target: per-block norm bounds a BatchNorm finalize launch leaves for the next split (common.h)
   int B, T, Tout;

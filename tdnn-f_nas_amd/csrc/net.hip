@@ -399,6 +399,7 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->planes_np = n->cfg.gemm_precision == 3 ? 2 : (n->cfg.gemm_precision == 2 && options().planes ? 3 : 0);
   n->plane_slots.clear();
   n->pw.assign(n->comps.size(), PlanesOperand());
+  n->pw_scale.assign(n->comps.size(), nullptr);
   n->planes_ws = nullptr;
   n->fro_buf = nullptr;
   if (n->planes_np) {
@@ -450,7 +451,8 @@ void layout_arena(tdnnf_net *n, Arena &A) {
       o.Rt = planes_rows_padded(((cd.cols + 255) / 256) * 256LL);
       o.P = A.take<char>(planes_bytes(np, o.R, planes_kblocks(cd.cols)) + 64);
       o.PT = A.take<char>(planes_bytes(np, o.Rt, planes_t_kblocks(cd.rows)) + 64);
-      o.scale = A.take<float>(4);
+      n->pw_scale[i] = A.take<float>(4);
+      o.scale = n->pw_scale[i];
     }
   }
   n->s3_scratch = nullptr;
@@ -1329,19 +1331,26 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     return TDNNF_OK;
   };
   auto hint_of = [&](const PlanesOperand &o) -> const PlanesOperand * { return o.base ? &o : nullptr; };
-  if (pl_on) {  // this step's weights as planes
-    for (size_t i = 0; i < n->comps.size(); i++) {
-      PlanesOperand &o = n->pw[i];
-      if (!o.P) continue;
-      o.base = Wp(n, (int)i);
-      PlanesSplitArgs a;
-      a.np = np; a.x = MatView{Wp(n, (int)i), o.rows, o.cols, o.cols}; a.lead = 0; a.R = o.R; a.P = const_cast<void *>(o.P); a.Rt = o.Rt;
-      a.PT = const_cast<void *>(o.PT); a.scale = const_cast<float *>(o.scale); a.sumsq_ws = n->planes_ws;
-      if (np != 2) o.scale = nullptr;
-      a.pads_done = n->fb_count > 1;  // (fixed shapes: the zero rows written by the first step stay)
-      TDNNF_HIP(planes_split(a, s));
-    }
-  }
+  // a component's weight matrix as planes (row-major: forward; transposed: backward-data); coef: a TdnnDARTSV3Component's effective tap
+  // coefficients (device, one per `period` columns), folded into the planes so that its GEMMs need none
+  auto split_weights = [&](int comp, const float *coef, int period) -> int {
+    PlanesOperand &o = n->pw[comp];
+    if (!o.P) return TDNNF_OK;
+    o.base = Wp(n, comp);
+    o.coef = coef;
+    o.coef_period = period;
+    PlanesSplitArgs a;
+    a.np = np; a.x = MatView{Wp(n, comp), o.rows, o.cols, o.cols}; a.lead = 0; a.R = o.R; a.P = const_cast<void *>(o.P); a.Rt = o.Rt;
+    a.PT = const_cast<void *>(o.PT); a.scale = n->pw_scale[comp]; a.sumsq_ws = n->planes_ws;
+    a.col_coef = coef; a.col_coef_period = period;
+    o.scale = np == 2 ? n->pw_scale[comp] : nullptr;
+    a.pads_done = n->fb_count > 1;  // (fixed shapes: the zero rows written by the first step stay)
+    TDNNF_HIP(planes_split(a, s));
+    return TDNNF_OK;
+  };
+  if (pl_on)  // this step's weights as planes (the DARTS components' again in the layer loop, once their coefficients are formed)
+    for (size_t i = 0; i < n->comps.size(); i++)
+      if (n->comps[i].num_alpha == 0 || n->comps[i].plain) CK(split_weights((int)i, nullptr, 0));
   auto wplanes = [&](int comp) -> const PlanesOperand * { return pl_on && n->pw[comp].P ? &n->pw[comp] : nullptr; };
   // where the fused BatchNorm / ReLU backward sweep may write the f16 planes of the derivative matrix `d` it produces (f16x3, 1536-wide
   // matrices with a slot): fills *bp for bn_relu_bwd and *po for the GEMMs that read `d` next; bp->P == null: not fused, split afterwards
@@ -1463,11 +1472,15 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       }
       lin_eff = L.lin.memo + TDNNF_MAX_OFFSETS;
       aff_eff = L.aff.memo + TDNNF_MAX_OFFSETS;
+      if (pl_on) {  // the effective coefficients folded into this step's weight planes
+        CK(split_weights(L.lin.comp, lin_eff, Hd));
+        CK(split_weights(L.aff.comp, aff_eff, L.bn));
+      }
     }
     // uniform-sample mode runs at most two taps of K (share + sampled): tell the FLOP accounting of the profiler
     ProfFlopsScale taps_active(L.lin.darts && (c.darts_flags & TDNNF_DARTS_UNIFORM_SAMPLE) && L.lin.K > 2 ? 2.0 / L.lin.K : 1.0);
     // (DARTS .linear: bias present but offsets[1] < 0 -> out is zeroed and the bias never added, :237-240)
-    const bool use_pl = pl_on && !L.lin.darts;  // (tap coefficients: the f32 kernels)
+    const bool use_pl = pl_on;
     if (use_pl) {  // (the planes are also the tile-row operand of this layer's weight gradient)
       if (po_next.base == in.data && po_next.rows == in.rows) po_in[layer_no - 1] = po_next;
       else CK(split(in, 0, kP | kT, &po_in[layer_no - 1], s, fb_next));
@@ -1961,7 +1974,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       for (int i = 0; i < td.K; i++) m = std::max(m, td.ix.row_offsets[i]);
       return m;
     };
-    const bool use_pl = pl_on && !L.lin.darts;
+    const bool use_pl = pl_on;
     PlanesOperand po_daff, po_dlin;
     BwdPlanes bp_daff{nullptr, 0, 0, nullptr};
     {

@@ -41,6 +41,9 @@ struct PlanesGemmArgs {
   int add_lo, add_hi;
   int nseg;
   PlanesSeg seg[16];
+  // optional (device, nseg floats; in tap mode ntap floats): a segment / tap whose coefficient is zero is skipped (the coefficients
+  // themselves are folded into the B planes or applied by the caller's reduce: this is only the skip)
+  const float *skip_coef;
   // optional (plain launches: ntap <= 1, ksplit <= 1): column sums and sums of squares of the STORED C values, one partial row per row tile --
   // colstats[tile_m * N + n] and colstats[(colstats_stride + tile_m) * N + n] (the BatchNorm statistics of a layer output as a by-product
   // of writing it, as RowsGemmArgs::colstats)
@@ -88,6 +91,10 @@ struct PlanesSplitArgs {
   // np == 2: [s, 1 / s, ||X||_F or its bound] (device, 3 floats) receives the scale record; `sumsq_ws` (device, planes_sumsq_ws_bytes()) is scratch of the norm pass
   float *scale;
   void *sumsq_ws;
+  // optional: element (r, c) is multiplied by col_coef[c / col_coef_period] (device) before it is split -- the tap coefficients of a
+  // TdnnDARTSV3Component folded into its weight planes (|coef| <= 1: the unscaled norm stays a valid bound for the scale)
+  const float *col_coef = nullptr;
+  int col_coef_period = 0;
   // np == 2, optional: the scale from an UPPER BOUND of the matrix's Frobenius norm instead of a pass over it (common.h FroBoundScope):
   //   ||X||_F <= fro_mul * sqrt(sum of fro2_bound[0 .. fro2_blocks)) + add_coef * add_rec[2]
   // (add_rec: the scale record [s, 1 / s, norm bound] of a matrix added into this one with coefficient add_coef: the bypass sum).
@@ -123,6 +130,10 @@ struct PlanesOperand {
   const void *PT = nullptr;  // planes of the transpose (k = row), Rt rows
   long long Rt = 0;
   const float *scale = nullptr;  // np == 2: [s, 1 / s] on the device
+  // a weight matrix split WITH tap coefficients (PlanesSplitArgs::col_coef): the planes hold coef[c / coef_period] * W[r][c]; a GEMM
+  // that passes exactly this coefficient vector (TdnnDARTSV3Component's effective coefficients) may use them, one that passes none or another may not
+  const float *coef = nullptr;
+  int coef_period = 0;
 };
 struct PlanesHintScope {
   const PlanesOperand *prev_a, *prev_b;

@@ -172,7 +172,8 @@ __global__ void planes_scale_kernel(const double *partial, int nb, double numel,
 // block (0, 0) writes the record; saves the launch of planes_scale_kernel in front of every small split
 template <int NP>
 __global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long long ld, int rows, int cols, const float *scale, int lead, long long R, void *Pv,
-                                                           long long Rt, void *PTv, int vec_ok, const double *sq_partial, int sq_nb, float *scale_out) {
+                                                           long long Rt, void *PTv, int vec_ok, const double *sq_partial, int sq_nb, float *scale_out,
+                                                           const float *col_coef, int col_coef_period) {
   typedef typename Plane<NP>::E E;
   __shared__ __attribute__((aligned(16))) E tile[NP][64][64 + 2];
   E *P = reinterpret_cast<E *>(Pv), *PT = reinterpret_cast<E *>(PTv);
@@ -204,6 +205,11 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long 
       for (int j = 0; j < 16; j++)
         if (c0 + j < cols) v[j] = src[j];
     }
+  }
+  if (col_coef) {  // tap coefficients folded into the planes
+#pragma unroll
+    for (int j = 0; j < 16; j++)
+      if (c0 + j < cols) v[j] *= col_coef[(c0 + j) / col_coef_period];
   }
   E pl[NP][16];
 #pragma unroll
@@ -297,8 +303,10 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
   // ---- the stages in K order: (segment, K block).  This block multiplies stages [g_begin, g_begin + total).
+  if (ntaps > 1 && p.skip_coef && p.skip_coef[tap] == 0.f) return;  // a tap with a zero coefficient (uniform-sample mode): its slab is not read either
   int all = 0;
-  for (int s = 0; s < p.nseg; s++) all += p.seg[s].nkb;
+  for (int s = 0; s < p.nseg; s++)
+    if (!(ntaps <= 1 && p.skip_coef && p.skip_coef[s] == 0.f)) all += p.seg[s].nkb;
   const int g_begin = nsplit > 1 ? sp * p.kb_per_split : 0;
   const int total = nsplit > 1 ? max(0, min(all - g_begin, p.kb_per_split)) : all;
   const int tap_akb = ntaps > 1 ? p.tap_a_kb[tap] : 0, tap_bkb = ntaps > 1 ? p.tap_b_kb[tap] : 0;
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     for (;;) {
       ld_seg++;
       if (ld_seg >= p.nseg) return;
+      if (ntaps <= 1 && p.skip_coef && p.skip_coef[ld_seg] == 0.f) continue;
       const PlanesSeg sg = p.seg[ld_seg];
       if (ld_skip >= sg.nkb) {  // (a split that starts behind this segment)
         ld_skip -= sg.nkb;
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     for (;;) {
       cs_seg++;
       if (cs_seg >= p.nseg) return;
+      if (ntaps <= 1 && p.skip_coef && p.skip_coef[cs_seg] == 0.f) continue;
       const PlanesSeg sg = p.seg[cs_seg];
       if (cs_skip >= sg.nkb) {
         cs_skip -= sg.nkb;
@@ -648,10 +658,10 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
   const dim3 grid((unsigned)((x.rows + 63) / 64), (unsigned)((x.cols + 63) / 64));
   if (a.np == 2)
     hipLaunchKernelGGL(planes_split_kernel<2>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)a.scale, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0,
-                       sq_partial, sq_nb, a.scale);
+                       sq_partial, sq_nb, a.scale, a.col_coef, a.col_coef_period);
   else
     hipLaunchKernelGGL(planes_split_kernel<3>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)nullptr, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0,
-                       (const double *)nullptr, 0, (float *)nullptr);
+                       (const double *)nullptr, 0, (float *)nullptr, a.col_coef, a.col_coef_period);
   return hipGetLastError();
 }
 
