@@ -1312,10 +1312,13 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
       cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
       (void)hipGetLastError();
     }
-    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, tiles = ntm * ntn, q = tiles / cus, r = tiles % cus;
+    g.M = a.M;
+    g.N = a.N;
+    const int BMl = planes_gemm_launch_tile_rows(g);  // (128-row tiles for short reductions: two blocks per CU)
+    const int ntm = (a.M + BMl - 1) / BMl, ntn = (a.N + BN - 1) / BN, tiles = ntm * ntn, slots = cus * (BMl == 128 ? 2 : 1), q = tiles / slots, r = tiles % slots;
     int nkb = 0;
     for (int i = 0; i < g.nseg; i++) nkb += g.seg[i].nkb;
-    const int main_mt = (q * cus) / ntn;  // whole row tiles inside the full rounds
+    const int main_mt = (q * slots) / ntn;  // whole row tiles inside the full rounds
     // BatchNorm statistics of the stored output from the epilogue (RowsGemmArgs::colstats): one partial row per row tile
     const bool stats = a.colstats && a.colstats_rows && g.init_mode != 0;
     if (stats) {
@@ -1326,7 +1329,7 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
     size_t scratch_bytes = 0;
     float *scratch = nullptr;
     // (a long K range only: with K = 320 the round that is saved is as short as the tail's two extra launches)
-    if (q >= 1 && r > 0 && 2 * r <= cus && main_mt > 0 && main_mt < ntm && nkb >= 48 && (scratch = splitk_scratch(&scratch_bytes))) {
+    if (q >= 1 && r > 0 && 2 * r <= slots && main_mt > 0 && main_mt < ntm && nkb >= 48 && BMl == BM && (scratch = splitk_scratch(&scratch_bytes))) {
       const int m_main = main_mt * BM, tail_rows = a.M - m_main, tail_tiles = ((tail_rows + BM - 1) / BM) * ntn;
       int S = std::min(cus / tail_tiles, nkb / 4);
       const long long ldp = (a.N + 3) & ~3;

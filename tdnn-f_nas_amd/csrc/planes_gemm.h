@@ -146,6 +146,8 @@ const PlanesOperand *planes_hint_a();
 const PlanesOperand *planes_hint_b();
 
 int planes_gemm_tile_rows(int N);
+// the tile rows planes_gemm() will use for THIS launch (256, or 128 for short reductions into 256-column tiles): what a caller needs to count its row tiles
+int planes_gemm_launch_tile_rows(const PlanesGemmArgs &a);
 int planes_gemm_tile_cols(int N);
 hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s);
 // epilogue of a split-K launch whose slabs hold whole output rows (ksplit > 1, ntap <= 1, ldp_n == 1): C[m][n] = f(scale * sum_sp partial[sp][m][n])

@@ -679,6 +679,17 @@ int planes_gemm_tile_cols(int N) {
   return N % 256 == 0 ? 256 : 128;  // (256 x 256 tiles: 2/3 of the 256 x 128 tile's operand bytes per flop)
 }
 
+// Short reductions (K = 320: the .affine forward and .linear backward-data GEMMs, 1536 columns out): a tile's 256 KB of output and
+// its 20 K steps of loads both run at what ONE CU can move (~20-50 GB/s), one after the other when the CU holds a single block.
+// 128 x 256 tiles of four waves take 72 KB of LDS: two blocks per CU, one storing while the other multiplies.
+static bool small_row_tile(const PlanesGemmArgs &a) {
+  if (a.np != 2 || a.a_rows_as_k || a.ntap > 1 || a.ksplit > 1 || a.M <= 4096 || planes_gemm_tile_cols(a.N) != 256) return false;
+  int nkb = 0;
+  for (int i = 0; i < a.nseg; i++) nkb += a.seg[i].nkb;
+  return nkb <= 40;
+}
+int planes_gemm_launch_tile_rows(const PlanesGemmArgs &a) { return small_row_tile(a) ? 128 : 256; }
+
 hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s) {
   if (a.M <= 0 || a.N <= 0 || a.nseg <= 0) return hipSuccess;
   if (a.np != 2 && a.np != 3) return hipErrorInvalidValue;
@@ -706,15 +717,7 @@ hipError_t planes_gemm(const PlanesGemmArgs &a, hipStream_t s) {
     return launch<3, 4, 2, 2, 2>(a, s);
   }
   if (bn == 160) return launch<2, 8, 1, 1, 5>(a, s);
-  if (bn == 256) {
-    // Short reductions (K = 320: the .affine forward and .linear backward-data GEMMs, 1536 columns out): a tile's 256 KB of output and
-    // its 20 K steps of loads both run at what ONE CU can move (~20-50 GB/s), one after the other when the CU holds a single block.
-    // 128 x 256 tiles of four waves take 72 KB of LDS: two blocks per CU, one storing while the other multiplies.
-    int nkb = 0;
-    for (int i = 0; i < a.nseg; i++) nkb += a.seg[i].nkb;
-    if (nkb <= 40 && a.ntap <= 1 && a.ksplit <= 1 && a.M > 4096) return launch<2, 2, 2, 2, 4>(a, s);
-    return launch<2, 4, 2, 2, 4>(a, s);
-  }
+  if (bn == 256) return small_row_tile(a) ? launch<2, 2, 2, 2, 4>(a, s) : launch<2, 4, 2, 2, 4>(a, s);
   return launch<2, 4, 2, 2, 2>(a, s);
 }
 

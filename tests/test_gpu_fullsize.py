@@ -335,6 +335,37 @@ def test_bench_shape_split_bf16_six_products_against_f32(pkg, bench_egs, arith):
     assert e < 3e-2, e
 
 
+@pytest.mark.parametrize("name", sorted(SUPERNETS))
+def test_bench_shape_supernets_on_the_f16_plane_kernels(pkg, bench_egs, name):
+    """The supernets at the bench shape with gemm_precision 3 (f16x3): the DARTS components' tap coefficients are folded into their weight
+    planes and zero taps skipped in the kernels, the bottleneck supernet's affine reads the planes of the masked blocks.  Against the
+    exact-f32 step from the same parameters and draws: the objective to 1e-4, the components between the loss and the first ReLU backward
+    (no derivative mask involved) to the 1e-3 bar, the architecture parameters' gradient to 2e-2 (tie noise of 3e8 ReLU elements)."""
+    kw = dict(SUPERNETS[name], use_natural_gradient=1)
+    stats = None
+    if kw.get("cv_update"):
+        _, parent = run_bench_shape(pkg, bench_egs, 1, **dict(SUPERNETS["darts-offset-pretrain"], use_natural_gradient=1))
+        stats = parent["stats"]
+    routed0 = (C.c_longlong(), C.c_longlong())
+    pkg.hipabi.load().tdnnf_planes_routed(C.byref(routed0[0]), C.byref(routed0[1]))
+    a, ea = run_bench_shape(pkg, bench_egs, 1, stats=stats, gemm_precision=3, **kw)
+    routed1 = (C.c_longlong(), C.c_longlong())
+    pkg.hipabi.load().tdnnf_planes_routed(C.byref(routed1[0]), C.byref(routed1[1]))
+    assert routed1[0].value - routed0[0].value >= 4 * 14 and routed1[1].value - routed0[1].value >= 14, "the plane kernels did not run"
+    b, eb = run_bench_shape(pkg, bench_egs, 1, stats=stats, **kw)
+    (ra, ga), (rb, gb) = a[0], b[0]
+    assert ra[5] == 1.0 and bool(torch.isfinite(ga).all())
+    assert abs(ra[0] - rb[0]) < 1e-4 * abs(rb[0]), (ra[0], rb[0])
+    comps = {c["name"]: c for c in eb["components"]}
+    for cn in ("output.affine", "prefinal-chain.linear", "output-xent.affine", "prefinal-xent.linear"):
+        sl = component_slice(comps[cn])
+        if float(gb[sl].double().norm()) > 0:  # (cv-update: frozen components carry no gradient)
+            e = float((ga[sl] - gb[sl]).double().norm() / gb[sl].double().norm())
+            assert e < 1e-3, (cn, e)
+    e = float((ga - gb).double().norm() / gb.double().norm())
+    assert e < 3e-2, e
+
+
 def test_bench_shape_denominator_forms_agree(pkg, bench_egs):
     """Persistent (LDS-resident state vectors) against wide (one launch per frame over all sequences) denominator on the
     bench's 4 000-state graph at 128 x 500 frames."""
