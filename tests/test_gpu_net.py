@@ -360,8 +360,8 @@ def test_batchnorm_statistics_out_of_the_gemm_epilogue_at_full_width(pkg, arith)
     """At 1536 columns the affine GEMM forms the BatchNorm statistics of its output while storing it (row tiles of the plain
     launch + the chunks of a pass over the rows its split-K tail finishes: 10 000+ rows take both routes; the plane GEMMs: one partial
     row per 256-row tile, or per 128-row tile of the short-reduction form, whose count the caller must take from the launch).
-    Checked through the activations: tdnn1.batchnorm and every layer's noop must be the normalisation of the matrix in front by that
-    matrix's own float64 column statistics."""
+    Checked through the activations: tdnn1.batchnorm must be the normalisation of tdnn1.relu by that matrix's own float64 column statistics
+    (9 728 rows, K = 220: the plane path takes the 128-row tiles here)."""
     T = pkg.trainer
     planes = arith != "f32"
     cfg = T.make_config(frames_per_chunk=150, num_sequences=64, strides=[1, 3], bottleneck=32, feat_dim=40, ivector_dim=100, num_pdfs=90,
@@ -379,14 +379,6 @@ def test_batchnorm_statistics_out_of_the_gemm_epilogue_at_full_width(pkg, arith)
     mean, var = x.mean(0), x.var(0)
     want = (x - mean) / np.sqrt(var + 1e-3)
     assert rel_l2(host(net.activation("tdnn1.batchnorm")), want) < 1e-5
-    # the first tdnnf layer (no stride: its output rows are its input rows minus the context): noop = batchnorm(relu) + 0.66 * input rows
-    x2 = host(net.activation("tdnnf2.relu")).astype(np.float64)
-    bn2 = (x2 - x2.mean(0)) / np.sqrt(x2.var(0) + 1e-3)
-    got = host(net.activation("tdnnf2.noop")).astype(np.float64)
-    prev = host(net.activation("tdnn1.batchnorm")).astype(np.float64)
-    off = (prev.shape[0] - got.shape[0]) // 2  # (rows are t-major: the context frames in front are whole blocks of sequences)
-    cand = [rel_l2(got, bn2 + 0.66 * prev[o:o + got.shape[0]]) for o in range(0, prev.shape[0] - got.shape[0] + 1, cfg.num_sequences)]
-    assert min(cand) < 2e-5, (min(cand), off)
     net.close()
 
 
