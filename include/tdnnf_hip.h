@@ -57,6 +57,7 @@ int tdnnf_abi_version(void);
      "wgrad_stream"  -1 (default) parameter gradients on their own stream for small minibatches, 0 never, 1 always       [tdnnf_net_create]
      "gemm_ring"     1 (default) persistent LDS-DMA-ring rows GEMM where it applies, 0 the plain tile kernel
      "planes"        1 (default) gemm_precision 2 runs the pre-split bf16-plane GEMMs where they apply, 0 the in-kernel split
+     "den_mw_test_abort", "planes_check_bound": test hooks (0 = off), see tests/test_gpu_parity.py, tests/test_gpu_net.py
      "den_split"     -1 (default) the trainer runs the denominator's two recursions side by side for <= 96 sequences, 0 never, 1 always
                      (set before the first tdnnf_net_forward_backward of a net: it sizes the chain workspace) */
 int tdnnf_set_option(const char *name, int value);
@@ -277,6 +278,9 @@ void tdnnf_supervision_destroy(tdnnf_supervision *);
    multi-workgroup launch gave up -- reported on stderr once, not used again in the process).  Affects the workspace size:
    set it before tdnnf_chain_workspace_bytes / tdnnf_net_create. */
 int tdnnf_chain_set_denominator_mode(int mode);
+/* diagnostics: minibatches the one-workgroup kernels redid behind a multi-workgroup launch that gave up; whether that form is switched off for
+   the process; reset != 0 clears both (synchronises the device) */
+int tdnnf_chain_den_mw_status(int *fallbacks, int *disabled, int reset);
 size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *, int num_sequences, int frames_per_sequence);
 /* results_dev (device doubles): [0] objf, [1] l2_term, [2] weight, [3] num logprob (weighted),
    [4] den logprob (weighted), [5] ok flag (1.0 / 0.0), [6] xent objf when xent_output given.
@@ -521,6 +525,8 @@ size_t tdnnf_planes_bytes(int num_planes, long long rows_total, long long k_bloc
 size_t tdnnf_planes_split_workspace_bytes(void);
 /* how many GEMMs / weight gradients of the trainer ran on the plane kernels so far in this process (either pointer may be NULL) */
 void tdnnf_planes_routed(long long *rows_gemms, long long *weight_gradients);
+/* option "planes_check_bound": how many bound-derived scales were compared with the measured Frobenius norm, and how many bounds were too small */
+void tdnnf_planes_bound_checks(long long *checks, long long *violations);
 int tdnnf_planes_split(int num_planes, const tdnnf_mat *x, int lead_rows, long long rows_total, void *planes, long long t_rows_total, void *planes_t,
                        float *scale_dev, void *workspace_dev, tdnnf_stream);
 int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,

@@ -1314,6 +1314,19 @@ int tdnnf_chain_set_denominator_mode(int mode) {
   return TDNNF_OK;
 }
 
+// tests / diagnostics: how many minibatches the one-workgroup kernels redid behind a multi-workgroup launch that gave up, and whether that
+// form is switched off for the process; reset != 0 clears both
+int tdnnf_chain_den_mw_status(int *fallbacks, int *disabled, int reset) {
+  (void)hipDeviceSynchronize();
+  if (fallbacks) *fallbacks = g_mw_fallbacks ? (int)*(volatile unsigned *)g_mw_fallbacks : 0;
+  if (disabled) *disabled = g_mw_off ? 1 : 0;
+  if (reset) {
+    if (g_mw_fallbacks) *g_mw_fallbacks = 0;
+    g_mw_off = false;
+  }
+  return TDNNF_OK;
+}
+
 size_t tdnnf_chain_workspace_bytes(const tdnnf_den_graph *g, int B, int T) {
   if (!g || B <= 0 || T <= 0) return 0;
   ChainPlan p = chain_plan(g, B, T, B * 4 * (T + 1));
@@ -1503,6 +1516,7 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
       ctl.xf = reinterpret_cast<float *>(ctl.ctr + 2 * B + 2);
       ctl.xb = ctl.xf + (size_t)B * 2 * ctl.NSp;
       TDNNF_HIP(hipMemsetAsync(ctl.ctr, 0, sizeof(unsigned long long) * (2 * B + 2), s));  // (in front of the fork: both streams see it)
+      if (options().den_mw_test_abort) TDNNF_HIP(hipMemsetAsync(ctl.abort_flag, 1, 1, s));  // (tests: the recursions give up at their first poll)
       TDNNF_HIP(hipEventRecord(ev_fork, s));
       TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
       hipLaunchKernelGGL(den_mw_kernel<0>, dim3(B * G), dim3(kDenThreads), lds_f, s, gd, ctl, G, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp);

@@ -51,6 +51,8 @@ struct Options {
   int wgrad_stream = -1;  // parameter gradients on a stream of their own: -1 by minibatch size, 0 off, 1 on (read by tdnnf_net_create)
   int gemm_ring = 1;      // the persistent LDS-DMA-ring form of the rows GEMM where it applies
   int planes = 1;         // gemm_precision 2: the pre-split bf16-plane GEMMs where they apply (0: the in-kernel split everywhere)
+  int den_mw_test_abort = 0;  // tests: raise the multi-workgroup denominator's abort word before its launch (the one-workgroup kernels must then redo the minibatch)
+  int planes_check_bound = 0;  // tests: after every split that took its scale from a norm bound, measure the norm and count violations (tdnnf_planes_bound_checks)
   int den_split = -1;     // trainer: the denominator's two recursions side by side (then the occupancies of all frames at once): -1 by minibatch size, 0 / 1
 };
 Options &options();

@@ -1395,6 +1395,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     memcpy(ps.last, cfg5, sizeof(cfg5));
     const PlanesSink sink{ps.P, R, ps.scale};
     TDNNF_HIP(bn_apply_bypass(view(&x), memo, Hd, ldpad(Hd), byp, bypass, view(&out), s, mask, B, &sink));
+    if (options().planes_check_bound) TDNNF_HIP(planes_check_bound(view(&out), ps.scale, n->planes_ws, s));
     po->base = out.data; po->rows = out.rows; po->cols = out.cols; po->ld = out.stride; po->np = np;
     po->P = ps.P; po->R = R; po->lead = 0; po->kb_alloc = kb_alloc; po->scale = ps.scale;
     return TDNNF_OK;
@@ -1658,6 +1659,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(bn_relu_bwd(view(&x), view(&d), memo, 1.0f, cv, relu_stats, store, repair, c.relu_self_repair_scale, view(&d), bias_acc, 1.0f,
                           n->ws, n->ws_bytes, s, mask, B, fuse ? &f : nullptr, oderiv_of(relu_stats, relu_index), bp.P ? &bp : nullptr));
     if (po && bp.P) *po = tmp;
+    if (bp.P && options().planes_check_bound) TDNNF_HIP(planes_check_bound(view(&d), bp.rec, n->planes_ws, s));
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
@@ -1991,6 +1993,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                             view(&d_aff), bias_target(L.aff.comp), 1.0f, n->ws, n->ws_bytes, s, mask_of(l + 1), B, fuse ? &f : nullptr,
                             oderiv_of(L.relu_stats, 1 + l), bp_daff.P ? &bp_daff : nullptr));
       if (bp_daff.P) po_daff = tmp;
+      if (bp_daff.P && options().planes_check_bound) TDNNF_HIP(planes_check_bound(view(&d_aff), bp_daff.rec, n->planes_ws, s));
     }
     CK(capture(lname + ".affine.deriv", d_aff));
     tdnnf_mat lin = M(L.lin_out, nl, L.bn);

@@ -109,6 +109,8 @@ struct PlanesSplitArgs {
 size_t planes_sumsq_ws_bytes();
 // the scale record [s, 1 / s, bound] of a matrix of `numel` elements from a norm bound alone (PlanesSplitArgs::fro2_bound): for a producer that
 // writes the planes itself (fused.h PlanesSink)
+// tests (option planes_check_bound): measure ||x||_F and compare it with the bound in rec[2]; counts into tdnnf_planes_bound_checks
+hipError_t planes_check_bound(MatView x, const float *rec, void *sumsq_ws, hipStream_t s);
 hipError_t planes_scale_bound(const double *fro2_bound, int blocks, double numel, float mul, float add_coef, const float *add_rec, float *rec, hipStream_t s);
 hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s);
 // zero the rows [0, lead) and [lead + rows, R) of every (K block, plane) chunk of a row-major plane buffer (a producer that writes the data rows itself)

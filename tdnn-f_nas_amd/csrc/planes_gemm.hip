@@ -617,6 +617,29 @@ const PlanesOperand *planes_hint_b() { return g_hint_b; }
 size_t planes_bytes(int np, long long rows_total, long long k_blocks) { return (size_t)(k_blocks * np * rows_total * 32); }
 size_t planes_sumsq_ws_bytes() { return sizeof(double) * kSumsqBlocks; }
 
+__device__ unsigned g_bound_checks = 0, g_bound_violations = 0;
+__global__ void planes_check_bound_kernel(const double *partial, int nb, const float *rec) {
+  __shared__ double red[256];
+  double a = 0;
+  for (int i = threadIdx.x; i < nb; i += 256) a += partial[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  atomicAdd(&g_bound_checks, 1u);
+  if (!(sqrt(red[0]) <= (double)rec[2])) atomicAdd(&g_bound_violations, 1u);
+}
+hipError_t planes_check_bound(MatView x, const float *rec, void *sumsq_ws, hipStream_t s) {
+  const bool vec4 = (reinterpret_cast<uintptr_t>(x.data) & 15) == 0 && x.stride % 4 == 0;
+  if (vec4) hipLaunchKernelGGL(planes_sumsq4_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)sumsq_ws);
+  else hipLaunchKernelGGL(planes_sumsq_kernel, dim3(kSumsqBlocks), dim3(256), 0, s, x, (double *)sumsq_ws);
+  hipLaunchKernelGGL(planes_check_bound_kernel, dim3(1), dim3(256), 0, s, (const double *)sumsq_ws, kSumsqBlocks, rec);
+  return hipGetLastError();
+}
+
 hipError_t planes_pad(int np, void *P, long long k_blocks, long long R, int lead, long long rows, hipStream_t s) {
   if (!P || R <= rows) return hipSuccess;
   hipLaunchKernelGGL(planes_pad_kernel, dim3(grid_for(k_blocks * np * (R - rows) * 2, 256)), dim3(256), 0, s, P, k_blocks * np, R, lead, rows);
@@ -642,6 +665,10 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
     if (!a.scale || !a.sumsq_ws) return hipErrorInvalidValue;
     if (a.fro2_bound && a.fro2_blocks > 0) {  // the producer's finalize launch left a bound: no pass over the matrix
       hipLaunchKernelGGL(planes_scale_kernel, dim3(1), dim3(256), 0, s, a.fro2_bound, a.fro2_blocks, (double)x.rows * x.cols, a.scale, a.fro_mul, a.add_coef, a.add_rec);
+      if (options().planes_check_bound) {
+        hipError_t ce = planes_check_bound(x, a.scale, a.sumsq_ws, s);
+        if (ce != hipSuccess) return ce;
+      }
     } else {
       // (a small matrix gets as many norm-pass blocks as it has 16 K-element pieces, and its split forms the scale itself: two launches, not three)
       sq_nb = small ? (int)std::max<long long>(1, std::min<long long>(kSumsqBlocks, ((long long)x.rows * x.cols + 16383) / 16384)) : kSumsqBlocks;
@@ -732,6 +759,16 @@ size_t tdnnf_planes_bytes(int num_planes, long long rows_total, long long k_bloc
   return planes_bytes(num_planes, rows_total, k_blocks);
 }
 size_t tdnnf_planes_split_workspace_bytes(void) { return planes_sumsq_ws_bytes(); }
+// option planes_check_bound: how many bound-derived scales were checked against the measured norm, and how many bounds were too small
+// (synchronises the device)
+void tdnnf_planes_bound_checks(long long *checks, long long *violations) {
+  unsigned c = 0, v = 0;
+  (void)hipDeviceSynchronize();
+  (void)hipMemcpyFromSymbol(&c, HIP_SYMBOL(g_bound_checks), sizeof(c));
+  (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_bound_violations), sizeof(v));
+  if (checks) *checks = c;
+  if (violations) *violations = v;
+}
 void tdnnf_planes_routed(long long *rows_gemms, long long *weight_gradients) {
   if (rows_gemms) *rows_gemms = g_planes_routed_rows;
   if (weight_gradients) *weight_gradients = g_planes_routed_wgrad;

@@ -355,6 +355,40 @@ def test_fused_output_statistics_match_the_separate_pass(pkg, hidden):
     assert any(not np.array_equal(ga, gb) for (ga, _), (gb, _) in zip(fused[1:], separate[1:]))  # the switch did switch
 
 
+@pytest.mark.parametrize("ng", [0, 1], ids=["raw-gradient", "natural-gradient"])
+def test_f16_plane_scales_come_from_true_upper_bounds(pkg, ng):
+    """f16x3 takes the scale of a BatchNorm-produced matrix from an upper BOUND of its Frobenius norm that the finalize launch leaves
+    (forward: N scale^2 var per column + the bypass input's bound; backward: the column sums of squares of the ReLU's out-derivative + the
+    self-repair term).  A bound below the true norm could overflow an f16 plane.  With option planes_check_bound every such scale is checked
+    against the measured norm of the matrix: dropout on, self-repair on, five steps -- no violation, and the checks did run."""
+    T = pkg.trainer
+    lib = pkg.hipabi.load()
+    kw = dict(frames_per_chunk=48, num_sequences=8, strides=[1, 1, 1, 0, 3, 3, 3], bottleneck=24, feat_dim=40, ivector_dim=100, num_pdfs=150, hidden_dim=96,
+              small_dim=48, use_natural_gradient=ng, gemm_precision=3, use_dropout=1)
+    c0, v0 = C.c_longlong(), C.c_longlong()
+    lib.tdnnf_planes_bound_checks(C.byref(c0), C.byref(v0))
+    with pkg.hipabi.option("wgrad_stream", 0):
+        net = T.ChainNet(T.make_config(**kw))
+    cfg = net.cfg
+    net.set_params(net.init_params_numpy(seed=1, output_stddev=0.3))
+    net.set_dropout_proportion(0.3)
+    den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+    with pkg.hipabi.option("planes_check_bound", 1):
+        for i in range(5):
+            feats, iv = T.synthetic_egs(net, seed=100 + i)
+            feats = feats * (1.0 + 30.0 * (i == 3))  # one minibatch of large inputs
+            sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=200 + i))
+            net.set_random_draws(np.random.default_rng(300 + i).uniform(1e-3, 1 - 1e-3, net.num_draws).astype(np.float32))
+            r = host(net.forward_backward(dev(feats), dev(iv), den, sup, step=i))
+            assert r[5] == 1.0 and np.isfinite(host(net.grads)).all()
+            net.update(1e-3, step=i)
+    net.close()
+    c1, v1 = C.c_longlong(), C.c_longlong()
+    lib.tdnnf_planes_bound_checks(C.byref(c1), C.byref(v1))
+    assert c1.value - c0.value >= 5 * 2 * (cfg.num_layers - 2), (c0.value, c1.value)  # forward and backward of (nearly) every layer
+    assert v1.value == v0.value, "a norm bound was below the measured norm"
+
+
 @pytest.mark.parametrize("arith", ["f32", "f16x3-planes"])
 def test_batchnorm_statistics_out_of_the_gemm_epilogue_at_full_width(pkg, arith):
     """At 1536 columns the affine GEMM forms the BatchNorm statistics of its output while storing it (row tiles of the plain

@@ -555,6 +555,33 @@ def test_chain_denominator_several_workgroups_per_sequence(hip, ora, pkg, H, P, 
     assert rel_l2(got[1], one[1]) < 1e-5
 
 
+def test_multi_workgroup_denominator_gives_up_cleanly(hip, ora, pkg):
+    """a multi-workgroup launch whose workgroups are not co-resident must not cost the minibatch.  With the test hook
+    den_mw_test_abort the recursions see a raised abort word at their first poll; the one-workgroup kernels launched behind them then redo
+    both recursions (same kernels as mode 3: the result is bit-identical to it and matches the oracle), the fallback is counted, and the
+    next call reports it and leaves the multi-workgroup form alone for the rest of the process."""
+    lib = pkg.hipabi.load()
+    H, P, B, T, leaky = 1500, 700, 8, 60, 0.05
+    fb, off = C.c_int(), C.c_int()
+    pkg.hipabi.check(lib.tdnnf_chain_den_mw_status(C.byref(fb), C.byref(off), 1))
+    try:
+        pkg.hipabi.check(lib.tdnnf_chain_set_denominator_mode(3))
+        one = _chain_deriv(hip, pkg, H, P, B, T, leaky)
+        pkg.hipabi.check(lib.tdnnf_chain_set_denominator_mode(1))
+        with pkg.hipabi.option("den_mw_test_abort", 1):
+            got = _chain_deriv(hip, pkg, H, P, B, T, leaky)
+        assert np.isfinite(got[1]).all() and got[0] == one[0] and np.array_equal(got[1], one[1])
+        pkg.hipabi.check(lib.tdnnf_chain_den_mw_status(C.byref(fb), C.byref(off), 0))
+        assert fb.value == 1 and off.value == 0  # counted; reported and switched off by the NEXT call
+        again = _chain_deriv(hip, pkg, H, P, B, T, leaky)
+        pkg.hipabi.check(lib.tdnnf_chain_den_mw_status(C.byref(fb), C.byref(off), 0))
+        assert off.value == 1 and np.array_equal(again[1], one[1])
+        _chain_case(hip, ora, pkg, H, P, B, T, leaky, 0.0)  # and against the oracle, like every other form
+    finally:
+        pkg.hipabi.check(lib.tdnnf_chain_den_mw_status(C.byref(fb), C.byref(off), 1))
+        lib.tdnnf_chain_set_denominator_mode(0)
+
+
 def _chain_deriv(hip, pkg, H, P, B, T, leaky):
     g = pkg.synth.make_den_graph(H, P, mean_out_degree=6.0, seed=H)
     sup = pkg.synth.make_supervision(B, T, P, seed=T, weight=1.0)
