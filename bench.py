@@ -381,6 +381,7 @@ def main():
     ap.add_argument("--natural-gradient", type=int, default=1, choices=[0, 1],
                     help="1 (default, what the reference's recipes train with) = OnlineNaturalGradient preconditioning of every "
                          "updatable component's gradient; 0 = raw-gradient SGD step")
+    ap.add_argument("--also-only", default=None, metavar="REGEX", help="run only the further line items whose description matches (diagnostics)")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="a tuning option of the library (tdnnf_set_option: ng_grouped, ng_fuse, ng_early_in, wgrad_stream, gemm_ring, planes); "
                          "repeatable -- same-box A/B runs of two code paths")
@@ -560,6 +561,8 @@ def main():
 
         def line_item(name, chunk, sequences, den_states, gemm=None, steps=None, natural_gradient=None, workload=None, stats=None, archive_minibatches=0,
                       want_stats=False, profile=False):
+            if args.also_only and not name.startswith("--gemm") and not __import__("re").search(args.also_only, name):
+                return {"what": name, "skipped": True, "value": 0.0, "ms_per_step": float("nan"), "_stats": None}
             j = Job(pkg, args, chunk, sequences, den_states, rank, world, gemm=gemm, natural_gradient=natural_gradient, workload=workload, stats=stats,
                     archive_minibatches=archive_minibatches)
             k = args.steps if steps is None else steps

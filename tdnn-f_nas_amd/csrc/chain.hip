@@ -1378,6 +1378,8 @@ SupDev sup_dev(const tdnnf_supervision *sp) {
 // A second stream for the backward recursion and the fork / join events: one set per DEVICE and calling thread (created on first
 // use on that device; a process that drives several devices, or several host threads, gets a set each -- the entry points are
 // still not re-entrant for one thread).  They live as long as the process: HIP tears them down with the context.
+// The stream is created only when the caller has none to lend (aux == nullptr: events only): a stream holds a share of one of the
+// device's four hardware queues for as long as it exists, used or not, and the trainer passes its own.
 int den_aux_stream(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join) {
   struct Set {
     hipStream_t st = nullptr;
@@ -1389,12 +1391,12 @@ int den_aux_stream(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join) {
   TDNNF_HIP(hipGetDevice(&dev));
   TDNNF_REQUIRE(dev >= 0 && dev < kMaxDev, "chain: device index %d out of range", dev);
   Set &S = sets[dev];
-  if (!S.st) {
-    TDNNF_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+  if (!S.ef) {
     TDNNF_HIP(hipEventCreateWithFlags(&S.ef, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&S.ej, hipEventDisableTiming));
   }
-  *aux = S.st;
+  if (aux && !S.st) TDNNF_HIP(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+  if (aux) *aux = S.st;
   *ev_fork = S.ef;
   *ev_join = S.ej;
   return TDNNF_OK;
@@ -1464,11 +1466,10 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     const int P4 = (g->P + 3) & ~3, H4 = (g->H + 3) & ~3;
     const size_t lds_beta = sizeof(float) * (P4 + H4), lds_gamma = sizeof(float) * (P4 + 2 * H4);
     float *b_all = b.gstate, *S_all = b_all + (size_t)B * (T + 1) * b.p.Hs;
-    hipStream_t aux;
     hipEvent_t ev_fork, ev_join;
-    int rc = den_aux_stream(&aux, &ev_fork, &ev_join);
+    hipStream_t aux = caller_aux;  // a stream the caller has idle (beyond four streams in flight they share hardware queues)
+    int rc = den_aux_stream(caller_aux ? nullptr : &aux, &ev_fork, &ev_join);
     if (rc) return rc;
-    if (caller_aux) aux = caller_aux;  // a stream the caller has idle (beyond four streams in flight they share hardware queues)
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_beta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beta));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gamma));

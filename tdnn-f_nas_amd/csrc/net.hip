@@ -1222,16 +1222,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_den, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_num, hipEventDisableTiming));
-    {
-      // the natural-gradient side stream carries small latency-bound launches that should fill idle slots, not take slots from
-      // the backward pass (a launch sized for one round of resident blocks runs two when a few slots are taken): lowest priority
-      // -- except for few sequences: there the stream also carries the second denominator recursion, whose workgroups (four per sequence,
-      // den_mw_kernel) poll for partners and must not be kept from the chip by the other streams' launches: normal priority
-      int lo = 0, hi = 0;
-      if (B > 32 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) TDNNF_HIP(hipStreamCreateWithPriority(&n->s3, hipStreamNonBlocking, lo));
-      else TDNNF_HIP(hipStreamCreateWithFlags(&n->s3, hipStreamNonBlocking));
-      (void)hipGetLastError();
-    }
+    // The side stream (natural-gradient statistics, the denominator's second recursion) at the default priority, as every stream of the
+    // library: rounds 2-3 gave it the lowest priority above 32 sequences, which is worth nothing measurable in the step any more
+    // (124.0 / 124.0 ms at 128 sequences, 22.9 / 23.0 at 16) and made a job's step time depend on what had run before it in the
+    // process -- once a stream of another priority has existed, HIP's hardware-queue pool maps the next net's streams differently (a
+    // 16-sequence step took 35 ms instead of 23 after a 128-sequence job, a 128-sequence step 142 ms after a 16-sequence one;
+    // docs/experiments.md r4-d).
+    TDNNF_HIP(hipStreamCreateWithFlags(&n->s3, hipStreamNonBlocking));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_s3, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fin0, hipEventDisableTiming));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fin, hipEventDisableTiming));
