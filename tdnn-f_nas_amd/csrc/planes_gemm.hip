@@ -41,7 +41,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int kStages = 3;
+// LDS ring depth per tile: the 256-row tiles of two planes hold one block per CU either way (96 KB at three stages), so they take a deeper
+// ring -- requests run kBigStages - 1 K steps ahead of the multiply; the 128-row tiles (two blocks per CU) and the three-plane tiles keep three.
+#ifndef TDNNF_PLANES_BIG_STAGES
+#define TDNNF_PLANES_BIG_STAGES 4
+#endif
+constexpr int kBigStages = TDNNF_PLANES_BIG_STAGES;
+template <int NP, int BM>
+constexpr int stages_of() { return (NP == 2 && BM >= 256) ? kBigStages : 3; }
 
 template <int NP>
 struct Plane;
@@ -279,6 +286,7 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
   constexpr int A_BYTES = NP * BM * 32, B_BYTES = NP * BN * 32, STAGE = A_BYTES + B_BYTES;
   constexpr int PIECES = STAGE / 16, PPT = (PIECES + NT - 1) / NT;  // 16-byte pieces per stage / per thread
   constexpr int STAGE_PAD = PPT * NT * 16;  // every thread copies PPT pieces per stage (the surplus ones into the pad): one vmcnt count for all waves
+  constexpr int NS = stages_of<NP, BM>();
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   // XCD-aware tile order (workgroups are dealt to the eight XCDs round-robin): each XCD a contiguous run of tiles, column tiles
@@ -358,14 +366,23 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     }
   };
   next_request_segment();
-  auto request = [&](int slot) {
-    char *dst = smem + slot * STAGE_PAD;
-#pragma unroll
-    for (int j = 0; j < PPT; j++) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcp[j]), (__attribute__((address_space(3))) void *)(dst + lds_off[j]), 16, 0, 0);
-      srcp[j] += kstride[j];
-    }
+  auto request_piece = [&](int slot, int j) {
+#if defined(TDNNF_PLANES_EXPERIMENT) && TDNNF_PLANES_EXPERIMENT == 2
+    if (slot != 0) return;
+#endif
+    // (as an instruction the compiler does not see: it books the builtin as a flat access pending on BOTH counters and, knowing nothing of the
+    // counted vmcnt waits below, turns every later lgkmcnt wait into lgkmcnt(0) -- the LDS reads could not be counted past each other)
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(smem + slot * STAGE_PAD + lds_off[j]));
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(srcp[j]), "s"(m0v) : "memory");  // (m0 is a reserved register nothing else in these kernels uses)
+    srcp[j] += kstride[j];
+  };
+  auto request_done = [&]() {
     if (--ld_left == 0) next_request_segment();
+  };
+  auto request = [&](int slot) {
+#pragma unroll
+    for (int j = 0; j < PPT; j++) request_piece(slot, j);
+    request_done();
   };
 
   // fragment addressing: lane (li, lh) of a 32 x 32 x 16 MFMA holds k = 8 lh .. 8 lh + 7 of row li; the halves of a row record are
@@ -405,65 +422,154 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
   next_compute_segment();
   // Fragments of stage g + 1 are read into a second register set while stage g is multiplied: a wave has its SIMD to itself, so
   // LDS latency (and the LDS bandwidth of the waves reading their fragments) would otherwise sit in front of every K step's MFMAs.
+  auto read_a = [&](const char *st, int q, V8 (&a)[NP][TM]) {
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      if constexpr (ATR) {
+        typedef __attribute__((address_space(3))) s16x4 *lds4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(st + q * BM * 32 + a_off[i]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(st + q * BM * 32 + a_off[i] + 256));
+        union { s16x4 h[2]; V8 v; } u;
+        u.h[0] = lo;
+        u.h[1] = hi;
+        a[q][i] = u.v;
+      } else {
+        a[q][i] = *reinterpret_cast<const V8 *>(st + q * BM * 32 + a_off[i]);
+      }
+    }
+  };
+  auto read_b = [&](const char *st, int q, V8 (&b)[NP][TN]) {
+#pragma unroll
+    for (int j = 0; j < TN; j++) b[q][j] = *reinterpret_cast<const V8 *>(st + q * BN * 32 + b_off[j]);
+  };
   auto read_frags = [&](int slot, V8 (&a)[NP][TM], V8 (&b)[NP][TN]) {
     const char *st = smem + slot * STAGE_PAD;
 #pragma unroll
     for (int q = 0; q < NP; q++) {
-#pragma unroll
-      for (int j = 0; j < TN; j++) b[q][j] = *reinterpret_cast<const V8 *>(st + q * BN * 32 + b_off[j]);
-#pragma unroll
-      for (int i = 0; i < TM; i++) {
-        if constexpr (ATR) {
-          typedef __attribute__((address_space(3))) s16x4 *lds4;
-          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(st + q * BM * 32 + a_off[i]));
-          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4)(st + q * BM * 32 + a_off[i] + 256));
-          union { s16x4 h[2]; V8 v; } u;
-          u.h[0] = lo;
-          u.h[1] = hi;
-          a[q][i] = u.v;
-        } else {
-          a[q][i] = *reinterpret_cast<const V8 *>(st + q * BM * 32 + a_off[i]);
-        }
-      }
+      read_b(st, q, b);
+      read_a(st, q, a);
     }
     if (--cs_left == 0) next_compute_segment();  // (the NEXT read belongs to the next segment: its rows may swap other halves)
   };
+  auto product = [&](const V8 (&a)[NP][TM], int qa, const V8 (&b)[NP][TN], int qb) {
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++) acc[i][j] = Plane<NP>::mfma(a[qa][i], b[qb][j], acc[i][j]);
+  };
   auto multiply = [&](const V8 (&a)[NP][TM], const V8 (&b)[NP][TN]) {
+#if defined(TDNNF_PLANES_EXPERIMENT) && TDNNF_PLANES_EXPERIMENT == 1
+    acc[0][0][0] += (float)a[0][0][0] + (float)b[0][0][0];
+    return;
+#endif
     // the products a_q b_(d - q), d = np - 1 .. 0: smallest terms first, the leading term last
 #pragma unroll
     for (int d = NP - 1; d >= 0; d--)
 #pragma unroll
-      for (int q = 0; q <= d; q++)
+      for (int q = 0; q <= d; q++) product(a, q, b, d - q);
+  };
+  // the same product with the request pieces [jlo, jhi) of `slot` issued between its MFMAs, evenly spaced (a piece issued alone costs the
+  // wave ~60 cycles, several in a row behind a barrier 100-185 each -- with both waves of a SIMD there together the matrix pipe idles)
+  auto product_req = [&](const V8 (&a)[NP][TM], int qa, const V8 (&b)[NP][TN], int qb, bool req, int slot, int jlo, int jhi) {
+    constexpr int total_m = TM * TN;
+    const int np = jhi - jlo;
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+    for (int k = 0; k < total_m; k++) {
+      acc[k / TN][k % TN] = Plane<NP>::mfma(a[qa][k / TN], b[qb][k % TN], acc[k / TN][k % TN]);
 #pragma unroll
-          for (int j = 0; j < TN; j++) acc[i][j] = Plane<NP>::mfma(a[q][i], b[d - q][j], acc[i][j]);
+      for (int n = 0; n < PPT; n++)
+        if (n < np && k == ((n + 1) * total_m) / (np + 1) - 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (req) request_piece(slot, jlo + n);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
   };
   // One K step.  On entry the fragments of stage g are in (a0, b0) and the requests of stages g + 1, g + 2 are in flight.
   //   wait until stage g + 1 has landed (at most stage g + 2's pieces outstanding); barrier: everybody's pieces of stage g + 1 are
   //   in LDS and everybody has read stage g's fragments, so slot g % 3 is free: request stage g + 3 into it; read the fragments of
   //   stage g + 1 into (a1, b1) while stage g is multiplied.
+  // wait until at most `k` stages' requests of this thread are outstanding (k <= NS - 1; uniform)
+  auto wait_stages = [&](int k) {
+    static_assert((NS - 1) * PPT <= 63, "vmcnt is a 6-bit count");
+    if (k >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPT > 63 ? 63 : 4 * PPT) : "memory");
+    else if (k == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PPT > 63 ? 63 : 3 * PPT) : "memory");
+    else if (k == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+    else if (k == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
   auto step = [&](int g, V8 (&a0)[NP][TM], V8 (&b0)[NP][TN], V8 (&a1)[NP][TM], V8 (&b1)[NP][TN]) {
     if (g + 1 < total) {
-      if (g + 2 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_stages(min(NS - 2, total - g - 2));  // stage g + 1 has landed; stages g + 2 .. may still be in flight
       __builtin_amdgcn_s_barrier();
-      if (g + 3 < total) request(g % kStages);
-      read_frags((g + 1) % kStages, a1, b1);
+      if (g + NS < total) request(g % NS);
+      read_frags((g + 1) % NS, a1, b1);
     }
     multiply(a0, b0);
   };
 
-  if constexpr (DB) {
-    // prologue: three stages requested, the first one's fragments read
-    V8 fa0[NP][TM], fb0[NP][TN], fa1[NP][TM], fb1[NP][TN];
-    if (total > 0) request(0);
-    if (total > 1) request(1);
-    if (total > 2) request(2);
+  if constexpr (NP == 2 && !DB) {
+    // Two planes, one register set, no exposed LDS phase: a K step's three products are ordered l h', h h', h l' and the fragments of the NEXT
+    // stage are read into each operand's registers as soon as its last product of THIS stage has been issued -- l after the first product,
+    // h' after the second, h and l' after the third -- so every LDS read has eight MFMAs (256 cycles of the matrix pipe) or more between
+    // its issue and its first use.  (Read all at once behind the barrier, the twelve reads of a step sat in front of its MFMAs in both
+    // waves of a SIMD together: the compute phase alone ran at 1.26 us per K step of a 256 x 256 tile where the MFMAs take 0.65-0.8.)
+    // The barrier sits behind the first product: stage g + 1 has landed for everybody and everybody's reads of stage g are complete
+    // (lgkmcnt(0): they were issued a product earlier), so slot g % NS takes stage g + NS.
+    V8 fa[NP][TM], fb[NP][TN];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+      if (total > i) request(i);
     if (total > 0) {
-      if (total > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
-      else if (total > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_stages(min(NS - 1, total - 1));
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), as an instruction the compiler's counter model sees: kernel-argument loads still pending here
+                                           // (scalar loads share the counter and return out of order) would make it wait for ALL LDS reads at the loop head
+      read_a(smem, 1, fa);  // (in the loop's order: the first product's operands are the oldest reads on either way into the loop)
+      read_b(smem, 0, fb);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(smem, 0, fa);
+      read_b(smem, 1, fb);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (total > 0) {
+      product(fa, 1, fb, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      // (the loop begins behind step g's first product, at its barrier: the one place of a step where no LDS read is outstanding, so the
+      // compiler's wait-count model, which gives up precision across a loop's back edge, has nothing to be conservative about)
+      for (int g = 0; g + 1 < total; g++) {
+        const char *st = smem + ((g + 1) % NS) * STAGE_PAD;
+        wait_stages(min(NS - 2, total - g - 2));
+        __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        if (--cs_left == 0) next_compute_segment();  // the fragment offsets of stage g + 1 (the segment table is read with scalar loads, which share the LDS reads' counter)
+        const bool req = g + NS < total;
+        read_a(st, 1, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        product_req(fa, 0, fb, 0, req, g % NS, 0, PPT / 2);
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(st, 0, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        product_req(fa, 0, fb, 1, req, g % NS, PPT / 2, PPT);
+        if (req) request_done();
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(st, 0, fa);
+        read_b(st, 1, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        product(fa, 1, fb, 0);  // (of step g + 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      product(fa, 0, fb, 0);
+      product(fa, 0, fb, 1);
+    }
+  } else if constexpr (DB) {
+    // prologue: NS stages requested, the first one's fragments read
+    V8 fa0[NP][TM], fb0[NP][TN], fa1[NP][TM], fb1[NP][TN];
+#pragma unroll
+    for (int i = 0; i < NS; i++)
+      if (total > i) request(i);
+    if (total > 0) {
+      wait_stages(min(NS - 1, total - 1));
       __builtin_amdgcn_s_barrier();
       read_frags(0, fa0, fb0);
     }
@@ -473,16 +579,16 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     }
   } else {
     // One register set (tiles whose accumulators leave no room for a second): stage g is read and multiplied behind the barrier
-    // that follows its wait; two stages are in flight meanwhile.
+    // that follows its wait; NS - 1 stages are in flight meanwhile.
     V8 fa[NP][TM], fb[NP][TN];
-    if (total > 0) request(0);
-    if (total > 1) request(1);
+#pragma unroll
+    for (int i = 0; i < NS - 1; i++)
+      if (total > i) request(i);
     for (int g = 0; g < total; g++) {
-      if (g + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_stages(min(NS - 2, total - g - 1));
       __builtin_amdgcn_s_barrier();  // everybody's pieces of stage g are in LDS; everybody is done reading stage g - 1
-      if (g + 2 < total) request((g + 2) % kStages);  // into the slot stage g - 1 used
-      read_frags(g % kStages, fa, fb);
+      if (g + NS - 1 < total) request((g + NS - 1) % NS);  // into the slot stage g - 1 used
+      read_frags(g % NS, fa, fb);
       multiply(fa, fb);
     }
   }
@@ -586,7 +692,7 @@ template <int NP, int WM, int WN, int TM, int TN, bool DB = false, bool ATR = fa
 hipError_t launch(const PlanesGemmArgs &a, hipStream_t s) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int NT = WM * WN * 64, PIECES = (NP * BM * 32 + NP * BN * 32) / 16, PPT = (PIECES + NT - 1) / NT;
-  constexpr size_t lds = (size_t)kStages * PPT * NT * 16;
+  constexpr size_t lds = (size_t)stages_of<NP, BM>() * PPT * NT * 16;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void *)planes_gemm_kernel<NP, WM, WN, TM, TN, DB, ATR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
