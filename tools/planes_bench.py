@@ -15,6 +15,7 @@ pkg = ge.load_package()
 abi = pkg.hipabi
 lib = abi.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+DATA = sys.argv[2] if len(sys.argv) > 2 else "randn"  # "zeros" / "ones": the same kernels on operands that toggle no multiplier bits (clock / power check)
 
 
 def timed(fn):
@@ -47,6 +48,10 @@ def run(name, M, N, Di, offs):
     rows_in = M + max(offs) - min(offs)
     X = torch.randn(rows_in, Di, device="cuda")
     W = torch.randn(N, K * Di, device="cuda") / (K * Di) ** 0.5
+    if DATA == "zeros":
+        X, W = X * 0, W * 0
+    elif DATA == "ones":
+        X, W = X * 0 + 1, W * 0 + 1
     Cm = torch.zeros(M, N, device="cuda")
     BN = 160 if ((N + 159) // 160) * 160 - N < ((N + 127) // 128) * 128 - N else (256 if N % 256 == 0 else 128)
     Nb = ((N + BN - 1) // BN) * BN
