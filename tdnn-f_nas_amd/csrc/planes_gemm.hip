@@ -41,10 +41,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// LDS ring depth per tile: the 256-row tiles of two planes hold one block per CU either way (96 KB at three stages), so they take a deeper
-// ring -- requests run kBigStages - 1 K steps ahead of the multiply; the 128-row tiles (two blocks per CU) and the three-plane tiles keep three.
+// LDS ring depth per tile.  Three everywhere: the 256-row tiles of two planes would have room for four (128 KB, still one block per CU), measured
+// on the trainer's shapes and in the step: no difference (the K loop is not bound by the latency of its loads) -- and 96 KB leave room beside it.
 #ifndef TDNNF_PLANES_BIG_STAGES
-#define TDNNF_PLANES_BIG_STAGES 4
+#define TDNNF_PLANES_BIG_STAGES 3
 #endif
 constexpr int kBigStages = TDNNF_PLANES_BIG_STAGES;
 template <int NP, int BM>
