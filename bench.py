@@ -644,6 +644,11 @@ def main():
                     it["vs_one_eighth_of_its_128_sequence_step"] = round(it["ms_per_step"] / (full["ms_per_step"] / 8.0), 3)
                     it["ideal_speedup_at_8_gpus_before_any_collective"] = round(8.0 / it["vs_one_eighth_of_its_128_sequence_step"], 2)
                     out["also"].append(it)
+                if not args.no_alt:  # the offset supernet on the plane kernels: tap coefficients folded into the weight planes, zero taps skipped in the kernels
+                    out["also"].append(line_item("DARTS offset supernet, pretrain, f32-equivalent 16-bit matrix-core arithmetic (--workload darts-offset --gemm f16x3)",
+                                                 args.chunk, seqs, args.den_states, steps=6, workload="darts-offset", gemm="f16x3"))
+                    out["also"].append(line_item("DARTS offset supernet, cv-update, f32-equivalent 16-bit matrix-core arithmetic (--workload darts-offset-cvupdate --gemm f16x3)",
+                                                 args.chunk, seqs, args.den_states, steps=6, workload="darts-offset-cvupdate", stats=stats, gemm="f16x3"))
                 if not args.no_alt:  # configs[4] as BASELINE.json words it: "fp32 objf / bf16 MFMA GEMM" -- the 16-bit matrix cores with an f32 objective
                     out["also"].append(line_item("bottleneck-dimension supernet with the f32-equivalent 16-bit matrix-core arithmetic (--workload bn-supernet --gemm f16x3: "
                                                  "BASELINE configs[4], fp32 objective / 16-bit MFMA GEMMs)", args.chunk, seqs, args.den_states, steps=6,

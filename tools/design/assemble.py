@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""DESIGN.md = the section texts in this directory with the figures of one default `python bench.py` run filled in (so that the document and
+the bench line it quotes cannot drift apart).  usage: python tools/design/assemble.py BENCH_JSON SYNCBN_TXT N_GPU_TESTS > DESIGN.md"""
+import json
+import os
+import re
+import sys
+
+here = os.path.dirname(os.path.abspath(__file__))
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+syncbn = [l.split() for l in open(sys.argv[2]).read().strip().splitlines()]
+ntests = sys.argv[3]
+
+
+def also(pat):
+    for a in j["also"]:
+        if re.search(pat, a["what"]):
+            return a
+    raise KeyError(pat)
+
+
+def M(v):
+    return "%.3f" % (v / 1e6)
+
+
+r, alt = j["roofline"], j["alt"]
+ar = alt["roofline"]
+cls = {c["kernel"]: c for c in r["all_kernels"]}
+f32_tf = " / ".join("%.1f" % cls[k]["tflops"] for k in ("rows_gemm_f32_128x128", "rows_gemm_f32_128x160", "wgrad_f32"))
+f32_fr = " / ".join("%.2f" % (cls[k]["tflops"] / r["peak"]) for k in ("rows_gemm_f32_128x128", "rows_gemm_f32_128x160", "wgrad_f32"))
+alt_tf = " / ".join("%.0f" % c["f32_equivalent_tflops"] for c in ar["all_kernels"])
+alt_fr = " / ".join("%.2f" % c["frac_of_16bit_peak"] for c in ar["all_kernels"])
+r150 = also("recipes' egs shape")
+sh7 = also(r"^the per-GPU shard")
+shd = also("DARTS offset supernet, pretrain: the per-GPU shard")
+shb = also("bottleneck-dimension supernet, Onehot pretrain: the per-GPU shard")
+d10, d30 = also("10 000-state"), also("30 000-state")
+ngoff = also("natural gradient off")
+pre, cv, bn = also(r"DARTS offset supernet, pretrain \(--workload"), also(r"cv-update: Gumbel"), also(r"bottleneck-dimension supernet, Onehot pretrain \(--workload")
+bn16 = also("bottleneck-dimension supernet with the f32-equivalent")
+pre16, cv16 = also(r"pretrain, f32-equivalent"), also(r"cv-update, f32-equivalent")
+arch = [a for a in j["also"] if a["what"].startswith("archive-fed")]
+sec = j["roofline_secondary"]
+par, apar = j["parity"], alt["parity"]
+cpu = j["cpu_baseline"]
+off = [float(l[3]) for l in syncbn if l[2] == "off"]
+on = [float(l[3]) for l in syncbn if l[2] == "on"]
+shards = ("7q %.2f ms = %.2f × an eighth of the headline step (at most %.2f × at 8 GPUs before any collective); offset supernet %.2f ms = %.2f × an eighth "
+          "of its own 128-sequence step (%.2f ×); bottleneck supernet %.2f ms = %.2f × (%.2f ×)" %
+          (sh7["ms_per_step"], sh7["vs_one_eighth_of_the_headline_step"], sh7["ideal_speedup_at_8_gpus_before_any_collective"],
+           shd["ms_per_step"], shd["vs_one_eighth_of_its_128_sequence_step"], shd["ideal_speedup_at_8_gpus_before_any_collective"],
+           shb["ms_per_step"], shb["vs_one_eighth_of_its_128_sequence_step"], shb["ideal_speedup_at_8_gpus_before_any_collective"]))
+hbm_rows = "; ".join("`%s` %.0f GB/s = **%.2f** of 8 TB/s (%.2f ms per step%s)" % (h["kernel"], h["achieved"], h["frac"], h["ms_per_step"],
+                     ", %.1f µs per frame step" % h["us_per_frame_step"] if h.get("us_per_frame_step") else "") for h in j["roofline_hbm"])
+vals = {
+    "F32_FPS": M(j["value"]), "F32_MS": "%.1f" % j["ms_per_step"], "F32_FRAC": "%.3f" % r["frac"], "F32_TF": f32_tf, "F32_FRACS": f32_fr,
+    "ALT_FPS": M(alt["value"]), "ALT_MS": "%.1f" % alt["ms_per_step"], "ALT_RATIO": "%.2f" % (j["ms_per_step"] / alt["ms_per_step"]),
+    "ALT_OBJF": "%.1e" % apar["objf_rel"], "ALT_GRAD": "%.1e" % apar["grad_rel_l2"], "ALT_TIES": str(apar["relu_ties"]), "ALT_TF": alt_tf, "ALT_FRACS": alt_fr,
+    "SUPER_ALT": "bottleneck supernet %.1f ms exact f32 → %.1f ms f16x3 (%s M frames/s); offset supernet pretrain %.1f → %.1f ms, cv-update %.1f → %.1f ms (%.0f k frames/s)" %
+                 (bn["ms_per_step"], bn16["ms_per_step"], M(bn16["value"]), pre["ms_per_step"], pre16["ms_per_step"], cv["ms_per_step"], cv16["ms_per_step"], cv16["value"] / 1e3),
+    "R150": "%.0f k frames/s (%.2f ms)" % (r150["value"] / 1e3, r150["ms_per_step"]),
+    "R150_PROF": "577 dispatches per step, half of the step without a kernel of the caller's stream in flight; the host is three steps ahead (docs/experiments.md r4-f)",
+    "SHARDS": shards,
+    "SYNCBN": "%.2f ms against %.2f ms per 1500 × 16 step (+%.2f ms; target ≤ 0.5)" % (sum(on) / len(on), sum(off) / len(off), sum(on) / len(on) - sum(off) / len(off)),
+    "TAPDOTS": "7.9 µs per launch (`profiles/r04_darts-offset-cvupdate_kernel_classes.csv`)",
+    "NGPU_TESTS": ntests,
+    "HBM_ROWS": hbm_rows,
+    "NG_ROW": "statistics passes %.0f GB/s algorithmic = %.3f of the HBM peak, %.1f ms of launches per step; natural gradient on − off = **%.1f ms** per step (off: %.1f ms)" %
+              (sec["achieved"], sec["frac"], sec["ms_per_step"], ngoff["natural_gradient_cost_ms_per_step"], ngoff["ms_per_step"]),
+    "DEN_ROWS": "10 000 states %.1f ms, 30 000 states %.1f ms per step (4 000: %.1f)" % (d10["ms_per_step"], d30["ms_per_step"], j["ms_per_step"]),
+    "SUPER_ROWS": "offset supernet pretrain %.1f ms (%.0f k frames/s); its cv-update (Gumbel over all 7 taps, BatchNormTest) %.1f ms (%.0f k; VERDICT r3 asked ≥ 360 k); "
+                  "bottleneck supernet %.1f ms (%s M); with f16x3: %.1f / %.1f / %.1f ms (%.0f k / %.0f k / %s M)" % (pre["ms_per_step"], pre["value"] / 1e3, cv["ms_per_step"], cv["value"] / 1e3,
+                                                                                 bn["ms_per_step"], M(bn["value"]), pre16["ms_per_step"], cv16["ms_per_step"], bn16["ms_per_step"],
+                                                                                 pre16["value"] / 1e3, cv16["value"] / 1e3, M(bn16["value"])),
+    "ARCHIVE": "; ".join("%s: %.3f × the resident-input rate" % ("1500 × 128" if a["frames_per_chunk"] == 1500 else "150 × 64", a["vs_resident_inputs"]) for a in arch),
+    "CPU": "%.0f frames/s on %d OpenMP threads, %.1f on one (`kind: port` — the oracle's float build, not Kaldi)" % (cpu["value"], cpu["cores"], cpu["single_thread"]["value"]),
+    "PARITY": "objective %.1e (tolerance 1e-4), gradient %.1e (1e-3), %d ReLU ties of %d elements taken from the GPU run" % (par["objf_rel"], par["grad_rel_l2"], par["relu_ties"], par["relu_elements"]),
+}
+r4 = {
+    "R4_SYNCBN": vals["SYNCBN"], "R4_SHARDS": shards, "R4_ALT_MS": "%.1f ms" % alt["ms_per_step"], "R4_F32_MS": "%.1f ms" % j["ms_per_step"],
+    "R4_ALT_FRAC": "%.3f for the class with the most time (%s), %s over the three classes — the ≥ 0.35 is not met: the shapes are bound by what a CU loads and stores "
+                   "per K step and the chip is power-limited on full-entropy f16 operands (§4b)" % (ar["frac"], ar["kernel"].split(" (")[0], alt_fr),
+    "R4_150x64": vals["R150"] + " (≥ 900 k not met)", "R4_1500x16": "%.2f ms = %.2f × (≤ 1.25 × not met)" % (sh7["ms_per_step"], sh7["vs_one_eighth_of_the_headline_step"]),
+    "R4_TAPDOTS": "556 → 7.9 µs per launch", "R4_CVUPDATE": "%.1f ms = %.0f k frames/s (was 608 ms / 316 k; ≥ 360 k not met)" % (cv["ms_per_step"], cv["value"] / 1e3),
+}
+out = []
+for name in sorted(os.listdir(here)):
+    if not name.endswith(".md"):
+        continue
+    t = open(os.path.join(here, name)).read()
+    t = re.sub(r"\{([A-Z0-9_]+)\}", lambda m: vals[m.group(1)] if m.group(1) in vals else m.group(0), t)
+    for k in sorted(r4, key=len, reverse=True):
+        t = t.replace(k, r4[k])
+    out.append(t.rstrip() + "\n")
+sys.stdout.write("\n".join(out))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Which stream is the step waiting for?  From a rocprofv3 --kernel-trace CSV (…_kernel_trace.csv): over the last STEPS
-steps (delimited by the once-per-step den_forward kernel) the busy time of every queue, the time it is the ONLY queue with a
+steps (delimited by the once-per-step splice_input kernel) the busy time of every queue, the time it is the ONLY queue with a
 kernel in flight, and the time no kernel is in flight at all.
 usage: stream_overlap.py KERNEL_TRACE_CSV [steps]"""
 import csv
@@ -13,7 +13,7 @@ with open(sys.argv[1]) as f:
         q = r.get("Stream_Id") or r.get("Queue_Id")
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "%s/%s" % (r.get("Queue_Id"), q), r["Kernel_Name"]))
 rows.sort()
-marks = [s for s, e, q, n in rows if "den_forward" in n or "den_wide_init" in n or "den_mw_kernel<0>" in n]
+marks = [s for s, e, q, n in rows if "splice_input" in n]  # the first kernel of a step's forward pass: once per step (the denominator kernels are not: the multi-workgroup form launches its fallback behind it)
 t0, t1 = marks[-steps - 1], marks[-1]
 win = [(max(s, t0), min(e, t1), q, n) for s, e, q, n in rows if e > t0 and s < t1]
 ev = []

@@ -12,7 +12,7 @@ with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id"), r["Kernel_Name"], r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size")))
 rows.sort()
-marks = [s for s, e, q, n, g, w in rows if "den_forward" in n or "den_wide_init" in n or "den_mw_kernel<0>" in n]
+marks = [s for s, e, q, n, g, w in rows if "splice_input" in n]  # the first kernel of a step's forward pass: once per step (the denominator kernels are not: the multi-workgroup form launches its fallback behind it)
 t0, t1 = marks[-steps - 1], marks[-1]
 acc = {}
 for s, e, q, n, g, w in rows:
