@@ -577,11 +577,13 @@ def main():
             if want_stats:
                 it["_stats"] = j.net.get_stats()
             if profile:  # the event-timed GEMM classes of this job (as the headline's "roofline")
-                it["_classes"], it["_event_steps"] = [], j.event_steps
-                for kc in range(4):
-                    n_, ms_, fl_ = C.c_double(), C.c_double(), C.c_double()
+                it["_classes"], it["_hbm_classes"], it["_event_steps"] = [], [], j.event_steps
+                for kc in range(8):
+                    n_, ms_, fl_, by_ = C.c_double(), C.c_double(), C.c_double(), C.c_double()
                     pkg.hipabi.check(lib.tdnnf_profile_read(kc, C.byref(n_), C.byref(ms_), C.byref(fl_)))
-                    it["_classes"].append(dict(name=lib.tdnnf_profile_class_name(kc).decode(), launches=n_.value, ms=ms_.value, flops=fl_.value))
+                    pkg.hipabi.check(lib.tdnnf_profile_read_bytes(kc, C.byref(by_)))
+                    it["_classes" if kc < 4 else "_hbm_classes"].append(dict(name=lib.tdnnf_profile_class_name(kc).decode(), launches=n_.value, ms=ms_.value, flops=fl_.value,
+                                                                             bytes=by_.value))
             j.close()
             torch.cuda.empty_cache()
             return it
@@ -610,6 +612,10 @@ def main():
                                                            "frac_of_16bit_peak": round(3.0 * c["flops"] / (c["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4)} for c in cl],
                                           "note": "event classes as in the headline's roofline (the class names are the f32 kernels'): forward / backward-data GEMMs by "
                                                   "output width, weight gradients; the plane splits (HBM passes, class planes_split) are not in these times but in ms_per_step"}
+                out["alt"]["roofline_hbm"] = [{"bound": "hbm", "kernel": hc["name"], "achieved": round(hc["bytes"] / (hc["ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                               "frac": round(hc["bytes"] / (hc["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": int(hc["launches"]),
+                                               "ms_per_step": round(hc["ms"] / max(it.get("_event_steps") or 1, 1), 3), "traffic": None}
+                                              for hc in it.get("_hbm_classes", []) if hc["ms"] > 0]
         if world == 1 and not args.no_also:
             # further line items, same net and step: the reference's own egs shape (chunk 150 x 64, ...pretrain.sh:46,197) and
             # SWBD-scale denominator graphs (10 000 and 30 000 states)

@@ -59,7 +59,7 @@ vals = {
     "SUPER_ALT": "bottleneck supernet %.1f ms exact f32 → %.1f ms f16x3 (%s M frames/s); offset supernet pretrain %.1f → %.1f ms, cv-update %.1f → %.1f ms (%.0f k frames/s)" %
                  (bn["ms_per_step"], bn16["ms_per_step"], M(bn16["value"]), pre["ms_per_step"], pre16["ms_per_step"], cv["ms_per_step"], cv16["ms_per_step"], cv16["value"] / 1e3),
     "R150": "%.0f k frames/s (%.2f ms)" % (r150["value"] / 1e3, r150["ms_per_step"]),
-    "R150_PROF": "577 dispatches per step, half of the step without a kernel of the caller's stream in flight; the host is three steps ahead (docs/experiments.md r4-f)",
+    "R150_PROF": "589 dispatches per step, no kernel in flight 1.5 ms of a 13.8 ms profiled step (1.5 of 23.7 ms at 1500 × 16), the caller's stream busy 8.8 ms; the host is three steps ahead (docs/experiments.md r4-f, r4-g)",
     "SHARDS": shards,
     "SYNCBN": "%.2f ms against %.2f ms per 1500 × 16 step (+%.2f ms; target ≤ 0.5)" % (sum(on) / len(on), sum(off) / len(off), sum(on) / len(on) - sum(off) / len(off)),
     "TAPDOTS": "7.9 µs per launch (`profiles/r04_darts-offset-cvupdate_kernel_classes.csv`)",
@@ -81,7 +81,8 @@ r4 = {
     "R4_ALT_FRAC": "%.3f for the class with the most time (%s), %s over the three classes — the ≥ 0.35 is not met: the shapes are bound by what a CU loads and stores "
                    "per K step and the chip is power-limited on full-entropy f16 operands (§4b)" % (ar["frac"], ar["kernel"].split(" (")[0], alt_fr),
     "R4_150x64": vals["R150"] + " (≥ 900 k not met)", "R4_1500x16": "%.2f ms = %.2f × (≤ 1.25 × not met)" % (sh7["ms_per_step"], sh7["vs_one_eighth_of_the_headline_step"]),
-    "R4_TAPDOTS": "556 → 7.9 µs per launch", "R4_CVUPDATE": "%.1f ms = %.0f k frames/s (was 608 ms / 316 k; ≥ 360 k not met)" % (cv["ms_per_step"], cv["value"] / 1e3),
+    "R4_TAPDOTS": "556 → 7.9 µs per launch", "R4_CVUPDATE": "%.1f ms = %.0f k frames/s in exact f32 (was 608 ms / 316 k; ≥ 360 k not met: its GEMM classes run at the 7q step's rates, the step is seven taps of FLOPs); "
+                   "with f16x3 %.1f ms = **%.0f k frames/s**" % (cv["ms_per_step"], cv["value"] / 1e3, cv16["ms_per_step"], cv16["value"] / 1e3),
 }
 out = []
 for name in sorted(os.listdir(here)):

@@ -16,11 +16,13 @@ trace_reports() {  # dir tag [marker kernel]
   python3 tools/trace_shapes.py "$F" 8 0.1 > gpurun_out/${1}_shapes.txt || true
   python3 - "$F" <<'PY' > gpurun_out/${1}_dispatches.txt || true
 import csv, sys
+sys.path.insert(0, "tools")
+from trace_util import step_window
 rows = [(int(r["Start_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
 marks = [s for s, n in rows if "splice_input" in n]
-t0, t1 = marks[-9], marks[-1]
-print("kernel dispatches per step over the last 8 steps: %.1f" % (sum(1 for s, n in rows if t0 <= s < t1) / 8.0))
+t0, t1, k = step_window(marks, 8)
+print("kernel dispatches per step over the last %d steps: %.1f" % (k, sum(1 for s, n in rows if t0 <= s < t1) / float(k)))
 PY
   rm -f "$F"
 }

@@ -4,7 +4,11 @@ steps (delimited by the once-per-step splice_input kernel) the busy time of ever
 kernel in flight, and the time no kernel is in flight at all.
 usage: stream_overlap.py KERNEL_TRACE_CSV [steps]"""
 import csv
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from trace_util import step_window  # noqa: E402
 
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 rows = []
@@ -14,7 +18,7 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "%s/%s" % (r.get("Queue_Id"), q), r["Kernel_Name"]))
 rows.sort()
 marks = [s for s, e, q, n in rows if "splice_input" in n]  # the first kernel of a step's forward pass: once per step (the denominator kernels are not: the multi-workgroup form launches its fallback behind it)
-t0, t1 = marks[-steps - 1], marks[-1]
+t0, t1, steps = step_window(marks, steps)
 win = [(max(s, t0), min(e, t1), q, n) for s, e, q, n in rows if e > t0 and s < t1]
 ev = []
 for s, e, q, n in win:

@@ -2,8 +2,12 @@
 """Per (kernel, grid) launch table of the last STEPS steps of a rocprofv3 --kernel-trace CSV: launches/step, average and total
 time -- which shapes a kernel class spends its time on.  usage: trace_shapes.py KERNEL_TRACE_CSV [steps] [min_ms_per_step]"""
 import csv
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from trace_util import step_window  # noqa: E402
 
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 floor = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
@@ -13,7 +17,7 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id"), r["Kernel_Name"], r.get("Grid_Size_X") or r.get("Grid_Size"), r.get("Workgroup_Size_X") or r.get("Workgroup_Size")))
 rows.sort()
 marks = [s for s, e, q, n, g, w in rows if "splice_input" in n]  # the first kernel of a step's forward pass: once per step (the denominator kernels are not: the multi-workgroup form launches its fallback behind it)
-t0, t1 = marks[-steps - 1], marks[-1]
+t0, t1, steps = step_window(marks, steps)
 acc = {}
 for s, e, q, n, g, w in rows:
     if s < t0 or s >= t1:
