@@ -532,6 +532,15 @@ int tdnnf_planes_split(int num_planes, const tdnnf_mat *x, int lead_rows, long l
 int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
                       const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col,
                       const int *b_first_col, const int *seg_cols, const float *bias, int init_mode, int relu, tdnnf_mat *c, tdnnf_stream);
+/* The same product with the trainer's epilogue options: `add` (may be NULL): C[m] += add_scale * add[m - add_first_row] for the output rows the
+   addend covers (the bypass term of the TDNN-F layers' Sum(Scale(0.66, .), .), fused into Backprop's data GEMM); `colstats` (may be NULL):
+   column sums and sums of squares of the STORED output, one partial row per row tile of the launch -- colstats[t * cols + n] and
+   colstats[(*colstats_rows + t) * cols + n], t < *colstats_rows (written by the call: the tile height depends on the shape; at most
+   ceil(rows / 128) rows each) -- what BatchNormComponent::Propagate needs of its input (nnet-normalize-component.cc:433-445). */
+int tdnnf_planes_gemm_epilogue(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
+                               const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col,
+                               const int *b_first_col, const int *seg_cols, const float *bias, int init_mode, int relu, const tdnnf_mat *add, float add_scale,
+                               int add_first_row, float *colstats, int *colstats_rows, tdnnf_mat *c, tdnnf_stream stream);
 /* Synchronised BatchNorm for a data-parallel caller ("BN [sum x, sum x^2] (2 D floats per BN) for exact single-GPU
    equivalence").  The reference's BatchNormComponent takes its statistics over ALL rows of the minibatch
    (/root/reference/src/nnet3/nnet-normalize-component.cc:433-445); when the minibatch is sharded over world_size ranks, every

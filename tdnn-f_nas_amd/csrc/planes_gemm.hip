@@ -979,19 +979,24 @@ int tdnnf_planes_split(int num_planes, const tdnnf_mat *x, int lead_rows, long l
   return TDNNF_OK;
 }
 
-int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
-                      const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col, const int *b_first_col,
-                      const int *seg_cols, const float *bias, int init_mode, int relu, tdnnf_mat *c, tdnnf_stream stream) {
+static int planes_gemm_abi(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
+                           const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col, const int *b_first_col,
+                           const int *seg_cols, const float *bias, int init_mode, int relu, const tdnnf_mat *add, float add_scale, int add_first_row, float *colstats,
+                           int *colstats_rows, tdnnf_mat *c, tdnnf_stream stream) {
   TDNNF_REQUIRE((num_planes == 2 || num_planes == 3) && a_planes && b_planes && mat_ok(c) && num_segments >= 1 && num_segments <= 16 && a_row && a_first_col &&
                     b_first_col && seg_cols,
                 "planes_gemm: bad arguments (2 or 3 planes, 1..16 segments)");
   TDNNF_REQUIRE(init_mode >= 0 && init_mode <= 2 && (init_mode != 1 || bias), "planes_gemm: init_mode 0 (+=), 1 (bias), 2 (=)");
+  TDNNF_REQUIRE(!add || (mat_ok(add) && add->cols == c->cols && add_first_row >= 0), "planes_gemm: the addend must have the output's columns");
   PlanesGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.np = num_planes;
   a.A = a_planes; a.RA = a_rows_total; a.B = b_planes; a.RB = b_rows_total; a.scale_a = a_scale_dev; a.scale_b = b_scale_dev;
   a.C = c->data; a.ldc = c->stride; a.M = c->rows; a.N = c->cols;
   a.bias = bias; a.init_mode = init_mode; a.relu = relu; a.nseg = num_segments;
+  if (add) {
+    a.add = add->data; a.ldadd = add->stride; a.add_scale = add_scale; a.add_lo = add_first_row; a.add_hi = add_first_row + add->rows;
+  }
   const int BM = planes_gemm_tile_rows(c->cols), BN = planes_gemm_tile_cols(c->cols);
   for (int i = 0; i < num_segments; i++) {
     const long long br = b_row ? b_row[i] : 0;
@@ -1007,8 +1012,30 @@ int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_tot
     a.seg[i].b_kb0 = b_first_col[i] / 16;
     a.seg[i].nkb = (seg_cols[i] + 15) / 16;
   }
+  if (colstats) {  // one partial row per row tile of THIS launch (the tile height depends on the shape), sums first, sums of squares behind them
+    TDNNF_REQUIRE(colstats_rows, "planes_gemm: colstats_rows must be given with colstats");
+    const int tile_rows = planes_gemm_launch_tile_rows(a);
+    a.colstats = colstats;
+    a.colstats_stride = (c->rows + tile_rows - 1) / tile_rows;
+    *colstats_rows = (int)a.colstats_stride;
+  }
   TDNNF_HIP(planes_gemm(a, (hipStream_t)stream));
   return TDNNF_OK;
+}
+
+int tdnnf_planes_gemm(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
+                      const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col, const int *b_first_col,
+                      const int *seg_cols, const float *bias, int init_mode, int relu, tdnnf_mat *c, tdnnf_stream stream) {
+  return planes_gemm_abi(num_planes, a_planes, a_rows_total, a_scale_dev, b_planes, b_rows_total, b_scale_dev, num_segments, a_row, b_row, a_first_col, b_first_col, seg_cols,
+                         bias, init_mode, relu, nullptr, 0.f, 0, nullptr, nullptr, c, stream);
+}
+
+int tdnnf_planes_gemm_epilogue(int num_planes, const void *a_planes, long long a_rows_total, const float *a_scale_dev, const void *b_planes, long long b_rows_total,
+                               const float *b_scale_dev, int num_segments, const long long *a_row, const long long *b_row, const int *a_first_col,
+                               const int *b_first_col, const int *seg_cols, const float *bias, int init_mode, int relu, const tdnnf_mat *add, float add_scale,
+                               int add_first_row, float *colstats, int *colstats_rows, tdnnf_mat *c, tdnnf_stream stream) {
+  return planes_gemm_abi(num_planes, a_planes, a_rows_total, a_scale_dev, b_planes, b_rows_total, b_scale_dev, num_segments, a_row, b_row, a_first_col, b_first_col, seg_cols,
+                         bias, init_mode, relu, add, add_scale, add_first_row, colstats, colstats_rows, c, stream);
 }
 
 }  // extern "C"

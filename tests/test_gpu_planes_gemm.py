@@ -58,8 +58,9 @@ def run(pkg, np_, M, N, Di, offs, init_mode=2, relu=0, seed=0, make=None):
     a_col = (C.c_int * K)(*([0] * K))
     b_col = (C.c_int * K)(*[i * Di for i in range(K)])
     cols = (C.c_int * K)(*([Di] * K))
+    bias_d = dev(bias)  # (kept in a variable: a temporary's memory goes back to the allocator before the launch)
     abi.check(lib.tdnnf_planes_gemm(np_, abi.ptr(ap), RA, abi.ptr(sa), abi.ptr(bp), RB, abi.ptr(sb), K, a_row, None, a_col, b_col, cols,
-                                    abi.ptr(dev(bias)), init_mode, relu, abi.pmat(Cd), abi.stream()))
+                                    abi.ptr(bias_d), init_mode, relu, abi.pmat(Cd), abi.stream()))
     ref = np.zeros((M, N))
     for i, o in enumerate(offs):
         ref += X[o - lo:o - lo + M].astype(np.float64) @ W[:, i * Di:(i + 1) * Di].astype(np.float64).T
@@ -160,3 +161,65 @@ def test_planes_split_layout_and_transposed_planes(pkg):
         rect = Tn[:, :, :cols].astype(np.float64).sum(1).transpose(1, 0, 2).reshape(cols, nkbt * 16)  # [column][row index]
         assert not rect[:, rows:].any()  # the K padding behind the last row
         assert np.array_equal(rect[:, :rows].T, rec[:, :cols])  # the same values, transposed
+
+
+EPI_SHAPES = [
+    # M, N, Di, offs, add rows [first, count), C column offset inside a wider buffer (0: 16-byte aligned rows; 1: not -> element-wise path)
+    (700, 1536, 160, [0, 2], (0, 700), 0),      # .linear backward-data with the bypass addend over all rows; 128-row tiles (K <= 640)
+    (700, 1536, 160, [0, 2], (130, 301), 0),    # the addend covers rows 130 .. 430 only: tile-interior and tile-crossing edges
+    (513, 160, 1536, [-3, 0], (5, 500), 0),     # 160-wide tile: chunks of 64, 64, 32 columns
+    (300, 200, 48, [0], (0, 300), 0),           # ragged right edge: the last chunk takes the element-wise path, the others the row path
+    (300, 256, 48, [0], (7, 100), 1),           # output rows not 16-byte aligned: everything element-wise
+    (1000, 256, 1536, [0], (0, 1000), 0),       # 256-row tiles, long K
+]
+
+
+@pytest.mark.parametrize("np_", [3, 2], ids=["bf16x6", "f16x3"])
+@pytest.mark.parametrize("M,N,Di,offs,addr,coff", EPI_SHAPES)
+def test_planes_gemm_epilogue_addend_and_column_statistics(pkg, np_, M, N, Di, offs, addr, coff):
+    """tdnnf_planes_gemm_epilogue against float64: bias, ReLU, the row-windowed addend, and the column sums / sums of squares of the STORED
+    output (one partial row per row tile), on the row-contiguous and the element-wise epilogue paths alike."""
+    lib, abi = pkg.hipabi.load(), pkg.hipabi
+    rng = np.random.default_rng(5)
+    K = len(offs)
+    lo, hi = min(0, min(offs)), max(0, max(offs))
+    X = rng.standard_normal((M + hi - lo, Di)).astype(np.float32)
+    W = (rng.standard_normal((N, K * Di)) / np.sqrt(K * Di)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = rng.standard_normal((addr[1], N)).astype(np.float32)
+    BN = tile_cols(N)
+    lead, tail = 3, 256 + 5
+    ap, RA, _, _, sa = planes_of(pkg, np_, dev(X), lead, tail)
+    bp, RB, _, _, sb = planes_of(pkg, np_, dev(W), 0, ((N + BN - 1) // BN) * BN - N)
+    ldc = ((N + coff + 3) // 4) * 4 + 4
+    Cbuf = torch.full((M, ldc), float("nan"), device="cuda")
+    Cd = Cbuf[:, coff:coff + N]
+    stats = torch.full((2 * ((M + 127) // 128) * N,), float("nan"), device="cuda")
+    nrows = C.c_int()
+    a_row = (C.c_longlong * K)(*[lead + (o - lo) for o in offs])
+    a_col = (C.c_int * K)(*([0] * K))
+    b_col = (C.c_int * K)(*[i * Di for i in range(K)])
+    cols = (C.c_int * K)(*([Di] * K))
+    bias_d, add_d = dev(bias), dev(add)  # (kept in variables: a temporary's memory goes back to the allocator, and to the next upload, before the launch)
+    abi.check(lib.tdnnf_planes_gemm_epilogue(np_, abi.ptr(ap), RA, abi.ptr(sa), abi.ptr(bp), RB, abi.ptr(sb), K, a_row, None, a_col, b_col, cols, abi.ptr(bias_d), 1, 1,
+                                             abi.pmat(add_d), 0.66, addr[0], abi.ptr(stats), C.byref(nrows), abi.pmat(Cd), abi.stream()))
+    ref = np.zeros((M, N))
+    for i, o in enumerate(offs):
+        ref += X[o - lo:o - lo + M].astype(np.float64) @ W[:, i * Di:(i + 1) * Di].astype(np.float64).T
+    ref += bias
+    ref[addr[0]:addr[0] + addr[1]] += 0.66 * add.astype(np.float64)
+    ref = np.maximum(ref, 0)
+    got = host(Cd)
+    assert np.isfinite(got).all()
+    assert rel_l2(got, ref) < 1e-6, rel_l2(got, ref)
+    assert np.isnan(host(Cbuf[:, :coff])).all() and np.isnan(host(Cbuf[:, coff + N:])).all()  # nothing outside the output's columns
+    t = nrows.value
+    assert t in ((M + 255) // 256, (M + 127) // 128)
+    st = host(stats)[:2 * t * N].reshape(2, t, N).astype(np.float64)
+    assert np.isfinite(st).all()
+    g64 = got.astype(np.float64)
+    assert np.allclose(st[0].sum(0), g64.sum(0), rtol=1e-5, atol=1e-3)
+    assert np.allclose(st[1].sum(0), (g64 * g64).sum(0), rtol=1e-5, atol=1e-3)
+    th = 128 if t != (M + 255) // 256 else 256  # the launch's tile height (one partial row per row tile)
+    for k in range(t):
+        assert np.allclose(st[0, k], g64[k * th:(k + 1) * th].sum(0), rtol=1e-5, atol=1e-3)

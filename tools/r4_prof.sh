@@ -9,7 +9,7 @@ grep '^{' gpurun_out/$TAG.log | tail -1 > gpurun_out/${TAG}_bench_line.json
 F=$(ls gpurun_out/$TAG/r_kernel_trace.csv gpurun_out/$TAG/*/r_kernel_trace.csv 2>/dev/null | head -1)
 python3 tools/stream_overlap.py "$F" 8 > gpurun_out/${TAG}_overlap.txt || true
 python3 tools/trace_shapes.py "$F" 8 0.1 > gpurun_out/${TAG}_shapes.txt || true
-python3 tools/trace_timeline.py "$F" 100 > gpurun_out/${TAG}_timeline.txt || true
+python3 tools/trace_timeline.py "$F" ${TIMELINE_MIN_US:-100} > gpurun_out/${TAG}_timeline.txt || true
 S=$(ls gpurun_out/$TAG/r_kernel_stats.csv gpurun_out/$TAG/*/r_kernel_stats.csv 2>/dev/null | head -1)
 cp "$S" gpurun_out/${TAG}_kernel_stats.csv
 rm -f "$F"
