@@ -243,13 +243,19 @@ class Job:
         import torch.distributed as dist
         self.rccl = None
         if (world > 1 and dist.get_backend() != "gloo") or (world == 1 and args.sync_batchnorm == "on"):
-            self.rccl = pkg.trainer.RcclComm(single=world == 1)
+            try:
+                self.rccl = pkg.trainer.RcclComm(single=world == 1)
+            except Exception as e:  # (no librccl.so to dlopen, or the communicator could not be created: torch.distributed issues the same exchanges)
+                print("bench.py: the library's own RCCL communicator is not available (%s): falling back to torch.distributed collectives" % e, file=sys.stderr)
+                self.rccl = None
         if self.sync_bn or (world == 1 and args.sync_batchnorm == "on"):
             if self.rccl is not None:
                 self.net.set_batchnorm_sync_rccl(self.rccl)
                 self.sync_bn = True
-            else:
+            elif world > 1:
                 self.net.set_batchnorm_sync(True)
+            else:
+                self.sync_bn = False
         self.gen = torch.Generator(device="cuda")
         self.gen.manual_seed(1234)  # same architecture sample on every rank (seed-shared draws)
         self.comm = torch.cuda.Stream() if world > 1 and not args.no_overlap else None
@@ -328,6 +334,8 @@ class Job:
             self.feed.close()
         self.keep = []
         self.net.close()
+        if self.rccl is not None:
+            self.rccl.close()
         if self.archive is not None:
             import shutil
             shutil.rmtree(os.path.dirname(self.archive), ignore_errors=True)
