@@ -87,6 +87,21 @@ struct DenDev {
   float init_sum;
 };
 
+// The frame's output row (P floats, from HBM) one frame ahead in registers: a frame used to begin with the dependent load of its own row --
+// 2-3 us of HBM latency in front of a 17-19 us frame, 500 times per recursion.  (More than kDenRowRegs * kDenThreads pdfs: the kernels load the rest
+// the old way.)
+constexpr int kDenRowRegs = 8;
+struct RowAhead {
+  float v[kDenRowRegs];
+  __device__ __forceinline__ void load(const float *yr, int P, int tid) {
+#pragma unroll
+    for (int i = 0; i < kDenRowRegs; i++) {
+      const int p = tid + i * kDenThreads;
+      v[i] = p < P ? yr[p] : 0.f;
+    }
+  }
+};
+
 // Forward: alpha_dash(t, .) for t = 0..T stored to `alpha` [(T+1) x Hs] per sequence, alpha sums to
 // `asum` [T+1], per-sequence log-prob to logprob[s].
 template <bool LDS_STATE>
@@ -112,10 +127,15 @@ __global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatV
   if (tid == 0) asum[0] = g.init_sum;
   float prev_sum = g.init_sum;
   double logcorr = 0.0;
+  RowAhead ra;
+  ra.load(y.data + (size_t)s * y.stride, P, tid);
   __syncthreads();
   for (int t = 1; t <= T; t++) {
-    const float *yr = y.data + (size_t)((t - 1) * B + s) * y.stride;
-    for (int p = tid; p < P; p += kDenThreads) x[p] = exp_limited(yr[p]);
+#pragma unroll
+    for (int i = 0; i < kDenRowRegs; i++)
+      if (tid + i * kDenThreads < P) x[tid + i * kDenThreads] = exp_limited(ra.v[i]);
+    for (int p = tid + kDenRowRegs * kDenThreads; p < P; p += kDenThreads) x[p] = exp_limited(y.data[(size_t)((t - 1) * B + s) * y.stride + p]);  // (more than 8 192 pdfs: the rest as before)
+    if (t < T) ra.load(y.data + (size_t)(t * B + s) * y.stride, P, tid);  // the next frame's row: lands while this frame's arcs are walked
     __syncthreads();
     const float inv = 1.0f / prev_sum;
     logcorr += (double)logf(prev_sum);
@@ -179,11 +199,16 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
     const float lsum = g.init_sum * bd;
     for (int h = tid; h < H; h += kDenThreads) bnext[h] = bd + leaky * lsum;
   }
+  RowAhead ra;
+  ra.load(y.data + (size_t)((T - 1) * B + s) * y.stride, P, tid);
   __syncthreads();
   for (int t = T - 1; t >= 0; t--) {
-    const float *yr = y.data + (size_t)(t * B + s) * y.stride;
     const float inv = 1.0f / asum[t];
-    for (int p = tid; p < P; p += kDenThreads) x[p] = exp_limited(yr[p]);
+#pragma unroll
+    for (int i = 0; i < kDenRowRegs; i++)
+      if (tid + i * kDenThreads < P) x[tid + i * kDenThreads] = exp_limited(ra.v[i]);
+    for (int p = tid + kDenRowRegs * kDenThreads; p < P; p += kDenThreads) x[p] = exp_limited(y.data[(size_t)(t * B + s) * y.stride + p]);
+    if (t > 0) ra.load(y.data + (size_t)((t - 1) * B + s) * y.stride, P, tid);
     for (int h = tid; h < H; h += kDenThreads) ad[h] = alpha[(size_t)t * Hs + h] * inv;
     __syncthreads();
     // beta_dash(t, i) = sum over out-arcs
@@ -257,10 +282,15 @@ __global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView
     bn[h] = 1.0f / g.init_sum + leaky;
   }
   if (tid == 0) S[T] = g.init_sum;
+  RowAhead ra;
+  ra.load(y.data + (size_t)((T - 1) * B + s) * y.stride, P, tid);
   __syncthreads();
   for (int t = T - 1; t >= 0; t--) {
-    const float *yr = y.data + (size_t)(t * B + s) * y.stride;
-    for (int p = tid; p < P; p += kDenThreads) x[p] = exp_limited(yr[p]);
+#pragma unroll
+    for (int i = 0; i < kDenRowRegs; i++)
+      if (tid + i * kDenThreads < P) x[tid + i * kDenThreads] = exp_limited(ra.v[i]);
+    for (int p = tid + kDenRowRegs * kDenThreads; p < P; p += kDenThreads) x[p] = exp_limited(y.data[(size_t)(t * B + s) * y.stride + p]);
+    if (t > 0) ra.load(y.data + (size_t)((t - 1) * B + s) * y.stride, P, tid);
     __syncthreads();
     float *bcur = brow + (size_t)t * Hs;
     float local = 0.f;
