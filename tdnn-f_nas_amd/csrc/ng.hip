@@ -399,7 +399,7 @@ int stats_after_h(tdnnf_ng *ng, const NgInput &in, const float *H, void *wg_ws, 
 // First half of one PreconditionDirections call, everything N x D sized: H = X W_t^T (with ||X||^2 per block into
 // `part`) and, on a refresh, J = H^T X.  W_t is left untouched.
 int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg_ws, size_t wg_bytes, bool upd, hipStream_t s) {
-  const int N = in.N, K = in.ix.num_offsets, Di = in.Di, Rp = ng->Rp, Dp = ng->Dp, D = ng->D;
+  const int N = in.N, K = in.ix.num_offsets, Di = in.Di, Rp = ng->Rp, Dp = ng->Dp;
   RowsGemmArgs a;
   memset(&a, 0, sizeof(a));
   a.A = in.x.data; a.lda = (long long)in.x.stride * in.ix.row_stride; a.B = ng->W; a.ldb = Dp; a.C = H; a.ldc = Rp; a.M = N; a.N = Rp;
