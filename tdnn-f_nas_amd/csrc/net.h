@@ -156,6 +156,8 @@ struct tdnnf_net {
   hipEvent_t ev_pg[2], ev_pg_in;
   unsigned pg_count;
   void *ws4;
+  void *ws2;           // the same for components whose weight gradients go to the denominator's stream (wg_two)
+  float *s2_scratch;
   float *s4_scratch;   // split-K scratch of the GEMMs launched on s4
   // Input-side natural-gradient statistics ahead of the backward pass: H_in = X~ W_x^T (and J = H^T X on refresh steps) of a component
   // needs its forward input and the preconditioner state only, so from the second grouped minibatch on they are launched on s4 as soon as
@@ -170,6 +172,7 @@ struct tdnnf_net {
   bool early_on = false, early_any = false;
   hipEvent_t ev_early_in = nullptr, ev_early = nullptr;
   size_t s4_scratch_bytes;
+  bool wg_two;  // this step, from the denominator's join on: weight-gradient components alternate between s4 and s2
   float *gtmp;         // this minibatch's gradient; committed into `grads` only when the objective was finite
   // NonlinearComponent::StoreBackpropStats skips a minibatch w.p. 1/4 only "&& oderiv_count_ != 0" (nnet-component-itf.cc:466): whether a
   // ReLU's oderiv_count is non-zero, in the order of stat_blocks() (host copy: set by set_stats / read_model and by every store);

@@ -547,6 +547,9 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->ws4 = s4_used ? A.take<char>(n->ws_bytes) : nullptr;
   n->s4_scratch_bytes = s4_used ? (32u << 20) : 0;
   n->s4_scratch = s4_used ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
+  const bool two = n->wg_on && options().wgrad_stream != 1;  // (option wgrad_stream: 1 = one weight-gradient stream as rounds 2-3, 2 = two, -1 = by size, two)
+  n->ws2 = two ? A.take<char>(n->ws_bytes) : nullptr;
+  n->s2_scratch = two ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
 }
 
 #define CK(expr)             \
@@ -893,6 +896,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   n->chain_ws = nullptr;
   n->chain_ws_bytes = 0;
   n->s2 = nullptr;
+  n->wg_two = false;
   n->ev_fork = n->ev_den = n->ev_num = nullptr;
   n->s3 = nullptr;
   n->ev_s3 = nullptr;
@@ -1670,8 +1674,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     for (auto &gb : n->buckets) {
       if (gb.close_key != key) continue;
       hipStream_t cs = s;
-      if (!use_ng && n->wg_on && n->pg_count > 0)  // the components' gradients were formed on s4
+      if (!use_ng && n->wg_on && n->pg_count > 0) {  // the components' gradients were formed on s4 (and s2)
         TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
+        if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[n->pg_count & 1], 0));
+      }
       if (use_ng) {
         TDNNF_HIP(hipEventRecord(gb.handoff, s));  // s-side writes of the range (bias sums, architecture parameters) are done
         TDNNF_HIP(hipStreamWaitEvent(n->s3, gb.handoff, 0));
@@ -1704,13 +1710,17 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // sw: where the gradient is formed -- the weight-gradient stream (its inputs are final on s now), or s itself
     hipStream_t sw = s;
     void *wsw = n->ws;
+    // Small minibatches: the weight-gradient side (gradient GEMM + slab reduce + the natural-gradient passes of the component) is the longer
+    // chain of the two -- 216 us per component against 145 on the caller's stream at 150 x 64 -- and the caller may only run one component
+    // ahead of it.  From the denominator's join on its stream is idle: components alternate between the two (event parity = stream parity).
+    const bool on_s2 = n->wg_on && n->wg_two && (n->pg_count & 1);
     if (n->wg_on) {
-      sw = n->s4;
-      wsw = n->ws4;
+      sw = on_s2 ? n->s2 : n->s4;
+      wsw = on_s2 ? n->ws2 : n->ws4;
       TDNNF_HIP(hipEventRecord(n->ev_pg_in, s));
       TDNNF_HIP(hipStreamWaitEvent(sw, n->ev_pg_in, 0));
     }
-    SplitKScratchOverride sw_scratch(n->wg_on ? n->s4_scratch : nullptr, n->wg_on ? n->s4_scratch_bytes : 0);
+    SplitKScratchOverride sw_scratch(n->wg_on ? (on_s2 ? n->s2_scratch : n->s4_scratch) : nullptr, n->wg_on ? n->s4_scratch_bytes : 0);
     // after this component is enqueued the caller's stream may only run ahead of it, not of the one before: what that one reads
     // (derivative scratch, the bias sums) is rewritten from here on
     auto handed_off = [&]() -> int {
@@ -1822,6 +1832,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // behind the last component's passes (on the weight-gradient stream when that is on)
     if (n->wg_on && n->pg_count > 0) {
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - 1) & 1], 0));
+      if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[n->pg_count & 1], 0));  // (the other stream's last component)
     } else {
       TDNNF_HIP(hipEventRecord(n->ev_ngc, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_ngc, 0));
@@ -1892,6 +1903,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (h == 0) {
       // objective, part 3: join the denominator stream, d_y += posteriors, objf / failure handling
       TDNNF_HIP(hipStreamWaitEvent(s, n->ev_den, 0));
+      n->wg_two = n->wg_on && n->ws2 != nullptr;  // the denominator's stream is idle from here on
       CK(chain_finish(den, sup, &y, c.chain_l2_regularize, results, &dy, nullptr, n->chain_ws, s));
     }
     tdnnf_mat dout = h == 0 ? dy : dx;
@@ -2083,6 +2095,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   CK(close_bucket(-1));
   if (n->wg_on && n->pg_count > 0) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));  // join the weight-gradient stream
+  if (n->wg_on && n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[n->pg_count & 1], 0));  // (and the second one)
+  n->wg_two = false;
   if (use_ng) {  // join the side stream: every bucket has been committed into grads
     TDNNF_HIP(hipEventRecord(n->ev_s3, n->s3));
     TDNNF_HIP(hipStreamWaitEvent(s, n->ev_s3, 0));
