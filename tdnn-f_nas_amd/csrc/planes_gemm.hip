@@ -43,10 +43,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // LDS ring depth per tile.  Three everywhere: the 256-row tiles of two planes would have room for four (128 KB, still one block per CU), measured
 // on the trainer's shapes and in the step: no difference (the K loop is not bound by the latency of its loads) -- and 96 KB leave room beside it.
-#ifndef TDNNF_PLANES_BIG_STAGES
-#define TDNNF_PLANES_BIG_STAGES 3
-#endif
-constexpr int kBigStages = TDNNF_PLANES_BIG_STAGES;
+constexpr int kBigStages = 3;
 template <int NP, int BM>
 constexpr int stages_of() { return (NP == 2 && BM >= 256) ? kBigStages : 3; }
 
@@ -367,9 +364,6 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
   };
   next_request_segment();
   auto request_piece = [&](int slot, int j) {
-#if defined(TDNNF_PLANES_EXPERIMENT) && TDNNF_PLANES_EXPERIMENT == 2
-    if (slot != 0) return;
-#endif
     // (as an instruction the compiler does not see: it books the builtin as a flat access pending on BOTH counters and, knowing nothing of the
     // counted vmcnt waits below, turns every later lgkmcnt wait into lgkmcnt(0) -- the LDS reads could not be counted past each other)
     const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void *)(smem + slot * STAGE_PAD + lds_off[j]));
@@ -458,10 +452,6 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
       for (int j = 0; j < TN; j++) acc[i][j] = Plane<NP>::mfma(a[qa][i], b[qb][j], acc[i][j]);
   };
   auto multiply = [&](const V8 (&a)[NP][TM], const V8 (&b)[NP][TN]) {
-#if defined(TDNNF_PLANES_EXPERIMENT) && TDNNF_PLANES_EXPERIMENT == 1
-    acc[0][0][0] += (float)a[0][0][0] + (float)b[0][0][0];
-    return;
-#endif
     // the products a_q b_(d - q), d = np - 1 .. 0: smallest terms first, the leading term last
 #pragma unroll
     for (int d = NP - 1; d >= 0; d--)
