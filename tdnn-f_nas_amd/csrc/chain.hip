@@ -102,6 +102,38 @@ struct RowAhead {
   }
 };
 
+// The sum over one row of a sliced-ELL table (ap: the lane's first arc, w: the slice's width, uniform over the wave), arcs in order.  A row is a chain
+// of dependent-latency loads from L2: batches of eight, then four, then ONE batch for the last one to three arcs (indices clamped, the surplus terms
+// replaced by exact zeros) -- "#pragma unroll 4" left up to three single loads behind every row, "#pragma unroll 8" up to seven (measured: slower).
+template <class Term>
+__device__ __forceinline__ float sell_row_sum(const uint2 *ap, int w, Term term) {
+  float acc = 0.f;
+  int j = 0;
+  for (; j + 8 <= w; j += 8) {
+    uint2 a[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = ap[(j + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 8; u++) acc += term(a[u]);
+  }
+  if (j + 4 <= w) {
+    uint2 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) a[u] = ap[(j + u) * 64];
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc += term(a[u]);
+    j += 4;
+  }
+  if (j < w) {
+    uint2 a[3];
+#pragma unroll
+    for (int u = 0; u < 3; u++) a[u] = ap[min(j + u, w - 1) * 64];
+#pragma unroll
+    for (int u = 0; u < 3; u++) acc += (j + u < w) ? term(a[u]) : 0.f;
+  }
+  return acc;
+}
+
 // Forward: alpha_dash(t, .) for t = 0..T stored to `alpha` [(T+1) x Hs] per sequence, alpha sums to
 // `asum` [T+1], per-sequence log-prob to logprob[s].
 template <bool LDS_STATE>
@@ -145,12 +177,8 @@ __global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatV
       const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_dst.base[sl], w = (g.by_dst.base[sl + 1] - b0) >> 6;
       const uint2 *ap = g.by_dst.arc + b0 + ln;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < w; j++) {
-        const uint2 a = ap[j * 64];
-        acc += prev[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16];
-      }
+      const float acc0 = sell_row_sum(ap, w, [&](const uint2 a) { return prev[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16]; });
+      float acc = acc0;
       const unsigned h = g.by_dst.row[slot];
       if (h != 0xffffffffu) {
         acc *= inv;
@@ -217,12 +245,8 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
       const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
       const uint2 *ap = g.by_src.arc + b0 + ln;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < w; j++) {
-        const uint2 a = ap[j * 64];
-        acc += __uint_as_float(a.y) * x[a.x >> 16] * bnext[a.x & 0xffffu];
-      }
+      const float acc0 = sell_row_sum(ap, w, [&](const uint2 a) { return __uint_as_float(a.y) * x[a.x >> 16] * bnext[a.x & 0xffffu]; });
+      float acc = acc0;
       const unsigned h = g.by_src.row[slot];
       if (h != 0xffffffffu) {
         acc *= inv;
@@ -236,12 +260,8 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
       const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
       const uint2 *ap = g.by_pdf.arc + b0 + ln;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < w; j++) {
-        const uint2 a = ap[j * 64];
-        acc += __uint_as_float(a.y) * ad[a.x & 0xffffu] * bnext[a.x >> 16];
-      }
+      const float acc0 = sell_row_sum(ap, w, [&](const uint2 a) { return __uint_as_float(a.y) * ad[a.x & 0xffffu] * bnext[a.x >> 16]; });
+      float acc = acc0;
       const unsigned p = g.by_pdf.row[slot];
       if (p != 0xffffffffu) dr[p] = deriv_weight * acc * x[p];
     }
@@ -298,12 +318,8 @@ __global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView
       const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
       const uint2 *ap = g.by_src.arc + b0 + ln;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < w; j++) {
-        const uint2 a = ap[j * 64];
-        acc += __uint_as_float(a.y) * x[a.x >> 16] * bn[a.x & 0xffffu];
-      }
+      const float acc0 = sell_row_sum(ap, w, [&](const uint2 a) { return __uint_as_float(a.y) * x[a.x >> 16] * bn[a.x & 0xffffu]; });
+      float acc = acc0;
       const unsigned h = g.by_src.row[slot];
       if (h != 0xffffffffu) {
         bcur[h] = acc;
@@ -463,12 +479,8 @@ __global__ __launch_bounds__(kDenThreads) void den_mw_kernel(DenDev g, MwCtl ctl
       const int i = q >> 6, ln = q & 63;
       const int w = (loff[i + 1] - loff[i]) >> 6;
       const uint2 *ap = arcs + loff[i] + ln;
-      float acc = 0.f;
-#pragma unroll 4
-      for (int j = 0; j < w; j++) {
-        const uint2 a = ap[j * 64];
-        acc += cur[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16];
-      }
+      const float acc0 = sell_row_sum(ap, w, [&](const uint2 a) { return cur[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16]; });
+      float acc = acc0;
       if (DIR == 0) acc *= inv;
       stage[q] = acc;  // (a padding slot: 0)
     }
@@ -562,12 +574,7 @@ __global__ __launch_bounds__(kGammaThreads) void den_gamma_kernel(DenDev g, MatV
     const int sl = slot >> 6, ln = slot & 63;
     const int b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
     const uint2 *ap = g.by_pdf.arc + b0 + ln;
-    float acc = 0.f;
-#pragma unroll 4
-    for (int j = 0; j < w; j++) {
-      const uint2 a = ap[j * 64];
-      acc += __uint_as_float(a.y) * ad[a.x & 0xffffu] * bn[a.x >> 16];
-    }
+    const float acc = sell_row_sum(ap, w, [&](const uint2 a) { return __uint_as_float(a.y) * ad[a.x & 0xffffu] * bn[a.x >> 16]; });
     const unsigned p = g.by_pdf.row[slot];
     if (p != 0xffffffffu) dr[p] = scale * acc * x[p];
   }
@@ -1085,17 +1092,48 @@ int build_sell(int nrows, const std::vector<std::vector<std::pair<unsigned, floa
   std::vector<unsigned> rowid((size_t)ns * 64, 0xffffffffu);
   std::vector<uint2> arc(base[ns], make_uint2(0u, 0u));  // padding: state 0 / pdf 0 with prob 0
   std::vector<uint4> arc4(base[ns], make_uint4(0u, 0u, 0u, 0u));
+  // The order of a row's arcs is free (a sum).  The j-th arcs of a slice's 64 rows are read by one wave instruction and become two LDS gathers
+  // (the two 16-bit halves of the key index state / pdf vectors): 64 random addresses put 4-5 on the worst of 64 banks.  Greedy per position: every
+  // row takes, among its arcs not placed yet, the one whose two banks are least used at this position so far (half a wave -- 32 lanes -- is what the
+  // LDS serves at once).  The persistent recursions are bound by these gathers, not by the arc loads (docs/experiments.md r4-i).
+  std::vector<std::vector<std::pair<unsigned, float>>> placed(nrows);
+  for (int k = 0; k < ns; k++) {
+    const int w = (base[k + 1] - base[k]) / 64;
+    std::vector<std::vector<char>> used(64);
+    for (int l = 0; l < 64 && 64 * k + l < nrows; l++) used[l].assign(rows[order[64 * k + l]].size(), 0);
+    for (int j = 0; j < w; j++) {
+      int load[2][2][64];  // [half-wave][which key half][bank]
+      memset(load, 0, sizeof(load));
+      for (int l = 0; l < 64 && 64 * k + l < nrows; l++) {
+        const auto &src = rows[order[64 * k + l]];
+        int best = -1, best_cost = 1 << 30;
+        for (size_t c = 0; c < src.size(); c++) {
+          if (used[l][c]) continue;
+          const int cost = load[l >> 5][0][src[c].first & 63u] + load[l >> 5][1][(src[c].first >> 16) & 63u];
+          if (cost < best_cost) {
+            best_cost = cost;
+            best = (int)c;
+          }
+        }
+        if (best < 0) continue;  // (this row is shorter than the slice: padding from here on)
+        used[l][best] = 1;
+        load[l >> 5][0][src[best].first & 63u]++;
+        load[l >> 5][1][(src[best].first >> 16) & 63u]++;
+        placed[order[64 * k + l]].push_back(src[best]);
+      }
+    }
+  }
   for (int s = 0; s < nrows; s++) {
     const int r = order[s];
     rowid[s] = (unsigned)r;
-    for (size_t j = 0; j < rows[r].size(); j++) {
+    for (size_t j = 0; j < placed[r].size(); j++) {
       unsigned bits;
-      memcpy(&bits, &rows[r][j].second, 4);
-      arc[base[s / 64] + j * 64 + s % 64] = make_uint2(rows[r][j].first, bits);
-      const float ip = init ? rows[r][j].second * (*init)[rows[r][j].first & 0xffffu] : 0.f;
+      memcpy(&bits, &placed[r][j].second, 4);
+      arc[base[s / 64] + j * 64 + s % 64] = make_uint2(placed[r][j].first, bits);
+      const float ip = init ? placed[r][j].second * (*init)[placed[r][j].first & 0xffffu] : 0.f;
       unsigned ibits;
       memcpy(&ibits, &ip, 4);
-      arc4[base[s / 64] + j * 64 + s % 64] = make_uint4(rows[r][j].first, bits, ibits, 0u);
+      arc4[base[s / 64] + j * 64 + s % 64] = make_uint4(placed[r][j].first, bits, ibits, 0u);
     }
   }
   out->nrows = nrows;
