@@ -136,10 +136,16 @@ __device__ __forceinline__ float sell_row_sum(const uint2 *ap, int w, Term term)
 
 // Forward: alpha_dash(t, .) for t = 0..T stored to `alpha` [(T+1) x Hs] per sequence, alpha sums to
 // `asum` [T+1], per-sequence log-prob to logprob[s].
-template <bool LDS_STATE>
+// FAST (the host checks: state vectors in LDS, at most kDenFastSlots rows and kDenFastStates states per thread): everything that does not change from
+// frame to frame -- a thread's slices, rows and initial probabilities -- stays in registers, and a frame's new vector is formed in a second LDS
+// buffer: no load inside a frame depends on another load or store of the same frame except the arcs themselves (the plain loop re-reads the slice
+// table, the row ids, init[] and -- after a global store -- its own alpha row, each a trip to L2 in front of the next barrier).
+// res_cap > 0: the first res_cap arcs of the table (its widest slices) stay in LDS for all frames -- used when the launch holds every CU anyway.
+constexpr int kDenFastSlots = 4, kDenFastStates = 4;  // (both tables of these kernels have one row per state)
+template <bool LDS_STATE, bool FAST = false>
 __global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatView y, int B, int T, float leaky,
                                                                   float *alpha_all, float *asum_all, int Hs,
-                                                                  double *logprob, float *gstate, const unsigned *only_if) {
+                                                                  double *logprob, float *gstate, const unsigned *only_if, int res_cap) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[kDenThreads / 64];
   if (only_if && *only_if == 0) return;  // fallback launch behind the multi-workgroup recursion: runs only when that one gave up
@@ -147,6 +153,28 @@ __global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatV
   const int H = g.H, P = g.P;
   float *x = smem;  // P
   float *prev = LDS_STATE ? smem + ((P + 3) & ~3) : gstate + (size_t)s * 2 * Hs;
+  float *nxt = smem + ((P + 3) & ~3) + Hs;  // FAST: the frame's new vector
+  uint2 *lres = reinterpret_cast<uint2 *>(smem + ((P + 3) & ~3) + (LDS_STATE ? Hs : 0) + (FAST ? Hs : 0));
+  for (int i = tid; i < res_cap; i += kDenThreads) lres[i] = g.by_dst.arc[i];
+  int sb0[kDenFastSlots], sw[kDenFastSlots];
+  unsigned srow[kDenFastSlots];
+  float hinit[kDenFastStates];
+  if constexpr (FAST) {
+#pragma unroll
+    for (int k = 0; k < kDenFastSlots; k++) {
+      const int slot = tid + k * kDenThreads;
+      sb0[k] = 0;
+      sw[k] = 0;
+      srow[k] = 0xffffffffu;
+      if (slot < g.by_dst.nslices * 64) {
+        sb0[k] = g.by_dst.base[slot >> 6];
+        sw[k] = (g.by_dst.base[(slot >> 6) + 1] - sb0[k]) >> 6;
+        srow[k] = g.by_dst.row[slot];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kDenFastStates; i++) hinit[i] = tid + i * kDenThreads < H ? g.init[tid + i * kDenThreads] : 0.f;
+  }
   float *alpha = alpha_all + (size_t)s * (T + 1) * Hs;
   float *asum = asum_all + (size_t)s * (T + 1);
 
@@ -173,12 +201,41 @@ __global__ __launch_bounds__(kDenThreads) void den_forward_kernel(DenDev g, MatV
     logcorr += (double)logf(prev_sum);
     float *cur = alpha + (size_t)t * Hs;
     float local = 0.f;
+    auto term = [&](const uint2 a) { return prev[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16]; };
+    if constexpr (FAST) {
+      const int ln = tid & 63;
+#pragma unroll
+      for (int k = 0; k < kDenFastSlots; k++) {
+        if (srow[k] == 0xffffffffu && sw[k] == 0) continue;
+        float acc = sb0[k] + sw[k] * 64 <= res_cap ? sell_row_sum(lres + sb0[k] + ln, sw[k], term) : sell_row_sum(g.by_dst.arc + sb0[k] + ln, sw[k], term);
+        if (srow[k] != 0xffffffffu) {
+          acc *= inv;
+          nxt[srow[k]] = acc;  // alpha(t,h) before the leaky term
+          local += acc;
+        }
+      }
+      const float sum = block_sum(local, red, kDenThreads / 64);  // (its barriers: every row of nxt is written)
+      if (tid == 0) asum[t] = sum;
+#pragma unroll
+      for (int i = 0; i < kDenFastStates; i++) {  // AlphaDash(t)
+        const int h = tid + i * kDenThreads;
+        if (h < H) {
+          const float a = nxt[h] + leaky * sum * hinit[i];
+          nxt[h] = a;
+          cur[h] = a;
+        }
+      }
+      float *other = prev;
+      prev = nxt;
+      nxt = other;
+      prev_sum = sum;
+      __syncthreads();
+      continue;
+    }
     for (int slot = tid; slot < g.by_dst.nslices * 64; slot += kDenThreads) {
       const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_dst.base[sl], w = (g.by_dst.base[sl + 1] - b0) >> 6;
-      const uint2 *ap = g.by_dst.arc + b0 + ln;
-      const float acc0 = sell_row_sum(ap, w, [&](const uint2 a) { return prev[a.x & 0xffffu] * __uint_as_float(a.y) * x[a.x >> 16]; });
-      float acc = acc0;
+      float acc = b0 + w * 64 <= res_cap ? sell_row_sum(lres + b0 + ln, w, term) : sell_row_sum(g.by_dst.arc + b0 + ln, w, term);
       const unsigned h = g.by_dst.row[slot];
       if (h != 0xffffffffu) {
         acc *= inv;
@@ -286,8 +343,9 @@ __global__ __launch_bounds__(kDenThreads) void den_backward_kernel(DenDev g, Mat
 // of its own, keeps the one-kernel backward pass: there the further stream bought nothing at 1500 x 128 (133.8 -> 134.6 ms) and
 // cost 7 ms at 150 x 64 (18.5 -> 25.7: with the weight-gradient stream that is a fifth stream in flight, and beyond four they
 // share hardware queues -- the same cliff as one side stream per natural-gradient buffer set).
+template <bool FAST = false>
 __global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView y, int B, int T, float leaky, float *b_all, float *S_all, int Hs,
-                                                               const unsigned *only_if) {
+                                                               const unsigned *only_if, int res_cap) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __shared__ float red[kDenThreads / 64];
   if (only_if && *only_if == 0) return;
@@ -295,6 +353,28 @@ __global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView
   const int H = g.H, P = g.P, P4 = (P + 3) & ~3;
   float *x = smem;       // P: exp of the frame's output row
   float *bn = smem + P4;  // H: b(t+1, .) / S(t+1) + leaky
+  float *nb = bn + ((H + 3) & ~3);  // FAST: the frame's raw sums (den_forward_kernel)
+  uint2 *lres = reinterpret_cast<uint2 *>(bn + ((H + 3) & ~3) * (FAST ? 2 : 1));  // (den_forward_kernel: the table's first res_cap arcs)
+  for (int i = tid; i < res_cap; i += kDenThreads) lres[i] = g.by_src.arc[i];
+  int sb0[kDenFastSlots], sw[kDenFastSlots];
+  unsigned srow[kDenFastSlots];
+  float sinit[kDenFastSlots];
+  if constexpr (FAST) {
+#pragma unroll
+    for (int k = 0; k < kDenFastSlots; k++) {
+      const int slot = tid + k * kDenThreads;
+      sb0[k] = 0;
+      sw[k] = 0;
+      srow[k] = 0xffffffffu;
+      sinit[k] = 0.f;
+      if (slot < g.by_src.nslices * 64) {
+        sb0[k] = g.by_src.base[slot >> 6];
+        sw[k] = (g.by_src.base[(slot >> 6) + 1] - sb0[k]) >> 6;
+        srow[k] = g.by_src.row[slot];
+        if (srow[k] != 0xffffffffu) sinit[k] = g.init[srow[k]];
+      }
+    }
+  }
   float *brow = b_all + (size_t)s * (T + 1) * Hs;
   float *S = S_all + (size_t)s * (T + 1);
   for (int h = tid; h < H; h += kDenThreads) {
@@ -314,12 +394,37 @@ __global__ __launch_bounds__(kDenThreads) void den_beta_kernel(DenDev g, MatView
     __syncthreads();
     float *bcur = brow + (size_t)t * Hs;
     float local = 0.f;
+    auto term = [&](const uint2 a) { return __uint_as_float(a.y) * x[a.x >> 16] * bn[a.x & 0xffffu]; };
+    if constexpr (FAST) {
+      const int ln = tid & 63;
+#pragma unroll
+      for (int k = 0; k < kDenFastSlots; k++) {
+        if (srow[k] == 0xffffffffu && sw[k] == 0) continue;
+        const float acc = sb0[k] + sw[k] * 64 <= res_cap ? sell_row_sum(lres + sb0[k] + ln, sw[k], term) : sell_row_sum(g.by_src.arc + sb0[k] + ln, sw[k], term);
+        if (srow[k] != 0xffffffffu) {
+          nb[srow[k]] = acc;
+          local += sinit[k] * acc;
+        }
+      }
+      const float St = block_sum(local, red, kDenThreads / 64);  // (its barriers: bn is no longer read, every row of nb is written)
+      if (tid == 0) S[t] = St;
+      const float inv = 1.0f / St;
+#pragma unroll
+      for (int i = 0; i < kDenFastStates; i++) {
+        const int h = tid + i * kDenThreads;
+        if (h < H) {
+          const float v = nb[h];
+          bcur[h] = v;
+          bn[h] = v * inv + leaky;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
     for (int slot = tid; slot < g.by_src.nslices * 64; slot += kDenThreads) {
       const int sl = slot >> 6, ln = slot & 63;
       const int b0 = g.by_src.base[sl], w = (g.by_src.base[sl + 1] - b0) >> 6;
-      const uint2 *ap = g.by_src.arc + b0 + ln;
-      const float acc0 = sell_row_sum(ap, w, [&](const uint2 a) { return __uint_as_float(a.y) * x[a.x >> 16] * bn[a.x & 0xffffu]; });
-      float acc = acc0;
+      float acc = b0 + w * 64 <= res_cap ? sell_row_sum(lres + b0 + ln, w, term) : sell_row_sum(g.by_src.arc + b0 + ln, w, term);
       const unsigned h = g.by_src.row[slot];
       if (h != 0xffffffffu) {
         bcur[h] = acc;
@@ -1539,7 +1644,7 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     int rc = den_aux_stream(caller_aux ? nullptr : &aux, &ev_fork, &ev_join);
     if (rc) return rc;
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
-    TDNNF_HIP(hipFuncSetAttribute((const void *)den_beta_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beta));
+    TDNNF_HIP(hipFuncSetAttribute((const void *)den_beta_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_beta));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_gamma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_gamma));
     TDNNF_HIP(hipEventRecord(ev_fork, s));
     TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
@@ -1593,24 +1698,53 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
       // behind them, the one-workgroup kernels: they return at once unless the abort word is set (then they redo the recursion, so that
       // the occupancy pass never reads half-written vectors and the minibatch is not lost)
       hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate,
-                         (const unsigned *)ctl.abort_flag);
-      hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)ctl.abort_flag);
+                         (const unsigned *)ctl.abort_flag, 0);
+      hipLaunchKernelGGL(den_beta_kernel<false>, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)ctl.abort_flag, 0);
       hipLaunchKernelGGL(den_mw_check_kernel, dim3(1), dim3(64), 0, s, (const unsigned *)ctl.abort_flag, g_mw_fallbacks);
     } else {
-      hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate,
-                         (const unsigned *)nullptr);
-      hipLaunchKernelGGL(den_beta_kernel, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)nullptr);
+      // FAST kernels where a thread's rows and states fit its registers (den_forward_kernel); and when the two launches hold every CU (one
+      // 1024-thread workgroup each), the LDS nothing else can use keeps the tables' widest slices
+      const bool fast = g->by_dst.nslices * 64 <= kDenFastSlots * kDenThreads && g->by_src.nslices * 64 <= kDenFastSlots * kDenThreads && g->H <= kDenFastStates * kDenThreads;
+      const size_t lf = b.p.lds_fwd + (fast ? sizeof(float) * b.p.Hs : 0), lb = lds_beta + (fast ? sizeof(float) * H4 : 0);
+      int dev = 0, res_f = 0, res_b = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && 2 * B >= prop.multiProcessorCount) {
+        const size_t budget = 150 * 1024;
+        if (lf < budget) res_f = (int)std::min<long long>(g->by_dst.entries, (long long)((budget - lf) / 8)) & ~63;
+        if (lb < budget) res_b = (int)std::min<long long>(g->by_src.entries, (long long)((budget - lb) / 8)) & ~63;
+      }
+      (void)hipGetLastError();
+      const size_t lds_f2 = lf + 8 * (size_t)res_f, lds_b2 = lb + 8 * (size_t)res_b;
+      if (fast) {
+        TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f2));
+        TDNNF_HIP(hipFuncSetAttribute((const void *)den_beta_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b2));
+        hipLaunchKernelGGL((den_forward_kernel<true, true>), dim3(B), dim3(kDenThreads), lds_f2, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate,
+                           (const unsigned *)nullptr, res_f);
+        hipLaunchKernelGGL(den_beta_kernel<true>, dim3(B), dim3(kDenThreads), lds_b2, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)nullptr, res_b);
+      } else {
+        TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f2));
+        TDNNF_HIP(hipFuncSetAttribute((const void *)den_beta_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b2));
+        hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), lds_f2, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate,
+                           (const unsigned *)nullptr, res_f);
+        hipLaunchKernelGGL(den_beta_kernel<false>, dim3(B), dim3(kDenThreads), lds_b2, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)nullptr, res_b);
+      }
     }
     TDNNF_HIP(hipEventRecord(ev_join, aux));
     TDNNF_HIP(hipStreamWaitEvent(s, ev_join, 0));
     hipLaunchKernelGGL(den_gamma_kernel, dim3(T, B), dim3(kGammaThreads), lds_gamma, s, gd, yv, B, T, leaky, b.alpha, b_all, S_all, b.p.Hs, -sp->weight, dv);
   } else if (b.p.lds_state) {
-    TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_bwd));
-    hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate, (const unsigned *)nullptr);
+    if (g->by_dst.nslices * 64 <= kDenFastSlots * kDenThreads && g->H <= kDenFastStates * kDenThreads) {
+      const size_t lf = b.p.lds_fwd + sizeof(float) * b.p.Hs;
+      TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lf));
+      hipLaunchKernelGGL((den_forward_kernel<true, true>), dim3(B), dim3(kDenThreads), lf, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate, (const unsigned *)nullptr, 0);
+    } else {
+      TDNNF_HIP(hipFuncSetAttribute((const void *)den_forward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_fwd));
+      hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate, (const unsigned *)nullptr, 0);
+    }
     hipLaunchKernelGGL(den_backward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_bwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, -sp->weight, dv, b.gstate);
   } else {
-    hipLaunchKernelGGL(den_forward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate, (const unsigned *)nullptr);
+    hipLaunchKernelGGL(den_forward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate, (const unsigned *)nullptr, 0);
     hipLaunchKernelGGL(den_backward_kernel<false>, dim3(B), dim3(kDenThreads), b.p.lds_bwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, -sp->weight, dv, b.gstate);
   }
   TDNNF_LAUNCH_CHECK();
