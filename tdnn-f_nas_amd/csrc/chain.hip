@@ -675,13 +675,32 @@ __global__ __launch_bounds__(kGammaThreads) void den_gamma_kernel(DenDev g, MatV
   const float Zd = block_sum(local, red, kGammaThreads / 64);  // (also the barrier before ad / bn / x are read)
   const float scale = deriv_weight / Zd;
   float *dr = deriv.data + (size_t)(t * B + s) * deriv.stride;
-  for (int slot = tid; slot < g.by_pdf.nslices * 64; slot += kGammaThreads) {
-    const int sl = slot >> 6, ln = slot & 63;
-    const int b0 = g.by_pdf.base[sl], w = (g.by_pdf.base[sl + 1] - b0) >> 6;
-    const uint2 *ap = g.by_pdf.arc + b0 + ln;
-    const float acc = sell_row_sum(ap, w, [&](const uint2 a) { return __uint_as_float(a.y) * ad[a.x & 0xffffu] * bn[a.x >> 16]; });
-    const unsigned p = g.by_pdf.row[slot];
-    if (p != 0xffffffffu) dr[p] = scale * acc * x[p];
+  // (the slice table and row ids of a thread's rows first, all at once: fetched row by row they sat, one trip to L2 each, in front of every row's arcs
+  // -- twelve rows per thread at 6 034 pdfs, 33 us per block of which the arcs themselves are a third)
+  constexpr int kRows = 12;
+  const int nslot = g.by_pdf.nslices * 64, ln = tid & 63;
+  auto term = [&](const uint2 a) { return __uint_as_float(a.y) * ad[a.x & 0xffffu] * bn[a.x >> 16]; };
+  for (int s0 = tid; s0 < nslot; s0 += kRows * kGammaThreads) {
+    int b0[kRows], w[kRows];
+    unsigned row[kRows];
+#pragma unroll
+    for (int k = 0; k < kRows; k++) {
+      const int slot = s0 + k * kGammaThreads;
+      b0[k] = 0;
+      w[k] = 0;
+      row[k] = 0xffffffffu;
+      if (slot < nslot) {
+        b0[k] = g.by_pdf.base[slot >> 6];
+        w[k] = (g.by_pdf.base[(slot >> 6) + 1] - b0[k]) >> 6;
+        row[k] = g.by_pdf.row[slot];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kRows; k++) {
+      if (row[k] == 0xffffffffu) continue;
+      const float acc = sell_row_sum(g.by_pdf.arc + b0[k] + ln, w[k], term);
+      dr[row[k]] = scale * acc * x[row[k]];
+    }
   }
 }
 // ---------------------------------------------------------------------------------------------- denominator, wide form

@@ -1205,7 +1205,13 @@ namespace {
 // step at 150 x 64 took 20.0 ms: they then share hardware queues).
 // [r4] with the pre-split plane GEMMs (planes = true) the xent head no longer covers a 25 ms denominator at 128 sequences: side by side there too
 // (same box, ms per step: f16x3 103.8 / 105.2 -> 102.1 / 102.4; exact f32 124.4 / 124.6 -> 125.4 / 125.0, so f32 keeps the one-kernel backward pass)
-bool den_uses_split(int B, bool planes) { return options().den_split >= 0 ? options().den_split != 0 : (B <= 96 || planes); }
+// [r4, later] with the recursions at 8.8 us per frame (chain.hip, FAST kernels) side by side wins for exact f32 at 128 sequences as well: 122.3 / 122.6 ms
+// against 122.7 / 122.9 on one box, and the GEMM launches beside it are stretched less (event-timed 128 x 128 class 0.642 of the peak against 0.617)
+bool den_uses_split(int B, bool planes) {
+  (void)B;
+  (void)planes;
+  return options().den_split >= 0 ? options().den_split != 0 : true;
+}
 }  // namespace
 
 int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *den,
