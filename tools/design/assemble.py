@@ -61,7 +61,8 @@ vals = {
     "R150": "%.0f k frames/s (%.2f ms)" % (r150["value"] / 1e3, r150["ms_per_step"]),
     "R150_PROF": "589 dispatches per step, no kernel in flight 1.5 ms of a 13.8 ms profiled step (1.5 of 23.7 ms at 1500 × 16), the caller's stream busy 8.8 ms; the host is three steps ahead (docs/experiments.md r4-f, r4-g)",
     "SHARDS": shards,
-    "SYNCBN": "%.2f ms against %.2f ms per 1500 × 16 step (+%.2f ms; target ≤ 0.5)" % (sum(on) / len(on), sum(off) / len(off), sum(on) / len(on) - sum(off) / len(off)),
+    "SYNCBN": "%.2f ms against %.2f ms per 1500 × 16 step (best of %d runs each, %+.2f ms; all runs: on %s, off %s; target ≤ 0.5)" %
+              (min(on), min(off), len(on), min(on) - min(off), " / ".join("%.2f" % v for v in on), " / ".join("%.2f" % v for v in off)),
     "TAPDOTS": "7.9 µs per launch (`profiles/r04_darts-offset-cvupdate_kernel_classes.csv`)",
     "NGPU_TESTS": ntests,
     "HBM_ROWS": hbm_rows,
