@@ -248,6 +248,7 @@ class Job:
             except Exception as e:  # (no librccl.so to dlopen, or the communicator could not be created: torch.distributed issues the same exchanges)
                 print("bench.py: the library's own RCCL communicator is not available (%s): falling back to torch.distributed collectives" % e, file=sys.stderr)
                 self.rccl = None
+        self.rccl_path = self.rccl.library_path() if self.rccl is not None else None
         if self.sync_bn or (world == 1 and args.sync_batchnorm == "on"):
             if self.rccl is not None:
                 self.net.set_batchnorm_sync_rccl(self.rccl)
@@ -315,6 +316,8 @@ class Job:
         if profile:
             self.pkg.hipabi.check(lib.tdnnf_profile_enable(1))
             sync()
+        r0 = (C.c_longlong(), C.c_longlong())
+        lib.tdnnf_planes_routed(C.byref(r0[0]), C.byref(r0[1]))
         t0 = time.perf_counter()
         for i in range(steps):
             if profile and i == event_steps:
@@ -322,10 +325,23 @@ class Job:
             self.step()
         sync()
         dt = time.perf_counter() - t0
+        r1 = (C.c_longlong(), C.c_longlong())
+        lib.tdnnf_planes_routed(C.byref(r1[0]), C.byref(r1[1]))
+        # GEMMs per step that really ran on the pre-split plane kernels (with the weight-gradient stream on -- minibatches of
+        # <= 32 768 rows -- gemm_precision 3 keeps the exact-f32 kernels; a line must say which arithmetic it measured)
+        self.planes_routed_per_step = {"rows_gemms": (r1[0].value - r0[0].value) / max(steps, 1), "weight_gradients": (r1[1].value - r0[1].value) / max(steps, 1)}
         if profile:
             self.pkg.hipabi.check(lib.tdnnf_profile_enable(0))
             self.event_steps = event_steps
         return dt
+
+    def arithmetic_run(self, gemm):
+        """What the timed steps computed in: the requested plane arithmetic only if GEMMs were routed to the plane kernels."""
+        if gemm in ("f16x3", "bf16x6"):
+            r = getattr(self, "planes_routed_per_step", None)
+            if r is not None and r["rows_gemms"] + r["weight_gradients"] == 0:
+                return "f32 (no GEMM was routed to the plane kernels at this minibatch size: the weight-gradient stream is on; exact v_mfma_f32_32x32x2_f32)"
+        return gemm
 
     def close(self):
         import torch
@@ -403,6 +419,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python3 bench.py --gpus N` from a bare shell: start the N ranks ourselves, one process per GPU, as the launcher would.  Nothing
+        # above has touched the device (a process that has is never re-exec'ed); the children are ordinary subprocesses, this process only
+        # waits and hands their status on.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call(cmd, env=env))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
@@ -417,6 +447,12 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+
+    n_ranks_seen = 1
+    if world > 1:  # every rank adds 1: what the process group really spans
+        one = torch.ones(1, dtype=torch.float32, device="cpu" if rehearse else "cuda")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        n_ranks_seen = int(one.item())
 
     lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
     for spec in args.option:
@@ -453,6 +489,8 @@ def main():
     res = job.net.results.cpu().numpy()
     den_arcs = int(len(job.den["src"]))
     sync_bn_main = job.sync_bn
+    rccl_path_main = job.rccl_path
+    arithmetic_main, routed_main = job.arithmetic_run(args.gemm), job.planes_routed_per_step
     # N > 1, weak scaling (what the driver runs): the same node also timed on ONE minibatch of --minibatch sequences sharded over the
     # ranks (strong scaling, synchronised BatchNorm) -- the regime north_star's ">= 6x at 8 GPUs" is the harder question in
     strong = None
@@ -501,10 +539,11 @@ def main():
         out = {
             "metric": "LF-MMI training frames/sec per node (SWBD 7q TDNN-F)",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": args.scaling, "n_ranks_seen": n_ranks_seen,
             "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 MFMA, 2 planes / 3 products, f32 accumulate)",
                                           "bf16x6": "bf16x6 (split-bf16 MFMA, 3 planes / 6 products, f32 accumulate; f32-equivalent)",
-                                          "f16x3": "f16x3 (operands pre-split into 2 scaled f16 planes, 3 products on the f16 MFMA, f32 accumulate; f32-equivalent)"}[args.gemm],
+                                          "f16x3": "f16x3 (operands pre-split into 2 scaled f16 planes, 3 products on the f16 MFMA, f32 accumulate; f32-equivalent)"}[args.gemm]
+                     if arithmetic_main == args.gemm else arithmetic_main,
             "data": "synthetic",
             "config": {"workload": workload_text(args),
                        "frames_per_chunk": args.chunk, "sequences_per_gpu": seqs, "global_batch": world * seqs,
@@ -513,7 +552,7 @@ def main():
                                             "setup_minibatches_before_warmup": burn,
                                             "refresh_steps_in_timed_region": sum(1 for t in range(burn + args.warmup, burn + args.warmup + args.steps)
                                                                                  if t <= 10 or (t - 10) % 4 == 0) if args.natural_gradient else 0},
-                       "parallelism": f"dp{world}", "sync_batchnorm": bool(sync_bn_main), "allreduce": None if world == 1 else ("one collective after backward" if args.no_overlap else
+                       "parallelism": f"dp{world}", "sync_batchnorm": bool(sync_bn_main), "rccl_library": rccl_path_main, "plane_gemms_routed_per_step": routed_main if args.gemm != "f32" else None, "allreduce": None if world == 1 else ("one collective after backward" if args.no_overlap else
                                                                                            "per gradient bucket, overlapped with backward"), "objf_per_frame": float(res[0] / res[2]) if res[2] else None},
             "roofline": {"bound": "mfma", "kernel": dom["name"], "kernel_choice": "the TDNN-F factored-GEMM class with the most time "
                          "(forward / backward-data 128x128, 128x160, weight gradient); the natural-gradient class is roofline_secondary",
@@ -580,6 +619,10 @@ def main():
             it = {"what": name, "value": round(sequences * chunk * k / d, 1), "unit": "frames/s", "ms_per_step": round(1e3 * d / k, 3),
                   "frames_per_chunk": chunk, "sequences": sequences, "den_graph": {"states": den_states, "arcs": arcs},
                   "objective_finite": bool(r[5] == 1.0 and np.isfinite(r[0]))}
+            g_ = args.gemm if gemm is None else gemm
+            if g_ != "f32":
+                it["plane_gemms_routed_per_step"] = j.planes_routed_per_step
+                it["arithmetic_run"] = j.arithmetic_run(g_)
             if archive_minibatches:
                 it["archive"] = {"minibatches": archive_minibatches, "bytes": j.archive_bytes, "features": "16-bit compressed (CompressedMatrix kTwoByteAuto)"}
             if want_stats:

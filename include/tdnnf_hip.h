@@ -554,15 +554,20 @@ typedef int TDNNF_ALLREDUCE_FN(void *ctx, double *buf, long long count, tdnnf_st
 int tdnnf_net_set_batchnorm_sync(tdnnf_net *, TDNNF_ALLREDUCE_FN *allreduce, void *ctx, int world_size);
 
 /* ---- The data-parallel exchanges on RCCL, issued from C++ on the library's streams (csrc/rccl_sync.hip).
-   librccl.so is resolved with dlopen on first use (no link-time dependency).  One process per GPU: rank 0 takes a unique id
+   RCCL is resolved on first use (no link-time dependency): the copy ALREADY MAPPED in the process if there is one (a launcher that
+   called torch.distributed's "nccl" backend has torch/lib/librccl.so live: a second copy must not be loaded beside it), else the
+   global symbol scope, else dlopen by name; tdnnf_rccl_library_path reports "<path> [<how>]".  One process per GPU: rank 0 takes a unique id
    (128 bytes), the launcher's own channel distributes it (e.g. a torch.distributed broadcast), every rank creates its communicator
    on its current device.
    tdnnf_net_set_batchnorm_sync_rccl: the synchronised BatchNorm above with ncclAllReduce (doubles, in place) on the compute stream
      as the collective -- nothing host-side between the two finalize launches; comm NULL switches it off.
    tdnnf_net_allreduce_grads_rccl: the gradient exchange of one minibatch, call right after tdnnf_net_forward_backward: one
      ncclAllReduce (sum, f32) per gradient bucket (tdnnf_net_grad_bucket) on comm_stream, each behind the event recorded when that
-     bucket became final, so the upper layers' reductions run under the lower layers' backward pass; `stream` then waits for the last. */
+     bucket became final, so the upper layers' reductions run under the lower layers' backward pass; `stream` then waits for the last.
+   The two run on DIFFERENT streams inside one step, so they must be given DIFFERENT communicators (RCCL serialises the operations of
+   one communicator in issue order: the buckets would queue behind every BatchNorm collective of the backward pass). */
 int tdnnf_rccl_available(void);
+int tdnnf_rccl_library_path(char *out, int out_bytes);
 int tdnnf_rccl_unique_id(void *out_128_bytes);
 int tdnnf_rccl_comm_create(const void *id_128_bytes, int world_size, int rank, void **comm_out);
 void tdnnf_rccl_comm_destroy(void *comm);

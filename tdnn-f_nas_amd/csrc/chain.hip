@@ -1290,8 +1290,24 @@ struct ChainPlan {
   size_t lds_fwd, lds_bwd;
 };
 int g_den_mode = 0;  // tdnnf_chain_set_denominator_mode: 0 automatic, 1 persistent, 2 wide, 3 persistent with one workgroup per sequence
-unsigned *g_mw_fallbacks = nullptr;  // pinned host memory, written by den_mw_check_kernel
-bool g_mw_off = false;               // a multi-workgroup launch gave up once: not used again
+// per device (a process may drive several): a time-out on one device says nothing about the others
+struct MwDev {
+  unsigned *fallbacks = nullptr;  // pinned host memory, written by den_mw_check_kernel
+  bool off = false;               // a multi-workgroup launch gave up once on this device: not used again there
+  int cus = 0;                    // compute units (0 = not asked yet, -1 = unknown)
+};
+constexpr int kMaxDev = 64;
+MwDev g_mw[kMaxDev];
+MwDev *mw_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+  MwDev &d = g_mw[dev];
+  if (d.cus == 0) {
+    hipDeviceProp_t prop;
+    d.cus = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
+  }
+  return &d;
+}
 // exchange buffers and counters of the multi-workgroup recursions (den_mw_kernel), behind b_all / S_all in the split region
 size_t mw_slots(const tdnnf_den_graph *g) { return (size_t)std::max(g->by_dst.nslices, g->by_src.nslices) * 64; }
 size_t mw_extra_floats(const tdnnf_den_graph *g, int B) { return 4 * (size_t)B * mw_slots(g) + 4 * (size_t)B + 64; }
@@ -1300,17 +1316,10 @@ size_t mw_extra_floats(const tdnnf_den_graph *g, int B) { return 4 * (size_t)B *
 // Four per sequence.  Measured in the step at 1500 x 16 (ms): one 27.3, two 27.5, four 23.8, eight 25.2 -- eight are faster alone (5.0 against
 // 5.6 ms for both recursions) but their 256 workgroups hold every CU while the xent head's backward pass wants them; two cost what they gain.
 int mw_groups(const tdnnf_den_graph *g, int B, int T) {
-  if (g_den_mode == 3 || g_mw_off || T < 8) return 0;
-  constexpr int kMaxDev = 64;
-  static int cus_of[kMaxDev];  // per device (a process may drive several; zero = not asked yet)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
-  if (cus_of[dev] == 0) {
-    hipDeviceProp_t prop;
-    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : -1;
-    (void)hipGetLastError();
-  }
-  const int cus = cus_of[dev], G = 4;
+  MwDev *md = mw_dev();
+  if (g_den_mode == 3 || !md || md->off || T < 8) return 0;
+  (void)hipGetLastError();
+  const int cus = md->cus, G = 4;
   if (cus <= 0 || 2 * B * G > cus) return 0;
   const int ns = std::min(g->by_dst.nslices, g->by_src.nslices), nsmax = std::max(g->by_dst.nslices, g->by_src.nslices);
   if (ns < G || (nsmax + G - 1) / G > 64) return 0;
@@ -1510,11 +1519,12 @@ int tdnnf_chain_set_denominator_mode(int mode) {
 // form is switched off for the process; reset != 0 clears both
 int tdnnf_chain_den_mw_status(int *fallbacks, int *disabled, int reset) {
   (void)hipDeviceSynchronize();
-  if (fallbacks) *fallbacks = g_mw_fallbacks ? (int)*(volatile unsigned *)g_mw_fallbacks : 0;
-  if (disabled) *disabled = g_mw_off ? 1 : 0;
-  if (reset) {
-    if (g_mw_fallbacks) *g_mw_fallbacks = 0;
-    g_mw_off = false;
+  MwDev *md = mw_dev();  // (the current device's)
+  if (fallbacks) *fallbacks = md && md->fallbacks ? (int)*(volatile unsigned *)md->fallbacks : 0;
+  if (disabled) *disabled = md && md->off ? 1 : 0;
+  if (reset && md) {
+    if (md->fallbacks) *md->fallbacks = 0;
+    md->off = false;
   }
   return TDNNF_OK;
 }
@@ -1668,19 +1678,21 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     TDNNF_HIP(hipEventRecord(ev_fork, s));
     TDNNF_HIP(hipStreamWaitEvent(aux, ev_fork, 0));
     int G = mw_groups(g, B, T);
-    if (G > 0 && !g_mw_fallbacks) {  // (first use: the host-visible fallback counter)
-      if (hipHostMalloc((void **)&g_mw_fallbacks, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
+    MwDev *md = mw_dev();
+    if (!md) G = 0;
+    if (G > 0 && !md->fallbacks) {  // (first use on this device: the host-visible fallback counter)
+      if (hipHostMalloc((void **)&md->fallbacks, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) {
         (void)hipGetLastError();
-        g_mw_fallbacks = nullptr;
+        md->fallbacks = nullptr;
         G = 0;
       } else {
-        *g_mw_fallbacks = 0;
+        *md->fallbacks = 0;
       }
     }
-    if (G > 0 && *(volatile unsigned *)g_mw_fallbacks != 0) {
+    if (G > 0 && *(volatile unsigned *)md->fallbacks != 0) {
       fprintf(stderr, "tdnnf: the multi-workgroup denominator recursion timed out (its workgroups were not co-resident); the one-workgroup kernels redid the "
-                      "minibatch and are used from here on\n");
-      g_mw_off = true;
+                      "minibatch and are used from here on (this device)\n");
+      md->off = true;
       G = 0;
     }
     const size_t stage_b = G > 0 ? 256 * (size_t)((std::max(g->by_dst.nslices, g->by_src.nslices) + G - 1) / G) : 0;
@@ -1691,11 +1703,10 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
       // (a CU mask, another process), so ask the occupancy calculator with the actual LDS sizes, and keep the bounded poll as the last resort.
       TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
       TDNNF_HIP(hipFuncSetAttribute((const void *)den_mw_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-      int occ_f = 0, occ_b = 0, dev = 0;
-      hipDeviceProp_t prop;
+      int occ_f = 0, occ_b = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_f, den_mw_kernel<0>, kDenThreads, lds_f) != hipSuccess ||
-          hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, den_mw_kernel<1>, kDenThreads, lds_b) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
-          hipGetDeviceProperties(&prop, dev) != hipSuccess || occ_f < 1 || occ_b < 1 || 2 * B * G > prop.multiProcessorCount) {
+          hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_b, den_mw_kernel<1>, kDenThreads, lds_b) != hipSuccess || occ_f < 1 || occ_b < 1 ||
+          md->cus <= 0 || 2 * B * G > md->cus) {
         (void)hipGetLastError();
         G = 0;
       }
@@ -1719,15 +1730,14 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
       hipLaunchKernelGGL(den_forward_kernel<true>, dim3(B), dim3(kDenThreads), b.p.lds_fwd, s, gd, yv, B, T, leaky, b.alpha, b.asum, b.p.Hs, b.den_lp, b.gstate,
                          (const unsigned *)ctl.abort_flag, 0);
       hipLaunchKernelGGL(den_beta_kernel<false>, dim3(B), dim3(kDenThreads), lds_beta, aux, gd, yv, B, T, leaky, b_all, S_all, b.p.Hs, (const unsigned *)ctl.abort_flag, 0);
-      hipLaunchKernelGGL(den_mw_check_kernel, dim3(1), dim3(64), 0, s, (const unsigned *)ctl.abort_flag, g_mw_fallbacks);
+      hipLaunchKernelGGL(den_mw_check_kernel, dim3(1), dim3(64), 0, s, (const unsigned *)ctl.abort_flag, md->fallbacks);
     } else {
       // FAST kernels where a thread's rows and states fit its registers (den_forward_kernel); and when the two launches hold every CU (one
       // 1024-thread workgroup each), the LDS nothing else can use keeps the tables' widest slices
       const bool fast = g->by_dst.nslices * 64 <= kDenFastSlots * kDenThreads && g->by_src.nslices * 64 <= kDenFastSlots * kDenThreads && g->H <= kDenFastStates * kDenThreads;
       const size_t lf = b.p.lds_fwd + (fast ? sizeof(float) * b.p.Hs : 0), lb = lds_beta + (fast ? sizeof(float) * H4 : 0);
-      int dev = 0, res_f = 0, res_b = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && 2 * B >= prop.multiProcessorCount) {
+      int res_f = 0, res_b = 0;
+      if (md && md->cus > 0 && 2 * B >= md->cus) {
         const size_t budget = 150 * 1024;
         if (lf < budget) res_f = (int)std::min<long long>(g->by_dst.entries, (long long)((budget - lf) / 8)) & ~63;
         if (lb < budget) res_b = (int)std::min<long long>(g->by_src.entries, (long long)((budget - lb) / 8)) & ~63;

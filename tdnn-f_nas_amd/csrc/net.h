@@ -180,6 +180,7 @@ struct tdnnf_net {
   std::vector<char> oderiv_nonzero_own;
   std::vector<char> *oderiv_nonzero = &oderiv_nonzero_own;
   tdnnf::BnSync bn_sync{nullptr, nullptr, nullptr, 1};  // tdnnf_net_set_batchnorm_sync; buf lives in the arena
+  bool den_split = true;  // the denominator's two recursions side by side (option den_split, read when the net's first step sizes the workspace)
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done
   hipEvent_t ev_comm = nullptr;        // tdnnf_net_allreduce_grads_rccl: the last bucket's collective

@@ -1207,11 +1207,7 @@ namespace {
 // (same box, ms per step: f16x3 103.8 / 105.2 -> 102.1 / 102.4; exact f32 124.4 / 124.6 -> 125.4 / 125.0, so f32 keeps the one-kernel backward pass)
 // [r4, later] with the recursions at 8.8 us per frame (chain.hip, FAST kernels) side by side wins for exact f32 at 128 sequences as well: 122.3 / 122.6 ms
 // against 122.7 / 122.9 on one box, and the GEMM launches beside it are stretched less (event-timed 128 x 128 class 0.642 of the peak against 0.617)
-bool den_uses_split(int B, bool planes) {
-  (void)B;
-  (void)planes;
-  return options().den_split >= 0 ? options().den_split != 0 : true;
-}
+bool den_uses_split() { return options().den_split >= 0 ? options().den_split != 0 : true; }
 }  // namespace
 
 int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf_mat *ivectors, const tdnnf_den_graph *den,
@@ -1226,7 +1222,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   hipStream_t s = (hipStream_t)stream;
   const bool cv = c.cv_update != 0;  // BatchNorm components are BatchNormTestComponents
   if (!n->chain_ws) {
-    n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B, n->planes_np != 0 && !n->wg_on) ? 0 : chain_split_region_bytes(den, B, n->Tout));
+    n->den_split = den_uses_split();  // latched: option den_split read once per net (the workspace is sized for it)
+    n->chain_ws_bytes = tdnnf_chain_workspace_bytes(den, B, n->Tout) - (n->den_split ? 0 : chain_split_region_bytes(den, B, n->Tout));
     TDNNF_HIP(hipMalloc(&n->chain_ws, n->chain_ws_bytes));
     TDNNF_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
@@ -1257,6 +1254,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_ngc, hipEventDisableTiming));
   }
   n->fb_count++;
+  n->wg_two = false;  // (a step that failed half-way may have left it set)
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
   if (n->ng_bsum_all && n->ng_bsum_floats) TDNNF_HIP(hipMemsetAsync(n->ng_bsum_all, 0, sizeof(float) * n->ng_bsum_floats, s));  // every component's raw bias gradient
   n->pg_count = 0;
@@ -1419,7 +1417,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     }
     hipLaunchKernelGGL(transpose_weights_kernel, dim3(256, nc), dim3(256), 0, s, n->params, n->paramsT, tb);
   }
-  TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout) - (den_uses_split(B, n->planes_np != 0 && !n->wg_on) ? 0 : chain_split_region_bytes(den, B, n->Tout)),
+  TDNNF_REQUIRE(n->chain_ws_bytes >= tdnnf_chain_workspace_bytes(den, B, n->Tout) - (n->den_split ? 0 : chain_split_region_bytes(den, B, n->Tout)),
                 "net_forward_backward: denominator graph changed size");
   // the reference's RandInt()/RandUniform() coin flips, made reproducible: k-th decision of this minibatch
   unsigned long long coin_k = 0;
@@ -1576,7 +1574,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       TDNNF_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
       // few sequences leave most CUs idle while one workgroup per sequence walks the frames: there the backward recursion runs
       // beside the forward one (den_beta_kernel on a further stream) and the occupancies of all frames at once
-      const bool den_split = den_uses_split(B, n->planes_np != 0 && !n->wg_on);
+      const bool den_split = n->den_split;
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fork, 0));
       CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, !den_split, n->s3));
       TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));

@@ -11,6 +11,8 @@
 // The communicator is created here from a unique id the caller distributes (tdnnf_rccl_unique_id on rank 0 -> every rank's
 // tdnnf_rccl_comm_create): one process per GPU, as torch.distributed's launcher starts them.
 #include <dlfcn.h>
+#include <link.h>
+#include <stdio.h>
 #include <string.h>
 
 #include "common.h"
@@ -35,20 +37,53 @@ struct Rccl {
   all_reduce_t all_reduce = nullptr;
   get_error_string_t error_string = nullptr;
   bool ok = false;
+  const char *how = "not found";
 };
+// Which RCCL: a process that already has one mapped (torch.distributed's "nccl" backend brings torch/lib/librccl.so) must use THAT
+// copy -- a second librccl.so in the process means two sets of proxy threads, two IPC caches and two views of the topology.  So:
+// (1) any loaded object whose path names librccl, re-opened with RTLD_NOLOAD; (2) the global symbol scope; (3) only when the process
+// has none, dlopen by name.  tdnnf_rccl_library_path reports what was taken.
+struct FindLoaded {
+  char path[1024];
+};
+int find_loaded_rccl(struct dl_phdr_info *info, size_t, void *data) {
+  if (info->dlpi_name && strstr(info->dlpi_name, "librccl")) {
+    snprintf(((FindLoaded *)data)->path, sizeof(FindLoaded::path), "%s", info->dlpi_name);
+    return 1;
+  }
+  return 0;
+}
+bool bind(Rccl &x, void *h) {
+  x.get_unique_id = (get_unique_id_t)dlsym(h, "ncclGetUniqueId");
+  x.comm_init_rank = (comm_init_rank_t)dlsym(h, "ncclCommInitRank");
+  x.comm_destroy = (comm_destroy_t)dlsym(h, "ncclCommDestroy");
+  x.all_reduce = (all_reduce_t)dlsym(h, "ncclAllReduce");
+  x.error_string = (get_error_string_t)dlsym(h, "ncclGetErrorString");
+  x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.all_reduce;
+  return x.ok;
+}
 const Rccl &rccl() {
   static const Rccl r = [] {
     Rccl x;
-    for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    FindLoaded f;
+    f.path[0] = 0;
+    if (dl_iterate_phdr(find_loaded_rccl, &f)) {
+      void *h = dlopen(f.path, RTLD_NOW | RTLD_NOLOAD);
+      if (h && bind(x, h)) {
+        x.how = "already mapped in the process";
+        return x;
+      }
+    }
+    if (bind(x, RTLD_DEFAULT)) {
+      x.how = "global symbol scope";
+      return x;
+    }
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"}) {
       void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (!h) continue;
-      x.get_unique_id = (get_unique_id_t)dlsym(h, "ncclGetUniqueId");
-      x.comm_init_rank = (comm_init_rank_t)dlsym(h, "ncclCommInitRank");
-      x.comm_destroy = (comm_destroy_t)dlsym(h, "ncclCommDestroy");
-      x.all_reduce = (all_reduce_t)dlsym(h, "ncclAllReduce");
-      x.error_string = (get_error_string_t)dlsym(h, "ncclGetErrorString");
-      x.ok = x.get_unique_id && x.comm_init_rank && x.comm_destroy && x.all_reduce;
-      if (x.ok) break;
+      if (h && bind(x, h)) {
+        x.how = "dlopen by name (the process had none)";
+        break;
+      }
     }
     return x;
   }();
@@ -74,6 +109,17 @@ using namespace tdnnf;
 extern "C" {
 
 int tdnnf_rccl_available(void) { return rccl().ok ? 1 : 0; }
+
+int tdnnf_rccl_library_path(char *out, int out_bytes) {
+  TDNNF_REQUIRE(out && out_bytes > 0, "rccl_library_path: bad arguments");
+  out[0] = 0;
+  if (!rccl().ok) return TDNNF_OK;
+  Dl_info di;
+  memset(&di, 0, sizeof(di));
+  if (dladdr((void *)rccl().all_reduce, &di) && di.dli_fname) snprintf(out, (size_t)out_bytes, "%s [%s]", di.dli_fname, rccl().how);
+  else snprintf(out, (size_t)out_bytes, "? [%s]", rccl().how);
+  return TDNNF_OK;
+}
 
 int tdnnf_rccl_unique_id(void *out_128_bytes) {
   TDNNF_REQUIRE(out_128_bytes, "rccl_unique_id: null argument");

@@ -301,7 +301,7 @@ class ChainNet:
         on the compute stream between the two finalize launches, no host code in between).  comm: an RcclComm, or None = off."""
         if comm is not None:
             _require_equal_shards(self.cfg.num_sequences, comm.group, comm.world)
-        hipabi.check(self.lib.tdnnf_net_set_batchnorm_sync_rccl(self.h, comm.h if comm is not None else None, comm.world if comm is not None else 1))
+        hipabi.check(self.lib.tdnnf_net_set_batchnorm_sync_rccl(self.h, comm.h_bn if comm is not None else None, comm.world if comm is not None else 1))
         self._bn_sync_cb = None
         return comm is not None
 
@@ -407,28 +407,62 @@ def _require_equal_shards(num_sequences, group, world):
 
 
 class RcclComm:
-    """A RCCL communicator owned by the library (csrc/rccl_sync.hip) for the exchanges it issues itself from C++: rank 0 takes the
-    unique id, torch.distributed's group (whatever its backend) carries the 128 bytes to the other ranks, every rank joins on its
-    current device.  single=True: a one-rank communicator without any process group (tests, rehearsals on one GPU)."""
+    """RCCL communicators owned by the library (csrc/rccl_sync.hip) for the exchanges it issues itself from C++: rank 0 takes the
+    unique ids, torch.distributed's group (whatever its backend) carries them to the other ranks, every rank joins on its current
+    device.  TWO communicators: `h` for the gradient buckets (communication stream) and `h_bn` for the synchronised BatchNorm sums
+    (compute stream) -- RCCL runs the operations of one communicator in issue order, and the buckets of a step are issued behind all
+    of its BatchNorm collectives: on one communicator no bucket could start before the backward pass has ended.
+    single=True: one-rank communicators without any process group (tests, rehearsals on one GPU).
+    The outcome is agreed collectively: a failure on any rank (no RCCL, ncclCommInitRank error) raises on EVERY rank, so the callers'
+    fallback to torch.distributed's collectives is taken by all ranks or none."""
 
     def __init__(self, group=None, single=False):
         import torch.distributed as dist
         self.lib = hipabi.load()
-        if not self.lib.tdnnf_rccl_available():
-            raise RuntimeError("librccl.so is not available")
         self.group = group
         self.world, self.rank = (1, 0) if single else (dist.get_world_size(group), dist.get_rank(group))
-        ident = None
+        self.h, self.h_bn = None, None
+        err = None
+        ids = None
         if self.rank == 0:
-            buf = (C.c_char * 128)()
-            hipabi.check(self.lib.tdnnf_rccl_unique_id(buf))
-            ident = bytes(buf)
+            try:
+                if not self.lib.tdnnf_rccl_available():
+                    raise RuntimeError("no RCCL in the process and none to dlopen")
+                ids = []
+                for _ in range(2):
+                    buf = (C.c_char * 128)()
+                    hipabi.check(self.lib.tdnnf_rccl_unique_id(buf))
+                    ids.append(bytes(buf))
+            except Exception as e:  # (the other ranks wait in the broadcast: tell them instead of raising here)
+                err, ids = "rank 0: %s" % e, None
         if self.world > 1:
-            box = [ident]
+            box = [(ids, err)]
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            ident = box[0]
-        self.h = C.c_void_p()
-        hipabi.check(self.lib.tdnnf_rccl_comm_create(ident, self.world, self.rank, C.byref(self.h)))
+            ids, err = box[0]
+        if err is None:
+            try:
+                if not self.lib.tdnnf_rccl_available():
+                    raise RuntimeError("no RCCL in the process and none to dlopen")
+                hs = []
+                for ident in ids:  # (same order on every rank: communicator creation is itself collective)
+                    h = C.c_void_p()
+                    hipabi.check(self.lib.tdnnf_rccl_comm_create(ident, self.world, self.rank, C.byref(h)))
+                    hs.append(h)
+                self.h, self.h_bn = hs
+            except Exception as e:
+                err = "rank %d: %s" % (self.rank, e)
+        if self.world > 1:
+            errs = [None] * self.world
+            dist.all_gather_object(errs, err, group=group)
+            err = next((e for e in errs if e), None)
+        if err is not None:
+            self.close()
+            raise RuntimeError("the library's RCCL communicators could not be created (%s)" % err)
+
+    def library_path(self):
+        buf = C.create_string_buffer(1200)
+        hipabi.check(self.lib.tdnnf_rccl_library_path(buf, 1200))
+        return buf.value.decode()
 
     def allreduce_sum(self, tensor, stream=None):
         """In-place sum of a contiguous float32 / float64 device tensor over the ranks, on `stream` (default: the current one)."""
@@ -440,9 +474,11 @@ class RcclComm:
         return tensor
 
     def close(self):
-        if getattr(self, "h", None):
-            self.lib.tdnnf_rccl_comm_destroy(self.h)
-            self.h = None
+        for name in ("h", "h_bn"):
+            h = getattr(self, name, None)
+            if h:
+                self.lib.tdnnf_rccl_comm_destroy(h)
+            setattr(self, name, None)
 
     def __del__(self):
         self.close()

@@ -343,3 +343,64 @@ def test_unequal_shards_are_refused_by_synchronised_batchnorm(pkg):
             mock.patch.object(dist, "get_backend", return_value="gloo"), mock.patch.object(dist, "all_gather", side_effect=fake_all_gather):
         with pytest.raises(ValueError, match="same number of sequences"):
             T._require_equal_shards(8, None, 2)
+
+
+def _one_rccl_main(rank, port, out_dir):
+    """torch.distributed's "nccl" backend first (it maps torch/lib/librccl.so), then the library's own communicators: they must bind
+    the copy that is already in the process, not load /opt/rocm's beside it."""
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    torch.cuda.set_device(0)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        comm = pkg.trainer.RcclComm(single=True)
+        path = comm.library_path()
+        x = torch.arange(8, device="cuda", dtype=torch.float32)
+        comm.allreduce_sum(x)
+        torch.cuda.synchronize()
+        maps = sorted({ln.split()[-1] for ln in open("/proc/self/maps") if "librccl" in ln})
+        with open(os.path.join(out_dir, "one_rccl.txt"), "w") as f:
+            f.write(path + "\n" + "\n".join(maps) + "\n")
+        assert comm.h and comm.h_bn and comm.h.value != comm.h_bn.value  # two communicators: buckets / BatchNorm sums (ADVICE r4)
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_the_library_binds_the_rccl_torch_already_loaded(pkg, tmp_path):
+    """one RCCL per process.  After dist.init_process_group("nccl") the library's communicators come from the copy
+    torch mapped (found among the loaded objects, re-opened with RTLD_NOLOAD); /proc/self/maps shows a single librccl."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_one_rccl_main, args=(port, str(tmp_path)), nprocs=1, join=True)
+    lines = open(tmp_path / "one_rccl.txt").read().split("\n")
+    assert "already mapped in the process" in lines[0], lines
+    mapped = [ln for ln in lines[1:] if ln]
+    assert len(mapped) == 1 and mapped[0] in lines[0], lines
+
+
+def test_bench_starts_its_own_ranks(pkg):
+    """`python3 bench.py --gpus 2` from a bare shell (no launcher, no WORLD_SIZE): bench.py starts the two ranks itself and exits 0
+    with a two-rank line.  Both ranks on this one GPU over gloo (TDNNF_BENCH_REHEARSE_ON_ONE_GPU=1), tiny shape."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TDNNF_BENCH_REHEARSE_ON_ONE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--ng-burn-in", "2", "--chunk", "150",
+                        "--minibatch", "8", "--den-states", "500", "--no-also", "--no-alt", "--no-parity", "--no-strong"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0
+    assert out["config"]["global_batch"] == 16
