@@ -318,13 +318,33 @@ class Job:
             sync()
         r0 = (C.c_longlong(), C.c_longlong())
         lib.tdnnf_planes_routed(C.byref(r0[0]), C.byref(r0[1]))
+        lead = getattr(self.args, "host_lead", False)
+        if lead:  # diagnostics: how far ahead of the GPU does the host return from step()?  (an event per step; read after the loop)
+            import torch
+            ev0 = torch.cuda.Event(enable_timing=True)
+            evs, ret = [torch.cuda.Event(enable_timing=True) for _ in range(steps)], []
+            ev0.record()
         t0 = time.perf_counter()
         for i in range(steps):
             if profile and i == event_steps:
                 self.pkg.hipabi.check(lib.tdnnf_profile_enable(0))  # (host side only: stops recording, nothing is synchronised)
             self.step()
+            if lead:
+                evs[i].record()
+                ret.append(time.perf_counter() - t0)
         sync()
         dt = time.perf_counter() - t0
+        if getattr(self.args, "phases", False):  # diagnostics: the LAST step's phases on the caller's stream (option phase_events)
+            ms, cnt = (C.c_double * 8)(), C.c_int()
+            self.pkg.hipabi.check(lib.tdnnf_net_phase_times(self.net.h, ms, 8, C.byref(cnt)))
+            names = ["fwd_trunk", "heads_fwd", "heads_bwd", "trunk_bwd", "join", "between", "update"]
+            self.phase_ms = {names[i]: round(ms[i], 3) for i in range(cnt.value)}
+            print("phases: " + json.dumps(self.phase_ms), file=sys.stderr)
+        if lead:
+            done = [ev0.elapsed_time(e) for e in evs]
+            self.host_lead_ms = {"gpu_done_minus_host_returned_ms": [round(d - 1e3 * r, 3) for d, r in zip(done, ret)],
+                                 "host_issue_ms_per_step": round(1e3 * ret[-1] / steps, 3), "gpu_ms_per_step": round(done[-1] / steps, 3)}
+            print("host lead: " + json.dumps(self.host_lead_ms), file=sys.stderr)
         r1 = (C.c_longlong(), C.c_longlong())
         lib.tdnnf_planes_routed(C.byref(r1[0]), C.byref(r1[1]))
         # GEMMs per step that really ran on the pre-split plane kernels (with the weight-gradient stream on -- minibatches of
@@ -406,6 +426,8 @@ def main():
                     help="1 (default, what the reference's recipes train with) = OnlineNaturalGradient preconditioning of every "
                          "updatable component's gradient; 0 = raw-gradient SGD step")
     ap.add_argument("--also-only", default=None, metavar="REGEX", help="run only the further line items whose description matches (diagnostics)")
+    ap.add_argument("--phases", action="store_true", help="diagnostics (stderr): the last timed step's time per phase on the caller's stream (sets option phase_events)")
+    ap.add_argument("--host-lead", action="store_true", help="diagnostics (stderr): per timed step, when the GPU finished it minus when the host returned from issuing it")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="a tuning option of the library (tdnnf_set_option: ng_grouped, ng_fuse, ng_early_in, wgrad_stream, gemm_ring, planes); "
                          "repeatable -- same-box A/B runs of two code paths")
@@ -455,6 +477,8 @@ def main():
         n_ranks_seen = int(one.item())
 
     lib = pkg.hipabi.load()  # raises if the HIP library is missing: there is no fallback path
+    if args.phases:
+        args.option = list(args.option) + ["phase_events=1"]
     for spec in args.option:
         name, _, value = spec.partition("=")
         pkg.hipabi.check(lib.tdnnf_set_option(name.encode(), int(value)))

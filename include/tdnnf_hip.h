@@ -612,6 +612,11 @@ int tdnnf_net_config_from_model(const char *path, int frames_per_chunk, int num_
    No GPU needed.  *needed (optional) receives the size including the terminating 0; out may be null with capacity 0 to
    query it. */
 int tdnnf_net_config_text(const tdnnf_net_config *cfg, char *out, size_t capacity, size_t *needed);
+/* diagnostics (tdnnf_set_option("phase_events", 1)): the last step's time between phase boundaries on the caller's stream, in ms:
+   [0] forward trunk, [1] heads forward + objective issue, [2] heads backward (incl. the wait for the denominator), [3] trunk backward,
+   [4] join of the side streams, [5] between forward_backward and update (collectives), [6] update.  *count = 7, or 0 when the option was
+   off.  Synchronises the last event. */
+int tdnnf_net_phase_times(tdnnf_net *, double *ms_out, int capacity, int *count);
 /* debugging / parity: on != 0 makes the following forward_backward calls keep copies of the backward pass's derivative
    matrices (which otherwise live in recycled scratch): "<layer>.noop.deriv" (w.r.t. the layer output), "<layer>.affine.deriv",
    "<layer>.linear.deriv" (w.r.t. those components' outputs), "prefinal-l.deriv", "prefinal-{chain,xent}.{batchnorm2,linear,

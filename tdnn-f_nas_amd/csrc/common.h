@@ -53,6 +53,9 @@ struct Options {
   int planes = 1;         // gemm_precision 2: the pre-split bf16-plane GEMMs where they apply (0: the in-kernel split everywhere)
   int den_mw_test_abort = 0;  // tests: raise the multi-workgroup denominator's abort word before its launch (the one-workgroup kernels must then redo the minibatch)
   int planes_check_bound = 0;  // tests: after every split that took its scale from a norm bound, measure the norm and count violations (tdnnf_planes_bound_checks)
+  int wgrad_lag = 3;      // trainer, weight-gradient stream on: the caller's stream runs 3 (default) or 1 component(s) ahead of the gradients (read by tdnnf_net_create)
+  int wgrad_on_caller = 0;  // trainer: the xent head's weight gradients on the caller's stream when the early statistics occupy the gradient stream
+  int phase_events = 0;   // diagnostics: the trainer records an event on the caller's stream at every phase boundary of a step (tdnnf_net_phase_times)
   int den_split = -1;     // trainer: the denominator's two recursions side by side (then the occupancies of all frames at once): -1 by minibatch size, 0 / 1
 };
 Options &options();

@@ -16,6 +16,7 @@ namespace tdnnf {
 
 struct NgGroup;
 struct NgFin;
+struct UpdGroup;
 
 struct Grid {
   int t0, step, n;
@@ -153,7 +154,9 @@ struct tdnnf_net {
   // GEMMs fill the chip by themselves (TDNNF_WGRAD_STREAM=0|1 forces it).
   bool wg_on;
   hipStream_t s4;
-  hipEvent_t ev_pg[2], ev_pg_in;
+  hipEvent_t ev_pg[4], ev_pg_in;
+  int wg_lag = 3;        // the caller's stream waits for the weight gradient of the component wg_lag back (option wgrad_lag: 1 or 3)
+  float *dC2 = nullptr, *dS[2] = {nullptr, nullptr};  // wg_lag 3: second buffers for the derivative matrices weight gradients read (net.hip)
   unsigned pg_count;
   void *ws4;
   void *ws2;           // the same for components whose weight gradients go to the denominator's stream (wg_two)
@@ -180,6 +183,11 @@ struct tdnnf_net {
   std::vector<char> oderiv_nonzero_own;
   std::vector<char> *oderiv_nonzero = &oderiv_nonzero_own;
   tdnnf::BnSync bn_sync{nullptr, nullptr, nullptr, 1};  // tdnnf_net_set_batchnorm_sync; buf lives in the arena
+  // diagnostics (option phase_events): events on the caller's stream at the phase boundaries of the last step
+  enum { kPhases = 8 };  // 0 start, 1 forward trunk done, 2 heads forward + xent objective issued, 3 heads' backward done, 4 trunk backward done, 5 side streams joined, 6 update start, 7 update done
+  hipEvent_t ev_phase[kPhases] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  bool phase_rec[kPhases] = {false, false, false, false, false, false, false, false};
+  tdnnf::UpdGroup *upd = nullptr;  // the optimizer step's grouped launches (optim_group.h): built at the first update for the parameter buffer in use
   bool den_split = true;  // the denominator's two recursions side by side (option den_split, read when the net's first step sizes the workspace)
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done

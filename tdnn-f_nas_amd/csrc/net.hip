@@ -25,6 +25,7 @@
 #include "gemm_ring.h"
 #include "net.h"
 #include "ng.h"
+#include "optim_group.h"
 
 namespace tdnnf {
 namespace {
@@ -36,13 +37,6 @@ struct UpdTable {
   float l2coef[128];
 };
 
-__global__ __launch_bounds__(256) void make_delta_kernel(float *grads, const float *params, UpdTable tb) {
-  const int c = blockIdx.y;
-  const long long b = tb.begin[c], e = tb.begin[c + 1];
-  const float lr = tb.lr[c], l2 = tb.l2coef[c];
-  for (long long i = b + blockIdx.x * 256LL + threadIdx.x; i < e; i += gridDim.x * 256LL)
-    grads[i] = lr * grads[i] + l2 * params[i];
-}
 // W_acc[o][i*Di + d] += coef[i] * G[o][i*Di + d]   (DARTS: fold the unscaled tap gradients into the accumulator)
 __global__ void add_scaled_taps_kernel(const float *G, const float *coef, float *acc, int Do, int KDi, int Di) {
   const long long total = (long long)Do * KDi;
@@ -384,6 +378,14 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->dC = A.mat(max_rows, Hd);
   n->d_small = A.mat(std::max(max_lin_rows, No), std::max(S, 512));
   n->d_small2 = A.mat(std::max(max_lin_rows, No), std::max(S, 512));
+  // weight gradients three components behind the caller's stream (wg_lag 3, net.h): a second buffer for the derivative the affine's
+  // gradient reads, two more for what the linear's reads -- layers alternate between them
+  n->wg_lag = options().wgrad_lag == 1 ? 1 : 3;
+  const bool wg_size = options().wgrad_stream >= 0 ? options().wgrad_stream != 0 : std::max(max_rows, N0) <= 32768;
+  const bool lag3 = wg_size && n->wg_lag == 3;
+  n->dC2 = lag3 ? A.mat(max_rows, Hd) : nullptr;
+  n->dS[0] = lag3 ? A.mat(std::max(max_lin_rows, No), std::max(S, 512)) : nullptr;
+  n->dS[1] = lag3 ? A.mat(std::max(max_lin_rows, No), std::max(S, 512)) : nullptr;
   size_t tg = 0;
   for (auto &L : n->layers)
     if (L.lin.darts) tg = std::max(tg, (size_t)L.bn * L.lin.K * Hd);
@@ -542,7 +544,10 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   n->ws_bytes = ws + 256;
   n->ws = A.take<char>(n->ws_bytes);
   n->wg_on = options().wgrad_stream >= 0 ? options().wgrad_stream != 0 : std::max(max_rows, N0) <= 32768;
-  n->early_on = n->cfg.use_natural_gradient && n->ng_grouped && options().ng_early_in != 0;
+  // (input-side statistics ahead of the backward pass: for minibatches whose GEMMs fill the chip.  With the weight-gradient streams three
+  // components behind the caller's stream the small minibatches lose by it -- 150 x 64 11.98 -> 11.25 ms, 1500 x 16 22.12 -> 21.60 on one box
+  // with it off: the statistics then run with their component's gradient instead of in front of the heads' gradients.  Option ng_early_in 2 forces it.)
+  n->early_on = n->cfg.use_natural_gradient && n->ng_grouped && (options().ng_early_in == 2 || (options().ng_early_in != 0 && !n->wg_on));
   const bool s4_used = n->wg_on || n->early_on;
   n->ws4 = s4_used ? A.take<char>(n->ws_bytes) : nullptr;
   n->s4_scratch_bytes = s4_used ? (32u << 20) : 0;
@@ -550,6 +555,15 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   const bool two = n->wg_on && options().wgrad_stream != 1;  // (option wgrad_stream: 1 = one weight-gradient stream as rounds 2-3, 2 = two, -1 = by size, two)
   n->ws2 = two ? A.take<char>(n->ws_bytes) : nullptr;
   n->s2_scratch = two ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
+}
+
+// diagnostics: phase boundary k of the step (option phase_events)
+static int phase_mark(tdnnf_net *n, int k, hipStream_t s) {
+  if (!tdnnf::options().phase_events) return TDNNF_OK;
+  if (!n->ev_phase[k]) TDNNF_HIP(hipEventCreate(&n->ev_phase[k]));
+  TDNNF_HIP(hipEventRecord(n->ev_phase[k], s));
+  n->phase_rec[k] = true;
+  return TDNNF_OK;
 }
 
 #define CK(expr)             \
@@ -902,7 +916,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   n->ev_s3 = nullptr;
   n->ev_fin0 = n->ev_fin = nullptr;
   n->s4 = nullptr;
-  n->ev_pg[0] = n->ev_pg[1] = n->ev_pg_in = nullptr;
+  n->ev_pg[0] = n->ev_pg[1] = n->ev_pg[2] = n->ev_pg[3] = n->ev_pg_in = nullptr;
   n->pg_count = 0;
   if (hipMalloc((void **)&n->arena, n->arena_bytes) != hipSuccess) {
     set_error("net_create: cannot allocate %zu bytes of activations", n->arena_bytes);
@@ -939,7 +953,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
     name(p + ".noop", L.noop_out, L.aff.rows_out, Hd);
   }
   if (!n->layers.empty() && !n->layers[0].perm)  // what the last backward step left: d objective / d tdnnf2.linear (debugging aid)
-    name("tdnnf2.linear.deriv", n->d_small, n->layers[0].lin.rows_out, n->layers[0].bn);
+    name("tdnnf2.linear.deriv", n->dS[0] ? n->dS[(c.num_layers - 1) & 1] : n->d_small, n->layers[0].lin.rows_out, n->layers[0].bn);
   name("prefinal-l", n->prefinal_l_out, n->Tout * B, S);
   name("prefinal-chain.relu", n->head[0].aff_relu, n->Tout * B, Hd);
   name("prefinal-xent.relu", n->head[1].aff_relu, n->Tout * B, Hd);
@@ -977,9 +991,12 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->ev_fin0) hipEventDestroy(n->ev_fin0);
   if (n->ev_fin) hipEventDestroy(n->ev_fin);
   if (n->s3) hipStreamDestroy(n->s3);
-  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg_in, n->ev_early_in, n->ev_early, n->ev_comm})
+  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg[2], n->ev_pg[3], n->ev_pg_in, n->ev_early_in, n->ev_early, n->ev_comm})
     if (e) hipEventDestroy(e);
   if (n->s4) hipStreamDestroy(n->s4);
+  for (hipEvent_t e : n->ev_phase)
+    if (e) hipEventDestroy(e);
+  upd_group_destroy(n->upd);
   delete n;
 }
 
@@ -1247,13 +1264,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (n->early_on && !n->wg_on) TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
     if (n->wg_on) {
       TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
-      TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[0], hipEventDisableTiming));
-      TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[1], hipEventDisableTiming));
+      for (int i = 0; i < 4; i++) TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[i], hipEventDisableTiming));
       TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg_in, hipEventDisableTiming));
     }
     TDNNF_HIP(hipEventCreateWithFlags(&n->ev_ngc, hipEventDisableTiming));
   }
   n->fb_count++;
+  CK(phase_mark(n, 0, s));
   n->wg_two = false;  // (a step that failed half-way may have left it set)
   TDNNF_HIP(hipMemsetAsync(n->gtmp, 0, sizeof(float) * (size_t)n->num_params, s));
   if (n->ng_bsum_all && n->ng_bsum_floats) TDNNF_HIP(hipMemsetAsync(n->ng_bsum_all, 0, sizeof(float) * n->ng_bsum_floats, s));  // every component's raw bias gradient
@@ -1533,6 +1550,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     else TDNNF_HIP(bn_apply_bypass(view(&x), L.bn_memo, Hd, ldpad(Hd), view(&byp), c.bypass_scale, view(&out), s, mask_of(layer_no), B));
     prev = L.noop_out;
   }
+  CK(phase_mark(n, 1, s));
   const int No = n->Tout * B;
   tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
   if (po_next.base == top.data && po_next.rows == top.rows) po_top = po_next;
@@ -1600,6 +1618,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   CK(chain_num_xent(den, sup, &y, &lsm, c.xent_regularize, &dx, n->chain_ws, s, dense_first));
   if (!dense_first) CK(tdnnf_log_softmax_backprop(&lsm, &dx, &dx, s));  // in place into d_xent
 
+  CK(phase_mark(n, 2, s));
   // ================================================================= backward
   // BatchNorm backward + ReLU backward (+ StoreStats / self-repair coin flips as in the reference:
   // RectifiedLinearComponent::StoreStats nnet-simple-component.cc:1084, RepairGradients :1017) in two fused
@@ -1668,6 +1687,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     return TDNNF_OK;
   };
   const bool use_ng = c.use_natural_gradient != 0;
+  // Weight gradients up to three components behind the caller's stream (option wgrad_lag, default 3; 1 = rounds 2-4: one behind).  A
+  // buffer that component k's gradient reads may be rewritten once the caller's stream has waited for k, i.e. from the hand-off of
+  // component k + 3 on: the derivative matrices those gradients read alternate between two buffers per role (layout_arena).
+  const bool lag3 = n->wg_on && n->wg_lag == 3 && n->dC2 != nullptr;
+  const int Ltop = c.num_layers - 1;
+  auto dC_of = [&](int l) -> float * { return !lag3 ? n->dC : (((Ltop - l) & 1) ? n->dC2 : n->dC); };      // d affine-out of tdnnf layer l
+  auto dS_of = [&](int l) -> float * { return !lag3 ? nullptr : n->dS[(Ltop - l) & 1]; };                  // what layer l's .linear gradient reads
   // A bucket of the flat gradient buffer is final once the last of its components (in backward order) has been enqueued:
   // grads[range] += this minibatch's gradient (unless the objective failed), then the bucket's event.  With natural gradient
   // the components' commits run on the side stream, so the bucket's commit follows them there.
@@ -1679,8 +1705,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       if (gb.close_key != key) continue;
       hipStream_t cs = s;
       if (!use_ng && n->wg_on && n->pg_count > 0) {  // the components' gradients were formed on s4 (and s2)
-        TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
-        if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[n->pg_count & 1], 0));
+        TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 3], 0));
+        if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 2) & 3], 0));
       }
       if (use_ng) {
         TDNNF_HIP(hipEventRecord(gb.handoff, s));  // s-side writes of the range (bias sums, architecture parameters) are done
@@ -1706,6 +1732,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (!use_ng) return Bg(n, comp);
     return n->ngc[comp].bsum;  // (zeroed with all the others at the start of the step)
   };
+  bool den_joined = false;   // the caller's stream has waited for the denominator
+  bool caller_used = false;  // some component of the open bucket formed its gradient on the caller's stream although wg_on
   auto param_grad = [&](int comp, const tdnnf_tdnn_indexes &ix, int K, int Di, int Do, tdnnf_mat *x, tdnnf_mat *dyv, const float *eff,
                         bool bias_done, const int *active, int max_active, bool from_tapgrad) -> int {
     const int ldw = K * Di;
@@ -1717,20 +1745,27 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // Small minibatches: the weight-gradient side (gradient GEMM + slab reduce + the natural-gradient passes of the component) is the longer
     // chain of the two -- 216 us per component against 145 on the caller's stream at 150 x 64 -- and the caller may only run one component
     // ahead of it.  From the denominator's join on its stream is idle: components alternate between the two (event parity = stream parity).
+    // (option wgrad_on_caller: the xent head's components -- before the denominator's join, with the input-side statistics of the whole net
+    // queued on s4 in front of them -- form their gradients on the caller's stream, which waits for the denominator anyway)
+    const bool on_caller = n->wg_on && options().wgrad_on_caller != 0 && n->early_any && !den_joined;
+    if (on_caller) caller_used = true;
     const bool on_s2 = n->wg_on && n->wg_two && (n->pg_count & 1);
-    if (n->wg_on) {
+    if (n->wg_on && !on_caller) {
       sw = on_s2 ? n->s2 : n->s4;
       wsw = on_s2 ? n->ws2 : n->ws4;
       TDNNF_HIP(hipEventRecord(n->ev_pg_in, s));
       TDNNF_HIP(hipStreamWaitEvent(sw, n->ev_pg_in, 0));
     }
-    SplitKScratchOverride sw_scratch(n->wg_on ? (on_s2 ? n->s2_scratch : n->s4_scratch) : nullptr, n->wg_on ? n->s4_scratch_bytes : 0);
+    SplitKScratchOverride sw_scratch(n->wg_on && !on_caller ? (on_s2 ? n->s2_scratch : n->s4_scratch) : nullptr, n->wg_on && !on_caller ? n->s4_scratch_bytes : 0);
     // after this component is enqueued the caller's stream may only run ahead of it, not of the one before: what that one reads
     // (derivative scratch, the bias sums) is rewritten from here on
     auto handed_off = [&]() -> int {
-      if (!n->wg_on) return TDNNF_OK;
-      TDNNF_HIP(hipEventRecord(n->ev_pg[n->pg_count & 1], sw));
-      if (n->pg_count > 0) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
+      if (!n->wg_on || on_caller) return TDNNF_OK;
+      // (a ring of four events; wg_lag 1: the caller's stream waits for the component before this one, 3: for the one three back --
+      // every component is waited for exactly once either way, so "waited for k" means every component up to k has finished)
+      TDNNF_HIP(hipEventRecord(n->ev_pg[n->pg_count & 3], sw));
+      const unsigned lag = lag3 ? 3u : 1u;
+      if (n->pg_count >= lag) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - lag) & 3], 0));
       n->pg_count++;
       return TDNNF_OK;
     };
@@ -1785,7 +1820,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (grouped) {  // the rest comes with the bucket (ng_close)
       n->ng_cur.push_back(comp);
       CK(handed_off());
-      if (from_tapgrad && n->wg_on) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
+      if (from_tapgrad && n->wg_on) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 3], 0));
       return TDNNF_OK;
     }
     // ---- per-object chain (first minibatch): the R x R work, the projections of the raw gradient and the commit, on the side stream
@@ -1801,7 +1836,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
                        ng_scale_dev(n->ng_out[comp]), Wg(n, comp), bias_acc);
     CK(handed_off());
     // (the unscaled tap gradients this one reads are rebuilt by the next DARTS component on the caller's stream)
-    if (from_tapgrad && n->wg_on) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));
+    if (from_tapgrad && n->wg_on) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 3], 0));
     return TDNNF_OK;
   };
   // Natural gradient, grouped: the chains of the components enqueued since the last bucket closed, as one sequence of grouped
@@ -1835,8 +1870,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_REQUIRE(nb->comps == n->ng_cur, "net_forward_backward: the components of gradient bucket %d changed between minibatches", key);
     // behind the last component's passes (on the weight-gradient stream when that is on)
     if (n->wg_on && n->pg_count > 0) {
-      TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - 1) & 1], 0));
-      if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[n->pg_count & 1], 0));  // (the other stream's last component)
+      TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - 1) & 3], 0));
+      if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - 2) & 3], 0));  // (the other stream's last component)
+      if (caller_used) {
+        TDNNF_HIP(hipEventRecord(n->ev_ngc, s));
+        TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_ngc, 0));
+        caller_used = false;
+      }
     } else {
       TDNNF_HIP(hipEventRecord(n->ev_ngc, s));
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_ngc, 0));
@@ -1907,12 +1947,15 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (h == 0) {
       // objective, part 3: join the denominator stream, d_y += posteriors, objf / failure handling
       TDNNF_HIP(hipStreamWaitEvent(s, n->ev_den, 0));
+      den_joined = true;
       n->wg_two = n->wg_on && n->ws2 != nullptr;  // the denominator's stream is idle from here on
       CK(chain_finish(den, sup, &y, c.chain_l2_regularize, results, &dy, nullptr, n->chain_ws, s));
     }
     tdnnf_mat dout = h == 0 ? dy : dx;
     tdnnf_mat b2 = M(H.bn2_out, No, S), b1 = M(H.bn1_out, No, Hd);
-    tdnnf_mat d_b2 = M(n->d_small2, No, S), d_b1 = M(n->dA, No, Hd);
+    // (lag3: head h = 1 takes the buffers of the top layer (Ltop), h = 0 those of the layer below: free again by the time those layers write them)
+    float *d_b1_buf = !lag3 ? n->dA : dC_of(h == 1 ? Ltop : Ltop - 1), *d_b2_buf = !lag3 ? n->d_small2 : n->dS[h == 1 ? 0 : 1];
+    tdnnf_mat d_b2 = M(d_b2_buf, No, S), d_b1 = M(d_b1_buf, No, Hd);
     const std::string hname = h == 0 ? "prefinal-chain" : "prefinal-xent";
     if (h == 1) CK(capture("output-xent.deriv", dout));
     PlanesOperand po_d;  // the derivative matrix being propagated: planes where a GEMM reads it
@@ -1942,7 +1985,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     FroBound fb_d;
     {
       FroBoundScope fbs(pl_on ? n->fro_buf : nullptr, &fb_d.blocks);
-      CK(bn_relu_backward(H.aff_relu, n->dA, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h, nullptr, &po_d));  // dA -> d affine out
+      CK(bn_relu_backward(H.aff_relu, d_b1_buf, No, H.bn1_memo, H.relu_stats, bias_target(H.c_affine), H.c_affine, c.num_layers + 1 + h, nullptr, &po_d));  // in place -> d affine out
     }
     CK(capture(hname + ".affine.deriv", d_b1));
     if (!po_d.base || po_d.base != d_b1.data) CK(split(d_b1, 0, kP | kT, &po_d, s, fb_d));
@@ -1955,7 +1998,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
       if (early_after_xent) CK(launch_early_in());
     } else {
-      tdnnf_mat tmp = M(n->d_small2, No, S);
+      tdnnf_mat tmp = M(!lag3 ? n->d_small2 : n->dS[0], No, S);  // (lag3: the xent head's d_b2 buffer -- its reader, three components back, has been waited for)
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &tmp, s));
       CK(tdnnf_add_scaled(&tmp, 1.0f, &d_pl, s));
     }
@@ -1968,6 +2011,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(param_grad(n->c_prefinal_l, ix1, 1, Hd, S, &top, &d_pl, nullptr, false, nullptr, 0, false));
   }
   CK(close_bucket(-2));
+  CK(phase_mark(n, 3, s));
   float *d_cur = n->dA, *d_next = n->dB;  // d_cur: deriv w.r.t. the current layer's output (noop)
   {
     tdnnf_mat d_top = M(d_cur, No, Hd);
@@ -1979,7 +2023,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     float *in_act = l > 0 ? n->layers[l - 1].noop_out : n->t1_bn;
     const int no = L.aff.rows_out, nl = L.lin.rows_out, ni = N_of(L.gin, B);
     // d_cur is needed again for the bypass term, so the derivative w.r.t. the affine output goes to dC
-    tdnnf_mat d_out = M(d_cur, no, Hd), d_aff = M(n->dC, no, Hd);
+    tdnnf_mat d_out = M(d_cur, no, Hd), d_aff = M(dC_of(l), no, Hd);
     const std::string lname = "tdnnf" + std::to_string(l + 2);
     TraceRange trace_layer(("backward " + lname).c_str());
     CK(capture(lname + ".noop.deriv", d_out));
@@ -2043,11 +2087,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       CK(tdnn_wgrad(L.aff, &aff_in, &d_aff, aff_eff, true));
     }
     PlanesHintScope ph_aff_bp(hint_of(po_daff), wplanes(L.aff.comp));  // (for the backward-data GEMM of the affine, either branch below)
-    tdnnf_mat d_lin = M(n->d_small, nl, L.bn);
+    // (lag3: the matrix the .linear's gradient reads lives in this layer's dS buffer; with rho > 1 that is the un-permuted copy)
+    // (and the permuted matrix is formed in d_small2: d_small still holds prefinal-l's output derivative, which its gradient may be reading)
+    tdnnf_mat d_lin = M(lag3 ? (L.perm ? n->d_small2 : dS_of(l)) : n->d_small, nl, L.bn);
     if (L.perm) {  // rho > 1: some row classes receive no tap -> zero first, then add; un-permute afterwards
       TDNNF_HIP(hipMemsetAsync(d_lin.data, 0, sizeof(float) * (size_t)nl * d_lin.stride, s));
       CK(tdnnf_tdnn_backprop_data(&L.aff.ix, &d_aff, Wp(n, L.aff.comp), L.aff.K * L.bn, Hd, L.bn, aff_eff, &d_lin, s));
-      tdnnf_mat un = M(n->d_small2, nl, L.bn);
+      tdnnf_mat un = M(lag3 ? dS_of(l) : n->d_small2, nl, L.bn);
       CK(tdnnf_reorder_rows(&d_lin, B, L.aff.ix.row_stride, 0, &un, s));
       d_lin = un;
     } else {
@@ -2098,14 +2144,31 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     CK(param_grad(n->tdnn1.comp, ix1, 1, lda_dim, Hd, &lda_out, &d_aff, nullptr, true, nullptr, 0, false));
   }
   CK(close_bucket(-1));
-  if (n->wg_on && n->pg_count > 0) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 1], 0));  // join the weight-gradient stream
-  if (n->wg_on && n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[n->pg_count & 1], 0));  // (and the second one)
+  CK(phase_mark(n, 4, s));
+  if (n->wg_on && n->pg_count > 0) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 3], 0));  // join the weight-gradient stream
+  if (n->wg_on && n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 2) & 3], 0));  // (and the second one)
   n->wg_two = false;
   if (use_ng) {  // join the side stream: every bucket has been committed into grads
     TDNNF_HIP(hipEventRecord(n->ev_s3, n->s3));
     TDNNF_HIP(hipStreamWaitEvent(s, n->ev_s3, 0));
   }
+  CK(phase_mark(n, 5, s));
   TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
+int tdnnf_net_phase_times(tdnnf_net *n, double *ms_out, int capacity, int *count) {
+  TDNNF_REQUIRE(n && ms_out && count && capacity >= tdnnf_net::kPhases - 1, "net_phase_times: bad arguments (capacity >= 7)");
+  *count = 0;
+  for (int k = 0; k < tdnnf_net::kPhases; k++)
+    if (!n->phase_rec[k]) return TDNNF_OK;  // (option phase_events was off for the last step)
+  TDNNF_HIP(hipEventSynchronize(n->ev_phase[tdnnf_net::kPhases - 1]));
+  for (int k = 0; k + 1 < tdnnf_net::kPhases; k++) {
+    float ms = 0.f;
+    TDNNF_HIP(hipEventElapsedTime(&ms, n->ev_phase[k], n->ev_phase[k + 1]));
+    ms_out[k] = ms;
+  }
+  *count = tdnnf_net::kPhases - 1;
   return TDNNF_OK;
 }
 
@@ -2114,6 +2177,7 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
   TDNNF_REQUIRE(lr >= 0.f && l2_scale >= 0.f, "net_update: learning rate and l2 scale must be >= 0 (nnet-utils.cc:2240)");
   TraceRange trace_update("tdnnf_net_update");
   hipStream_t s = (hipStream_t)stream;
+  CK(phase_mark(n, 6, s));
   const int nc = (int)n->comps.size();
   UpdTable tb;
   memset(&tb, 0, sizeof(tb));
@@ -2128,10 +2192,19 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
     mc[i] = c.max_change;
   }
   begin[nc] = tb.begin[nc] = n->num_params;
-  // component i owns [begin[i], begin[i+1]) including alignment padding (padding stays zero)
-  hipLaunchKernelGGL(make_delta_kernel, dim3(32, nc), dim3(256), 0, s, n->grads, n->params, tb);
-  CK(tdnnf_update_with_max_change(n->params, n->grads, nc, begin.data(), mc.data(), n->cfg.max_param_change, 1.0f, 1.0f, 1,
-                                  n->ws, n->ws_bytes, nullptr, s));
+  // component i owns [begin[i], begin[i+1]) including alignment padding (padding stays zero).  delta = lr g + l2 theta, max-change and the
+  // update as two launches over all components (optim_group.hip)
+  if (!n->upd || upd_group_params(n->upd) != n->params) {
+    upd_group_destroy(n->upd);
+    n->upd = nullptr;
+    std::vector<UpdComp> uc(nc);
+    for (int i = 0; i < nc; i++) {
+      const CompDesc &c = n->comps[i];
+      uc[i] = UpdComp{begin[i], begin[i + 1], c.rows, c.cols, c.orthonormal};
+    }
+    CK(upd_group_create(uc, n->params, &n->upd));
+  }
+  CK(upd_group_step(n->upd, n->params, n->grads, tb.lr, tb.l2coef, mc.data(), n->cfg.max_param_change, s));
   // ScaleBatchnormStats
   if (n->cfg.batchnorm_stats_scale != 1.0f && !n->cfg.cv_update) {  // (BatchNormTestComponents are not scaled)
     const int Hd = n->cfg.hidden_dim, S = n->cfg.prefinal_small_dim;
@@ -2155,12 +2228,16 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
     TDNNF_REQUIRE(nb == (int)n->layers.size() + 5, "net_update: too many BatchNorm components for one launch");
     hipLaunchKernelGGL(scale_doubles_kernel, dim3((maxn + 255) / 256, nb), dim3(256), 0, s, tb, (double)n->cfg.batchnorm_stats_scale);
   }
-  // ConstrainOrthonormal: each constrained component with probability 1/4 (nnet-utils.cc:1062)
+  // ConstrainOrthonormal: each constrained component with probability 1/4 (nnet-utils.cc:1062); the ones chosen this minibatch run
+  // together as grouped launches (tall matrices -- none in the recipes' graphs -- keep the per-component path on the transpose)
+  std::vector<int> chosen;
   for (int i = 0; i < nc; i++) {
     const CompDesc &c = n->comps[i];
     if (c.orthonormal == 0.f) continue;
     if (::tdnnf::tdnnf_decision((unsigned long long)step, 2 * (unsigned long long)i + 1) % 4 != 0) continue;  // RandInt(0,3) != 0
-    if (c.rows <= c.cols) {
+    if (upd_group_can_ortho(n->upd, i)) {
+      chosen.push_back(i);
+    } else if (c.rows <= c.cols) {
       CK(tdnnf_constrain_orthonormal(c.orthonormal, n->params + c.begin, c.rows, c.cols, c.cols, n->ws, n->ws_bytes, s));
     } else {  // tall matrix: constrain the transpose (nnet-utils.cc:1068-1075)
       TDNNF_REQUIRE(n->orthoT, "net_update: no transpose buffer for %s", c.name.c_str());
@@ -2170,6 +2247,8 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
       hipLaunchKernelGGL(transpose_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, n->orthoT, c.cols, c.rows, n->params + c.begin);
     }
   }
+  if (!chosen.empty()) CK(upd_group_ortho(n->upd, chosen, s));
+  CK(phase_mark(n, 7, s));
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
 }
