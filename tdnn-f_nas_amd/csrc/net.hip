@@ -2193,7 +2193,7 @@ int tdnnf_net_update(tdnnf_net *n, float lr, float l2_scale, long long step, tdn
   }
   begin[nc] = tb.begin[nc] = n->num_params;
   // component i owns [begin[i], begin[i+1]) including alignment padding (padding stays zero).  delta = lr g + l2 theta, max-change and the
-  // update as two launches over all components (optim_group.hip)
+  // update as three launches over all components (optim_group.hip)
   if (!n->upd || upd_group_params(n->upd) != n->params) {
     upd_group_destroy(n->upd);
     n->upd = nullptr;

@@ -18,7 +18,7 @@ int upd_group_create(const std::vector<UpdComp> &comps, float *params, UpdGroup 
 void upd_group_destroy(UpdGroup *g);
 const float *upd_group_params(const UpdGroup *g);
 // delta = lr_c * grads + l2coef_c * params (written into grads), per-component and global max-change (UpdateNnetWithMaxChange with
-// scale = max_change_scale = 1), params += factor_c * delta, grads = 0: two launches.
+// scale = max_change_scale = 1), params += factor_c * delta, grads = 0: three launches.
 int upd_group_step(UpdGroup *g, float *params, float *grads, const float *lr, const float *l2coef, const float *max_change, float max_param_change,
                    hipStream_t s);
 // ConstrainOrthonormalInternal for the selected components (indices into `comps`; each must be constrained and have rows <= cols),

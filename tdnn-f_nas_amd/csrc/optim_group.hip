@@ -5,10 +5,10 @@
 // one chain of small launches per call; in the trainer that was 4 launches for the update plus 6 per constrained component selected
 // this minibatch (each with probability 1/4: four on average, eight in a bad step) -- 0.65 ms of a 12.4 ms step at the recipes'
 // minibatch (chunk 150 x 64), strictly serial at the end of the step where nothing else can run.  Here:
-//   1  upd_delta_dot_kernel   delta = lr g + l2 theta into the gradient buffer, its squared norm per 4096-element item; the LAST block
-//                             to finish (a counter) adds the items per component in order and forms the max-change factors
-//   2  upd_apply_kernel       theta += f_c delta, gradient buffer back to zero
-//   3..7 the selected components' orthonormal steps TOGETHER: P = M M^T as split-K tile tasks + their reduction (ggemm.h), the
+//   1  upd_delta_dot_kernel   delta = lr g + l2 theta into the gradient buffer, its squared norm per 4096-element item
+//   2  upd_factors_kernel     the items per component in order, the max-change factors (one block)
+//   3  upd_apply_kernel       theta += f_c delta, gradient buffer back to zero
+//   4..8 the selected components' orthonormal steps TOGETHER: P = M M^T as split-K tile tasks + their reduction (ggemm.h), the
 //        scalars of every P (and P <- -4 nu / s^2 (P - s^2 I)), U = P M as tile tasks, M += U.
 // Every sum has a fixed order: results do not depend on scheduling.
 #include <string.h>
@@ -32,11 +32,8 @@ struct UpdTable {
   float max_param_change;
 };
 
-__global__ __launch_bounds__(256) void upd_delta_dot_kernel(float *grads, const float *params, const UpdItem *items, UpdTable tb, double *partial, unsigned *counter,
-                                                            float *factors) {
+__global__ __launch_bounds__(256) void upd_delta_dot_kernel(float *grads, const float *params, const UpdItem *items, UpdTable tb, double *partial) {
   __shared__ double red[4];
-  __shared__ double dots[128];
-  __shared__ int last;
   const UpdItem it = items[blockIdx.x];
   const float lr = tb.lr[it.comp], l2 = tb.l2coef[it.comp];
   const int t = threadIdx.x;
@@ -58,15 +55,15 @@ __global__ __launch_bounds__(256) void upd_delta_dot_kernel(float *grads, const 
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if ((t & 63) == 0) red[t >> 6] = s;
   __syncthreads();
-  if (t == 0) {
-    partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    __threadfence();  // the partial is visible device-wide before the counter moves
-    last = atomicAdd(counter, 1u) == (unsigned)tb.nitems - 1u;
-  }
-  __syncthreads();
-  if (!last) return;
-  __threadfence();
-  // the last block: per-component sums in item order, then UpdateNnetWithMaxChange :2095-2172 (scale = max_change_scale = 1)
+  if (t == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// One block: per-component sums of the item partials in item order, then UpdateNnetWithMaxChange :2095-2172 (scale = max_change_scale = 1).
+// (A launch of its own: folded into the kernel above as "the last block to finish does it", every block pays an agent-scope release
+// fence behind 16 KB of stores -- the launch took 330 us instead of 30.)
+__global__ __launch_bounds__(256) void upd_factors_kernel(const double *partial, UpdTable tb, float *factors) {
+  __shared__ double dots[128];
+  const int t = threadIdx.x;
   for (int c = t; c < tb.nc; c += 256) {
     double d = 0;
     for (int i = tb.item0[c]; i < tb.item0[c + 1]; i++) d += partial[i];
@@ -90,7 +87,6 @@ __global__ __launch_bounds__(256) void upd_delta_dot_kernel(float *grads, const 
   }
   for (int i = 0; i < tb.nc; i++) factors[i] = ok != 0.f ? factors[i] * scale : 0.f;
   factors[tb.nc] = ok;
-  *counter = 0u;  // ready for the next minibatch
 }
 
 __global__ __launch_bounds__(256) void upd_apply_kernel(float *params, float *delta, const UpdItem *items, const float *factors) {
@@ -129,13 +125,13 @@ struct OrthoSel {
 };
 // one block per selected component: tr(P), tr(P P^T), the floating scale and the update speed (nnet-utils.cc:938-986), then
 // P <- -4 nu / s^2 (P - s^2 I)   (:987, :1019-1030: M += -4 nu / s^2 (P - s^2 I) M)
-__global__ __launch_bounds__(256) void ortho_scalars_group_kernel(const OrthoDesc *descs, OrthoSel sel) {
-  __shared__ double red[2][4];
+__global__ __launch_bounds__(1024) void ortho_scalars_group_kernel(const OrthoDesc *descs, OrthoSel sel) {
+  __shared__ double red[2][16];
   __shared__ float coef_s, scale2_s;
   const OrthoDesc &d = descs[sel.comp[blockIdx.x]];
   const int rows = d.rows, n = rows * rows;
   double tr = 0, trpp = 0;
-  for (int e = threadIdx.x; e < n; e += 256) {
+  for (int e = threadIdx.x; e < n; e += 1024) {
     const double v = d.P[e];
     trpp += v * v;
     if (e / rows == e % rows) tr += v;
@@ -150,8 +146,11 @@ __global__ __launch_bounds__(256) void ortho_scalars_group_kernel(const OrthoDes
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    tr = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-    trpp = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    tr = trpp = 0;
+    for (int w = 0; w < 16; w++) {
+      tr += red[0][w];
+      trpp += red[1][w];
+    }
     float update_speed = 0.125f, scale = d.scale_in;
     if (d.scale_in < 0.f) {
       scale = sqrtf((float)(trpp / tr));
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(256) void ortho_scalars_group_kernel(const OrthoDes
   }
   __syncthreads();
   const float coef = coef_s, s2 = scale2_s;
-  for (int e = threadIdx.x; e < n; e += 256) {
+  for (int e = threadIdx.x; e < n; e += 1024) {
     float v = d.P[e];
     if (e / rows == e % rows) v -= s2;
     d.P[e] = coef * v;
@@ -340,7 +339,8 @@ int upd_group_step(UpdGroup *g, float *params, float *grads, const float *lr, co
     tb.max_change[c] = max_change[c];
   }
   tb.max_param_change = max_param_change;
-  hipLaunchKernelGGL(upd_delta_dot_kernel, dim3(tb.nitems), dim3(256), 0, s, grads, params, g->items, tb, g->partial, g->counter, g->factors);
+  hipLaunchKernelGGL(upd_delta_dot_kernel, dim3(tb.nitems), dim3(256), 0, s, grads, params, g->items, tb, g->partial);
+  hipLaunchKernelGGL(upd_factors_kernel, dim3(1), dim3(256), 0, s, g->partial, tb, g->factors);
   hipLaunchKernelGGL(upd_apply_kernel, dim3(tb.nitems), dim3(256), 0, s, params, grads, g->items, g->factors);
   TDNNF_LAUNCH_CHECK();
   return TDNNF_OK;
@@ -368,7 +368,7 @@ int upd_group_ortho(UpdGroup *g, const std::vector<int> &selected, hipStream_t s
     }
     if (pt.start[n]) hipLaunchKernelGGL(ggemm_sel_kernel, dim3(pt.start[n]), dim3(256), 0, s, g->pl.tasks, pt);
     if (pr.start[n]) hipLaunchKernelGGL(ggemm_reduce_sel_kernel, dim3(pr.start[n]), dim3(256), 0, s, g->pl.rtasks, pr);
-    hipLaunchKernelGGL(ortho_scalars_group_kernel, dim3(n), dim3(256), 0, s, g->descs, os);
+    hipLaunchKernelGGL(ortho_scalars_group_kernel, dim3(n), dim3(1024), 0, s, g->descs, os);
     hipLaunchKernelGGL(ggemm_sel_kernel, dim3(ut.start[n]), dim3(256), 0, s, g->ul.tasks, ut);
     hipLaunchKernelGGL(ortho_add_group_kernel, dim3(os.add_start[n]), dim3(256), 0, s, g->descs, os);
   }

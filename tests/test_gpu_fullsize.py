@@ -41,14 +41,14 @@ FULL = [
     # with the masks agreed, the gradient is 7-9e-5 from the float64-accumulating oracle (tools/fullsize_diag.py prec=1) -- the
     # 0.3-1.1e-3 measured on the toy nets of test_gpu_net.py was mask flips, not arithmetic
     ("7q-bf16x3", dict(gemm_precision=1)),
-    ("7q-NG-bf16x3", dict(gemm_precision=1, use_natural_gradient=1)),
     ("bn-supernet-320-onehot-NG-bf16x3", dict(bn_choice_dims=[80, 80, 80, 80], bn_mode=0, use_natural_gradient=1, gemm_precision=1)),
     # the pre-split plane kernels (planes_gemm.hip) at full width, on the one-stream schedule they need ("planes": see the test): two scaled
     # f16 planes / three products and three bf16 planes / six products, both f32-equivalent -> the exact-f32 bars
     ("7q-f16x3-planes", dict(gemm_precision=3, planes=1)),
     ("7q-NG-f16x3-planes", dict(gemm_precision=3, use_natural_gradient=1, planes=1)),
     ("manual-offset6-NG-f16x3-planes", dict(strides=[1, 1, 1, 0] + [6] * 10, use_natural_gradient=1, gemm_precision=3, planes=1)),
-    ("7q-NG-bf16x6-planes", dict(gemm_precision=2, use_natural_gradient=1, planes=1)),
+    # (bf16x6 on planes -- six bytes per operand element, slower than exact f32 in the step, DESIGN.md 4b -- keeps its case on the small net:
+    # test_gpu_net.py "7q-shape-small-NG-bf16x6-planes"; and split-bf16 with natural gradient the bottleneck-supernet case above)
 ]
 
 
@@ -74,7 +74,9 @@ def component_slice(c):
 def test_full_width_net_step_matches_oracle(pkg, name, kw):
     kw = dict(kw)
     planes = kw.pop("planes", 0)
-    cfg = pkg.trainer.make_config(frames_per_chunk=150, num_sequences=8, **kw)
+    # the two reference-arithmetic 7q cases at 8 sequences; the variants at 4 (the CPU oracle is most of this test's time, and the suite has
+    # 900 s on the driver's box: VERDICT r4 housekeeping)
+    cfg = pkg.trainer.make_config(frames_per_chunk=150, num_sequences=8 if name in ("7q", "7q-NG") else 4, **kw)
     assert cfg.hidden_dim == 1536 and cfg.num_pdfs == 6034 and cfg.num_layers == 14
     with pkg.hipabi.option("wgrad_stream", 0 if planes else -1):  # (read by tdnnf_net_create)
         net = pkg.trainer.ChainNet(cfg)
