@@ -55,6 +55,8 @@ struct Options {
   int planes_check_bound = 0;  // tests: after every split that took its scale from a norm bound, measure the norm and count violations (tdnnf_planes_bound_checks)
   int wgrad_lag = 3;      // trainer, weight-gradient stream on: the caller's stream runs 3 (default) or 1 component(s) ahead of the gradients (read by tdnnf_net_create)
   int wgrad_on_caller = 0;  // trainer: the xent head's weight gradients on the caller's stream when the early statistics occupy the gradient stream
+  int splitk_partial_round = 1;  // rows GEMM: split K when the tiles fill only part of one round of resident blocks (gemm_f32.hip launch_rows_balanced)
+  int ng_bk = 0;          // natural-gradient statistics passes H = X W^T: 1 = K steps of 64 (rank <= 32) / 32 (rank <= 96) instead of 32 / 16
   int phase_events = 0;   // diagnostics: the trainer records an event on the caller's stream at every phase boundary of a step (tdnnf_net_phase_times)
   int den_split = -1;     // trainer: the denominator's two recursions side by side (then the occupancies of all frames at once): -1 by minibatch size, 0 / 1
 };

@@ -1034,6 +1034,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const RowsGemmArgs p
   }
 }
 
+inline int device_cus() {  // compute units of the current device (cached per device)
+  static int cus_of[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (cus_of[dev] == 0) {
+    hipDeviceProp_t prop;
+    cus_of[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    (void)hipGetLastError();
+  }
+  return cus_of[dev];
+}
+template <int WM, int WN, int TM, int TN, int BK>
+int rows_slots_per_cu(int prec) {
+  int per_cu = (WM * TM == 4 && WN * TN == 4 && BK == 16 && prec == 0) ? 3 : 2;
+  if (prec == 3 && WN * TN == 5) per_cu = 1;
+  if (WM * TM == 2 && prec == 0) per_cu = 4;  // 64-row tiles (27 KiB of LDS, 32 accumulator registers)
+  return per_cu;
+}
 template <int WM, int WN, int TM, int TN, int BK>
 int rows_slots(bool b_kc, int prec) {  // resident blocks on the chip for this tile variant
   // Blocks per CU are MEASURED (tools/residency_probe.py: time of a plain launch steps up when one more tile needs one
@@ -1052,10 +1070,7 @@ int rows_slots(bool b_kc, int prec) {  // resident blocks on the chip for this t
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     (void)hipGetLastError();
   }
-  int per_cu = (WM * TM == 4 && WN * TN == 4 && BK == 16 && prec == 0) ? 3 : 2;
-  if (prec == 3 && WN * TN == 5) per_cu = 1;
-  if (WM * TM == 2 && prec == 0) per_cu = 4;  // 64-row tiles (27 KiB of LDS, 32 accumulator registers)
-  return per_cu * cus;
+  return rows_slots_per_cu<WM, WN, TM, TN, BK>(prec) * cus;
 }
 
 // scratch for split-K partial tiles: allocated once, on first use (64 MiB covers slots x BM x BN floats)
@@ -1103,9 +1118,26 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   // A handful of tiles with a long reduction (the R x D products of the natural-gradient state, P = M M^T of the
   // orthonormal constraint): one block per tile would crawl through K at load latency on a few CUs, so split K
   // over the idle ones.
-  if (!stats && tiles * 4 <= slots && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
+  // (and a launch of more than slots / 4 but fewer than `slots` tiles -- one partly filled round: 188 row tiles of the 1500 x 16 shard's
+  // full-rate .linear layers leave 68 of 256 CUs idle for the whole launch -- splits K by the factor S that fills whole rounds of CUs
+  // best, ceil(tiles S / CUs) / S smallest: 188 tiles -> S = 4, 752 quarter tiles = 2.94 rounds of 256 instead of 4 quarters on 188 CUs)
+  int S_partial = 0;
+  if (!stats && q == 0 && tiles * 4 > slots && k4 && options().splitk_partial_round) {
+    const int cus = device_cus();
     const long long kt = (ktot + BK - 1) / BK;
-    int S = slots / tiles;
+    double best = (double)((tiles + cus - 1) / cus);  // S = 1
+    for (int S = 2; S <= 8; S++) {
+      if (kt / S < 24) break;  // at least 24 K steps per slice
+      const double cost = (double)(((long long)tiles * S + cus - 1) / cus) / S + 0.02 * S;  // (+ the partial tiles' round trip)
+      if (cost < best - 1e-9) {
+        best = cost;
+        S_partial = S;
+      }
+    }
+  }
+  if (!stats && (tiles * 4 <= slots || S_partial >= 2) && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
+    const long long kt = (ktot + BK - 1) / BK;
+    int S = S_partial >= 2 ? S_partial : slots / tiles;
     if (S > kt / 4) S = (int)(kt / 4);
     const size_t need = sizeof(float) * (size_t)S * a.M * ((a.N + 3) & ~3);
     if (S >= 2 && need <= scratch_bytes) {
@@ -1434,15 +1466,16 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     if (a.N > 128) return hipErrorInvalidValue;
     a.sumsq_cap = rows_gemm_sumsq_blocks(a.M);
     ProfScope ps(0, flops, s);
-    if (a.N <= 32) return launch_rows_sumsq<4, 1, 1, 1, 32>(a, b_kc, vec, s);
-    if (a.N <= 96) return launch_rows_sumsq<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
+    // (option ng_bk: 1 = K steps twice as long for these HBM-bound passes -- twice the bytes in flight per resident block)
+    if (a.N <= 32) return options().ng_bk ? launch_rows_sumsq<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    if (a.N <= 96) return options().ng_bk ? launch_rows_sumsq<4, 1, 1, 3, 32>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
     return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);
   }
   // skinny outputs (the natural-gradient projections X W^T, rank <= 32): a 128x32 tile wastes no MFMA columns and
   // keeps three blocks per CU resident to pull the A operand at HBM rate
   if (a.N <= 32 && a.M >= 1024) {
     ProfScope ps(0, flops, s);
-    return launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    return options().ng_bk ? launch_rows<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
   }
   if (waste160 < waste128) return launch_rows_balanced<4, 1, 1, 5, 16>(a, b_kc, vec, 1, flops, s);
   {
