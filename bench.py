@@ -37,7 +37,62 @@ sys.path.insert(0, ROOT)
 MFMA_F32_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 HBM_PEAK_GBS = 8000.0
 BF16_PEAK_TFLOPS = 2500.0       # the same guide: dense bf16 MFMA peak (not the 2:1-sparsity figure)
-TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")  # tools/make_profiles.py: separate rocprofv3 --pmc passes of this command
+# tools/make_profiles.py: separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this command with THIS round's kernels; the f16x3 step has its own
+TRAFFIC_FILE = os.path.join("profiles", "r05_pmc_traffic.json")
+TRAFFIC_FILE_F16X3 = os.path.join("profiles", "r05_f16x3_pmc_traffic.json")
+L2_GATHER_PEAK_GBS = 16800.0    # /opt/skills/guides/MI355X_MICROARCH.md, gather table: rows shared by every workgroup served by the XCDs' L2, 16.8-18.8 TB/s
+
+
+def load_traffic(path):
+    """The committed PMC summary (per kernel class: HBM bytes per launch = (2 FETCH_SIZE + WRITE_SIZE) KB, the guide's gfx950 correction;
+    per HBM-bound pass under "hbm_pass:<name>": bytes per pass over all its kernels), or {} when the file is missing."""
+    full = os.path.join(ROOT, path)
+    try:
+        return json.load(open(full)) if os.path.exists(full) else {}
+    except Exception:
+        return {}
+
+
+def hbm_entries(hbm_classes, event_steps, chunk, traffic, traffic_file):
+    """roofline_hbm: the HBM-bound passes of the step, each timed live with HIP events on its launch stream.  achieved = algorithmic bytes /
+    event time against the 8 TB/s peak; traffic = the measured PMC bytes per pass from the committed profile of this command.  The denominator is
+    NOT an HBM pass: its arcs are gathered from L2 -- its entry carries the gather rate against the guide's L2 figure and, separately, the HBM
+    bytes the PMC passes count against 8 TB/s; no fraction of an HBM peak is formed from L2 bytes."""
+    what = {"bn_apply_bypass": "BatchNorm apply + dropout mask + Sum(Scale(0.66, bypass), .): reads x [and the bypass rows], writes the layer output [and, "
+                               "--gemm f16x3, its f16 planes]",
+            "bn_relu_bwd": "BatchNorm backward + ReLU backward + self-repair + ReLU statistics + bias column sums, two stages: (x, dz) read twice, d_aff written",
+            "planes_split": "operand split into 16-bit planes (--gemm f16x3 / bf16x6): the matrix read once, each plane layout written once"}
+    out = []
+    for hc in hbm_classes:
+        if hc["ms"] <= 0:
+            continue
+        sec = hc["ms"] * 1e-3
+        tr = traffic.get("hbm_pass:" + hc["name"], {}).get("hbm_bytes_per_pass")
+        per_pass_ms = hc["ms"] / max(hc["launches"], 1)
+        if hc["name"] == "denominator":
+            gbs = hc["bytes"] / sec / 1e9
+            ent = {"bound": "l2", "kernel": "denominator",
+                   "what": "chain denominator forward-backward, both recursions and the occupancies (fork .. join): per (frame, sequence) the arcs once per "
+                           "recursion (8 B forward, 16 B backward) gathered from L2 (the graph's three sliced tables, 1.2 MB, stay there), the output row read "
+                           "twice, the derivative row written; bound by the dependent gathers of a frame, not by bandwidth",
+                   "achieved": round(gbs, 1), "peak": L2_GATHER_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / L2_GATHER_PEAK_GBS, 4),
+                   "peak_source": "MI355X_MICROARCH.md gather table: rows shared by every workgroup (the XCD's L2) 16.8-18.8 TB/s",
+                   "launches": int(hc["launches"]), "ms_per_step": round(hc["ms"] / event_steps, 3),
+                   "gather_bytes_per_step": round(hc["bytes"] / event_steps, 1),
+                   "us_per_frame_step": round(1e3 * per_pass_ms / (chunk // 3), 2),
+                   "hbm": {"traffic": tr, "traffic_source": traffic_file if tr else None,
+                           "achieved": round(tr / (per_pass_ms * 1e-3) / 1e9, 1) if tr else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": round(tr / (per_pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
+                           "what": "HBM bytes of the pass (PMC: 2 FETCH_SIZE + WRITE_SIZE over its kernels) / event time of the pass"}}
+        else:
+            gbs = hc["bytes"] / sec / 1e9
+            ent = {"bound": "hbm", "kernel": hc["name"], "what": what.get(hc["name"], ""), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": int(hc["launches"]), "ms_per_step": round(hc["ms"] / event_steps, 3),
+                   "algorithmic_bytes_per_step": round(hc["bytes"] / event_steps, 1), "traffic": tr, "traffic_source": traffic_file if tr else None,
+                   "traffic_over_algorithmic": round(tr / (hc["bytes"] / max(hc["launches"], 1)), 3) if tr and hc["bytes"] else None}
+        out.append(ent)
+    return out
+
 
 # parity bars of BASELINE.json's north_star: objective 1e-4 relative, parameter-gradient L2 1e-3; with natural gradient the
 # first step also held to 1e-3 (measured 1e-5 once ReLU ties are agreed; later steps feed the eigen-decompositions back)
@@ -543,16 +598,11 @@ def main():
     achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
     # HBM traffic per launch from the PMC passes of THIS command (tools/make_profiles.py writes the file; null when the
     # file is not from this round's kernels)
-    traffic, traffic_src = None, None
-    tpath = os.path.join(ROOT, TRAFFIC_FILE)
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
-            traffic_src = ("committed PMC profile of this command (%s: separate rocprofv3 --pmc passes, FETCH_SIZE / WRITE_SIZE as the MI355X "
-                           "guide prescribes), NOT counters of this process" % TRAFFIC_FILE)
-        except Exception:
-            traffic = None
+    tfile = TRAFFIC_FILE_F16X3 if args.gemm == "f16x3" else TRAFFIC_FILE
+    tj = load_traffic(tfile) if args.workload == "7q" and args.chunk == 1500 and args.minibatch == 128 else {}
+    traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
+    traffic_src = ("committed PMC profile of this command with this round's kernels (%s: separate rocprofv3 --pmc passes, FETCH_SIZE / WRITE_SIZE as the MI355X "
+                   "guide prescribes, 2 FETCH + WRITE), NOT counters of this process" % tfile) if traffic else None
     alg_per_launch = dom["bytes"] / max(dom["launches"], 1)
     job.event_steps_ = getattr(job, "event_steps", 1)
     ngc = classes[3]
@@ -603,29 +653,11 @@ def main():
             out["roofline_secondary"] = {"bound": "hbm", "kernel": ngc["name"], "what": "natural-gradient statistics passes (H = X W^T either side, J = H^T X on a "
                                          "refresh, the rank-R products): algorithmic bytes / HIP-event time of the class", "achieved": round(gbs, 1),
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "tflops": round(ngc["flops"] / (ngc["ms"] * 1e-3) / 1e12, 2),
-                                         "launches": int(ngc["launches"]), "ms_per_step": round(ngc["ms"] / job.event_steps_, 3), "traffic": None}
+                                         "launches": int(ngc["launches"]), "ms_per_step": round(ngc["ms"] / job.event_steps_, 3),
+                                         "traffic": tj.get(ngc["name"], {}).get("hbm_bytes_per_launch"), "algorithmic_bytes": round(ngc["bytes"] / max(ngc["launches"], 1), 1)}
 
-        # "fraction of HBM roofline on elementwise / denominator work" -- the HBM-bound passes of the step, each timed live
-        # with HIP events on its launch stream over the same event steps: algorithmic bytes (every element the pass must touch, once per
-        # stage) / event time against the 8 TB/s peak; the measured PMC traffic of the same kernels is in profiles/ (make_profiles.py)
-        what = {"bn_apply_bypass": "BatchNorm apply + dropout mask + Sum(Scale(0.66, bypass), .): reads x [and the bypass rows], writes the layer output [and, "
-                                   "--gemm f16x3, its f16 planes]",
-                "bn_relu_bwd": "BatchNorm backward + ReLU backward + self-repair + ReLU statistics + bias column sums, two stages: (x, dz) read twice, d_aff written",
-                "denominator": "chain denominator forward-backward, both recursions (fork .. join): per (frame, sequence) the arcs once per recursion "
-                               "(8 B forward, 16 B backward), the output row read twice, the derivative row written; L2 gather + latency bound, not HBM",
-                "planes_split": "operand split into 16-bit planes (--gemm f16x3 / bf16x6): the matrix read once, each plane layout written once"}
-        out["roofline_hbm"] = []
-        for hc in hbm_classes:
-            if hc["ms"] <= 0:
-                continue
-            gbs = hc["bytes"] / (hc["ms"] * 1e-3) / 1e9
-            ent = {"bound": "hbm", "kernel": hc["name"], "what": what.get(hc["name"], ""), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                   "frac": round(gbs / HBM_PEAK_GBS, 4), "launches": int(hc["launches"]), "ms_per_step": round(hc["ms"] / job.event_steps_, 3),
-                   "algorithmic_bytes_per_step": round(hc["bytes"] / job.event_steps_, 1), "traffic": None}
-            if hc["name"] == "denominator":
-                ent["us_per_frame_step"] = round(1e3 * hc["ms"] / max(hc["launches"], 1) / (args.chunk // 3), 2)
-                ent["note"] = "one persistent workgroup per sequence walks the frames of both recursions (128 CUs at 128 sequences) beside the xent head on another stream"
-            out["roofline_hbm"].append(ent)
+        # "fraction of HBM roofline on elementwise / denominator work" (hbm_entries above)
+        out["roofline_hbm"] = hbm_entries(hbm_classes, job.event_steps_, args.chunk, tj, tfile)
 
         if strong is not None:
             out["strong"] = strong
@@ -674,6 +706,7 @@ def main():
             # algorithm is three f16 MFMA multiply-adds here (h h' + h l' + l h'), so the matrix cores do 3 x the algorithmic FLOPs; both rates are
             # given, the fraction is of the DENSE 16-bit peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s for bf16 and f16 alike)
             cl = [c for c in it.get("_classes", [])[:3] if c["ms"] > 0]
+            tj16 = load_traffic(TRAFFIC_FILE_F16X3) if args.workload == "7q" and args.chunk == 1500 and args.minibatch == 128 else {}
             if cl:
                 dm = max(cl, key=lambda c: c["ms"])
                 eq = dm["flops"] / (dm["ms"] * 1e-3) / 1e12
@@ -681,16 +714,15 @@ def main():
                       "rows_gemm_f32_128x160": "planes_gemm_f16x3 (160-column tiles)", "wgrad_f32": "planes_gemm_f16x3 (weight gradients, split-K)"}
                 out["alt"]["roofline"] = {"bound": "mfma", "kernel": nm.get(dm["name"], dm["name"]), "achieved": round(3.0 * eq, 2), "peak": BF16_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": round(3.0 * eq / BF16_PEAK_TFLOPS, 4), "f32_equivalent_tflops": round(eq, 2),
-                                          "f16_mfma_flops_per_algorithmic_flop": 3, "traffic": None, "event_steps": it.get("_event_steps"),
+                                          "f16_mfma_flops_per_algorithmic_flop": 3, "traffic": tj16.get(dm["name"], {}).get("hbm_bytes_per_launch"),
+                                          "traffic_source": TRAFFIC_FILE_F16X3 if tj16.get(dm["name"]) else None,
+                                          "algorithmic_bytes": round(dm["bytes"] / max(dm["launches"], 1), 1), "event_steps": it.get("_event_steps"),
                                           "all_kernels": [{"kernel": nm.get(c["name"], c["name"]), "launches": int(c["launches"]), "ms": round(c["ms"], 3),
                                                            "f32_equivalent_tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2),
                                                            "frac_of_16bit_peak": round(3.0 * c["flops"] / (c["ms"] * 1e-3) / 1e12 / BF16_PEAK_TFLOPS, 4)} for c in cl],
                                           "note": "event classes as in the headline's roofline (the class names are the f32 kernels'): forward / backward-data GEMMs by "
                                                   "output width, weight gradients; the plane splits (HBM passes, class planes_split) are not in these times but in ms_per_step"}
-                out["alt"]["roofline_hbm"] = [{"bound": "hbm", "kernel": hc["name"], "achieved": round(hc["bytes"] / (hc["ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                               "frac": round(hc["bytes"] / (hc["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches": int(hc["launches"]),
-                                               "ms_per_step": round(hc["ms"] / max(it.get("_event_steps") or 1, 1), 3), "traffic": None}
-                                              for hc in it.get("_hbm_classes", []) if hc["ms"] > 0]
+                out["alt"]["roofline_hbm"] = hbm_entries(it.get("_hbm_classes", []), max(it.get("_event_steps") or 1, 1), args.chunk, tj16, TRAFFIC_FILE_F16X3)
         if world == 1 and not args.no_also:
             # further line items, same net and step: the reference's own egs shape (chunk 150 x 64, ...pretrain.sh:46,197) and
             # SWBD-scale denominator graphs (10 000 and 30 000 states)

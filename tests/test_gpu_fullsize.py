@@ -122,9 +122,11 @@ def test_full_width_net_step_matches_oracle(pkg, name, kw):
         assert abs(r[6] - res_ref["xent_objf"]) < 1e-4 * abs(res_ref["xent_objf"])
         g = host(net.grads)
         assert np.isfinite(g).all()
-        # with the ReLU ties agreed the gradients are 1e-5 .. 2e-4 apart on step 0; after a natural-gradient update the
-        # preconditioners' eigen-decompositions feed differences back (5e-3 on the toy nets)
-        gtol = 1e-3 if (step == 0 or not ng) else 5e-3
+        # BASELINE's bar for both steps, with natural gradient too: with the ReLU ties agreed the gradients are 3e-6 .. 4e-5 from the oracle
+        # (exact f32, f16x3), 0.7e-4 .. 2.6e-4 with 16 operand bits (bf16x3) -- measured, round 5 (gpurun_out/r5_parity_values.txt); rounds
+        # 2-4 allowed 5e-3 after the first natural-gradient update without having measured it
+        gtol = 1e-3
+        print("PARITY test_gpu_fullsize %s step %d gradient %.3e (bar %.0e) objective %.2e ties %d" % (name, step, rel_l2(g, g_ref), gtol, abs(r[0] - res_ref["objf"]) / abs(res_ref["objf"]), ties))
         assert rel_l2(g, g_ref) < gtol, rel_l2(g, g_ref)
         for c in net.components[1:]:
             sl = component_slice(c)
@@ -133,7 +135,8 @@ def test_full_width_net_step_matches_oracle(pkg, name, kw):
         p_ref = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
         net.update(1e-3, step=step)
         p = host(net.params)
-        assert rel_l2(p - params, p_ref - params) < (1e-2 if ng else 2e-3), rel_l2(p - params, p_ref - params)
+        print("PARITY test_gpu_fullsize %s step %d update %.3e" % (name, step, rel_l2(p - params, p_ref - params)))
+        assert rel_l2(p - params, p_ref - params) < (5e-3 if x3 else 2e-3), rel_l2(p - params, p_ref - params)
         params = p_ref
         net.set_params(params)
     net.close()
@@ -342,7 +345,10 @@ def test_bench_shape_supernets_on_the_f16_plane_kernels(pkg, bench_egs, name):
     """The supernets at the bench shape with gemm_precision 3 (f16x3): the DARTS components' tap coefficients are folded into their weight
     planes and zero taps skipped in the kernels, the bottleneck supernet's affine reads the planes of the masked blocks.  Against the
     exact-f32 step from the same parameters and draws: the objective to 1e-4, the components between the loss and the first ReLU backward
-    (no derivative mask involved) to the 1e-3 bar, the architecture parameters' gradient to 2e-2 (tie noise of 3e8 ReLU elements)."""
+    (no derivative mask involved) to the 1e-3 bar, the whole gradient to 3e-2: two HIP runs cannot agree their ReLU masks as the oracle tests
+    do (tests/oracle_net.py takes tied masks over from the run it checks), so the whole-gradient figure here is the tie noise of 3e8 ReLU
+    elements, not an arithmetic bound -- the arithmetic is bounded by the mask-free components above and by the full-width oracle cases
+    of test_full_width_net_step_matches_oracle (f16x3: 7e-6 .. 3e-5 with the ties agreed)."""
     kw = dict(SUPERNETS[name], use_natural_gradient=1)
     stats = None
     if kw.get("cv_update"):

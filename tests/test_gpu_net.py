@@ -181,12 +181,18 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
         assert abs(r[0] - res_ref["objf"]) < 1e-4 * abs(res_ref["objf"]), (r[0], res_ref["objf"])
         assert abs(r[6] - res_ref["xent_objf"]) < 1e-4 * abs(res_ref["xent_objf"])
         g = host(net.grads)
-        # natural gradient: the low-rank state is refreshed from an eigen-decomposition -> small differences feed back
-        # split-bf16 GEMMs: measured 0.3e-3 .. 1.1e-3 on these cases, i.e. AT the BASELINE bar of 1e-3, not safely inside it --
-        # which is why gemm_precision 1 is an option and exact f32 the default; the test holds it to 2e-3
-        gtol = 5e-3 if cfg.use_natural_gradient else (2e-3 if x3 else 1e-3)
-        if cfg.use_natural_gradient and x3:
-            gtol = 3e-2  # the preconditioners' eigen-decomposition (initialised from this very minibatch) amplifies the 1e-5 input differences
+        # BASELINE's bar: parameter-gradient L2 within 1e-3 -- held with natural gradient on too, on the initialising minibatch (the
+        # preconditioners start from this very minibatch's statistics, three self-iterations of the eigen-decomposition) and on the next one:
+        # measured 2e-6 .. 5e-5 over every exact-f32 / f16x3 / bf16x6 case of this file (round 5, gpurun_out/r5_parity_values.txt; rounds
+        # 2-4 asked 5e-3 here without having measured it).
+        # Split-bf16 (gemm_precision 1, 16 operand bits, NOT the default arithmetic): forward values carry ~1e-4, measured gradient
+        # 0.7e-4 .. 1.8e-3 without natural gradient (bar 2e-3); with it the eigen-decomposition of the second minibatch's refresh sees
+        # statistics that differ by that 1e-4 and the step-1 gradient is 1.5e-2 from the oracle (step 0: 7e-5) -- the one bar above 1e-3
+        # in this file, kept for that arithmetic only and stated here: 3e-2.
+        gtol = 2e-3 if x3 else 1e-3
+        if cfg.use_natural_gradient and x3 and step > 0:
+            gtol = 3e-2
+        print("PARITY test_gpu_net %s step %d gradient %.3e (bar %.0e) objective %.2e" % (name, step, rel_l2(g, g_ref), gtol, abs(r[0] - res_ref["objf"]) / abs(res_ref["objf"])))
         assert rel_l2(g, g_ref) < gtol, (rel_l2(g, g_ref), "ReLU ties in layers %s: choose other inputs for this case" % ties if ties else "")
         for c in net.components[1:]:
             sl = slice(c["begin"], c["begin"] + c["rows"] * c["cols"] + c["num_alpha"] + (c["rows"] if c["has_bias"] else 0))
@@ -198,7 +204,8 @@ def test_net_step_matches_oracle(pkg, name, kw, H):
         p_ref = ref.update(params, g_ref, 1e-3, float(cfg.num_sequences), step)
         net.update(1e-3, step=step)
         p = host(net.params)
-        assert rel_l2(p - params, p_ref - params) < (6e-2 if cfg.use_natural_gradient and x3 else 1e-2 if cfg.use_natural_gradient or x3 else 2e-3), rel_l2(p - params, p_ref - params)
+        print("PARITY test_gpu_net %s step %d update %.3e" % (name, step, rel_l2(p - params, p_ref - params)))
+        assert rel_l2(p - params, p_ref - params) < (6e-2 if cfg.use_natural_gradient and x3 else 1e-2 if x3 else 2e-3), rel_l2(p - params, p_ref - params)
         assert not host(net.grads).any()
         params = p_ref
         net.set_params(params)

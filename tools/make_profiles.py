@@ -85,6 +85,31 @@ for k, t in traffic.items():
         out[k] = dict(launches=t["launches"], fetch_size_kb_per_launch=t["fetch_kb"] / t["launches"],
                       write_size_kb_per_launch=t["write_kb"] / t["launches"],
                       hbm_bytes_per_launch=(2 * t["fetch_kb"] + t["write_kb"]) * 1024 / t["launches"])
+# the HBM-bound passes bench.py times as one range each (roofline_hbm): bytes per pass = the bytes of ALL the pass's kernels in the
+# profiled run / the launches of its primary kernel (one per pass)
+PASSES = {"bn_apply_bypass": (("bn_apply_bypass_kernel",), "bn_apply_bypass_kernel"),
+          "bn_relu_bwd": (("bn_relu_bwd_reduce_kernel", "bn_relu_bwd_finalize_kernel", "bn_relu_bwd_apply_kernel", "bn_relu_bwd_apply_ng_kernel", "colsum_add_kernel"),
+                          "bn_relu_bwd_finalize_kernel"),
+          "denominator": (("den_forward_kernel", "den_beta_kernel", "den_gamma_kernel", "den_backward_kernel", "den_mw_kernel", "den_mw_check_kernel", "den_wide"),
+                          "den_gamma_kernel|den_backward_kernel"),
+          "planes_split": (("planes_split_kernel", "planes_sumsq", "planes_scale_kernel", "planes_pad_kernel"), "planes_split_kernel")}
+raw = collections.defaultdict(lambda: dict(launches=0, fetch_kb=0.0, write_kb=0.0))
+for r in load(pmc_prefix + "_fetch"):
+    t = raw[short(r["Kernel_Name"])]
+    t["launches"] += 1
+    t["fetch_kb"] += float(r["Counter_Value"])
+for r in load(pmc_prefix + "_write"):
+    raw[short(r["Kernel_Name"])]["write_kb"] += float(r["Counter_Value"])
+for name, (members, primary) in PASSES.items():
+    tot_b, nprim, used = 0.0, 0, []
+    for k, t in raw.items():
+        if k.startswith(members):
+            tot_b += (2 * t["fetch_kb"] + t["write_kb"]) * 1024
+            used.append(k)
+        if any(k.startswith(p) for p in primary.split("|")):
+            nprim += t["launches"]
+    if nprim and tot_b:
+        out["hbm_pass:" + name] = dict(hbm_bytes_per_pass=tot_b / nprim, passes=nprim, kernels=sorted(used))
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1, sort_keys=True)
 # the bench line of the profiled run (its per-class FLOPs and algorithmic bytes per step come from the launch shapes inside the
 # library), the per-stream busy / alone times and the dispatch count per step
