@@ -297,6 +297,9 @@ int tdnnf_chain_objf_and_deriv(const tdnnf_den_graph *, const tdnnf_supervision 
  * src/nnet3/nnet-tdnn-component.cc:598-599, nnet-simple-component.cc:3001-3002). */
 int tdnnf_ng_create(int rank, int update_period, float num_samples_history, float alpha, tdnnf_ng **out);
 void tdnnf_ng_destroy(tdnnf_ng *);
+/* OnlineNaturalGradient::Freeze (UpdatableComponent::FreezeNaturalGradient, nnet-tdnn-component.cc:979-982): freeze != 0 keeps the
+   current low-rank state (no refresh steps) */
+int tdnnf_ng_freeze(tdnnf_ng *, int freeze);
 /* X is modified in place; *scale_host (may be NULL) receives the scalar, which costs a stream synchronisation.
    The R x R eigen-problem of a refresh step is solved on a host worker thread and W_{t+1} is installed at the
    next call on the same object, so a call with scale_host == NULL never blocks.  rank <= 128. */
@@ -313,6 +316,9 @@ int tdnnf_constrain_orthonormal(float scale, float *M_dev, int rows, int cols, i
                                 size_t workspace_bytes, tdnnf_stream);
 /* ApplyL2Regularization :2223-2245 : delta += scale * params */
 int tdnnf_axpy(const float *x_dev, float a, float *y_dev, size_t n, tdnnf_stream);
+/* UpdatableComponent::DotProduct (nnet-tdnn-component.cc:949-958): <x, y> accumulated in double, result on the HOST -- synchronises the
+   stream (model averaging / diagnostics, not the training step) */
+int tdnnf_dot(const float *x_dev, const float *y_dev, size_t n, double *result_host, tdnnf_stream);
 /* UpdateNnetWithMaxChange :2085-2175 on a flat parameter vector partitioned into num_comp components
    (comp_begin_host[num_comp+1] element offsets).  params += factor_i * delta_i with the per-component and
    global max-change factors computed ON DEVICE (no D2H of the dot products).  delta is zeroed afterwards

@@ -292,8 +292,9 @@ struct Parsed {  // what one component block contributed
   int rows = 0, cols = 0;
   double count = 0;
   std::vector<int> offsets;
+  std::vector<int> flops;  // <Flops> of FlopsConstraintComponent (an integer vector, nnet-simple-component.cc:9436-9437)
   bool have_stats = false;
-  std::map<std::string, double> num;  // every scalar token of the block (bools as 0 / 1; pairs keep the first value)
+  std::map<std::string, double> num;  // every scalar token of the block (bools as 0 / 1; the second value of a pair under "<Token>#2")
 };
 
 // Reads the tokens of one component after its opening tag up to and including the closing tag.  `kinds` says how the
@@ -311,7 +312,7 @@ inline bool read_block(In &in, const std::string &type, Parsed *p) {
       {"<NumDimsSelfRepaired>", 'f'}, {"<NumDimsProcessed>", 'f'}, {"<SelfRepairLowerThreshold>", 'f'},
       {"<SelfRepairUpperThreshold>", 'f'}, {"<SelfRepairScale>", 'f'}, {"<TimePeriod>", 'i'}, {"<DropoutProportion>", 'f'},
       {"<Continuous>", '-'}, {"<SpecAugmentMaxProportion>", 'f'}, {"<SpecAugmentMaxRegions>", 'i'}, {"<BackpropScale>", 'f'},
-      {"<InputDim>", 'i'}, {"<OutputDim>", 'i'}, {"<Output>", 'v'}, {"<IsUpdatable>", 'b'}, {"<Scale>", 'f'}, {"<TempProportion>", 'f'}};
+      {"<InputDim>", 'i'}, {"<OutputDim>", 'i'}, {"<Output>", 'v'}, {"<IsUpdatable>", 'b'}, {"<Scale>", 'f'}, {"<TempProportion>", 'f'}, {"<Flops>", 'F'}};
   const std::string closing = "</" + type + ">";
   p->type = type;
   // BatchNorm and GeneralDropout write "<TestMode>" differently: a bool value in the former, a bare flag in the latter
@@ -320,6 +321,7 @@ inline bool read_block(In &in, const std::string &type, Parsed *p) {
     std::string t;
     if (!in.token(&t)) return false;
     if (t == closing) return true;
+    if (t == "<" + type + ">") continue;  // the opening tag, when the caller has not consumed it (ExpectOneOrTwoTokens)
     auto it = kinds.find(t);
     if (it == kinds.end()) return in.fail("component " + type + ": unknown token " + t);
     char kind = it->second;
@@ -330,6 +332,7 @@ inline bool read_block(In &in, const std::string &type, Parsed *p) {
     std::vector<float> v;
     switch (kind) {
       case '-':
+        p->num[t] = 1.0;  // a bare flag: present
         break;
       case 'i':
         if (!in.i32(&i)) return false;
@@ -338,6 +341,7 @@ inline bool read_block(In &in, const std::string &type, Parsed *p) {
       case 'J':
         if (!in.i32(&i) || !in.i32(&i2)) return false;
         p->num[t] = i;
+        p->num[t + "#2"] = i2;
         break;
       case 'f':
         if (!in.real(&f)) return false;
@@ -347,6 +351,7 @@ inline bool read_block(In &in, const std::string &type, Parsed *p) {
       case '2':
         if (!in.real(&f) || !in.real(&f2)) return false;
         p->num[t] = f;
+        p->num[t + "#2"] = f2;
         break;
       case 'b':
         if (!in.boolean(&b)) return false;
@@ -354,6 +359,9 @@ inline bool read_block(In &in, const std::string &type, Parsed *p) {
         break;
       case 'I':
         if (!in.intvec(&p->offsets)) return false;
+        break;
+      case 'F':
+        if (!in.intvec(&p->flops)) return false;
         break;
       case 'm':
         if (!in.mat(&p->W, &p->rows, &p->cols)) return false;

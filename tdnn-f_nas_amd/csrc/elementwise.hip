@@ -719,6 +719,15 @@ __global__ void alpha_update_kernel(double *dots, int nslab, const float *coef, 
   for (int i = 0; i < K; i++) acc[i] *= mul;
 }
 
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float *x, const float *y, size_t n, double *partial) {
+  __shared__ double red[4];
+  double s = 0;
+  for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256ull) s += (double)x[i] * (double)y[i];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
 __global__ void axpy_kernel(const float *x, float a, float *y, size_t n) {
   for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) y[i] += a * x[i];
 }
@@ -1123,6 +1132,28 @@ int tdnnf_tdnn_darts_alpha_update(const float *tap_grad, int ldg, const float *W
   }
   hipLaunchKernelGGL(alpha_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tap_dots, tap_grad ? nslab : 0, coef_memo, K, flags, share_index, temp, lr, alpha_acc);
   TDNNF_LAUNCH_CHECK();
+  return TDNNF_OK;
+}
+
+// UpdatableComponent::DotProduct (e.g. /root/reference/src/nnet3/nnet-tdnn-component.cc:949-958: TraceMatMat + VecVec): <x, y> in double
+// over two device vectors; the result goes to the host, so the call synchronises the stream (model combination / diagnostics, not the
+// training step).  Two stages, fixed order: 256 block partials, then the host adds them.
+int tdnnf_dot(const float *x, const float *y, size_t n, double *result_host, tdnnf_stream stream) {
+  TDNNF_REQUIRE(result_host && (n == 0 || (x && y)), "dot: null pointer");
+  *result_host = 0.0;
+  if (n == 0) return TDNNF_OK;
+  constexpr int kBlocks = 256;
+  double *partial = nullptr;
+  TDNNF_HIP(hipMalloc((void **)&partial, sizeof(double) * kBlocks));
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(kBlocks), dim3(256), 0, (hipStream_t)stream, x, y, n, partial);
+  double host[kBlocks];
+  hipError_t e = hipMemcpyAsync(host, partial, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(partial);
+  TDNNF_HIP(e);
+  double acc = 0;
+  for (int i = 0; i < kBlocks; i++) acc += host[i];
+  *result_host = acc;
   return TDNNF_OK;
 }
 

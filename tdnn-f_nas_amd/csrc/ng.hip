@@ -651,6 +651,14 @@ int tdnnf_ng_create(int rank, int update_period, float num_samples_history, floa
   return TDNNF_OK;
 }
 
+// OnlineNaturalGradient::Freeze (UPSTREAM; called by FreezeNaturalGradient, /root/reference/src/nnet3/nnet-tdnn-component.cc:979-982):
+// a frozen object keeps preconditioning with its current state and never refreshes it
+int tdnnf_ng_freeze(tdnnf_ng *ng, int freeze) {
+  TDNNF_REQUIRE(ng, "ng_freeze: null object");
+  ng->frozen = freeze ? 1 : 0;
+  return TDNNF_OK;
+}
+
 void tdnnf_ng_destroy(tdnnf_ng *ng) {
   if (!ng) return;
   if (ng->pending) pool().wait(ng);  // the worker still reads this object's pinned buffers

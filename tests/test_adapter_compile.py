@@ -118,3 +118,68 @@ def test_component_classes_register_under_the_factory_names(tmp_path, pkg):
     assert int(props["GumbelSoftmaxComponent"]) == k["bp_in_place"] | k["simple"] | k["needs_in"] | k["needs_out"] | k["random"]
     assert int(props["GeneralDropoutComponent"]) == k["random"] | k["prop_in_place"] | k["bp_in_place"] | k["memo"]
     assert len(props) == 20
+
+
+def test_surface_driver_compiles_and_the_host_side_pieces_work(tmp_path, pkg):
+    """The whole virtual surface of the Component classes (tests/surface_driver.cc, run by the -m gpu adapter test) compiles and links without a
+    GPU; and the pieces that need none -- ConfigLine, the Kaldi stream encodings, the Tdnn index bookkeeping -- run here with g++."""
+    hipcc = "/opt/rocm/bin/hipcc"
+    lib_dir = os.path.dirname(pkg.hipabi.LIB_PATH)
+    if os.path.exists(hipcc):
+        subprocess.check_call([hipcc, "-std=c++17", "-O0", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "surface_driver.cc"),
+                               "-L", lib_dir, "-ltdnnf_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(tmp_path / "surface_driver")])
+    src = tmp_path / "host_check.cc"
+    src.write_text(textwrap.dedent('''
+        #include <cstdio>
+        #include <sstream>
+        #include "tdnnf_nnet3_components.h"
+        namespace n3 = tdnnf_nnet3;
+        #define REQ(c) do { if (!(c)) { std::printf("FAILED %d: %s\\n", __LINE__, #c); return 1; } } while (0)
+        int main() {
+          // ConfigLine: the line generate_config.py writes for a searched layer (tests/golden/r01_configs_golden.json)
+          n3::ConfigLine cfl;
+          REQ(cfl.ParseLine("component name=tdnnf2.linear type=TdnnDARTSV3Component input-dim=1536 output-dim=160 l2-regularize=0.01 use-bias=true "
+                            "Temp-Proportion=1.0 time-offsets=-6,-5,-4,-3,-2,-1,0 orthonormal-constraint=-1.0"));
+          REQ(cfl.FirstToken() == "component");
+          int d = 0; float f = 0; bool b = false; std::string s;
+          REQ(cfl.GetValue("input-dim", &d) && d == 1536);
+          REQ(cfl.GetValue("orthonormal-constraint", &f) && f == -1.0f);
+          REQ(cfl.GetValue("use-bias", &b) && b);
+          REQ(!cfl.GetValue("no-such-key", &d));
+          REQ(cfl.HasUnusedValues() && cfl.UnusedValues().find("time-offsets=-6,-5") != std::string::npos);
+          std::vector<int> offs;
+          REQ(cfl.GetValue("time-offsets", &s) && n3::SplitStringToIntegers(s, &offs) && offs.size() == 7 && offs[0] == -6 && offs[6] == 0);
+          REQ(!cfl.ParseLine("a b=1 c"));
+          // Kaldi encodings: a matrix, a vector, an integer vector, scalars, text and binary, read back exactly
+          for (int binary = 0; binary < 2; binary++) {
+            std::stringstream ss(std::ios::in | std::ios::out | std::ios::binary);
+            tdnnf_kaldi_io::Out o{ss, binary != 0};
+            const float m[6] = {1.5f, -2.25f, 3.0e-8f, 4.0f, 1.0e20f, -0.0f}, v[3] = {0.1f, 0.2f, 0.3f};
+            o.token("<M>"); o.mat(m, 2, 3, 3);
+            o.token("<V>"); o.vec(v, 3);
+            o.token("<I>"); o.intvec(std::vector<int>{-3, 0, 7});
+            o.token("<S>"); o.i32(-5); o.f32(0.1f); o.f64(1.0 / 3.0); o.boolean(true);
+            tdnnf_kaldi_io::In in{ss, binary != 0, std::string()};
+            std::vector<float> rm, rv; std::vector<int> ri; int r = 0, c = 0, i5 = 0; float f1 = 0; double d3 = 0; bool bt = false;
+            REQ(in.expect("<M>") && in.mat(&rm, &r, &c) && r == 2 && c == 3);
+            for (int k = 0; k < 6; k++) REQ(rm[k] == m[k]);
+            REQ(in.expect("<V>") && in.vec(&rv) && rv.size() == 3 && rv[1] == v[1]);
+            REQ(in.expect("<I>") && in.intvec(&ri) && ri.size() == 3 && ri[0] == -3 && ri[2] == 7);
+            REQ(in.expect("<S>") && in.i32(&i5) && i5 == -5 && in.f32(&f1) && f1 == 0.1f && in.real(&d3) && d3 == 1.0 / 3.0 && in.boolean(&bt) && bt);
+          }
+          // the Tdnn index bookkeeping on a subsampled grid: 3 sequences, output every 3rd frame, offsets {-3, 0}
+          std::vector<n3::Index> in, out;
+          for (int t = -3; t <= 27; t += 3) for (int n = 0; n < 3; n++) in.push_back(n3::Index(n, t));
+          for (int t = 0; t <= 27; t += 3) for (int n = 0; n < 3; n++) out.push_back(n3::Index(n, t));
+          n3::TdnnComputationIo io;
+          n3::GetComputationIo(in, out, &io);
+          n3::ModifyComputationIo(&io);
+          REQ(io.start_t_in == -3 && io.t_step_in == 3 && io.num_t_in == 11 && io.t_step_out == 3 && io.num_t_out == 10 && io.num_images == 3 && io.reorder_t_in == 1);
+          std::printf("host pieces ok\\n");
+          return 0;
+        }
+    '''))
+    exe = tmp_path / "host_check"
+    subprocess.check_call(["g++", "-std=c++17", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", lib_dir, "-ltdnnf_hip", f"-Wl,-rpath,{lib_dir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "host pieces ok" in out.stdout, out.stdout + out.stderr

@@ -292,3 +292,55 @@ def test_remaining_factory_names_through_the_component_classes(driver, ora, tmp_
     dP = np.zeros((N, Cn), F)
     L.oracle_flops_constraint_backprop(ora.fptr(flops), fscale, N, Cn, ora.omat(dP))
     assert rel_l2(got["dP"], dP) < 1e-6
+
+
+def surface_lines(tmp_path):
+    """One config line per factory name: the lines the reference's own scripts emit (tests/golden/r01_configs_golden.json holds the outputs of
+    generate_config.py / generate_bottleneckCB8share_onehottrain_config.py / add_flopsconstraint.py run from /root/reference, make_configs_golden.py)
+    for the 16 types they instantiate, written by hand after the reference's InitFromConfig for the four they do not."""
+    import json
+    import re
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "r01_configs_golden.json")))
+    texts = []
+    for key in ("darts", "bottleneck", "bottleneck_offsets", "flops"):
+        items = gold[key] if isinstance(gold[key], list) else [gold[key]]
+        for it in items:
+            out = it.get("out", it)
+            texts += [v for v in out.values() if isinstance(v, str) and "component name=" in v]
+    first = {}
+    for t in texts:
+        for ln in t.split("\n"):
+            if ln.startswith("component name="):
+                first.setdefault(re.search(r"type=(\S+)", ln).group(1), ln[len("component "):])
+    assert len(first) == 16, sorted(first)
+    # the lda matrix the recipes point FixedAffineComponent at (matrix=configs/lda.mat): a Kaldi text matrix [W | b]
+    lda = tmp_path / "lda.mat"
+    m = np.random.default_rng(0).standard_normal((220, 221)).astype(F) * 0.1
+    lda.write_text(" [\n" + "\n".join("  " + " ".join("%.9g" % x for x in row) for row in m) + " ]\n")
+    first["FixedAffineComponent"] = first["FixedAffineComponent"].replace("configs/lda.mat", str(lda))
+    first["AffineComponent"] = "name=a type=AffineComponent input-dim=64 output-dim=32 param-stddev=0.1 bias-stddev=0.5 max-change=0.75"
+    first["BatchNormTestComponent"] = "name=b type=BatchNormTestComponent"
+    first["FlopsConstraintComponent"] = "name=f type=FlopsConstraintComponent input-dim=8 output-dim=8 flops=25,50,80,100,120,160,200,240 scale=0.5"
+    first["GumbelSoftmaxComponent"] = "name=g type=GumbelSoftmaxComponent dim=8 temp-proportion=0.7"
+    order = sorted(first, key=lambda t: (t == "BatchNormTestComponent", t))  # (the test-mode component is made from the BatchNormComponent's text)
+    return [(t, first[t]) for t in order]
+
+
+def test_every_component_class_through_its_whole_virtual_surface(pkg, tmp_path):
+    """for each of the 20 factory names NewComponentOfType -> InitFromConfig (the reference scripts' own config line) ->
+    Write (text, binary) -> ReadNew -> byte-identical Write -> Copy -> identical Propagate on the GPU; Scale / Add / DotProduct /
+    NumParameters / Vectorize / UnVectorize / PerturbParams / FreezeNaturalGradient for the updatable ones; PrecomputeIndexes /
+    ReorderIndexes / GetInputIndexes for the Tdnn classes; the cv-update sed edits on the text form (tests/surface_driver.cc)."""
+    exe = tmp_path / "surface_driver"
+    lib_dir = os.path.dirname(pkg.hipabi.LIB_PATH)
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "surface_driver.cc"),
+                           "-L", lib_dir, "-ltdnnf_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)])
+    rows = surface_lines(tmp_path)
+    assert len(rows) == 20
+    lines = tmp_path / "lines.txt"
+    lines.write_text("".join("%s\t%s\n" % r for r in rows))
+    p = subprocess.run([str(exe), str(lines)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + "\n" + p.stderr[-3000:]
+    ok = [ln.split()[1] for ln in p.stdout.splitlines() if ln.startswith("OK ") and len(ln.split()) == 2]
+    assert sorted(ok) == sorted(t for t, _ in rows), p.stdout
+    assert "OK cv-update edits" in p.stdout and "DONE 20" in p.stdout
