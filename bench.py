@@ -654,7 +654,14 @@ def main():
                                          "refresh, the rank-R products): algorithmic bytes / HIP-event time of the class", "achieved": round(gbs, 1),
                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "tflops": round(ngc["flops"] / (ngc["ms"] * 1e-3) / 1e12, 2),
                                          "launches": int(ngc["launches"]), "ms_per_step": round(ngc["ms"] / job.event_steps_, 3),
-                                         "traffic": tj.get(ngc["name"], {}).get("hbm_bytes_per_launch"), "algorithmic_bytes": round(ngc["bytes"] / max(ngc["launches"], 1), 1)}
+                                         "traffic": tj.get(ngc["name"], {}).get("hbm_bytes_per_launch"), "algorithmic_bytes": round(ngc["bytes"] / max(ngc["launches"], 1), 1),
+                                         # [r5] these passes are NOT purely HBM-bound in exact f32: H = X W^T at rank 80 is 48 FLOP per operand byte (rank 20
+                                         # padded to a 32-column MFMA tile: 16), and the f32 matrix cores give 157 TFLOP/s -- the rank-80 pass over the
+                                         # 6034-wide output derivative runs at 75-100 TFLOP/s of MFMA work, i.e. at the matrix cores' rate; longer K steps
+                                         # (twice the bytes in flight) change nothing (docs/experiments.md r5-g).  Both fractions, algorithmic FLOPs:
+                                         "mfma": {"achieved": round(ngc["flops"] / (ngc["ms"] * 1e-3) / 1e12, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                  "frac": round(ngc["flops"] / (ngc["ms"] * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                                                  "note": "algorithmic FLOPs (rank 20 / 80); the kernels' MFMA tiles are 32 / 96 columns wide: 1.6 x / 1.2 x this in issued work"}}
 
         # "fraction of HBM roofline on elementwise / denominator work" (hbm_entries above)
         out["roofline_hbm"] = hbm_entries(hbm_classes, job.event_steps_, args.chunk, tj, tfile)

@@ -56,7 +56,9 @@ struct Options {
   int wgrad_lag = 3;      // trainer, weight-gradient stream on: the caller's stream runs 3 (default) or 1 component(s) ahead of the gradients (read by tdnnf_net_create)
   int wgrad_on_caller = 0;  // trainer: the xent head's weight gradients on the caller's stream when the early statistics occupy the gradient stream
   int splitk_partial_round = 1;  // rows GEMM: split K when the tiles fill only part of one round of resident blocks (gemm_f32.hip launch_rows_balanced)
-  int ng_bk = 0;          // natural-gradient statistics passes H = X W^T: 1 = K steps of 64 (rank <= 32) / 32 (rank <= 96) instead of 32 / 16
+  int splitk_per_cu = 2;  // rows GEMM, few tiles and a long reduction: K slices per CU (2: fill every resident slot; 1: half the partial tiles)
+  int wgrad_small = 0;    // weight gradients of launches with at most this many rows on 64 x 64 tiles (0: off)
+  int ng_bk = 0;          // natural-gradient statistics passes H = X W^T, longer K steps: bit 0 = 64 instead of 32 for rank <= 32, bit 1 = 32 instead of 16 for rank <= 96
   int phase_events = 0;   // diagnostics: the trainer records an event on the caller's stream at every phase boundary of a step (tdnnf_net_phase_times)
   int den_split = -1;     // trainer: the denominator's two recursions side by side (then the occupancies of all frames at once): -1 by minibatch size, 0 / 1
 };

@@ -1138,6 +1138,7 @@ hipError_t launch_rows_balanced(const RowsGemmArgs &a, bool b_kc, bool vec, int 
   if (!stats && (tiles * 4 <= slots || S_partial >= 2) && k4 && ktot >= 16 * BK && (scratch = splitk_scratch(&scratch_bytes))) {
     const long long kt = (ktot + BK - 1) / BK;
     int S = S_partial >= 2 ? S_partial : slots / tiles;
+    if (S_partial < 2 && options().splitk_per_cu == 1) S = std::max(2, device_cus() / tiles);  // (one slice per CU: half the partial tiles)
     if (S > kt / 4) S = (int)(kt / 4);
     const size_t need = sizeof(float) * (size_t)S * a.M * ((a.N + 3) & ~3);
     if (S >= 2 && need <= scratch_bytes) {
@@ -1467,15 +1468,15 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     a.sumsq_cap = rows_gemm_sumsq_blocks(a.M);
     ProfScope ps(0, flops, s);
     // (option ng_bk: 1 = K steps twice as long for these HBM-bound passes -- twice the bytes in flight per resident block)
-    if (a.N <= 32) return options().ng_bk ? launch_rows_sumsq<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 1, 32>(a, b_kc, vec, s);
-    if (a.N <= 96) return options().ng_bk ? launch_rows_sumsq<4, 1, 1, 3, 32>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
+    if (a.N <= 32) return (options().ng_bk & 1) ? launch_rows_sumsq<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    if (a.N <= 96) return (options().ng_bk & 2) ? launch_rows_sumsq<4, 1, 1, 3, 32>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
     return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);
   }
   // skinny outputs (the natural-gradient projections X W^T, rank <= 32): a 128x32 tile wastes no MFMA columns and
   // keeps three blocks per CU resident to pull the A operand at HBM rate
   if (a.N <= 32 && a.M >= 1024) {
     ProfScope ps(0, flops, s);
-    return options().ng_bk ? launch_rows<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    return (options().ng_bk & 1) ? launch_rows<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows<4, 1, 1, 1, 32>(a, b_kc, vec, s);
   }
   if (waste160 < waste128) return launch_rows_balanced<4, 1, 1, 5, 16>(a, b_kc, vec, 1, flops, s);
   {
@@ -2003,8 +2004,12 @@ struct WgradTile {
   int BM, BN, variant;  // variant 0: 128x128, 1: 160x128 (Do == 160-ish), 2: 128x160 (Di == 160-ish), 3: 32x128 (Do <= 32)
 };
 inline int waste_of(int n, int t) { return ((n + t - 1) / t) * t - n; }
-WgradTile wgrad_tile(int Do, int Di, bool x3 = false) {
+WgradTile wgrad_tile(int Do, int Di, bool x3 = false, int N = 1 << 30) {
   if (Do <= 32) return {32, 128, 3};
+  // few rows (the recipes' minibatch: 3 000 - 10 000): with the 160 x 128 / 128 x 160 tiles the reduction is so short that a block is mostly
+  // prologue and a 80 KB partial tile (13 slabs of 256 rows: 25 MB of partials for 43 MB of operands); 64 x 64 tiles give six times the
+  // tiles, so two or three slabs fill the chip (option wgrad_small)
+  if (!x3 && options().wgrad_small && N <= options().wgrad_small) return {64, 64, 4};
   // split-bf16 arithmetic is not MFMA bound: the 160-wide tiles (92 KiB of LDS in bf16 planes, one block per CU) lose to
   // plain 128x128 tiles with a few wasted columns
   if (x3) return {128, 128, 0};  // J = H^T X of a rank <= 32 preconditioner: HBM-bound on X, no wasted MFMA rows
@@ -2031,6 +2036,7 @@ int wgrad_slots_of() {
   return slots;
 }
 int wgrad_slots(int variant) {
+  if (variant == 4) return wgrad_slots_of<2, 2, 1, 1>();
   return variant == 1 ? wgrad_slots_of<1, 4, 5, 1>() : variant == 2 ? wgrad_slots_of<4, 1, 1, 5>() : variant == 3 ? wgrad_slots_of<1, 4, 1, 1>()
                                                                                                    : wgrad_slots_of<2, 2, 2, 2>();
 }
@@ -2042,7 +2048,7 @@ inline int wgrad_min_rounds() { return 2; }
 WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0, bool x3 = false) {
   if (ktaps > 0) { WgradPlan p2 = wgrad_plan(Do, Di, ktaps, N, slots, 0, x3); p2.slab_floats = (size_t)p2.splits * Do * K * Di; return p2; }
   WgradPlan pl;
-  const WgradTile wt = wgrad_tile(Do, Di, x3);
+  const WgradTile wt = wgrad_tile(Do, Di, x3, N);
   const int tiles = ((Do + wt.BM - 1) / wt.BM) * K * ((Di + wt.BN - 1) / wt.BN);
   const int max_splits = std::max(1, (N + 255) / 256);  // at least 256 rows per split
   int splits = 1;
@@ -2054,6 +2060,7 @@ WgradPlan wgrad_plan(int Do, int Di, int K, int N, int slots, int ktaps = 0, boo
     splits = (rounds * slots) / tiles;
     if (splits >= 1 && (rounds * slots) / tiles * tiles >= rounds * slots * 3 / 4) break;  // >= 75 % of the round used
   }
+  if (wt.variant == 4) splits = std::max(1, (2 * device_cus()) / tiles);  // two blocks per CU, long slabs
   if (splits < 1) splits = 1;
   if (splits > max_splits) splits = max_splits;
   int rps = (N + splits - 1) / splits;
@@ -2180,7 +2187,7 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
     planes = prec == 1 ? 2 : prec == 3 ? 3 : 0;
   }
   const bool use_x3 = planes != 0;
-  const WgradTile wt = wgrad_tile(a.Do, a.Di, use_x3);
+  const WgradTile wt = wgrad_tile(a.Do, a.Di, use_x3, a.N);
   const int ktaps = a.active && a.max_active > 0 && a.max_active < a.K ? a.max_active : a.K;
   WgradArgs a_x = a;
   a_x.xcd_order = ktaps > 1 ? 1 : 0;  // the taps of a tile side by side on one XCD
@@ -2239,7 +2246,8 @@ hipError_t wgrad(const WgradArgs &a, void *workspace, size_t workspace_bytes, hi
   if (g_prof_override == 3) WG_LAUNCH_T(WM, WN, TM, TN, 1)         \
   else WG_LAUNCH_T(WM, WN, TM, TN, 0)
     // (wgrad_tile() gives the split-bf16 arithmetic the 128x128 and 32x128 tiles only: the 160-wide ones need 92 KiB of LDS)
-    if (wt.variant == 1) { WG_LAUNCH_F32(1, 4, 5, 1) }
+    if (wt.variant == 4) { WG_LAUNCH_F32(2, 2, 1, 1) }
+    else if (wt.variant == 1) { WG_LAUNCH_F32(1, 4, 5, 1) }
     else if (wt.variant == 2) { WG_LAUNCH_F32(4, 1, 1, 5) }
     else if (wt.variant == 3) { WG_LAUNCH(1, 4, 1, 1) }
     else { WG_LAUNCH(2, 2, 2, 2) }
