@@ -56,6 +56,7 @@ struct RowsGemmArgs {
   // to ~2^-16 relative, f32 accumulation); needs a k-contiguous B and 16-byte alignment, otherwise the f32 kernel runs.
   int prec;
   int serial_epilogue;  // 1: the one-segment-at-a-time epilogue for every tile (rows_gemm() sets 0)
+  int alt_seg_order;    // set by rows_gemm(): odd row tiles visit the K segments in reverse order (taps = row shifts of one matrix, gemm_f32.hip)
   int nseg;
   GemmSeg seg[kMaxSeg];
 };

@@ -189,16 +189,22 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
 
   // ---- K iterator over (segment, chunk), skipping zero-coefficient segments
   // (a split-K block only visits the part of each segment inside its [k_begin, k_end) slice)
-  int seg = -1, kc = 0, klen = 0;
+  // (alt_seg_order: odd row tiles visit the segments in reverse.  The taps of a TDNN-F layer are row shifts of ONE matrix by a tile's worth
+  // of rows, so row block i is the tap-0 operand of tile i and the tap-(-1) operand of tile i + 1: with every tile going tap by tap in the
+  // same order the two reads are half a launch apart and both come from HBM -- PMC traffic 2.07 x the algorithmic bytes for the 160-wide
+  // class in rounds 2-4; in alternating order both consumers of a row block read it in the same phase, at the same K step, on one XCD)
+  const bool rev_seg = p.alt_seg_order && (tile_m & 1);
+  int seg = -1, sgi = 0, kc = 0, klen = 0;  // seg: position in this tile's visiting order; sgi: the segment's index in p.seg
   long long seg_kstart = 0, seg_knext = 0;
   float cf = 1.f;
   auto next_seg = [&]() {
     for (++seg; seg < p.nseg; ++seg) {
+      sgi = rev_seg ? p.nseg - 1 - seg : seg;
       seg_kstart = seg_knext;
-      seg_knext += p.seg[seg].klen;
-      cf = p.coef ? p.coef[seg] : 1.f;
+      seg_knext += p.seg[sgi].klen;
+      cf = p.coef ? p.coef[sgi] : 1.f;
       const long long lo = k_begin > seg_kstart ? k_begin - seg_kstart : 0;
-      const long long hi = k_end < seg_knext ? k_end - seg_kstart : p.seg[seg].klen;
+      const long long hi = k_end < seg_knext ? k_end - seg_kstart : p.seg[sgi].klen;
       if (cf != 0.f && hi > lo) {
         kc = (int)lo;
         klen = (int)hi;
@@ -228,7 +234,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
   int astep[A_F4], bstep[B_F4];
   int ptr_seg = -1;
   auto setup_ptrs = [&]() {
-    const GemmSeg sg = p.seg[seg];
+    const GemmSeg sg = p.seg[sgi];
     const float *zero = reinterpret_cast<const float *>(&g_zero4);
 #pragma unroll
     for (int j = 0; j < A_F4; j++) {
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       cf_tile = cf;
       return;
     }
-    const GemmSeg sg = p.seg[seg];
+    const GemmSeg sg = p.seg[sgi];
     const float *Ab = p.A + sg.a_off;
     const float *Bb = p.B + sg.b_off;
 #pragma unroll
@@ -1453,6 +1459,9 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     g_prof_next_flops = flops;
   }
   a.serial_epilogue = 0;
+  // two taps of one matrix (same reduction length, A offsets whole rows apart): alternate the order row tile by row tile (rows_gemm_kernel)
+  a.alt_seg_order = options().gemm_alt_taps && a.nseg == 2 && a.seg[0].klen == a.seg[1].klen && a.lda > 0 && a.seg[0].a_off != a.seg[1].a_off &&
+                    (a.seg[1].a_off - a.seg[0].a_off) % a.lda == 0;
   if (a.prec == 0) a.prec = g_gemm_prec;
   if (a.prec == 2) a.prec = 0;  // 2 = exact f32 regardless of the default
   if (a.prec == 4 || (a.prec == 3 && options().planes)) {  // pre-split planes (f16x3 / bf16x6) when the caller hinted them for these operands
