@@ -1334,6 +1334,7 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
     }
   }
   g.nseg = a.nseg;
+  g.alt_seg_order = a.alt_seg_order && a.nseg == 2 && g.seg[0].nkb == g.seg[1].nkb && g.seg[0].a_kb0 == g.seg[1].a_kb0 && g.seg[0].a_row != g.seg[1].a_row;
   g.skip_coef = a.coef;
   g.C = a.C; g.ldc = a.ldc; g.M = a.M; g.N = a.N;
   g.bias = a.bias; g.init_mode = a.init_mode; g.relu = a.relu;

@@ -65,6 +65,7 @@ struct PlanesGemmArgs {
   int ksplit, kb_per_split;
   float *partial;
   long long partial_stride, ldp_m, ldp_n;
+  int alt_seg_order;  // odd row tiles visit the K segments in reverse order (two taps = row shifts of one matrix; gemm_f32.hip rows_gemm_kernel)
 };
 
 // P16 layout of an R x C matrix:  e16 P[kb][plane][row][16],  kb = c / 16, plane 0..np-1, row 0..R-1, R = lead + rows + tail

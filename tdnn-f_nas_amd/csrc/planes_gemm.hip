@@ -312,6 +312,9 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
   int all = 0;
   for (int s = 0; s < p.nseg; s++)
     if (!(ntaps <= 1 && p.skip_coef && p.skip_coef[s] == 0.f)) all += p.seg[s].nkb;
+  // (alt_seg_order, as rows_gemm_kernel: odd row tiles visit the two taps in reverse order, so that the row block two neighbouring tiles
+  // share is fetched by both in the same phase of the launch)
+  const bool rev_seg = p.alt_seg_order && (tile_m & 1);
   const int g_begin = nsplit > 1 ? sp * p.kb_per_split : 0;
   const int total = nsplit > 1 ? max(0, min(all - g_begin, p.kb_per_split)) : all;
   const int tap_akb = ntaps > 1 ? p.tap_a_kb[tap] : 0, tap_bkb = ntaps > 1 ? p.tap_b_kb[tap] : 0;
@@ -346,8 +349,9 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     for (;;) {
       ld_seg++;
       if (ld_seg >= p.nseg) return;
-      if (ntaps <= 1 && p.skip_coef && p.skip_coef[ld_seg] == 0.f) continue;
-      const PlanesSeg sg = p.seg[ld_seg];
+      const int si = rev_seg ? p.nseg - 1 - ld_seg : ld_seg;
+      if (ntaps <= 1 && p.skip_coef && p.skip_coef[si] == 0.f) continue;
+      const PlanesSeg sg = p.seg[si];
       if (ld_skip >= sg.nkb) {  // (a split that starts behind this segment)
         ld_skip -= sg.nkb;
         continue;
@@ -387,8 +391,9 @@ __global__ __launch_bounds__(WM *WN * 64) __attribute__((amdgpu_waves_per_eu(2, 
     for (;;) {
       cs_seg++;
       if (cs_seg >= p.nseg) return;
-      if (ntaps <= 1 && p.skip_coef && p.skip_coef[cs_seg] == 0.f) continue;
-      const PlanesSeg sg = p.seg[cs_seg];
+      const int si = rev_seg ? p.nseg - 1 - cs_seg : cs_seg;
+      if (ntaps <= 1 && p.skip_coef && p.skip_coef[si] == 0.f) continue;
+      const PlanesSeg sg = p.seg[si];
       if (cs_skip >= sg.nkb) {
         cs_skip -= sg.nkb;
         continue;
