@@ -1335,6 +1335,26 @@ static bool planes_try_rows(const RowsGemmArgs &a, bool b_kc, int np, double flo
   }
   g.nseg = a.nseg;
   g.alt_seg_order = a.alt_seg_order && a.nseg == 2 && g.seg[0].nkb == g.seg[1].nkb && g.seg[0].a_kb0 == g.seg[1].a_kb0 && g.seg[0].a_row != g.seg[1].a_row;
+  if (g.alt_seg_order && options().gemm_alt_taps == 2 && g.seg[0].nkb >= 24 && !a.coef) {
+    // the two taps in chunks of a few K blocks, alternating: a row block's two reads (as tap 0 by one tile, as the other tap by that tile or its
+    // neighbour -- 256-row tiles, 128-row shift) are then a chunk apart instead of half a launch
+    const PlanesSeg s0 = g.seg[0], s1 = g.seg[1];
+    const int nchunk = std::min(16, s0.nkb / 6), per = (s0.nkb + nchunk - 1) / nchunk;
+    int n = 0;
+    for (int c = 0; c < nchunk; c++) {
+      const int k0 = c * per, kn = std::min(per, s0.nkb - k0);
+      if (kn <= 0) break;
+      for (const PlanesSeg *sp : {&s0, &s1}) {
+        PlanesSeg q = *sp;
+        q.a_kb0 += k0;
+        q.b_kb0 += k0;
+        q.nkb = kn;
+        g.seg[n++] = q;
+      }
+    }
+    g.nseg = n;
+    g.alt_seg_order = 0;
+  }
   g.skip_coef = a.coef;
   g.C = a.C; g.ldc = a.ldc; g.M = a.M; g.N = a.N;
   g.bias = a.bias; g.init_mode = a.init_mode; g.relu = a.relu;

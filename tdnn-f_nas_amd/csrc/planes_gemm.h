@@ -40,7 +40,7 @@ struct PlanesGemmArgs {
   float add_scale;
   int add_lo, add_hi;
   int nseg;
-  PlanesSeg seg[16];
+  PlanesSeg seg[32];
   // optional (device, nseg floats; in tap mode ntap floats): a segment / tap whose coefficient is zero is skipped (the coefficients
   // themselves are folded into the B planes or applied by the caller's reduce: this is only the skip)
   const float *skip_coef;
