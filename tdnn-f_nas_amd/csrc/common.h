@@ -56,6 +56,7 @@ struct Options {
   int wgrad_lag = 3;      // trainer, weight-gradient stream on: the caller's stream runs 3 (default) or 1 component(s) ahead of the gradients (read by tdnnf_net_create)
   int wgrad_on_caller = 0;  // trainer: the xent head's weight gradients on the caller's stream when the early statistics occupy the gradient stream
   int splitk_partial_round = 1;  // rows GEMM: split K when the tiles fill only part of one round of resident blocks (gemm_f32.hip launch_rows_balanced)
+  int reverse_passes = 0;  // HBM-bound passes walk their matrix from the last rows to the first: bit 0 bn_apply_bypass, bit 1 bn_relu_bwd's apply pass
   int gemm_alt_taps = 1;  // rows GEMM with two taps of one matrix: odd row tiles visit the taps in reverse order, so that both readers of a row block fetch it together
   int splitk_per_cu = 2;  // rows GEMM, few tiles and a long reduction: K slices per CU (2: fill every resident slot; 1: half the partial tiles)
   int wgrad_small = 0;    // weight gradients of launches with at most this many rows on 64 x 64 tiles (0: off)

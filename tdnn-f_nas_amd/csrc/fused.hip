@@ -55,14 +55,17 @@ __device__ __forceinline__ void store_planes4(const PlanesSink &pk, float ps, lo
 // (cols = k * D): the column parameters repeat with period D.
 template <int VEC, bool PLANES>
 __global__ __launch_bounds__(256) void bn_apply_bypass_kernel(MatView x, const float *mean, const float *scale, int D, int period,
-                                                              MatView prev, float bypass, MatView out, const float *mask, int B, PlanesSink pk) {
+                                                              MatView prev, float bypass, MatView out, const float *mask, int B, PlanesSink pk, int rev) {
   const int cv = x.cols / VEC;
   const float ps = PLANES ? pk.rec[0] : 1.0f;
   // PLANES: a wave covers 8 rows x 32 columns (not 1 row x 256): its plane stores are then two runs of 8 consecutive 32-byte row records per
   // plane (256 contiguous bytes) instead of 32 scattered records, and the f32 accesses are still whole 128-byte lines
   const int ncb = PLANES ? cv / 8 : 1;
   const long long total = PLANES ? (long long)((x.rows + 7) / 8) * 8 * cv : (long long)x.rows * cv;
-  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+  for (long long e0 = blockIdx.x * 256LL + threadIdx.x; e0 < total; e0 += gridDim.x * 256LL) {
+    // (rev: from the matrix's last rows to its first -- what the GEMM that produced x wrote last is still in L2 / the Infinity Cache when this
+    // pass starts, and what this pass writes last, the first rows, is what the next GEMM reads first)
+    const long long e = rev ? total - 1 - e0 : e0;
     int r, c;
     if (PLANES) {
       const long long blk = e >> 6;
@@ -210,12 +213,13 @@ template <int VEC, bool PLANES>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatView dz, const float *memo, int D,
                                                                 const double *repair_stats, float self_repair_scale,
                                                                 int rows_per_chunk, int chunks, MatView d_aff, float *partial, const float *mask, int B,
-                                                                PlanesSink pk, int pk_lead) {
+                                                                PlanesSink pk, int pk_lead, int rev) {
   const float pks = PLANES ? pk.rec[0] : 1.0f;
   __shared__ float red[4][64 * 4 + 4];
   const int tc = threadIdx.x & 63, tr = threadIdx.x >> 6;
   const int col = (blockIdx.x * 64 + tc) * VEC;
-  const int r0 = blockIdx.y * rows_per_chunk, r1 = min(x.rows, r0 + rows_per_chunk);
+  const int chunk = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;  // (rev: the chunks the reduce pass read last, first)
+  const int r0 = chunk * rows_per_chunk, r1 = min(x.rows, r0 + rows_per_chunk);
   float s[4] = {0, 0, 0, 0};
   if (col < x.cols) {
     float mu[4], sc[4], vdm[4], tmp[4], rep[4];
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       const int k = tc * VEC + j;
-      partial[(long long)blockIdx.y * x.cols + col + j] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+      partial[(long long)chunk * x.cols + col + j] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
     }
   }
 }
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(MatView x, MatVi
 template <int NT, bool MASK, bool FULL, bool PLANES>
 __device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
                                                                    float self_repair_scale, MatView d_aff, float *partial, const float *mask, int B,
-                                                                   NgFuse ng, PlanesSink pk, int pk_lead) {
+                                                                   NgFuse ng, PlanesSink pk, int pk_lead, int blk) {
   const float pks = PLANES ? pk.rec[0] : 1.0f;
   constexpr int BM = 128, BK = 32, LD = BK + 4;
   __shared__ __attribute__((aligned(16))) float As[BM * LD];
@@ -306,7 +310,7 @@ __device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz,
   __shared__ double red[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int c4 = t & 7, rr = t >> 3;  // this thread's float4 of a 32-column row segment, rows rr + 32 i
-  const int r0 = blockIdx.x * BM;
+  const int r0 = blk * BM;
   typedef float acc_t __attribute__((ext_vector_type(16)));
   acc_t acc[NT];
 #pragma unroll
@@ -430,7 +434,7 @@ __device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz,
         }
       }
     }
-    if (t < BK) partial[(long long)blockIdx.x * D + k0 + t] = (colred[0][t] + colred[1][t]) + (colred[2][t] + colred[3][t]);
+    if (t < BK) partial[(long long)blk * D + k0 + t] = (colred[0][t] + colred[1][t]) + (colred[2][t] + colred[3][t]);
     __syncthreads();  // the tile buffers are rewritten next
   }
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -447,18 +451,19 @@ __device__ __forceinline__ void bn_relu_bwd_apply_ng_body(MatView x, MatView dz,
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   if (lane == 0) red[wave] = v;
   __syncthreads();
-  if (t == 0) ng.part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-  if (blockIdx.x == 0)
+  if (t == 0) ng.part[blk] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (blk == 0)
     for (int i = gridDim.x + t; i < ng.part_cap; i += 256) ng.part[i] = 0.0;
 }
 
 template <int NT, bool MASK, bool PLANES>
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_ng_kernel(MatView x, MatView dz, const float *memo, int D, const double *repair_stats,
                                                                    float self_repair_scale, MatView d_aff, float *partial, const float *mask, int B,
-                                                                   NgFuse ng, PlanesSink pk, int pk_lead) {
-  if ((int)blockIdx.x * 128 + 128 <= x.rows)
-    bn_relu_bwd_apply_ng_body<NT, MASK, true, PLANES>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng, pk, pk_lead);
-  else bn_relu_bwd_apply_ng_body<NT, MASK, false, PLANES>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng, pk, pk_lead);
+                                                                   NgFuse ng, PlanesSink pk, int pk_lead, int rev) {
+  const int blk = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;  // (rev: the row blocks the reduce pass read last, first)
+  if (blk * 128 + 128 <= x.rows)
+    bn_relu_bwd_apply_ng_body<NT, MASK, true, PLANES>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng, pk, pk_lead, blk);
+  else bn_relu_bwd_apply_ng_body<NT, MASK, false, PLANES>(x, dz, memo, D, repair_stats, self_repair_scale, d_aff, partial, mask, B, ng, pk, pk_lead, blk);
 }
 
 __global__ __launch_bounds__(kFinThreads) void colsum_add_kernel(const float *partial, int chunks, int D, float scale, float *acc) {
@@ -481,9 +486,9 @@ hipError_t bn_apply_bypass(MatView x, const float *memo, int D, int period, MatV
   if (planes && !(vec && x.cols == D && D % 32 == 0 && planes->P && planes->rec)) return hipErrorInvalidValue;
   ProfHbmRange prof(4, 4.0 * x.rows * x.cols * ((prev.data ? 3.0 : 2.0) + (planes ? 1.0 : 0.0)), s);  // reads x [and the bypass rows], writes out [and its planes]
   const PlanesSink none{nullptr, 0, nullptr};
-  if (planes) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, true>), dim3(grid_for((long long)((x.rows + 7) / 8) * 8 * (x.cols / 4), 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, *planes);
-  else if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none);
-  else hipLaunchKernelGGL((bn_apply_bypass_kernel<1, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none);
+  if (planes) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, true>), dim3(grid_for((long long)((x.rows + 7) / 8) * 8 * (x.cols / 4), 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, *planes, 0);
+  else if (vec) hipLaunchKernelGGL((bn_apply_bypass_kernel<4, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none, options().reverse_passes & 1);
+  else hipLaunchKernelGGL((bn_apply_bypass_kernel<1, false>), dim3(grid_for(work, 256)), dim3(256), 0, s, x, memo, memo + 2 * D, D, period, prev, bypass, out, mask, B, none, 0);
   return hipGetLastError();
 }
 
@@ -568,10 +573,10 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     const int blocks = (x.rows + 127) / 128;
 #define APPLY_NG(NT)                                                                                                                                     \
   do {                                                                                                                                               \
-    if (pk.P && mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead); \
-    else if (pk.P) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead); \
-    else if (mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead); \
-    else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead);    \
+    if (pk.P && mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead, (options().reverse_passes >> 1) & 1); \
+    else if (pk.P) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false, true>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead, (options().reverse_passes >> 1) & 1); \
+    else if (mask) hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, true, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead, (options().reverse_passes >> 1) & 1); \
+    else hipLaunchKernelGGL((bn_relu_bwd_apply_ng_kernel<NT, false, false>), dim3(blocks), block, 0, s, x, dz, memo, D, rep, self_repair_scale, d_aff, bias_partial, mask, B, *ng, pk, pk_lead, (options().reverse_passes >> 1) & 1);    \
   } while (0)
     if (ng->Rp <= 32) APPLY_NG(1);
     else if (ng->Rp <= 64) APPLY_NG(2);
@@ -580,9 +585,9 @@ hipError_t bn_relu_bwd(MatView x, MatView dz, float *memo, float target_rms, boo
     if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, bias_partial, blocks, D, bias_scale, bias_acc);
     return hipGetLastError();
   }
-  if (pk.P) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4, true>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead);
-  else if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4, false>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead);
-  else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1, false>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead);
+  if (pk.P) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4, true>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead, (options().reverse_passes >> 1) & 1);
+  else if (vec) hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<4, false>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead, (options().reverse_passes >> 1) & 1);
+  else hipLaunchKernelGGL((bn_relu_bwd_apply_kernel<1, false>), grid, block, 0, s, x, dz, memo, D, rep, self_repair_scale, pl.rows_per_chunk, pl.chunks, d_aff, bias_partial, mask, B, pk, pk_lead, (options().reverse_passes >> 1) & 1);
   if (bias_acc) hipLaunchKernelGGL(colsum_add_kernel, dim3(finalize_grid(D)), dim3(kFinThreads), 0, s, bias_partial, pl.chunks, D, bias_scale, bias_acc);
   return hipGetLastError();
 }
