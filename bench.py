@@ -714,6 +714,8 @@ def main():
             # given, the fraction is of the DENSE 16-bit peak (MI355X_MICROARCH.md: ~2.5 PFLOP/s for bf16 and f16 alike)
             cl = [c for c in it.get("_classes", [])[:3] if c["ms"] > 0]
             tj16 = load_traffic(TRAFFIC_FILE_F16X3) if args.workload == "7q" and args.chunk == 1500 and args.minibatch == 128 else {}
+            # the PMC summary names the plane kernels by their own classes (tools/make_profiles.py klass())
+            pmc16 = {"rows_gemm_f32_128x128": "planes_gemm_f16x3_256x256", "rows_gemm_f32_128x160": "planes_gemm_f16x3_256x160", "wgrad_f32": "planes_gemm_f16x3_wgrad"}
             if cl:
                 dm = max(cl, key=lambda c: c["ms"])
                 eq = dm["flops"] / (dm["ms"] * 1e-3) / 1e12
@@ -721,8 +723,10 @@ def main():
                       "rows_gemm_f32_128x160": "planes_gemm_f16x3 (160-column tiles)", "wgrad_f32": "planes_gemm_f16x3 (weight gradients, split-K)"}
                 out["alt"]["roofline"] = {"bound": "mfma", "kernel": nm.get(dm["name"], dm["name"]), "achieved": round(3.0 * eq, 2), "peak": BF16_PEAK_TFLOPS,
                                           "unit": "TFLOP/s", "frac": round(3.0 * eq / BF16_PEAK_TFLOPS, 4), "f32_equivalent_tflops": round(eq, 2),
-                                          "f16_mfma_flops_per_algorithmic_flop": 3, "traffic": tj16.get(dm["name"], {}).get("hbm_bytes_per_launch"),
-                                          "traffic_source": TRAFFIC_FILE_F16X3 if tj16.get(dm["name"]) else None,
+                                          "f16_mfma_flops_per_algorithmic_flop": 3, "traffic": tj16.get(pmc16.get(dm["name"], ""), {}).get("hbm_bytes_per_launch"),
+                                          "traffic_source": ("%s, class %s: PMC bytes per launch of the plane kernels of this event class (the event class also holds "
+                                                             "the few launches left on the f32 kernels)" % (TRAFFIC_FILE_F16X3, pmc16.get(dm["name"])))
+                                          if tj16.get(pmc16.get(dm["name"], "")) else None,
                                           "algorithmic_bytes": round(dm["bytes"] / max(dm["launches"], 1), 1), "event_steps": it.get("_event_steps"),
                                           "all_kernels": [{"kernel": nm.get(c["name"], c["name"]), "launches": int(c["launches"]), "ms": round(c["ms"], 3),
                                                            "f32_equivalent_tflops": round(c["flops"] / (c["ms"] * 1e-3) / 1e12, 2),
