@@ -304,6 +304,14 @@ int tdnnf_ng_freeze(tdnnf_ng *, int freeze);
    The R x R eigen-problem of a refresh step is solved on a host worker thread and W_{t+1} is installed at the
    next call on the same object, so a call with scale_host == NULL never blocks.  rank <= 128. */
 int tdnnf_ng_precondition(tdnnf_ng *, tdnnf_mat *X, float *scale_host, tdnnf_stream);
+/* The N-sized statistics pass of one PreconditionDirections call by itself (what X W_t^T costs; tests, micro-benchmarks):
+   H (N x rank, ld = H->stride) = X~ WT, row m of X~ = the concatenation over the taps of eff[i] * X[m * ix->row_stride + ix->row_offsets[i]]
+   (Di columns each; eff_dev NULL = ones) [+ bias_dev: the row of W_t^T that meets the appended column of ones]; WT_dev is W_t^T, (taps * Di) x
+   rank, k-major, followed by at least 64 finite rows; sumsq_dev (NULL or sumsq_cap doubles): their sum = ||X~||_F^2.  use_valu != 0: the
+   vector-ALU kernel (csrc/ng_valu.hip; rank 20 / 40 / 80, TDNNF_EINVAL otherwise), 0: the MFMA rows GEMM (needs W_dev = W_t, rank x ldw). */
+int tdnnf_ng_stats_pass(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *X, int Di, const float *eff_dev, const float *WT_dev,
+                        const float *W_dev, int ldw, const float *bias_dev, tdnnf_mat *H, double *sumsq_dev, int sumsq_cap, int use_valu,
+                        tdnnf_stream);
 /* device float holding the scale of the object's last tdnnf_ng_precondition call (NULL before the first call) */
 const float *tdnnf_ng_scale_dev(const tdnnf_ng *);
 

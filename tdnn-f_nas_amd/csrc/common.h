@@ -61,6 +61,8 @@ struct Options {
   int splitk_per_cu = 2;  // rows GEMM, few tiles and a long reduction: K slices per CU (2: fill every resident slot; 1: half the partial tiles)
   int wgrad_small = 0;    // weight gradients of launches with at most this many rows on 64 x 64 tiles (0: off)
   int ng_bk = 0;          // natural-gradient statistics passes H = X W^T, longer K steps: bit 0 = 64 instead of 32 for rank <= 32, bit 1 = 32 instead of 16 for rank <= 96
+  int ng_valu = 0;        // natural-gradient statistics passes H = X W^T on the vector ALUs (ng_valu.hip) where the rank is 20 / 40 / 80 (measured: no gain, docs/experiments.md r5-m); 0: the MFMA rows GEMM
+  int ng_diag_skip = 0;   // diagnostics (timing only, results wrong): skip the statistics passes H = X W^T -- bit 0 two-tap inputs >= 1024 wide, bit 1 every other
   int phase_events = 0;   // diagnostics: the trainer records an event on the caller's stream at every phase boundary of a step (tdnnf_net_phase_times)
   int den_split = -1;     // trainer: the denominator's two recursions side by side (then the occupancies of all frames at once): -1 by minibatch size, 0 / 1
 };
@@ -96,10 +98,13 @@ inline unsigned long long tdnnf_decision(unsigned long long step, unsigned long 
   return (z ^ (z >> 31)) >> 8;
 }
 
-// Second stage of the column reductions: a 1024-thread block owns 32 columns, its 32 lanes per column walk the partial rows
+// Second stage of the column reductions: a 256-thread block owns 8 columns, its 32 lanes per column walk the partial rows
 // four requests deep, then lane 0 adds the lanes' sums in a fixed order (deterministic).  The partial rows are few MB at most,
-// the stage is pure latency: with 4 lanes x 24 blocks it took 45-300 us per call, ~5 ms per training step.
-constexpr int kFinCols = 32, kFinLanes = 32, kFinThreads = kFinCols * kFinLanes;
+// the stage is pure latency: with 4 lanes x 24 blocks it took 45-300 us per call, ~5 ms per training step.  Rounds 2-4 ran it as
+// 1024-thread blocks of 32 columns: beside another stream's kernels such a block waits until one CU has sixteen free wave slots at once
+// (the BatchNorm finalize of the xent head beside the denominator and the statistics passes: 9 us alone, 234 us on average, 4.3 ms
+// at worst in the round-5 trace); four-wave blocks fit wherever anything fits, and there are four times as many of them.
+constexpr int kFinCols = 8, kFinLanes = 32, kFinThreads = kFinCols * kFinLanes;
 inline unsigned finalize_grid(int D) { return (unsigned)((D + kFinCols - 1) / kFinCols); }
 #ifdef __HIPCC__
 // q[k] = sum over c < chunks of partial[((long long)k * qstride_rows + c) * D + d] for the calling thread's column d;

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(kFinThreads) void bn_fwd_finalize_kernel(const floa
       store[1 + D + d] += (double)store_frames * uvar;
     }
   }
-  if (fro2 && threadIdx.x < 64) {  // (kFinCols = 32 columns live in the first wave; the other lanes carry zeros)
+  if (fro2 && threadIdx.x < 64) {  // (the kFinCols <= 32 owning threads are the first lanes of the first wave; the other lanes carry zeros)
     for (int o = 16; o > 0; o >>= 1) bound += __shfl_xor(bound, o, 32);
     if (threadIdx.x == 0) fro2[blockIdx.x] = bound;
   }

@@ -78,6 +78,14 @@ struct ProfHbmRange {
   ~ProfHbmRange();
 };
 
+// Event pair + algorithmic work of ONE launch made outside gemm_f32.hip that belongs to a GEMM class (0 .. 3; ng_valu.hip: class 3).
+struct ProfGemmRange {
+  void *c;
+  hipStream_t s;
+  ProfGemmRange(int cls, double flops, double bytes, hipStream_t stream);
+  ~ProfGemmRange();
+};
+
 // Scales the algorithmic FLOPs recorded for the launches made while alive: the host cannot see device-side tap
 // coefficients, so a caller that knows only `active` of K taps are non-zero (DARTS uniform-sample mode) says so.
 struct ProfFlopsScale {

@@ -121,6 +121,22 @@ ProfHbmRange::~ProfHbmRange() {
   p->used += 2;
 }
 
+ProfGemmRange::ProfGemmRange(int cls, double flops, double bytes, hipStream_t stream) : c(nullptr), s(stream) {
+  if (!g_prof_on || cls < 0 || cls >= 4) return;
+  ProfClass &p = g_prof[cls];
+  if (p.used + 2 > p.ev.size()) return;
+  c = &p;
+  p.flops += flops;
+  p.bytes += bytes;
+  hipEventRecord(p.ev[p.used], s);
+}
+ProfGemmRange::~ProfGemmRange() {
+  if (!c) return;
+  ProfClass *p = static_cast<ProfClass *>(c);
+  hipEventRecord(p->ev[p->used + 1], s);
+  p->used += 2;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {

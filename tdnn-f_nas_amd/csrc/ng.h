@@ -56,6 +56,28 @@ struct NgInput {
   int max_active;
 };
 
+// H = X~ W^T on the vector ALUs (ng_valu.hip): thread per row, W^T from SGPRs.  Row m of X~ is the concatenation over the nseg taps of
+// eff[i] * X[m * row_stride * ldx + seg_off[i] + (0 .. Di)]; WT is D x Rp (k-major), D = nseg * Di [+ 1: the column of ones, whose
+// row of W^T comes in as `bias`]; kWtPadRows finite rows must follow its D.  part (optional): part_cap doubles, their sum = ||X~||_F^2 without the ones.
+constexpr int kWtPadRows = 64;  // zero rows every W^T buffer holds behind its D rows
+struct NgRowdotArgs {
+  const float *X;
+  long long ldx;        // floats between consecutive rows of X
+  int row_stride;       // X rows between consecutive rows of X~
+  int nseg, Di;
+  long long seg_off[16];  // floats from X to tap i's view (row offset * ldx)
+  const float *eff;     // device, nseg floats, or null
+  const float *WT;
+  int Rp;               // 20, 40 or 80
+  const float *bias;    // Rp floats or null
+  float *H;
+  int ldh, N;
+  double *part;
+  int part_cap;
+};
+bool ng_rowdot_ok(const NgRowdotArgs &a);  // shapes / alignments the kernel takes (otherwise: the MFMA rows GEMM)
+hipError_t ng_rowdot(const NgRowdotArgs &a, hipStream_t s);
+
 size_t ng_stats_workspace_bytes(int rank, int D, int K, int N);
 // Statistics of one PreconditionDirections call: H = X W_t^T into H (N x ld, ld = ng_h_ld()), tr(X X^T),
 // tr(X^ X^^T) and the scale on the device; on refresh steps also J, K, L and the (asynchronous) host update that

@@ -218,14 +218,16 @@ int alloc_state(tdnnf_ng *ng, int D) {
   ng->Dp = Dp;
   ng->Rp = Rp;
   const size_t fRD = (size_t)Rp * Dp, fRR = (size_t)Rp * Rp;
-  const size_t floats = 3 * fRD + pad4z((size_t)D * Rp) + 4 * fRR + 3 * Rp + 8 + 8;
+  // (W^T: kWtPadRows zero rows behind its D -- ng_valu.hip reads whole K steps of up to 64 rows, the tile's columns there are zeros)
+  const size_t fWT = pad4z((size_t)(D + kWtPadRows) * Rp);
+  const size_t floats = 3 * fRD + fWT + 4 * fRR + 3 * Rp + 8 + 8;
   TDNNF_HIP(hipMalloc((void **)&ng->dev, sizeof(float) * floats));
   TDNNF_HIP(hipMemset(ng->dev, 0, sizeof(float) * floats));
   float *p = ng->dev;
   ng->W = p; p += fRD;
   ng->J = p; p += fRD;
   ng->W1 = p; p += fRD;
-  ng->WT = p; p += pad4z((size_t)D * Rp);
+  ng->WT = p; p += fWT;
   ng->WWT = p; p += fRR;
   ng->Kd = p; p += fRR;
   ng->Ld = p; p += fRR;
@@ -415,7 +417,21 @@ int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg
     a.seg[i].m_lo = 0;
     a.seg[i].m_hi = N;
   }
-  TDNNF_HIP(rows_gemm(a, true, s));  // H = X W^T (+ ||X||_F^2 per block)
+  // the same product on the vector ALUs, beside the matrix-core GEMMs of the other streams (ng_valu.hip), where its shape allows
+  NgRowdotArgs v;
+  memset(&v, 0, sizeof(v));
+  v.X = in.x.data; v.ldx = in.x.stride; v.row_stride = in.ix.row_stride; v.nseg = K; v.Di = Di; v.eff = in.eff; v.WT = ng->WT; v.Rp = Rp;
+  v.bias = in.ones ? ng->wlast : nullptr; v.H = H; v.ldh = Rp; v.N = N; v.part = part; v.part_cap = rows_gemm_sumsq_blocks(N);
+  for (int i = 0; i < K; i++) v.seg_off[i] = (long long)in.ix.row_offsets[i] * in.x.stride;
+  const int skip = options().ng_diag_skip;
+  if (skip && ng->D != 0 && (((skip & 1) && K == 2 && Di >= 1024) || ((skip & 2) && !(K == 2 && Di >= 1024)))) {
+    TDNNF_HIP(hipMemsetAsync(H, 0, sizeof(float) * (size_t)N * Rp, s));
+    TDNNF_HIP(hipMemsetAsync(part, 0, sizeof(double) * rows_gemm_sumsq_blocks(N), s));
+  } else if (options().ng_valu && !in.active && ng_rowdot_ok(v)) {
+    TDNNF_HIP(ng_rowdot(v, s));
+  } else {
+    TDNNF_HIP(rows_gemm(a, true, s));  // H = X W^T (+ ||X||_F^2 per block)
+  }
   return stats_after_h(ng, in, H, wg_ws, wg_bytes, upd, s);
 }
 
@@ -623,6 +639,43 @@ using namespace tdnnf;
 extern "C" {
 
 const float *tdnnf_ng_scale_dev(const tdnnf_ng *ng) { return ng && ng->dev ? ng->scale_f : nullptr; }
+
+int tdnnf_ng_stats_pass(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *X, int Di, const float *eff, const float *WT, const float *W, int ldw,
+                        const float *bias, tdnnf_mat *H, double *sumsq, int sumsq_cap, int use_valu, tdnnf_stream stream) {
+  TDNNF_REQUIRE(ix && X && X->data && H && H->data && Di > 0 && ix->num_offsets >= 1 && ix->num_offsets <= kMaxSeg && ix->row_stride >= 1,
+                "ng_stats_pass: bad arguments");
+  const int K = ix->num_offsets, N = H->rows, Rp = H->cols;
+  for (int i = 0; i < K; i++)
+    TDNNF_REQUIRE(ix->row_offsets[i] >= 0 && (long long)(N - 1) * ix->row_stride + ix->row_offsets[i] < X->rows && Di <= X->cols,
+                  "ng_stats_pass: tap %d reads outside X (%d x %d)", i, X->rows, X->cols);
+  TDNNF_REQUIRE(!sumsq || sumsq_cap >= rows_gemm_sumsq_blocks(N), "ng_stats_pass: sumsq needs %d entries", rows_gemm_sumsq_blocks(N));
+  hipStream_t s = (hipStream_t)stream;
+  if (use_valu) {
+    NgRowdotArgs v;
+    memset(&v, 0, sizeof(v));
+    v.X = X->data; v.ldx = X->stride; v.row_stride = ix->row_stride; v.nseg = K; v.Di = Di; v.eff = eff; v.WT = WT; v.Rp = Rp;
+    v.bias = bias; v.H = H->data; v.ldh = H->stride; v.N = N; v.part = sumsq; v.part_cap = sumsq_cap;
+    for (int i = 0; i < K; i++) v.seg_off[i] = (long long)ix->row_offsets[i] * X->stride;
+    TDNNF_REQUIRE(WT && ng_rowdot_ok(v), "ng_stats_pass: the vector-ALU kernel takes rank 20 / 40 / 80 and 16-byte aligned rows");
+    TDNNF_HIP(ng_rowdot(v, s));
+    return TDNNF_OK;
+  }
+  TDNNF_REQUIRE(W && ldw >= K * Di, "ng_stats_pass: the MFMA form needs W (rank x ldw)");
+  GemmPrecisionScope exact_f32(2);
+  RowsGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = X->data; a.lda = (long long)X->stride * ix->row_stride; a.B = W; a.ldb = ldw; a.C = H->data; a.ldc = H->stride; a.M = N; a.N = Rp;
+  a.bias = bias; a.init_mode = bias ? 1 : 2; a.coef = eff; a.sumsq = sumsq; a.nseg = K;
+  for (int i = 0; i < K; i++) {
+    a.seg[i].a_off = (long long)ix->row_offsets[i] * X->stride;
+    a.seg[i].b_off = (long long)i * Di;
+    a.seg[i].klen = Di;
+    a.seg[i].m_lo = 0;
+    a.seg[i].m_hi = N;
+  }
+  TDNNF_HIP(rows_gemm(a, true, s));
+  return TDNNF_OK;
+}
 
 int tdnnf_ng_create(int rank, int update_period, float num_samples_history, float alpha, tdnnf_ng **out) {
   TDNNF_REQUIRE(out && rank >= 0 && update_period >= 1 && num_samples_history > 0 && alpha >= 0, "ng_create: bad configuration");
