@@ -308,10 +308,14 @@ int tdnnf_ng_precondition(tdnnf_ng *, tdnnf_mat *X, float *scale_host, tdnnf_str
    H (N x rank, ld = H->stride) = X~ WT, row m of X~ = the concatenation over the taps of eff[i] * X[m * ix->row_stride + ix->row_offsets[i]]
    (Di columns each; eff_dev NULL = ones) [+ bias_dev: the row of W_t^T that meets the appended column of ones]; WT_dev is W_t^T, (taps * Di) x
    rank, k-major, followed by at least 64 finite rows; sumsq_dev (NULL or sumsq_cap doubles): their sum = ||X~||_F^2.  use_valu != 0: the
-   vector-ALU kernel (csrc/ng_valu.hip; rank 20 / 40 / 80, TDNNF_EINVAL otherwise), 0: the MFMA rows GEMM (needs W_dev = W_t, rank x ldw). */
+   form: 0 the MFMA rows GEMM, one tap after the other (needs W_dev = W_t, rank x ldw); 1 the vector-ALU kernel (csrc/ng_valu.hip; rank 20 / 40 / 80,
+   TDNNF_EINVAL otherwise); 2 the one-pass form for taps that are row shifts of one matrix (csrc/ng.hip pform_pass: P = X [W_0^T | W_1^T ..], then
+   H[m] = sum_i P[m + o_i][block i]; taps whole 128-row tiles apart, N % 128 == 0, N >= 32768, taps x rank <= 64, H dense; needs W_dev and
+   workspace_dev of tdnnf_ng_stats_pass_workspace_bytes()). */
+size_t tdnnf_ng_stats_pass_workspace_bytes(int rank, int Di, int num_taps, int N);
 int tdnnf_ng_stats_pass(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *X, int Di, const float *eff_dev, const float *WT_dev,
-                        const float *W_dev, int ldw, const float *bias_dev, tdnnf_mat *H, double *sumsq_dev, int sumsq_cap, int use_valu,
-                        tdnnf_stream);
+                        const float *W_dev, int ldw, const float *bias_dev, tdnnf_mat *H, double *sumsq_dev, int sumsq_cap, int form,
+                        void *workspace_dev, size_t workspace_bytes, tdnnf_stream);
 /* device float holding the scale of the object's last tdnnf_ng_precondition call (NULL before the first call) */
 const float *tdnnf_ng_scale_dev(const tdnnf_ng *);
 

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
     double *red = reinterpret_cast<double *>(smem);
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    if (t == 0) p.sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t == 0) p.sumsq[p.ksplit > 1 ? (int)blockIdx.x : bid] = (red[0] + red[1]) + (red[2] + red[3]);  // (no K split: entry = row tile)
     if (blockIdx.x == 0)  // entries no block owns (the array is sized for a split-K launch)
       for (int i = gridDim.x + t; i < p.sumsq_cap; i += 256) p.sumsq[i] = 0.0;
     __syncthreads();
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void rows_gemm_x3_kernel(const RowsGemmArgs
     double *red = reinterpret_cast<double *>(smem);
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    if (t == 0) p.sumsq[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (t == 0) p.sumsq[p.ksplit > 1 ? (int)blockIdx.x : bid] = (red[0] + red[1]) + (red[2] + red[3]);  // (no K split: entry = row tile)
     if (blockIdx.x == 0)  // entries no block owns (the array is sized for a split-K launch)
       for (int i = gridDim.x + t; i < p.sumsq_cap; i += 256) p.sumsq[i] = 0.0;
     __syncthreads();
@@ -1515,6 +1515,8 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     ProfScope ps(0, flops, s);
     // (option ng_bk: 1 = K steps twice as long for these HBM-bound passes -- twice the bytes in flight per resident block)
     if (a.N <= 32) return (options().ng_bk & 1) ? launch_rows_sumsq<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 1, 32>(a, b_kc, vec, s);
+    if (a.N <= 64 && a.N > 32 && (options().ng_bk & 8) == 0) return launch_rows_sumsq<4, 1, 1, 2, 32>(a, b_kc, vec, s);  // both taps' rank-20 products side by side (ng.hip, P form)
+    if (a.N <= 96 && (options().ng_bk & 4)) return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);  // (measured: the 128 x 128 tile with 48 idle columns)
     if (a.N <= 96) return (options().ng_bk & 2) ? launch_rows_sumsq<4, 1, 1, 3, 32>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
     return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);
   }

@@ -162,6 +162,9 @@ struct tdnnf_net {
   void *ws2;           // the same for components whose weight gradients go to the denominator's stream (wg_two)
   float *s2_scratch;
   float *s4_scratch;   // split-K scratch of the GEMMs launched on s4
+  hipStream_t s5 = nullptr;  // option wgrad_stream 3: a third weight-gradient stream with its workspace and split-K scratch
+  void *ws5 = nullptr;
+  float *s5_scratch = nullptr;
   // Input-side natural-gradient statistics ahead of the backward pass: H_in = X~ W_x^T (and J = H^T X on refresh steps) of a component
   // needs its forward input and the preconditioner state only, so from the second grouped minibatch on they are launched on s4 as soon as
   // the forward pass is enqueued -- beside the denominator and the xent head, HBM-bound work beside MFMA-bound work -- with the

@@ -555,6 +555,10 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   const bool two = n->wg_on && options().wgrad_stream != 1;  // (option wgrad_stream: 1 = one weight-gradient stream as rounds 2-3, 2 = two, -1 = by size, two)
   n->ws2 = two ? A.take<char>(n->ws_bytes) : nullptr;
   n->s2_scratch = two ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
+  // (option wgrad_stream 3: a third weight-gradient stream, s5 -- beside s4 from the start of the backward pass, beside s4 and s2 once the denominator has joined)
+  const bool three = two && options().wgrad_stream == 3;
+  n->ws5 = three ? A.take<char>(n->ws_bytes) : nullptr;
+  n->s5_scratch = three ? A.take<float>(n->s4_scratch_bytes / sizeof(float)) : nullptr;
 }
 
 // diagnostics: phase boundary k of the step (option phase_events)
@@ -916,6 +920,7 @@ static int net_create_impl(const tdnnf_net_config *cfg, const tdnnf_net *share, 
   n->ev_s3 = nullptr;
   n->ev_fin0 = n->ev_fin = nullptr;
   n->s4 = nullptr;
+  n->s5 = nullptr;
   n->ev_pg[0] = n->ev_pg[1] = n->ev_pg[2] = n->ev_pg[3] = n->ev_pg_in = nullptr;
   n->pg_count = 0;
   if (hipMalloc((void **)&n->arena, n->arena_bytes) != hipSuccess) {
@@ -968,6 +973,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (!n) return;
   if (n->s3) hipStreamSynchronize(n->s3);  // its kernels use the preconditioners' buffers
   if (n->s4) hipStreamSynchronize(n->s4);
+  if (n->s5) hipStreamSynchronize(n->s5);
   if (n->s2) hipStreamSynchronize(n->s2);
   for (auto &nb : n->ng_buckets) ng_group_destroy(nb.group);
   ng_fin_destroy(n->ngfin);
@@ -994,6 +1000,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg[2], n->ev_pg[3], n->ev_pg_in, n->ev_early_in, n->ev_early, n->ev_comm})
     if (e) hipEventDestroy(e);
   if (n->s4) hipStreamDestroy(n->s4);
+  if (n->s5) hipStreamDestroy(n->s5);
   for (hipEvent_t e : n->ev_phase)
     if (e) hipEventDestroy(e);
   upd_group_destroy(n->upd);
@@ -1264,6 +1271,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (n->early_on && !n->wg_on) TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
     if (n->wg_on) {
       TDNNF_HIP(hipStreamCreateWithFlags(&n->s4, hipStreamNonBlocking));
+      if (n->ws5) TDNNF_HIP(hipStreamCreateWithFlags(&n->s5, hipStreamNonBlocking));
       for (int i = 0; i < 4; i++) TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg[i], hipEventDisableTiming));
       TDNNF_HIP(hipEventCreateWithFlags(&n->ev_pg_in, hipEventDisableTiming));
     }
@@ -1699,14 +1707,14 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   // the components' commits run on the side stream, so the bucket's commit follows them there.
   // (forward declaration of the natural-gradient group chain of the components enqueued since the last bucket closed)
   std::function<int(int)> ng_close;
+  auto side_streams = [&]() -> unsigned { return 1u + (n->wg_two ? 1u : 0u) + (n->s5 ? 1u : 0u); };  // weight-gradient streams in use now (<= 3 <= the event ring's lag)
   auto close_bucket = [&](int key) -> int {
     if (use_ng) CK(ng_close(key));
     for (auto &gb : n->buckets) {
       if (gb.close_key != key) continue;
       hipStream_t cs = s;
       if (!use_ng && n->wg_on && n->pg_count > 0) {  // the components' gradients were formed on s4 (and s2)
-        TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 3], 0));
-        if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 2) & 3], 0));
+        for (unsigned b = 1; b <= side_streams() && b <= n->pg_count; b++) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - b) & 3], 0));
       }
       if (use_ng) {
         TDNNF_HIP(hipEventRecord(gb.handoff, s));  // s-side writes of the range (bias sums, architecture parameters) are done
@@ -1749,14 +1757,18 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // queued on s4 in front of them -- form their gradients on the caller's stream, which waits for the denominator anyway)
     const bool on_caller = n->wg_on && options().wgrad_on_caller != 0 && n->early_any && !den_joined;
     if (on_caller) caller_used = true;
-    const bool on_s2 = n->wg_on && n->wg_two && (n->pg_count & 1);
+    // which of the weight-gradient streams: s4 [s5] before the denominator's join, s4 s2 [s5] in turn after it
+    float *scr = nullptr;
     if (n->wg_on && !on_caller) {
-      sw = on_s2 ? n->s2 : n->s4;
-      wsw = on_s2 ? n->ws2 : n->ws4;
+      const int ns = (n->wg_two ? 2 : 1) + (n->s5 ? 1 : 0), k = (int)(n->pg_count % (unsigned)ns);
+      const int which = k == 0 ? 0 : (k == 1 && n->wg_two) ? 1 : 2;  // 0: s4, 1: s2, 2: s5
+      sw = which == 0 ? n->s4 : which == 1 ? n->s2 : n->s5;
+      wsw = which == 0 ? n->ws4 : which == 1 ? n->ws2 : n->ws5;
+      scr = which == 0 ? n->s4_scratch : which == 1 ? n->s2_scratch : n->s5_scratch;
       TDNNF_HIP(hipEventRecord(n->ev_pg_in, s));
       TDNNF_HIP(hipStreamWaitEvent(sw, n->ev_pg_in, 0));
     }
-    SplitKScratchOverride sw_scratch(n->wg_on && !on_caller ? (on_s2 ? n->s2_scratch : n->s4_scratch) : nullptr, n->wg_on && !on_caller ? n->s4_scratch_bytes : 0);
+    SplitKScratchOverride sw_scratch(scr, scr ? n->s4_scratch_bytes : 0);
     // after this component is enqueued the caller's stream may only run ahead of it, not of the one before: what that one reads
     // (derivative scratch, the bias sums) is rewritten from here on
     auto handed_off = [&]() -> int {
@@ -1870,8 +1882,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     TDNNF_REQUIRE(nb->comps == n->ng_cur, "net_forward_backward: the components of gradient bucket %d changed between minibatches", key);
     // behind the last component's passes (on the weight-gradient stream when that is on)
     if (n->wg_on && n->pg_count > 0) {
-      TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - 1) & 3], 0));
-      if (n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - 2) & 3], 0));  // (the other stream's last component)
+      // (the last component of every weight-gradient stream in use)
+      for (unsigned b = 1; b <= side_streams() && b <= n->pg_count; b++) TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_pg[(n->pg_count - b) & 3], 0));
       if (caller_used) {
         TDNNF_HIP(hipEventRecord(n->ev_ngc, s));
         TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_ngc, 0));
@@ -2145,8 +2157,8 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   }
   CK(close_bucket(-1));
   CK(phase_mark(n, 4, s));
-  if (n->wg_on && n->pg_count > 0) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 1) & 3], 0));  // join the weight-gradient stream
-  if (n->wg_on && n->wg_two && n->pg_count > 1) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - 2) & 3], 0));  // (and the second one)
+  if (n->wg_on)  // join the weight-gradient streams
+    for (unsigned b = 1; b <= 3 && b <= n->pg_count; b++) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_pg[(n->pg_count - b) & 3], 0));
   n->wg_two = false;
   if (use_ng) {  // join the side stream: every bucket has been committed into grads
     TDNNF_HIP(hipEventRecord(n->ev_s3, n->s3));

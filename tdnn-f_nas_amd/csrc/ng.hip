@@ -49,6 +49,39 @@ __global__ void derive_kernel(const float *W, int Rp, int D, int Dp, float *WT, 
     if (dd == D - 1) wlast[r] = v;
   }
 }
+// WP[(i * Rp + r) * Di + k] = W[r * Dp + i * Di + k]: the taps' blocks of W_t one below the other (K Rp x Di, k contiguous)
+__global__ void stack_taps_kernel(const float *W, int Rp, int Dp, int Di, int K, float *WP) {
+  const long long total = (long long)K * Rp * Di;
+  for (long long e = blockIdx.x * 256LL + threadIdx.x; e < total; e += gridDim.x * 256LL) {
+    const int k = (int)(e % Di), ir = (int)(e / Di), i = ir / Rp, r = ir % Rp;
+    WP[e] = W[(size_t)r * Dp + (size_t)i * Di + k];
+  }
+}
+// H[m][r] = sum_i P[m + o_i][i * Rp + r] (+ bias[r]);  part[b] = sum_i psum[b + o_i / 128] for the 128-row block b (o_i % 128 == 0)
+struct PformTaps {
+  int K, o[kMaxSeg];
+};
+__global__ __launch_bounds__(256) void pform_combine_kernel(const float *P, int ldp, PformTaps tp, int Rp, const float *bias, float *H, int N,
+                                                            const double *psum, double *part, int part_cap) {
+  const int m0 = blockIdx.x * 128, per = Rp / 4;  // float4 per row of H
+  for (int e = threadIdx.x; e < 128 * per; e += 256) {
+    const int m = m0 + e / per, q = e % per;
+    if (m >= N) break;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) v = *reinterpret_cast<const float4 *>(bias + 4 * q);
+    for (int i = 0; i < tp.K; i++) {
+      const float4 t = *reinterpret_cast<const float4 *>(P + (size_t)(m + tp.o[i]) * ldp + i * Rp + 4 * q);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    *reinterpret_cast<float4 *>(H + (size_t)m * Rp + 4 * q) = v;
+  }
+  if (threadIdx.x == 0) {
+    double sacc = 0;
+    for (int i = 0; i < tp.K; i++) sacc += psum[blockIdx.x + tp.o[i] / 128];
+    part[blockIdx.x] = sacc;
+  }
+  for (int i = gridDim.x + blockIdx.x * 256 + threadIdx.x; i < part_cap; i += gridDim.x * 256) part[i] = 0.0;
+}
 __global__ void scatter_col_kernel(const float *v, int R, float *J, int ld, int col) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < R) J[(size_t)r * ld + col] = v[r];
@@ -372,9 +405,17 @@ int finalize(tdnnf_ng *ng, hipStream_t s) {
   return derive(ng, s);
 }
 
+// P form of H = X~ W^T for K taps that are row shifts of ONE matrix: P = X [W_0^T | W_1^T | ...] in one pass over X (each row read
+// once instead of K times), then H[m] = sum_i P[m + o_i][block i].  Workspace: W's blocks stacked, P, the pass's per-tile ||x||^2.
+constexpr int kPformSpanCap = 4096;  // rows between the first and the last tap (<= 2 x 3 frames x 512 sequences)
+size_t pform_ws_bytes(int Rp, int Di, int K, int N) {
+  if (K < 2 || K * Rp > 64) return 0;
+  const size_t M = (size_t)N + kPformSpanCap;
+  return sizeof(float) * ((size_t)K * Rp * Di + 64) + sizeof(float) * (M * K * Rp + 64) + sizeof(double) * ((size_t)rows_gemm_sumsq_blocks((int)M) + 8) + 256;
+}
 size_t stats_ws_bytes(int Rp, int Di, int K, int N) {
   const size_t part = ((size_t)rows_gemm_sumsq_blocks(N) * sizeof(double) + 63) & ~(size_t)63;
-  return part + std::max(wgrad_workspace_bytes(Rp, Rp, 1, N), wgrad_workspace_bytes(Rp, Di, K, N));
+  return part + std::max(std::max(wgrad_workspace_bytes(Rp, Rp, 1, N), wgrad_workspace_bytes(Rp, Di, K, N)), pform_ws_bytes(Rp, Di, K, N));
 }
 
 // What follows H in the first half: the bookkeeping of the call in flight and, on a refresh, J = H^T X.
@@ -395,6 +436,51 @@ int stats_after_h(tdnnf_ng *ng, const NgInput &in, const float *H, void *wg_ws, 
   j.active = in.active; j.max_active = in.max_active;
   TDNNF_HIP(wgrad(j, wg_ws, wg_bytes, s));  // J = H^T X  (last column: column sums of H)
   if (in.ones) hipLaunchKernelGGL(scatter_col_kernel, dim3((Rp + 63) / 64), dim3(64), 0, s, ng->tmpR, Rp, ng->J, Dp, D - 1);
+  return TDNNF_OK;
+}
+
+// (see pform_ws_bytes)  Applies to: taps of one matrix at rows 128 apart in whole tiles (o_i % 128 == 0, N % 128 == 0: the pass's
+// per-tile ||x||^2 then add up to each tap's window exactly), no tap coefficients, every row a row of X (row_stride 1), minibatches
+// whose passes are bound by the read of X (>= 32 768 rows; below, the K-tap kernel's rows are latency-bound launches either way).
+bool pform_ok(int Rp, const NgInput &in, size_t ws_bytes) {
+  const int K = in.ix.num_offsets, N = in.N;
+  if (!options().ng_pform || K < 2 || K * Rp > 64 || in.eff || in.active || in.ix.row_stride != 1 || N % 128 != 0 || N < 32768) return false;
+  int lo = in.ix.row_offsets[0], hi = lo;
+  for (int i = 1; i < K; i++) {
+    lo = std::min(lo, in.ix.row_offsets[i]);
+    hi = std::max(hi, in.ix.row_offsets[i]);
+  }
+  for (int i = 0; i < K; i++)
+    if ((in.ix.row_offsets[i] - lo) % 128 != 0) return false;
+  if (hi - lo > kPformSpanCap || in.Di % 4 != 0 || (in.x.stride % 4) != 0 || in.Di < 1024) return false;  // (narrow matrices -- 160 columns -- measured slower: 78 against 61 us)
+  return ws_bytes >= pform_ws_bytes(Rp, in.Di, K, N);
+}
+// W: rank_padded x ldw (row r = [tap 0's Di columns | tap 1's | ... | the ones' column]); bias: that last column, or null
+int pform_pass(const float *W, int Rp, int Dp, const float *bias, const NgInput &in, float *H, double *part, void *ws, hipStream_t s) {
+  const int K = in.ix.num_offsets, N = in.N, Di = in.Di;
+  PformTaps tp;
+  memset(&tp, 0, sizeof(tp));
+  tp.K = K;
+  int lo = in.ix.row_offsets[0], hi = lo;
+  for (int i = 1; i < K; i++) {
+    lo = std::min(lo, in.ix.row_offsets[i]);
+    hi = std::max(hi, in.ix.row_offsets[i]);
+  }
+  for (int i = 0; i < K; i++) tp.o[i] = in.ix.row_offsets[i] - lo;
+  const int M = N + (hi - lo);
+  float *WP = (float *)ws;
+  float *P = WP + (((size_t)K * Rp * Di + 63) & ~(size_t)63);
+  double *psum = (double *)(P + (((size_t)M * K * Rp + 63) & ~(size_t)63));
+  hipLaunchKernelGGL(stack_taps_kernel, dim3(grid_for((long long)K * Rp * Di, 256)), dim3(256), 0, s, W, Rp, Dp, Di, K, WP);
+  RowsGemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = in.x.data + (size_t)lo * in.x.stride; a.lda = in.x.stride; a.B = WP; a.ldb = Di; a.C = P; a.ldc = K * Rp; a.M = M; a.N = K * Rp;
+  a.init_mode = 2; a.sumsq = psum; a.nseg = 1;
+  a.seg[0].klen = Di; a.seg[0].m_lo = 0; a.seg[0].m_hi = M;
+  TDNNF_HIP(rows_gemm(a, true, s));  // P = X [W_0^T | W_1^T ...]  (+ ||x||^2 per 128-row tile)
+  hipLaunchKernelGGL(pform_combine_kernel, dim3(N / 128), dim3(256), 0, s, P, K * Rp, tp, Rp, bias, H, N, psum, part,
+                     rows_gemm_sumsq_blocks(N));
+  TDNNF_HIP(hipGetLastError());
   return TDNNF_OK;
 }
 
@@ -427,6 +513,9 @@ int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg
   if (skip && ng->D != 0 && (((skip & 1) && K == 2 && Di >= 1024) || ((skip & 2) && !(K == 2 && Di >= 1024)))) {
     TDNNF_HIP(hipMemsetAsync(H, 0, sizeof(float) * (size_t)N * Rp, s));
     TDNNF_HIP(hipMemsetAsync(part, 0, sizeof(double) * rows_gemm_sumsq_blocks(N), s));
+  } else if (pform_ok(Rp, in, wg_bytes)) {
+    int rc = pform_pass(ng->W, Rp, Dp, in.ones ? ng->wlast : nullptr, in, H, part, wg_ws, s);
+    if (rc) return rc;
   } else if (options().ng_valu && !in.active && ng_rowdot_ok(v)) {
     TDNNF_HIP(ng_rowdot(v, s));
   } else {
@@ -640,8 +729,11 @@ extern "C" {
 
 const float *tdnnf_ng_scale_dev(const tdnnf_ng *ng) { return ng && ng->dev ? ng->scale_f : nullptr; }
 
+size_t tdnnf_ng_stats_pass_workspace_bytes(int rank, int Di, int num_taps, int N) { return pform_ws_bytes((rank + 3) & ~3, Di, num_taps, N) + 64; }
+
 int tdnnf_ng_stats_pass(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *X, int Di, const float *eff, const float *WT, const float *W, int ldw,
-                        const float *bias, tdnnf_mat *H, double *sumsq, int sumsq_cap, int use_valu, tdnnf_stream stream) {
+                        const float *bias, tdnnf_mat *H, double *sumsq, int sumsq_cap, int use_valu, void *workspace, size_t workspace_bytes,
+                        tdnnf_stream stream) {
   TDNNF_REQUIRE(ix && X && X->data && H && H->data && Di > 0 && ix->num_offsets >= 1 && ix->num_offsets <= kMaxSeg && ix->row_stride >= 1,
                 "ng_stats_pass: bad arguments");
   const int K = ix->num_offsets, N = H->rows, Rp = H->cols;
@@ -650,6 +742,14 @@ int tdnnf_ng_stats_pass(const tdnnf_tdnn_indexes *ix, const tdnnf_mat *X, int Di
                   "ng_stats_pass: tap %d reads outside X (%d x %d)", i, X->rows, X->cols);
   TDNNF_REQUIRE(!sumsq || sumsq_cap >= rows_gemm_sumsq_blocks(N), "ng_stats_pass: sumsq needs %d entries", rows_gemm_sumsq_blocks(N));
   hipStream_t s = (hipStream_t)stream;
+  if (use_valu == 2) {  // the P form: one pass over X for all taps
+    NgInput in;
+    memset(&in, 0, sizeof(in));
+    in.x = view(X); in.ix = *ix; in.Di = Di; in.ones = bias ? 1 : 0; in.N = N; in.eff = eff;
+    TDNNF_REQUIRE(W && ldw >= K * Di && sumsq && H->stride == Rp && workspace && pform_ok(Rp, in, workspace_bytes),
+                  "ng_stats_pass: the one-pass form takes >= 2 taps of one matrix whole 128-row tiles apart, N %% 128 == 0, N >= 32768, taps x rank <= 64, no coefficients");
+    return pform_pass(W, Rp, ldw, bias, in, H->data, sumsq, workspace, s);
+  }
   if (use_valu) {
     NgRowdotArgs v;
     memset(&v, 0, sizeof(v));

@@ -64,7 +64,7 @@ def test_stats_pass_on_the_vector_alus(hip, pkg, R, N, offs, rs, Di, ones, use_e
         H = torch.full((N, R), float("nan"), device="cuda")
         part = torch.full((cap,), float("nan"), dtype=torch.float64, device="cuda")
         hip.ng_stats_pass(C.byref(ix), xbuf[:, :Di], Di, hip.vec(effd) if use_eff else None, hip.vec(wt), hip.vec(wd), ldw,
-                          hip.vec(bias) if ones else None, H, hip.vec(part), cap, valu, hip.stream())
+                          hip.vec(bias) if ones else None, H, hip.vec(part), cap, valu, None, 0, hip.stream())
         out[valu] = (host(H), float(host(part).sum()))
         assert np.isfinite(out[valu][0]).all()
         assert rel_l2(out[valu][0], ref) < 2e-6, valu
@@ -78,4 +78,45 @@ def test_stats_pass_rejects_other_ranks(hip, pkg):
     wt = torch.zeros((32 + 64, 12), device="cuda")
     H = torch.zeros((64, 12), device="cuda")
     with pytest.raises(pkg.hipabi.HipAbiError, match="rank 20 / 40 / 80"):
-        hip.ng_stats_pass(C.byref(ix), X, 32, None, hip.vec(wt), None, 0, None, H, None, 0, 1, hip.stream())
+        hip.ng_stats_pass(C.byref(ix), X, 32, None, hip.vec(wt), None, 0, None, H, None, 0, 1, None, 0, hip.stream())
+
+
+@pytest.mark.parametrize("offs,ones", [((0, 256), False), ((128, 0, 384), True)])
+def test_stats_pass_one_pass_over_the_taps(hip, pkg, offs, ones):
+    """K taps that are row shifts of one matrix (a .linear's spliced input): P = X [W_0^T | W_1^T ..] in one pass, H[m] = sum_i P[m + o_i][block i],
+    the taps' ||x||^2 from the pass's per-tile sums -- against float64 and the tap-by-tap MFMA pass."""
+    rng = np.random.default_rng(len(offs))
+    R, N, Di, K = 20, 32768 + 128, 1024, len(offs)
+    rows_x = N + max(offs)
+    ldx = Di + 32
+    xbuf = torch.full((rows_x, ldx), float("nan"), device="cuda")
+    X = rng.standard_normal((rows_x, Di)).astype(F)
+    xbuf[:, :Di] = dev(X)
+    D = K * Di + (1 if ones else 0)
+    W = (rng.standard_normal((R, D)) / np.sqrt(D)).astype(F)
+    ldw = ((D + 3) // 4) * 4
+    wd = torch.zeros((R, ldw), device="cuda")
+    wd[:, :D] = dev(W)
+    bias = dev(np.ascontiguousarray(W[:, D - 1])) if ones else None
+    cap = max(1024, (N + 127) // 128)
+    ix = pkg.hipabi.indexes(1, offs)
+    ref = np.zeros((N, R))
+    sq = 0.0
+    for i, o in enumerate(offs):
+        xi = X[o:o + N].astype(np.float64)
+        ref += xi @ W[:, i * Di:(i + 1) * Di].astype(np.float64).T
+        sq += (xi * xi).sum()
+    if ones:
+        ref += W[:, D - 1].astype(np.float64)
+    nb = hip.lib.tdnnf_ng_stats_pass_workspace_bytes(R, Di, K, N)
+    ws = hip.ws(nb)
+    out = {}
+    for form in (2, 0):
+        H = torch.full((N, R), float("nan"), device="cuda")
+        part = torch.full((cap,), float("nan"), dtype=torch.float64, device="cuda")
+        hip.ng_stats_pass(C.byref(ix), xbuf[:, :Di], Di, None, None, hip.vec(wd), ldw, hip.vec(bias) if ones else None, H, hip.vec(part), cap, form,
+                          hip.vec(ws), nb, hip.stream())
+        out[form] = (host(H), float(host(part).sum()))
+        assert rel_l2(out[form][0], ref) < 2e-6, form
+        assert abs(out[form][1] - sq) < 1e-6 * sq, form
+    assert rel_l2(out[2][0], out[0][0]) < 2e-6

@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 abi = importlib.import_module("tdnn-f_nas_amd.hipabi")
 lib = abi.load()
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+for kv in sys.argv[2:]:  # further arguments: library options NAME=VALUE
+    k, v = kv.split("=")
+    abi.check(lib.tdnnf_set_option(k.encode(), int(v)))
 # (name, rank, rows N, row offsets, Di)
 SHAPES = [
     ("linear in, full rate 1500x128", 20, 200192, (0, 256), 1536),
@@ -39,10 +42,13 @@ for name, R, N, offs, Di in SHAPES:
     ix = abi.indexes(1, offs)
     ref = None
     line = "%-34s N %6d D %5d R %2d :" % (name, N, D, R)
-    for valu in (0, 1):
+    nb = lib.tdnnf_ng_stats_pass_workspace_bytes(R, Di, K, N)
+    ws = torch.zeros((nb // 4 + 16,), device="cuda")
+    forms = (0, 1, 2) if (K > 1 and N % 128 == 0 and N >= 32768 and all(o % 128 == 0 for o in offs)) else (0, 1)
+    for valu in forms:
         def run():
             abi.check(lib.tdnnf_ng_stats_pass(C.byref(ix), abi.pmat(X[:, :Di]), Di, None, abi.ptr(wt), abi.ptr(W), ldw, None, abi.pmat(H), abi.ptr(part), cap,
-                                              valu, abi.stream()))
+                                              valu, abi.ptr(ws), nb, abi.stream()))
         run()
         torch.cuda.synchronize()
         if ref is None:
@@ -57,5 +63,5 @@ for name, R, N, offs, Di in SHAPES:
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / reps
         gb = 4.0 * ((N + max(offs)) * Di + N * R) / 1e9
-        line += "  %s %7.1f us %5.1f TFLOP/s %5.2f TB/s" % ("valu" if valu else "mfma", us, 2.0 * N * D * R / us / 1e6, gb / us * 1e6 / 1e3)
+        line += "  %s %7.1f us %5.1f TFLOP/s %5.2f TB/s" % (("mfma", "valu", "1pass")[valu], us, 2.0 * N * D * R / us / 1e6, gb / us * 1e6 / 1e3)
     print(line + "  rel diff %.1e" % err)

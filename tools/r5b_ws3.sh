@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT"
+{
+timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-also --no-alt --chunk 150 --minibatch 64 --steps 8 --option wgrad_stream=3 2>&1 | tail -1 | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('parity', d.get('parity'), d['ms_per_step'])"
+bash tools/r5_ab.sh 3 "" "--option wgrad_stream=3"
+} 2>&1 | tee gpurun_out/r5b_ws3.txt
