@@ -47,7 +47,7 @@ inline bool vec4_ok(const MatView &m) {
 struct Options {
   int ng_grouped = 1;     // natural gradient: 1 the side chain of a gradient bucket as grouped launches, 0 per object (read by tdnnf_net_create)
   int ng_fuse = 1;        // output-side statistic H = dY Wy^T: 0 by its own GEMM, 1 inside the BatchNorm / ReLU backward sweep when that pays, 2 always
-  int ng_early_in = 1;    // input-side statistics ahead of the backward pass (read by tdnnf_net_create)
+  int ng_early_in = 1;    // input-side statistics ahead of the backward pass: 0 never, 1 for minibatches without the weight-gradient streams, 2 always (a launch per component), 3 always, with the weight-gradient streams as ONE grouped launch (read by tdnnf_net_create)
   int wgrad_stream = -1;  // parameter gradients on a stream of their own: -1 by minibatch size, 0 off, 1 on (read by tdnnf_net_create)
   int gemm_ring = 1;      // the persistent LDS-DMA-ring form of the rows GEMM where it applies
   int planes = 1;         // gemm_precision 2: the pre-split bf16-plane GEMMs where they apply (0: the in-kernel split everywhere)
@@ -116,18 +116,34 @@ __device__ __forceinline__ void finalize_sums(const float *partial, int chunks, 
 #pragma unroll
   for (int k = 0; k < NQ; k++) q[k] = 0;
   if (d < D) {
-    for (int k = 0; k < NQ; k++) {
-      if (k >= nq) break;
-      const float *p = partial + (long long)k * qstride_rows * D + d;
-      Acc s = 0;
-      int c = lane;
-      for (; c + 3 * kFinLanes < chunks; c += 4 * kFinLanes) {
-        const float v0 = p[(long long)c * D], v1 = p[(long long)(c + kFinLanes) * D], v2 = p[(long long)(c + 2 * kFinLanes) * D],
-                    v3 = p[(long long)(c + 3 * kFinLanes) * D];
-        s += v0; s += v1; s += v2; s += v3;
+    // (the NQ quantities side by side: their loads of a round are issued together -- one after the other, five quantities took 15 us
+    // where two took 5)
+    const float *p = partial + d;
+    const long long qs = qstride_rows * D;
+    int c = lane;
+    for (; c + 3 * kFinLanes < chunks; c += 4 * kFinLanes) {
+      float v[NQ][4];
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        if (k < nq) {
+          const float *pk = p + (long long)k * qs;
+          v[k][0] = pk[(long long)c * D]; v[k][1] = pk[(long long)(c + kFinLanes) * D];
+          v[k][2] = pk[(long long)(c + 2 * kFinLanes) * D]; v[k][3] = pk[(long long)(c + 3 * kFinLanes) * D];
+        }
       }
-      for (; c < chunks; c += kFinLanes) s += p[(long long)c * D];
-      q[k] = s;
+#pragma unroll
+      for (int k = 0; k < NQ; k++) {
+        if (k < nq) { q[k] += v[k][0]; q[k] += v[k][1]; q[k] += v[k][2]; q[k] += v[k][3]; }
+      }
+    }
+    for (; c < chunks; c += kFinLanes) {
+      float v[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; k++)
+        if (k < nq) v[k] = p[(long long)k * qs + (long long)c * D];
+#pragma unroll
+      for (int k = 0; k < NQ; k++)
+        if (k < nq) q[k] += v[k];
     }
   }
 #pragma unroll

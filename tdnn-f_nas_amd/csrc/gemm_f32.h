@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <vector>
+
 namespace tdnnf {
 
 constexpr int kMaxSeg = 16;
@@ -129,6 +131,14 @@ inline int rows_gemm_sumsq_blocks(int M) { return (M + 127) / 128 > 1024 ? (M + 
 
 // b_kcontig: B element (k, n) at B[n*ldb + k] (true) or B[k*ldb + n] (false).
 hipError_t rows_gemm(const RowsGemmArgs &args, bool b_kcontig, hipStream_t stream);
+
+// Several statistics passes (sumsq set, N <= 32, k-contiguous B, 16-byte aligned operands: rows_gemm_group_ok) as ONE launch: task i runs
+// exactly the blocks a launch of its own without K split would.  *cache keeps the device-side task table between calls (null at first;
+// rows_gemm_group_destroy at the end); the table is uploaded again only when the calls differ from the last ones.
+struct RowsGemmGroup;
+bool rows_gemm_group_ok(const RowsGemmArgs &a);
+hipError_t rows_gemm_group(const std::vector<RowsGemmArgs> &calls, RowsGemmGroup **cache, hipStream_t stream);
+void rows_gemm_group_destroy(RowsGemmGroup *g);
 
 // Weight gradient: G[o][i*Di + d] (+)= scale * coef[i] * sum_r dY[r][o] * X[(row_off[i] + r*row_stride)][d]
 struct WgradArgs {

@@ -160,8 +160,9 @@ __device__ __forceinline__ float4 ld4(const float *p, bool v0, bool v1, bool v2,
 // ------------------------------------------------------------------------ rows_gemm
 // TAG only gives the launches of the natural-gradient statistics (ProfClassOverride(3)) their own kernel symbol, so
 // that per-kernel profiler summaries keep them apart from the TDNN-F GEMMs; the code is identical.
-template <int WM, int WN, int TM, int TN, int BK, bool B_KC, int VEC, int TAG = 0>
-__global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, int ntm, int ntn) {
+// (the body of a block: block `bx` of the `gx` blocks that work on `p` -- the whole grid of a plain launch, one task's share of a grouped one)
+template <int WM, int WN, int TM, int TN, int BK, bool B_KC, int VEC>
+__device__ __forceinline__ void rows_gemm_block(const RowsGemmArgs &p, int ntm, int ntn, int bx, int gx) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int LDAS = BK + 4;
   constexpr int LDBS = B_KC ? BK + 4 : BN + 4;
@@ -178,15 +179,15 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
   // XCD a contiguous run of logical tile ids; within it tile_n varies fastest so the blocks
   // that re-read the same A rows (and the taps' neighbouring rows) hit the same L2.
   const int nblk = ntm * ntn;
-  int bid = blockIdx.x;
+  int bid = bx;
   {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, j = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   int sp = 0;
   if (p.ksplit > 1) {  // split-K launch: consecutive block ids share a tile
-    sp = blockIdx.x % p.ksplit;
-    bid = blockIdx.x / p.ksplit;
+    sp = bx % p.ksplit;
+    bid = bx / p.ksplit;
   }
   const long long k_begin = (long long)sp * p.kchunk, k_end = p.ksplit > 1 ? k_begin + p.kchunk : (1LL << 60);
   const int tile_m = bid / ntn, tile_n = bid % ntn;
@@ -415,9 +416,9 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
     double *red = reinterpret_cast<double *>(smem);
     if (lane == 0) red[wave] = v;
     __syncthreads();
-    if (t == 0) p.sumsq[p.ksplit > 1 ? (int)blockIdx.x : bid] = (red[0] + red[1]) + (red[2] + red[3]);  // (no K split: entry = row tile)
-    if (blockIdx.x == 0)  // entries no block owns (the array is sized for a split-K launch)
-      for (int i = gridDim.x + t; i < p.sumsq_cap; i += 256) p.sumsq[i] = 0.0;
+    if (t == 0) p.sumsq[p.ksplit > 1 ? bx : bid] = (red[0] + red[1]) + (red[2] + red[3]);  // (no K split: entry = row tile)
+    if (bx == 0)  // entries no block owns (the array is sized for a split-K launch)
+      for (int i = gx + t; i < p.sumsq_cap; i += 256) p.sumsq[i] = 0.0;
     __syncthreads();
   }
   constexpr bool kColStats = 256 % (BN / 4) == 0 && (HALF * (BN / 4)) % 256 == 0;  // a thread keeps one float4 column group
@@ -553,6 +554,30 @@ __global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, in
       p.colstats[((long long)p.colstats_stride + tile_m) * p.N + n0 + t] = a1;
     }
   }
+}
+
+template <int WM, int WN, int TM, int TN, int BK, bool B_KC, int VEC, int TAG = 0>
+__global__ __launch_bounds__(256) void rows_gemm_kernel(const RowsGemmArgs p, int ntm, int ntn) {
+  rows_gemm_block<WM, WN, TM, TN, BK, B_KC, VEC>(p, ntm, ntn, (int)blockIdx.x, (int)gridDim.x);
+}
+// Grouped launch: task i owns the blocks [first[i], first[i + 1]) and runs them exactly as a launch of its own would (one column tile,
+// no K split: its arguments say so).  The natural-gradient input-side statistics of a whole net at the recipes' minibatch: 33 launches
+// of 26 .. 78 blocks each as one.
+struct RowsGemmTasks {
+  const RowsGemmArgs *args;  // device, ntasks
+  const int *first;          // device, ntasks + 1
+  int ntasks;
+};
+template <int WM, int WN, int TM, int TN, int BK, bool B_KC, int VEC>
+__global__ __launch_bounds__(256) void rows_gemm_group_kernel(RowsGemmTasks g) {
+  int lo = 0, hi = g.ntasks;  // the task whose block range holds blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if ((int)blockIdx.x >= g.first[mid]) lo = mid;
+    else hi = mid;
+  }
+  const int b0 = g.first[lo], nb = g.first[lo + 1] - b0;
+  rows_gemm_block<WM, WN, TM, TN, BK, B_KC, VEC>(g.args[lo], nb, 1, (int)blockIdx.x - b0, nb);
 }
 
 // ------------------------------------------------------------------------ rows_gemm, split-bf16 arithmetic
@@ -1540,6 +1565,80 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     if ((kt <= 512 && a.prec == 0) || a.prec == 3) return launch_rows_balanced<2, 2, 2, 2, 16>(a, b_kc, vec, 0, flops, s);
   }
   return launch_rows_balanced<2, 2, 2, 2, 32>(a, b_kc, vec, 0, flops, s);
+}
+
+// ---- grouped launch of skinny statistics passes (rows_gemm_group_kernel)
+struct RowsGemmGroup {
+  std::vector<RowsGemmArgs> args;  // as uploaded
+  std::vector<int> first;
+  RowsGemmArgs *d_args = nullptr;
+  int *d_first = nullptr;
+  int capacity = 0;
+};
+void rows_gemm_group_destroy(RowsGemmGroup *g) {
+  if (!g) return;
+  if (g->d_args) hipFree(g->d_args);
+  if (g->d_first) hipFree(g->d_first);
+  delete g;
+}
+// what the group kernel takes: exact f32, one 32-column tile with the ||A||^2 by-product, k-contiguous B, 16-byte aligned operands
+bool rows_gemm_group_ok(const RowsGemmArgs &a) {
+  if (a.M <= 0 || a.N <= 0 || a.N > 32 || !a.sumsq || a.nseg <= 0 || a.ksplit > 1 || a.colstats || a.add) return false;
+  bool vec = aligned16(a.A) && aligned16(a.B) && a.lda % 4 == 0 && a.ldb % 4 == 0;
+  for (int i = 0; i < a.nseg; i++) vec = vec && a.seg[i].a_off % 4 == 0 && a.seg[i].b_off % 4 == 0;
+  return vec;
+}
+hipError_t rows_gemm_group(const std::vector<RowsGemmArgs> &calls, RowsGemmGroup **cache, hipStream_t s) {
+  if (calls.empty()) return hipSuccess;
+  if (!*cache) *cache = new RowsGemmGroup();
+  RowsGemmGroup &g = **cache;
+  std::vector<RowsGemmArgs> prep(calls.size());
+  std::vector<int> first(calls.size() + 1, 0);
+  double flops = 0, bytes = 0;
+  for (size_t i = 0; i < calls.size(); i++) {
+    RowsGemmArgs a = calls[i];
+    if (!rows_gemm_group_ok(a)) return hipErrorInvalidValue;
+    a.c_vec = aligned16(a.C) && a.ldc % 4 == 0 && (a.init_mode != 1 || aligned16(a.bias));
+    a.sumsq_cap = rows_gemm_sumsq_blocks(a.M);
+    a.serial_epilogue = 0;
+    a.ksplit = 0;
+    a.partial = nullptr;
+    a.prec = 0;
+    a.colstats = nullptr;
+    a.colstats_rows = nullptr;
+    a.alt_seg_order = options().gemm_alt_taps && a.nseg == 2 && a.seg[0].klen == a.seg[1].klen && a.lda > 0 && a.seg[0].a_off != a.seg[1].a_off &&
+                      (a.seg[1].a_off - a.seg[0].a_off) % a.lda == 0;
+    prep[i] = a;
+    first[i + 1] = first[i] + (a.M + 127) / 128;
+    double kt = 0;
+    for (int j = 0; j < a.nseg; j++) kt += a.seg[j].klen;
+    flops += 2.0 * a.M * a.N * kt;
+    bytes += 4.0 * ((double)a.M * kt + kt * a.N + (double)a.M * a.N);
+  }
+  const bool same = g.args.size() == prep.size() && memcmp(g.args.data(), prep.data(), sizeof(RowsGemmArgs) * prep.size()) == 0 && g.first == first;
+  if (!same) {  // (fixed shapes and buffers: uploaded once; the copy is ordered on the launch's stream)
+    if (g.capacity < (int)prep.size()) {
+      if (g.d_args) hipFree(g.d_args);
+      if (g.d_first) hipFree(g.d_first);
+      hipError_t e = hipMalloc((void **)&g.d_args, sizeof(RowsGemmArgs) * prep.size());
+      if (e != hipSuccess) return e;
+      e = hipMalloc((void **)&g.d_first, sizeof(int) * (prep.size() + 1));
+      if (e != hipSuccess) return e;
+      g.capacity = (int)prep.size();
+    }
+    g.args = prep;
+    g.first = first;
+    hipError_t e = hipMemcpyAsync(g.d_args, g.args.data(), sizeof(RowsGemmArgs) * prep.size(), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(g.d_first, g.first.data(), sizeof(int) * first.size(), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+  }
+  constexpr int BK = 32;
+  const size_t lds = sizeof(float) * 2 * (128 * (BK + 4) + 32 * (BK + 4));
+  ProfGemmRange prof(3, flops, bytes, s);
+  RowsGemmTasks t{g.d_args, g.d_first, (int)prep.size()};
+  hipLaunchKernelGGL((rows_gemm_group_kernel<4, 1, 1, 1, BK, true, 4>), dim3(first.back()), dim3(256), lds, s, t);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------- wgrad

@@ -13,6 +13,7 @@
 #include "tdnnf_hip.h"
 
 namespace tdnnf {
+struct RowsGemmGroup;  // gemm_f32.h
 
 struct NgGroup;
 struct NgFin;
@@ -176,6 +177,8 @@ struct tdnnf_net {
   std::vector<EarlyIn> early;
   long long fb_count = 0;
   bool early_on = false, early_any = false;
+  bool early_group = false;                    // the early passes as ONE grouped launch on s4 (minibatches with the weight-gradient streams)
+  tdnnf::RowsGemmGroup *early_launch = nullptr;  // its device-side task table
   hipEvent_t ev_early_in = nullptr, ev_early = nullptr;
   size_t s4_scratch_bytes;
   bool wg_two;  // this step, from the denominator's join on: weight-gradient components alternate between s4 and s2

@@ -547,7 +547,11 @@ void layout_arena(tdnnf_net *n, Arena &A) {
   // (input-side statistics ahead of the backward pass: for minibatches whose GEMMs fill the chip.  With the weight-gradient streams three
   // components behind the caller's stream the small minibatches lose by it -- 150 x 64 11.98 -> 11.25 ms, 1500 x 16 22.12 -> 21.60 on one box
   // with it off: the statistics then run with their component's gradient instead of in front of the heads' gradients.  Option ng_early_in 2 forces it.)
-  n->early_on = n->cfg.use_natural_gradient && n->ng_grouped && (options().ng_early_in == 2 || (options().ng_early_in != 0 && !n->wg_on));
+  // (option ng_early_in 3, weight-gradient streams on: the passes of ALL components as ONE grouped launch on s4 -- rows_gemm_group, 33 launches of
+  // 26 .. 78 blocks each at 150 x 64 -- and J of a refresh step left to the component's own gradient call.  Measured 11.01 against 10.92 ms at
+  // 150 x 64, 21.28 / 21.28 at 1500 x 16: fewer launches, the same work, no faster -- off.)
+  n->early_on = n->cfg.use_natural_gradient && n->ng_grouped && (options().ng_early_in >= 2 || (options().ng_early_in != 0 && !n->wg_on));
+  n->early_group = n->early_on && n->wg_on && options().ng_early_in == 3;
   const bool s4_used = n->wg_on || n->early_on;
   n->ws4 = s4_used ? A.take<char>(n->ws_bytes) : nullptr;
   n->s4_scratch_bytes = s4_used ? (32u << 20) : 0;
@@ -1001,6 +1005,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
     if (e) hipEventDestroy(e);
   if (n->s4) hipStreamDestroy(n->s4);
   if (n->s5) hipStreamDestroy(n->s5);
+  rows_gemm_group_destroy(n->early_launch);
   for (hipEvent_t e : n->ev_phase)
     if (e) hipEventDestroy(e);
   upd_group_destroy(n->upd);
@@ -1813,6 +1818,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       // H_in (and J on a refresh) were formed ahead of the backward pass from the arguments recorded one minibatch ago: they must be these
       TDNNF_REQUIRE(memcmp(n->early[comp].xin, &xin, sizeof(xin)) == 0, "net_forward_backward: the input of component %s moved between minibatches",
                     n->comps[comp].name.c_str());
+      if (n->early_group) {  // H came with the grouped launch on s3: the bookkeeping -- and J of a refresh step -- here, behind it
+        TDNNF_HIP(hipStreamWaitEvent(sw, n->ev_early, 0));
+        CK(ng_stats_main_finish(n->ng_in[comp], xin, S.H_in, wsw, n->ws_bytes, sw));
+      }
     } else {
       CK(ng_stats_main(n->ng_in[comp], xin, S.H_in, S.part_in, wsw, n->ws_bytes, sw));
     }
@@ -1925,6 +1934,35 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     // input-side statistics of every component whose backward call of the previous minibatch recorded its arguments (and has not come yet
     // in this one) and whose preconditioners exist (the grouped chain will take them): on s4, behind the forward pass and the refresh uploads
     bool forked = false;
+    if (n->early_group) {  // one grouped launch on s4 (behind the numerator, in front of the heads' weight gradients; s3 carries the denominator's second recursion)
+      std::vector<RowsGemmArgs> calls;
+      std::vector<int> who;
+      for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
+        auto &E = n->early[comp];
+        if (E.recorded != n->fb_count - 1 || !n->ng_in[comp] || !n->ng_out[comp] || ng_dim(n->ng_in[comp]) == 0 || ng_dim(n->ng_out[comp]) == 0) continue;
+        if (n->comps[comp].lr_factor == 0.f || !n->ngc[comp].H_in) continue;
+        NgInput xin;
+        memcpy(&xin, E.xin, sizeof(xin));
+        if (!forked) {
+          TDNNF_HIP(hipEventRecord(n->ev_early_in, s));
+          TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_early_in, 0));
+          if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_fin, 0));
+          forked = true;
+        }
+        RowsGemmArgs a;
+        CK(ng_stats_main_prepare(n->ng_in[comp], xin, n->ngc[comp].H_in, n->ngc[comp].part_in, n->s4, &a));
+        if (!rows_gemm_group_ok(a)) continue;  // (this one in its own gradient call, as without the early launch)
+        calls.push_back(a);
+        who.push_back(comp);
+      }
+      if (!calls.empty()) {
+        TDNNF_HIP(rows_gemm_group(calls, &n->early_launch, n->s4));
+        for (int comp : who) n->early[comp].done = n->fb_count;
+        TDNNF_HIP(hipEventRecord(n->ev_early, n->s4));
+        n->early_any = true;
+      }
+      return TDNNF_OK;
+    }
     SplitKScratchOverride early_scratch(n->s4_scratch, n->s4_scratch_bytes);
     for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
       auto &E = n->early[comp];

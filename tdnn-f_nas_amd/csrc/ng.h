@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_f32.h"
 #include "tdnnf_hip.h"
 
 // State of one OnlineNaturalGradient object (ng.hip owns it; ng_group.hip reads the device pointers for its grouped launches).
@@ -90,6 +91,11 @@ int ng_stats_step(tdnnf_ng *ng, const NgInput &in, float *H, void *ws, size_t ws
 // ng_stats_workspace_bytes(); ws of ng_stats_side wgrad_workspace_bytes(rank_padded, rank_padded, 1, N).
 int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *ws, size_t ws_bytes, hipStream_t s);
 int ng_stats_side(tdnnf_ng *ng, const float *H, const double *part, void *ws, size_t ws_bytes, hipStream_t s);
+// ng_stats_main in two steps for a caller that launches the H passes of several objects as ONE grouped launch (rows_gemm_group,
+// gemm_f32.h): prepare completes a pending refresh on s and hands out the arguments of the pass (the object must be initialised, rank > 0);
+// after the caller's launch has been enqueued, finish (on a stream ordered behind it) does the bookkeeping and, on a refresh, J = H^T X.
+int ng_stats_main_prepare(tdnnf_ng *ng, const NgInput &in, float *H, double *part, hipStream_t s, RowsGemmArgs *out);
+int ng_stats_main_finish(tdnnf_ng *ng, const NgInput &in, const float *H, void *ws, size_t ws_bytes, hipStream_t s);
 // The first half with H formed by the caller's own kernel (fused.hip: the BatchNorm/ReLU backward pass produces dY and
 // H = dY W^T in one sweep): ng_external_begin completes a pending refresh and hands out W_t (rank_padded x ldw, rows
 // >= rank are zero); *W == nullptr means "use ng_stats_main" (first minibatch, W_0 is initialised from the data).  After

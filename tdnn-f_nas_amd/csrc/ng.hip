@@ -486,7 +486,7 @@ int pform_pass(const float *W, int Rp, int Dp, const float *bias, const NgInput 
 
 // First half of one PreconditionDirections call, everything N x D sized: H = X W_t^T (with ||X||^2 per block into
 // `part`) and, on a refresh, J = H^T X.  W_t is left untouched.
-int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg_ws, size_t wg_bytes, bool upd, hipStream_t s) {
+RowsGemmArgs stats_h_args(const tdnnf_ng *ng, const NgInput &in, float *H, double *part) {
   const int N = in.N, K = in.ix.num_offsets, Di = in.Di, Rp = ng->Rp, Dp = ng->Dp;
   RowsGemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -503,6 +503,11 @@ int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg
     a.seg[i].m_lo = 0;
     a.seg[i].m_hi = N;
   }
+  return a;
+}
+int stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void *wg_ws, size_t wg_bytes, bool upd, hipStream_t s) {
+  const int N = in.N, K = in.ix.num_offsets, Di = in.Di, Rp = ng->Rp, Dp = ng->Dp;
+  const RowsGemmArgs a = stats_h_args(ng, in, H, part);
   // the same product on the vector ALUs, beside the matrix-core GEMMs of the other streams (ng_valu.hip), where its shape allows
   NgRowdotArgs v;
   memset(&v, 0, sizeof(v));
@@ -637,6 +642,24 @@ int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void 
   int rc = finalize(ng, s);  // a refresh started by the previous call on this object
   if (rc) return rc;
   return stats_main(ng, in, H, part, ws, ws_bytes, updating(ng), s);
+}
+
+int ng_stats_main_prepare(tdnnf_ng *ng, const NgInput &in, float *H, double *part, hipStream_t s, RowsGemmArgs *out) {
+  const int K = in.ix.num_offsets, D = K * in.Di + (in.ones ? 1 : 0);
+  TDNNF_REQUIRE(ng && H && part && out && in.N > 0 && K >= 1 && K <= kMaxSeg && ng->D == D && ng->rank > 0, "ng_stats_main_prepare: bad arguments");
+  ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
+  ng->cur_N = 0;
+  int rc = finalize(ng, s);  // a refresh started by the previous call on this object
+  if (rc) return rc;
+  *out = stats_h_args(ng, in, H, part);
+  return TDNNF_OK;
+}
+int ng_stats_main_finish(tdnnf_ng *ng, const NgInput &in, const float *H, void *ws, size_t ws_bytes, hipStream_t s) {
+  TDNNF_REQUIRE(ng && H && ng->D != 0 && ng->rank > 0 && in.N > 0, "ng_stats_main_finish: bad arguments");
+  ProfClassOverride prof_as_ng(3);
+  GemmPrecisionScope exact_f32(2);
+  return stats_after_h(ng, in, H, ws, ws_bytes, updating(ng), s);
 }
 
 int ng_finalize_if_ready(tdnnf_ng *ng, hipStream_t s, int *did) {

@@ -590,6 +590,11 @@ def test_early_input_statistics_are_bit_identical_to_the_in_order_ones(pkg, kind
     for i, ((ga, ra), (gb, rb)) in enumerate(zip(a, b)):
         assert np.array_equal(ga, gb), (kind, wg, i, rel_l2(ga, gb))
         assert ra is None or np.array_equal(ra, rb)
+    if wg:  # option 3 with the weight-gradient streams: the passes of all components as ONE grouped launch (rows_gemm_group), J with the
+        # component's own gradient call -- at these widths the grouped kernel runs the very blocks the in-order launches do
+        c = run(3)
+        for i, ((gc, rc), (gb, rb)) in enumerate(zip(c, b)):
+            assert np.array_equal(gc, gb), (kind, "grouped", i, rel_l2(gc, gb))
     v = C.c_int()
     pkg.hipabi.check(lib.tdnnf_get_option(b"ng_early_in", C.byref(v)))
     assert v.value == 1  # the context managers restored the defaults
