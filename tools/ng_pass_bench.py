@@ -17,8 +17,8 @@ for kv in sys.argv[2:]:  # further arguments: library options NAME=VALUE
     abi.check(lib.tdnnf_set_option(k.encode(), int(v)))
 # (name, rank, rows N, row offsets, Di)
 SHAPES = [
-    ("linear in, full rate 1500x128", 20, 200192, (0, 256), 1536),
-    ("linear in, 1/3 rate 1500x128", 20, 66688, (0, 256), 1536),
+    ("linear in, full rate 1500x128", 20, 200192, (0, 128), 1536),
+    ("linear in, 1/3 rate 1500x128", 20, 66688, (0, 128), 1536),
     ("prefinal in 1500x128", 20, 64000, (0,), 1536),
     ("affine in, full rate", 20, 200192, (0, 128), 160),
     ("linear out, full rate", 80, 200192, (0,), 160),
@@ -44,7 +44,7 @@ for name, R, N, offs, Di in SHAPES:
     line = "%-34s N %6d D %5d R %2d :" % (name, N, D, R)
     nb = lib.tdnnf_ng_stats_pass_workspace_bytes(R, Di, K, N)
     ws = torch.zeros((nb // 4 + 16,), device="cuda")
-    forms = (0, 1, 2) if (K > 1 and N % 128 == 0 and N >= 32768 and all(o % 128 == 0 for o in offs)) else (0, 1)
+    forms = (0, 1, 2) if (K > 1 and Di >= 1024 and N % 128 == 0 and N >= 32768 and all(o % 128 == 0 for o in offs)) else (0, 1)
     for valu in forms:
         def run():
             abi.check(lib.tdnnf_ng_stats_pass(C.byref(ix), abi.pmat(X[:, :Di]), Di, None, abi.ptr(wt), abi.ptr(W), ldw, None, abi.pmat(H), abi.ptr(part), cap,
