@@ -62,7 +62,7 @@ struct Options {
   int wgrad_small = 0;    // weight gradients of launches with at most this many rows on 64 x 64 tiles (0: off)
   int ng_bk = 0;          // natural-gradient statistics passes H = X W^T, longer K steps: bit 0 = 64 instead of 32 for rank <= 32, bit 1 = 32 instead of 16 for rank <= 96
   int ng_pform = 1;       // natural-gradient statistics of a component whose K taps are row shifts of one matrix (the .linear inputs): one pass over the matrix for all taps' products (ng.hip pform_pass) instead of K
-  int ng_valu = 0;        // natural-gradient statistics passes H = X W^T on the vector ALUs (ng_valu.hip) where the rank is 20 / 40 / 80 (measured: no gain, docs/experiments.md r5-m); 0: the MFMA rows GEMM
+  int ng_valu = 0;        // natural-gradient statistics passes H = X W^T on the vector ALUs (ng_valu.hip) where the rank is 20 / 40 / 80 (measured: no gain, docs/experiments.md r5-n); 0: the MFMA rows GEMM
   int ng_diag_skip = 0;   // diagnostics (timing only, results wrong): skip the statistics passes H = X W^T -- bit 0 two-tap inputs >= 1024 wide, bit 1 every other
   int phase_events = 0;   // diagnostics: the trainer records an event on the caller's stream at every phase boundary of a step (tdnnf_net_phase_times)
   int den_split = -1;     // trainer: the denominator's two recursions side by side (then the occupancies of all frames at once): -1 by minibatch size, 0 / 1

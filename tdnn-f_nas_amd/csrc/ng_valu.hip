@@ -18,7 +18,7 @@
 // pitch K step + 4 floats: conflict-free ds_read_b128 down a column of rows), one K step ahead in registers, two LDS buffers, one barrier per
 // K step.  LDS array cycles per wave and k: (5 + 1) reads x 4 = 24 against 160 VALU cycles -- four SIMDs stay under the array's rate.
 // A tap's Di % (K step) last columns do not go through the tile: each thread adds them from global memory at the end.
-// (First form, kept in docs/experiments.md r5-m: one row per thread, W^T from SGPRs through s_load -- instruction-perfect, and 8 x slower
+// (First form, kept in docs/experiments.md r5-n: one row per thread, W^T from SGPRs through s_load -- instruction-perfect, and 8 x slower
 // than its VALU time: every s_load of a 245 KB W^T misses the 16 KB scalar cache.)
 // ||X~||_F^2 (the trace the preconditioner's scale needs) is a by-product: the waves of output group 0 also square what they read.
 #include <hip/hip_runtime.h>
