@@ -1608,7 +1608,8 @@ int den_aux_stream(hipStream_t *aux, hipEvent_t *ev_fork, hipEvent_t *ev_join) {
 // denominator (one workgroup per sequence: half the CUs at 128 sequences) on a second stream beside the xent head.
 // (1) denominator forward + backward: deriv = -weight * gamma_den (whole matrix overwritten), den log-probs -> workspace
 int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws,
-              hipStream_t s, bool beside_other_work, hipStream_t caller_aux) {
+              hipStream_t s, bool beside_other_work, hipStream_t caller_aux, hipEvent_t ev_recursions, bool *ev_recorded) {
+  if (ev_recorded) *ev_recorded = false;
   const int B = sp->B, T = sp->T;
   ChainBufs b = chain_bufs(g, B, T, ws);
   DenDev gd{g->H, g->P, g->by_dst, g->by_src, g->by_pdf, g->init, g->init_sum};
@@ -1760,6 +1761,10 @@ int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf
     }
     TDNNF_HIP(hipEventRecord(ev_join, aux));
     TDNNF_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    if (ev_recursions) {  // both recursions are done here, the occupancies (a launch that fills the chip) come next
+      TDNNF_HIP(hipEventRecord(ev_recursions, s));
+      if (ev_recorded) *ev_recorded = true;
+    }
     hipLaunchKernelGGL(den_gamma_kernel, dim3(T, B), dim3(kGammaThreads), lds_gamma, s, gd, yv, B, T, leaky, b.alpha, b_all, S_all, b.p.Hs, -sp->weight, dv);
   } else if (b.p.lds_state) {
     TDNNF_HIP(hipFuncSetAttribute((const void *)den_backward_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)b.p.lds_bwd));

@@ -61,6 +61,7 @@ struct Options {
   int splitk_per_cu = 2;  // rows GEMM, few tiles and a long reduction: K slices per CU (2: fill every resident slot; 1: half the partial tiles)
   int wgrad_small = 0;    // weight gradients of launches with at most this many rows on 64 x 64 tiles (0: off)
   int ng_bk = 0;          // natural-gradient statistics passes H = X W^T, longer K steps: bit 0 = 64 instead of 32 for rank <= 32, bit 1 = 32 instead of 16 for rank <= 96
+  int xent_behind_den = -1;  // trainer: the xent head's forward pass waits for the denominator's two recursions (their 1024-thread workgroups pin half the CUs): -1 minibatches without weight-gradient streams, 0 never, 1 always
   int ng_pform = 1;       // natural-gradient statistics of a component whose K taps are row shifts of one matrix (the .linear inputs): one pass over the matrix for all taps' products (ng.hip pform_pass) instead of K
   int ng_valu = 0;        // natural-gradient statistics passes H = X W^T on the vector ALUs (ng_valu.hip) where the rank is 20 / 40 / 80 (measured: no gain, docs/experiments.md r5-n); 0: the MFMA rows GEMM
   int ng_diag_skip = 0;   // diagnostics (timing only, results wrong): skip the statistics passes H = X W^T -- bit 0 two-tap inputs >= 1024 wide, bit 1 every other
@@ -216,8 +217,10 @@ float chain_supervision_weight(const tdnnf_supervision *sp);
 // beside_other_work: the caller runs other kernels next to the denominator (the trainer: the xent head), so the persistent form keeps
 // its one-kernel backward pass instead of running the two recursions side by side on a further stream
 size_t chain_split_region_bytes(const tdnnf_den_graph *g, int B, int T);
+// ev_recursions (optional): recorded on s once both recursions of the side-by-side form are done, in front of the occupancies; *ev_recorded says
+// whether this call's form did
 int chain_den(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, float leaky, tdnnf_mat *deriv, void *ws, hipStream_t s,
-              bool beside_other_work = false, hipStream_t caller_aux = nullptr);
+              bool beside_other_work = false, hipStream_t caller_aux = nullptr, hipEvent_t ev_recursions = nullptr, bool *ev_recorded = nullptr);
 int chain_num_recursion(const tdnnf_supervision *sp, const tdnnf_den_graph *g, const tdnnf_mat *y, void *ws, hipStream_t s);
 int chain_num_xent(const tdnnf_den_graph *g, const tdnnf_supervision *sp, const tdnnf_mat *y, const tdnnf_mat *xent_output, float xent_regularize,
                    tdnnf_mat *xent_deriv, void *ws, hipStream_t s, bool xent_deriv_initialised = false);

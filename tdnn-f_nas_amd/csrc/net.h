@@ -197,6 +197,7 @@ struct tdnnf_net {
   bool den_split = true;  // the denominator's two recursions side by side (option den_split, read when the net's first step sizes the workspace)
   hipStream_t s2;      // the denominator runs here, beside the xent head on the caller's stream
   hipEvent_t ev_fork, ev_den, ev_num;  // ev_num: the numerator recursion (side stream) is done
+  hipEvent_t ev_den_rec = nullptr;     // option xent_behind_den: the denominator's two recursions are done
   hipEvent_t ev_comm = nullptr;        // tdnnf_net_allreduce_grads_rccl: the last bucket's collective
   int num_draws;
   bool owns_ng = true;    // false: created by tdnnf_net_create_shared, the preconditioners belong to the primary net

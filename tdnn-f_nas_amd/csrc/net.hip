@@ -1001,7 +1001,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->ev_fin0) hipEventDestroy(n->ev_fin0);
   if (n->ev_fin) hipEventDestroy(n->ev_fin);
   if (n->s3) hipStreamDestroy(n->s3);
-  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg[2], n->ev_pg[3], n->ev_pg_in, n->ev_early_in, n->ev_early, n->ev_comm})
+  for (hipEvent_t e : {n->ev_pg[0], n->ev_pg[1], n->ev_pg[2], n->ev_pg[3], n->ev_pg_in, n->ev_early_in, n->ev_early, n->ev_comm, n->ev_den_rec})
     if (e) hipEventDestroy(e);
   if (n->s4) hipStreamDestroy(n->s4);
   if (n->s5) hipStreamDestroy(n->s5);
@@ -1607,7 +1607,17 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
       // beside the forward one (den_beta_kernel on a further stream) and the occupancies of all frames at once
       const bool den_split = n->den_split;
       TDNNF_HIP(hipStreamWaitEvent(n->s3, n->ev_fork, 0));
-      CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, !den_split, n->s3));
+      // (option xent_behind_den: the xent head's forward GEMMs start when the recursions are done.  Beside the recursions' 1024-thread workgroups,
+      // which hold half the CUs for 4.4 ms, those GEMMs run at 94 instead of 103 TFLOP/s exact f32 (157 instead of 183 f32-equivalent on the plane
+      // kernels) -- and the step takes as long either way: three interleaved pairs 120.15 / 120.32 ms exact f32, 82.66 / 82.72 f16x3.  Rounds 2-4
+      // had this order by accident, through a 1024-thread BatchNorm finalize block that could not start beside the recursions.  Kept explicit:
+      // the same step, GEMM launches that are not stretched by a neighbour.)
+      const int xbd = options().xent_behind_den;
+      const bool behind = den_split && (xbd > 0 || (xbd < 0 && !n->wg_on));
+      if (behind && !n->ev_den_rec) TDNNF_HIP(hipEventCreateWithFlags(&n->ev_den_rec, hipEventDisableTiming));
+      bool rec = false;
+      CK(chain_den(den, sup, &y, c.leaky_hmm, &dy, n->chain_ws, n->s2, !den_split, n->s3, behind ? n->ev_den_rec : nullptr, &rec));
+      if (rec) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_den_rec, 0));
       TDNNF_HIP(hipEventRecord(n->ev_den, n->s2));
       // ... and so does the numerator's forward-backward recursion (one wave per sequence): on a stream that is idle until the
       // backward pass -- the weight-gradient stream when there is one, else behind the second recursion on the side stream
