@@ -61,6 +61,7 @@ struct Options {
   int splitk_per_cu = 2;  // rows GEMM, few tiles and a long reduction: K slices per CU (2: fill every resident slot; 1: half the partial tiles)
   int wgrad_small = 0;    // weight gradients of launches with at most this many rows on 64 x 64 tiles (0: off)
   int ng_bk = 0;          // natural-gradient statistics passes H = X W^T, longer K steps: bit 0 = 64 instead of 32 for rank <= 32, bit 1 = 32 instead of 16 for rank <= 96
+  int ng_early_fork = 1;  // trainer, minibatches without weight-gradient streams: the trunk components' early input statistics start where the trunk's forward pass ends (beside the denominator's recursions) instead of behind the xent head's backward pass
   int xent_behind_den = -1;  // trainer: the xent head's forward pass waits for the denominator's two recursions (their 1024-thread workgroups pin half the CUs): -1 minibatches without weight-gradient streams, 0 never, 1 always
   int ng_pform = 1;       // natural-gradient statistics of a component whose K taps are row shifts of one matrix (the .linear inputs): one pass over the matrix for all taps' products (ng.hip pform_pass) instead of K
   int ng_valu = 0;        // natural-gradient statistics passes H = X W^T on the vector ALUs (ng_valu.hip) where the rank is 20 / 40 / 80 (measured: no gain, docs/experiments.md r5-n); 0: the MFMA rows GEMM

@@ -1564,6 +1564,100 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     prev = L.noop_out;
   }
   CK(phase_mark(n, 1, s));
+  // ---- natural gradient: pending refreshes, and the input-side statistics that need nothing but forward activations
+  const bool use_ng = c.use_natural_gradient != 0;
+  auto finish_refreshes = [&]() -> int {
+    if (use_ng && n->ng_grouped) {
+      // refreshes still pending when the step began: W_{t+1} of ALL of them now, as grouped launches on the side stream (the host
+      // waits for the eigen-decompositions here; the GPU has the forward pass and the denominator in its queues meanwhile)
+      if (!n->ngfin) {
+        bool ready = false;
+        for (tdnnf_ng *g : all_ng()) ready = ready || ng_dim(g) != 0;
+        if (ready) CK(ng_fin_create(all_ng(), &n->ngfin));
+      }
+      if (n->ngfin) {
+        int did = 0;
+        SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
+        CK(ng_fin_run(n->ngfin, n->s3, true, &did));
+        if (did) {
+          TDNNF_HIP(hipEventRecord(n->ev_fin, n->s3));
+          early_refresh = true;
+        }
+      }
+    }
+    if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_fin, 0));  // the preconditioners refreshed on s3 (at the start of the step, or just now)
+    return TDNNF_OK;
+  };
+  n->early_any = false;
+  auto is_head_comp = [&](int comp) { return comp == n->c_prefinal_l || comp == n->head[0].c_affine || comp == n->head[0].c_linear || comp == n->head[0].c_output ||
+                                             comp == n->head[1].c_affine || comp == n->head[1].c_linear || comp == n->head[1].c_output; };
+  // which: 0 the trunk's components (their inputs exist once the trunk's forward pass is enqueued), 1 the heads' (and whatever was not launched yet), 2 all
+  auto launch_early_in = [&](int which) -> int {
+    if (!(use_ng && n->early_on)) return TDNNF_OK;
+    // input-side statistics of every component whose backward call of the previous minibatch recorded its arguments (and has not come yet
+    // in this one) and whose preconditioners exist (the grouped chain will take them): on s4, behind the forward pass and the refresh uploads
+    bool forked = false;
+    if (n->early_group) {  // one grouped launch on s4 (behind the numerator, in front of the heads' weight gradients; s3 carries the denominator's second recursion)
+      std::vector<RowsGemmArgs> calls;
+      std::vector<int> who;
+      for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
+        auto &E = n->early[comp];
+        if (E.done == n->fb_count || (which == 0 && is_head_comp(comp))) continue;
+        if (E.recorded != n->fb_count - 1 || !n->ng_in[comp] || !n->ng_out[comp] || ng_dim(n->ng_in[comp]) == 0 || ng_dim(n->ng_out[comp]) == 0) continue;
+        if (n->comps[comp].lr_factor == 0.f || !n->ngc[comp].H_in) continue;
+        NgInput xin;
+        memcpy(&xin, E.xin, sizeof(xin));
+        if (!forked) {
+          TDNNF_HIP(hipEventRecord(n->ev_early_in, s));
+          TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_early_in, 0));
+          if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_fin, 0));
+          forked = true;
+        }
+        RowsGemmArgs a;
+        CK(ng_stats_main_prepare(n->ng_in[comp], xin, n->ngc[comp].H_in, n->ngc[comp].part_in, n->s4, &a));
+        if (!rows_gemm_group_ok(a)) continue;  // (this one in its own gradient call, as without the early launch)
+        calls.push_back(a);
+        who.push_back(comp);
+      }
+      if (!calls.empty()) {
+        TDNNF_HIP(rows_gemm_group(calls, &n->early_launch, n->s4));
+        for (int comp : who) n->early[comp].done = n->fb_count;
+        TDNNF_HIP(hipEventRecord(n->ev_early, n->s4));
+        n->early_any = true;
+      }
+      return TDNNF_OK;
+    }
+    SplitKScratchOverride early_scratch(n->s4_scratch, n->s4_scratch_bytes);
+    for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
+      auto &E = n->early[comp];
+      if (E.done == n->fb_count || (which == 0 && is_head_comp(comp))) continue;
+      if (E.recorded != n->fb_count - 1 || !n->ng_in[comp] || !n->ng_out[comp] || ng_dim(n->ng_in[comp]) == 0 || ng_dim(n->ng_out[comp]) == 0) continue;
+      if (n->comps[comp].lr_factor == 0.f || !n->ngc[comp].H_in) continue;
+      if (!forked) {
+        TDNNF_HIP(hipEventRecord(n->ev_early_in, s));
+        TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_early_in, 0));
+        if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_fin, 0));
+        forked = true;
+      }
+      NgInput xin;
+      memcpy(&xin, E.xin, sizeof(xin));
+      CK(ng_stats_main(n->ng_in[comp], xin, n->ngc[comp].H_in, n->ngc[comp].part_in, n->ws4, n->ws_bytes, n->s4));
+      E.done = n->fb_count;
+    }
+    if (forked) {
+      TDNNF_HIP(hipEventRecord(n->ev_early, n->s4));
+      n->early_any = true;
+    }
+    return TDNNF_OK;
+  };
+  // Minibatches whose GEMMs fill the chip (no weight-gradient streams): the TRUNK components' statistics start here, where the trunk's forward
+  // pass ends -- the caller's stream is about to wait 4.4 ms for the denominator's two latency-bound recursions (xent_behind_den), with the matrix
+  // cores and HBM idle; the heads' components follow where all of them used to start, behind the xent head's backward pass.
+  const bool early_at_fork = n->early_on && !n->wg_on && !n->early_group && options().ng_early_fork != 0;
+  if (early_at_fork) {
+    CK(finish_refreshes());
+    CK(launch_early_in(0));
+  }
   const int No = n->Tout * B;
   tdnnf_mat top = M(prev, No, Hd), pl = M(n->prefinal_l_out, No, S);
   if (po_next.base == top.data && po_next.rows == top.rows) po_top = po_next;
@@ -1709,7 +1803,6 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     if (bp.P && options().planes_check_bound) TDNNF_HIP(planes_check_bound(view(&d), bp.rec, n->planes_ws, s));
     return TDNNF_OK;
   };
-  const bool use_ng = c.use_natural_gradient != 0;
   // Weight gradients up to three components behind the caller's stream (option wgrad_lag, default 3; 1 = rounds 2-4: one behind).  A
   // buffer that component k's gradient reads may be rewritten once the caller's stream has waited for k, i.e. from the hand-off of
   // component k + 3 on: the derivative matrices those gradients read alternate between two buffers per role (layout_arena).
@@ -1919,88 +2012,13 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   };
   n->ng_cur.clear();
   tdnnf_mat d_pl = M(n->d_small, No, S);  // deriv w.r.t. prefinal-l output, summed over both heads
-  if (use_ng && n->ng_grouped) {
-    // refreshes still pending when the step began: W_{t+1} of ALL of them now, as grouped launches on the side stream (the host
-    // waits for the eigen-decompositions here; the GPU has the forward pass and the denominator in its queues meanwhile)
-    if (!n->ngfin) {
-      bool ready = false;
-      for (tdnnf_ng *g : all_ng()) ready = ready || ng_dim(g) != 0;
-      if (ready) CK(ng_fin_create(all_ng(), &n->ngfin));
-    }
-    if (n->ngfin) {
-      int did = 0;
-      SplitKScratchOverride side_scratch(n->s3_scratch, n->s3_scratch_bytes);
-      CK(ng_fin_run(n->ngfin, n->s3, true, &did));
-      if (did) {
-        TDNNF_HIP(hipEventRecord(n->ev_fin, n->s3));
-        early_refresh = true;
-      }
-    }
-  }
-  if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(s, n->ev_fin, 0));  // the preconditioners refreshed on s3 (at the start of the step, or just now)
-  n->early_any = false;
-  auto launch_early_in = [&]() -> int {
-    if (!(use_ng && n->early_on)) return TDNNF_OK;
-    // input-side statistics of every component whose backward call of the previous minibatch recorded its arguments (and has not come yet
-    // in this one) and whose preconditioners exist (the grouped chain will take them): on s4, behind the forward pass and the refresh uploads
-    bool forked = false;
-    if (n->early_group) {  // one grouped launch on s4 (behind the numerator, in front of the heads' weight gradients; s3 carries the denominator's second recursion)
-      std::vector<RowsGemmArgs> calls;
-      std::vector<int> who;
-      for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
-        auto &E = n->early[comp];
-        if (E.recorded != n->fb_count - 1 || !n->ng_in[comp] || !n->ng_out[comp] || ng_dim(n->ng_in[comp]) == 0 || ng_dim(n->ng_out[comp]) == 0) continue;
-        if (n->comps[comp].lr_factor == 0.f || !n->ngc[comp].H_in) continue;
-        NgInput xin;
-        memcpy(&xin, E.xin, sizeof(xin));
-        if (!forked) {
-          TDNNF_HIP(hipEventRecord(n->ev_early_in, s));
-          TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_early_in, 0));
-          if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_fin, 0));
-          forked = true;
-        }
-        RowsGemmArgs a;
-        CK(ng_stats_main_prepare(n->ng_in[comp], xin, n->ngc[comp].H_in, n->ngc[comp].part_in, n->s4, &a));
-        if (!rows_gemm_group_ok(a)) continue;  // (this one in its own gradient call, as without the early launch)
-        calls.push_back(a);
-        who.push_back(comp);
-      }
-      if (!calls.empty()) {
-        TDNNF_HIP(rows_gemm_group(calls, &n->early_launch, n->s4));
-        for (int comp : who) n->early[comp].done = n->fb_count;
-        TDNNF_HIP(hipEventRecord(n->ev_early, n->s4));
-        n->early_any = true;
-      }
-      return TDNNF_OK;
-    }
-    SplitKScratchOverride early_scratch(n->s4_scratch, n->s4_scratch_bytes);
-    for (int comp = (int)n->comps.size() - 1; comp >= 0; comp--) {
-      auto &E = n->early[comp];
-      if (E.recorded != n->fb_count - 1 || !n->ng_in[comp] || !n->ng_out[comp] || ng_dim(n->ng_in[comp]) == 0 || ng_dim(n->ng_out[comp]) == 0) continue;
-      if (n->comps[comp].lr_factor == 0.f || !n->ngc[comp].H_in) continue;
-      if (!forked) {
-        TDNNF_HIP(hipEventRecord(n->ev_early_in, s));
-        TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_early_in, 0));
-        if (early_refresh) TDNNF_HIP(hipStreamWaitEvent(n->s4, n->ev_fin, 0));
-        forked = true;
-      }
-      NgInput xin;
-      memcpy(&xin, E.xin, sizeof(xin));
-      CK(ng_stats_main(n->ng_in[comp], xin, n->ngc[comp].H_in, n->ngc[comp].part_in, n->ws4, n->ws_bytes, n->s4));
-      E.done = n->fb_count;
-    }
-    if (forked) {
-      TDNNF_HIP(hipEventRecord(n->ev_early, n->s4));
-      n->early_any = true;
-    }
-    return TDNNF_OK;
-  };
+  if (!early_at_fork) CK(finish_refreshes());
   // Where in the host's order: minibatches whose GEMMs fill the chip start the statistics BEHIND the xent head's backward pass -- they then run
   // while the caller's stream waits for the denominator instead of beside the xent head's GEMMs (same step time, 124.0 against 124.1 ms, and the
   // 128 x 128 class is not slowed: 99.5 against 96.4 TFLOP/s, weight gradients 107 against 102); the small ones start them at once (behind the
   // xent head: 13.03 -> 13.10 ms at 150 x 64, 23.16 -> 23.31 at 1500 x 16).
   const bool early_after_xent = !n->wg_on;
-  if (!early_after_xent) CK(launch_early_in());
+  if (!early_after_xent) CK(launch_early_in(2));
   for (int h = 1; h >= 0; h--) {  // xent head first: it does not depend on the denominator
     auto &H = n->head[h];
     TraceRange trace_head(h == 0 ? "backward prefinal-chain / output" : "backward prefinal-xent / output-xent");
@@ -2056,7 +2074,7 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     PlanesHintScope ph_bp(hint_of(po_d), wplanes(H.c_affine));
     if (h == 1) {
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &d_pl, s));
-      if (early_after_xent) CK(launch_early_in());
+      if (early_after_xent) CK(launch_early_in(early_at_fork ? 1 : 2));
     } else {
       tdnnf_mat tmp = M(!lag3 ? n->d_small2 : n->dS[0], No, S);  // (lag3: the xent head's d_b2 buffer -- its reader, three components back, has been waited for)
       CK(tdnnf_affine_backprop(&d_b1, Wp(n, H.c_affine), S, S, &tmp, s));
