@@ -29,7 +29,9 @@ def klass(nm):
     if (s.startswith("rows_gemm_kernel") or s.startswith("wgrad_kernel")) and (s.endswith(", 1>") or s.startswith("rows_gemm_kernel<4, 1, 1, 1")
                                                                                 or s.startswith("rows_gemm_kernel<4, 1, 1, 3")):
         return "ng_skinny_gemm_f32"
-    if s.startswith(("ggemm_", "ng_l_", "ng_commit", "ng_set_columns", "ng_stage", "ng_fin_")):
+    if s.startswith(("rows_gemm_group_kernel", "ng_rowdot_kernel")):
+        return "ng_skinny_gemm_f32"
+    if s.startswith(("ggemm_", "ng_l_", "ng_commit", "ng_set_columns", "ng_stage", "ng_fin_", "pform_combine_kernel", "stack_taps_kernel")):
         return "ng_grouped_side_chain"
     if s.startswith("rows_gemm_kernel<2, 2, 2, 2") or s.startswith("rows_gemm_kernel<2, 2, 1, 2") or s.startswith("rows_gemm_ring_kernel<2, 2, 2, 2"):
         return "rows_gemm_f32_128x128"
