@@ -598,3 +598,34 @@ def test_early_input_statistics_are_bit_identical_to_the_in_order_ones(pkg, kind
     v = C.c_int()
     pkg.hipabi.check(lib.tdnnf_get_option(b"ng_early_in", C.byref(v)))
     assert v.value == 1  # the context managers restored the defaults
+
+
+def test_three_weight_gradient_streams_give_the_same_step(pkg):
+    """Option wgrad_stream 3 (a third weight-gradient stream beside s4 / s2): the same kernels on the same operands in another stream
+    order -- gradients, objective and parameters bit for bit those of the default two streams, natural gradient on, over a refresh."""
+    T = pkg.trainer
+    kw = dict(frames_per_chunk=30, num_sequences=8, strides=[1, 1, 0, 3, 3], bottleneck=16, feat_dim=8, ivector_dim=4, hidden_dim=64, small_dim=32,
+              num_pdfs=50, use_natural_gradient=1)
+
+    def run(streams):
+        with pkg.hipabi.option("wgrad_stream", streams):
+            net = T.ChainNet(T.make_config(**kw))
+        cfg = net.cfg
+        net.set_params(net.init_params_numpy(seed=1, output_stddev=0.1))
+        den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+        out = []
+        for i in range(6):
+            feats, iv = T.synthetic_egs(net, seed=100 + i)
+            sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=200 + i))
+            net.grads.zero_()
+            r = host(net.forward_backward(dev(feats), dev(iv), den, sup, step=i))
+            out.append((host(net.grads).copy(), r.copy()))
+            net.update(1e-3, step=i)
+        out.append((host(net.params).copy(), None))
+        net.close()
+        return out
+
+    a, b = run(3), run(2)
+    for i, ((ga, ra), (gb, rb)) in enumerate(zip(a, b)):
+        assert np.array_equal(ga, gb), (i, rel_l2(ga, gb))
+        assert ra is None or np.array_equal(ra, rb)
