@@ -646,7 +646,12 @@ int ng_stats_main(tdnnf_ng *ng, const NgInput &in, float *H, double *part, void 
 
 int ng_stats_main_prepare(tdnnf_ng *ng, const NgInput &in, float *H, double *part, hipStream_t s, RowsGemmArgs *out) {
   const int K = in.ix.num_offsets, D = K * in.Di + (in.ones ? 1 : 0);
-  TDNNF_REQUIRE(ng && H && part && out && in.N > 0 && K >= 1 && K <= kMaxSeg && ng->D == D && ng->rank > 0, "ng_stats_main_prepare: bad arguments");
+  TDNNF_REQUIRE(ng && H && part && out && in.N > 0 && K >= 1 && K <= kMaxSeg && ng->D == D, "ng_stats_main_prepare: bad arguments");
+  if (ng->rank == 0) {  // nothing to precondition: no pass (out->M = 0 fails rows_gemm_group_ok, the caller leaves the object to its own call)
+    memset(out, 0, sizeof(*out));
+    ng->cur_N = 0;
+    return TDNNF_OK;
+  }
   ProfClassOverride prof_as_ng(3);
   GemmPrecisionScope exact_f32(2);
   ng->cur_N = 0;
