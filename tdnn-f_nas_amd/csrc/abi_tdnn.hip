@@ -87,7 +87,7 @@ static int *option_slot(const char *name) {
   Options &o = options();
   if (!name) return nullptr;
   const struct { const char *n; int *p; } table[] = {{"ng_grouped", &o.ng_grouped}, {"ng_fuse", &o.ng_fuse}, {"ng_early_in", &o.ng_early_in},
-                                                     {"wgrad_stream", &o.wgrad_stream}, {"gemm_ring", &o.gemm_ring}, {"planes", &o.planes}, {"den_split", &o.den_split}, {"phase_events", &o.phase_events}, {"wgrad_lag", &o.wgrad_lag}, {"ng_bk", &o.ng_bk}, {"ng_valu", &o.ng_valu}, {"ng_pform", &o.ng_pform}, {"xent_behind_den", &o.xent_behind_den}, {"ng_early_fork", &o.ng_early_fork}, {"ng_diag_skip", &o.ng_diag_skip}, {"wgrad_small", &o.wgrad_small}, {"splitk_per_cu", &o.splitk_per_cu}, {"gemm_alt_taps", &o.gemm_alt_taps}, {"reverse_passes", &o.reverse_passes}, {"splitk_partial_round", &o.splitk_partial_round}, {"wgrad_on_caller", &o.wgrad_on_caller}, {"den_mw_test_abort", &o.den_mw_test_abort}, {"planes_check_bound", &o.planes_check_bound}};
+                                                     {"wgrad_stream", &o.wgrad_stream}, {"gemm_ring", &o.gemm_ring}, {"planes", &o.planes}, {"den_split", &o.den_split}, {"phase_events", &o.phase_events}, {"wgrad_lag", &o.wgrad_lag}, {"ng_bk", &o.ng_bk}, {"ng_valu", &o.ng_valu}, {"ng_pform", &o.ng_pform}, {"planes_group", &o.planes_group}, {"xent_behind_den", &o.xent_behind_den}, {"ng_early_fork", &o.ng_early_fork}, {"ng_diag_skip", &o.ng_diag_skip}, {"wgrad_small", &o.wgrad_small}, {"splitk_per_cu", &o.splitk_per_cu}, {"gemm_alt_taps", &o.gemm_alt_taps}, {"reverse_passes", &o.reverse_passes}, {"splitk_partial_round", &o.splitk_partial_round}, {"wgrad_on_caller", &o.wgrad_on_caller}, {"den_mw_test_abort", &o.den_mw_test_abort}, {"planes_check_bound", &o.planes_check_bound}};
   for (auto &e : table)
     if (strcmp(e.n, name) == 0) return e.p;
   return nullptr;

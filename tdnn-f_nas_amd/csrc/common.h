@@ -52,6 +52,7 @@ struct Options {
   int gemm_ring = 1;      // the persistent LDS-DMA-ring form of the rows GEMM where it applies
   int planes = 1;         // gemm_precision 2: the pre-split bf16-plane GEMMs where they apply (0: the in-kernel split everywhere)
   int den_mw_test_abort = 0;  // tests: raise the multi-workgroup denominator's abort word before its launch (the one-workgroup kernels must then redo the minibatch)
+  int planes_group = 1;   // f16x3 trainer: the plain components' weight matrices split by ONE grouped pair of launches per step (planes_split_group)
   int planes_check_bound = 0;  // tests: after every split that took its scale from a norm bound, measure the norm and count violations (tdnnf_planes_bound_checks)
   int wgrad_lag = 3;      // trainer, weight-gradient stream on: the caller's stream runs 3 (default) or 1 component(s) ahead of the gradients (read by tdnnf_net_create)
   int wgrad_on_caller = 0;  // trainer: the xent head's weight gradients on the caller's stream when the early statistics occupy the gradient stream

@@ -14,6 +14,7 @@
 
 namespace tdnnf {
 struct RowsGemmGroup;  // gemm_f32.h
+struct PlanesSplitGroup;  // planes_gemm.h
 
 struct NgGroup;
 struct NgFin;
@@ -179,6 +180,7 @@ struct tdnnf_net {
   bool early_on = false, early_any = false;
   bool early_group = false;                    // the early passes as ONE grouped launch on s4 (minibatches with the weight-gradient streams)
   tdnnf::RowsGemmGroup *early_launch = nullptr;  // its device-side task table
+  tdnnf::PlanesSplitGroup *wsplit_group = nullptr;  // f16x3: the task table of the grouped split of a step's weight matrices
   hipEvent_t ev_early_in = nullptr, ev_early = nullptr;
   size_t s4_scratch_bytes;
   bool wg_two;  // this step, from the denominator's join on: weight-gradient components alternate between s4 and s2

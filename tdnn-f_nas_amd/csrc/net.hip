@@ -1006,6 +1006,7 @@ void tdnnf_net_destroy(tdnnf_net *n) {
   if (n->s4) hipStreamDestroy(n->s4);
   if (n->s5) hipStreamDestroy(n->s5);
   rows_gemm_group_destroy(n->early_launch);
+  planes_split_group_destroy(n->wsplit_group);
   for (hipEvent_t e : n->ev_phase)
     if (e) hipEventDestroy(e);
   upd_group_destroy(n->upd);
@@ -1368,7 +1369,10 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
   auto hint_of = [&](const PlanesOperand &o) -> const PlanesOperand * { return o.base ? &o : nullptr; };
   // a component's weight matrix as planes (row-major: forward; transposed: backward-data); coef: a TdnnDARTSV3Component's effective tap
   // coefficients (device, one per `period` columns), folded into the planes so that its GEMMs need none
-  auto split_weights = [&](int comp, const float *coef, int period) -> int {
+  // (`group`: collect the split instead of launching it -- the plain components' weights of a step go as ONE grouped pair of launches)
+  std::vector<PlanesSplitArgs> wsplits;
+  bool darts_coef_done = false;  // (pl_on: the DARTS components' coefficients and planes were formed at the start of the step)
+  auto split_weights = [&](int comp, const float *coef, int period, bool group = false) -> int {
     PlanesOperand &o = n->pw[comp];
     if (!o.P) return TDNNF_OK;
     o.base = Wp(n, comp);
@@ -1380,12 +1384,32 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     a.col_coef = coef; a.col_coef_period = period;
     o.scale = np == 2 ? n->pw_scale[comp] : nullptr;
     a.pads_done = n->fb_count > 1;  // (fixed shapes: the zero rows written by the first step stay)
-    TDNNF_HIP(planes_split(a, s));
+    if (group && options().planes_group && planes_split_group_ok(a)) wsplits.push_back(a);
+    else TDNNF_HIP(planes_split(a, s));
     return TDNNF_OK;
   };
-  if (pl_on)  // this step's weights as planes (the DARTS components' again in the layer loop, once their coefficients are formed)
+  if (pl_on) {  // this step's weights as planes (the DARTS components' again in the layer loop, once their coefficients are formed)
+    // 36 components x (norm pass + split) were 72 launches of 6 - 12 us, serial on the caller's stream with nothing else in flight: two launches now
     for (size_t i = 0; i < n->comps.size(); i++)
-      if (n->comps[i].num_alpha == 0 || n->comps[i].plain) CK(split_weights((int)i, nullptr, 0));
+      if (n->comps[i].num_alpha == 0 || n->comps[i].plain) CK(split_weights((int)i, nullptr, 0, true));
+    // the TdnnDARTSV3Components' too: their tap coefficients depend on the architecture logits and this step's draws only, so they are formed
+    // here, ahead of the layer loop, and the coefficient-folded weight planes join the same two launches
+    if (options().planes_group && n->draws) {
+      for (auto &L : n->layers) {
+        if (!L.lin.darts) continue;
+        for (Tdnn *td : {&L.lin, &L.aff}) {
+          const float *u = n->draws + td->draw0;
+          CK(tdnnf_tdnn_darts_coef(Ap(n, td->comp), td->K, c.darts_flags, c.darts_temp_proportion, u, u + td->K, td->share, td->memo,
+                                   td->memo + TDNNF_MAX_OFFSETS, s));
+          hipLaunchKernelGGL(active_taps_kernel, dim3(1), dim3(64), 0, s, td->memo + TDNNF_MAX_OFFSETS, td->K, td->active);
+        }
+        CK(split_weights(L.lin.comp, L.lin.memo + TDNNF_MAX_OFFSETS, c.hidden_dim, true));
+        CK(split_weights(L.aff.comp, L.aff.memo + TDNNF_MAX_OFFSETS, L.bn, true));
+      }
+      darts_coef_done = true;
+    }
+    TDNNF_HIP(planes_split_group(wsplits, &n->wsplit_group, s));
+  }
   auto wplanes = [&](int comp) -> const PlanesOperand * { return pl_on && n->pw[comp].P ? &n->pw[comp] : nullptr; };
   // where the fused BatchNorm / ReLU backward sweep may write the f16 planes of the derivative matrix `d` it produces (f16x3, 1536-wide
   // matrices with a slot): fills *bp for bn_relu_bwd and *po for the GEMMs that read `d` next; bp->P == null: not fused, split afterwards
@@ -1500,15 +1524,16 @@ int tdnnf_net_forward_backward(tdnnf_net *n, const tdnnf_mat *feats, const tdnnf
     const float *lin_eff = nullptr, *aff_eff = nullptr;
     if (L.lin.darts) {  // TdnnDARTSV3Component::Propagate :250-289 for both components of the layer
       TDNNF_REQUIRE(n->draws, "net_forward_backward: a DARTS net needs net_set_random_draws before every step");
-      for (Tdnn *td : {&L.lin, &L.aff}) {
-        const float *u = n->draws + td->draw0;
-        CK(tdnnf_tdnn_darts_coef(Ap(n, td->comp), td->K, c.darts_flags, c.darts_temp_proportion, u, u + td->K, td->share, td->memo,
-                                 td->memo + TDNNF_MAX_OFFSETS, s));
-        hipLaunchKernelGGL(active_taps_kernel, dim3(1), dim3(64), 0, s, td->memo + TDNNF_MAX_OFFSETS, td->K, td->active);
-      }
+      if (!darts_coef_done)
+        for (Tdnn *td : {&L.lin, &L.aff}) {
+          const float *u = n->draws + td->draw0;
+          CK(tdnnf_tdnn_darts_coef(Ap(n, td->comp), td->K, c.darts_flags, c.darts_temp_proportion, u, u + td->K, td->share, td->memo,
+                                   td->memo + TDNNF_MAX_OFFSETS, s));
+          hipLaunchKernelGGL(active_taps_kernel, dim3(1), dim3(64), 0, s, td->memo + TDNNF_MAX_OFFSETS, td->K, td->active);
+        }
       lin_eff = L.lin.memo + TDNNF_MAX_OFFSETS;
       aff_eff = L.aff.memo + TDNNF_MAX_OFFSETS;
-      if (pl_on) {  // the effective coefficients folded into this step's weight planes
+      if (pl_on && !darts_coef_done) {  // the effective coefficients folded into this step's weight planes
         CK(split_weights(L.lin.comp, lin_eff, Hd));
         CK(split_weights(L.aff.comp, aff_eff, L.bn));
       }

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
+#include <vector>
+
 #include "common.h"
 
 namespace tdnnf {
@@ -114,6 +116,13 @@ size_t planes_sumsq_ws_bytes();
 hipError_t planes_check_bound(MatView x, const float *rec, void *sumsq_ws, hipStream_t s);
 hipError_t planes_scale_bound(const double *fro2_bound, int blocks, double numel, float mul, float add_coef, const float *add_rec, float *rec, hipStream_t s);
 hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s);
+// The splits of several small f16x3 matrices whose zero rows are in place (planes_split_group_ok: np 2, <= 4 M elements, 16-byte aligned rows,
+// pads_done, no norm bound) as TWO launches -- the norm passes, then the splits; each matrix gets exactly the blocks, partial sums and scale
+// planes_split() would give it.  *cache keeps the device-side table (null at first; planes_split_group_destroy at the end).
+struct PlanesSplitGroup;
+bool planes_split_group_ok(const PlanesSplitArgs &a);
+hipError_t planes_split_group(const std::vector<PlanesSplitArgs> &v, PlanesSplitGroup **cache, hipStream_t s);
+void planes_split_group_destroy(PlanesSplitGroup *g);
 // zero the rows [0, lead) and [lead + rows, R) of every (K block, plane) chunk of a row-major plane buffer (a producer that writes the data rows itself)
 hipError_t planes_pad(int np, void *P, long long k_blocks, long long R, int lead, long long rows, hipStream_t s);
 // tile shape the GEMM uses for an N-column output: the A buffer needs tail >= tile rows beyond the last row read, the B buffer rows padded to the tile's columns

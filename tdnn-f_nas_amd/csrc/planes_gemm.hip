@@ -175,19 +175,19 @@ __global__ void planes_scale_kernel(const double *partial, int nb, double numel,
 // sq_partial != null (small matrices): the scale is formed here from the norm pass's partials -- by every block, identically -- and
 // block (0, 0) writes the record; saves the launch of planes_scale_kernel in front of every small split
 template <int NP>
-__global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long long ld, int rows, int cols, const float *scale, int lead, long long R, void *Pv,
-                                                           long long Rt, void *PTv, int vec_ok, const double *sq_partial, int sq_nb, float *scale_out,
-                                                           const float *col_coef, int col_coef_period) {
+__device__ __forceinline__ void planes_split_block(const float *X, long long ld, int rows, int cols, const float *scale, int lead, long long R, void *Pv,
+                                                   long long Rt, void *PTv, int vec_ok, const double *sq_partial, int sq_nb, float *scale_out,
+                                                   const float *col_coef, int col_coef_period, int bx, int by) {
   typedef typename Plane<NP>::E E;
   __shared__ __attribute__((aligned(16))) E tile[NP][64][64 + 2];
   E *P = reinterpret_cast<E *>(Pv), *PT = reinterpret_cast<E *>(PTv);
   const int t = threadIdx.x, lr = t >> 2, cq = t & 3;
-  const int r = blockIdx.x * 64 + lr, c0 = blockIdx.y * 64 + cq * 16;
+  const int r = bx * 64 + lr, c0 = by * 64 + cq * 16;
   float s = scale ? scale[0] : 1.0f;
   if (sq_partial) {
     double fro;
     s = planes_scale_of(sq_partial, sq_nb, (double)rows * cols, 1.0f, 0.0f, nullptr, reinterpret_cast<double *>(&tile[0][0][0]), &fro);
-    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+    if (bx == 0 && by == 0 && t == 0) {
       scale_out[0] = s;
       scale_out[1] = 1.0f / s;
       scale_out[2] = (float)(fro * 1.000001);
@@ -240,9 +240,9 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long 
 #pragma unroll
     for (int j = 0; j < 16; j++) tile[p][lr][cq * 16 + j] = pl[p][j];
   __syncthreads();
-  const int c = blockIdx.y * 64 + (t & 63), kq = t >> 6;
+  const int c = by * 64 + (t & 63), kq = t >> 6;
   if (c >= cols) return;  // (rows of PT beyond `cols` are zeroed by the pad kernel)
-  const long long kbt = (long long)blockIdx.x * 4 + kq;
+  const long long kbt = (long long)bx * 4 + kq;
   const int sw = (c >> 3) & 1;
 #pragma unroll
   for (int p = 0; p < NP; p++) {
@@ -253,6 +253,72 @@ __global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long 
     *reinterpret_cast<uint4 *>(dst + (0 ^ sw) * 8) = *reinterpret_cast<const uint4 *>(&rec[0]);
     *reinterpret_cast<uint4 *>(dst + (1 ^ sw) * 8) = *reinterpret_cast<const uint4 *>(&rec[8]);
   }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void planes_split_kernel(const float *X, long long ld, int rows, int cols, const float *scale, int lead, long long R, void *Pv,
+                                                           long long Rt, void *PTv, int vec_ok, const double *sq_partial, int sq_nb, float *scale_out,
+                                                           const float *col_coef, int col_coef_period) {
+  planes_split_block<NP>(X, ld, rows, cols, scale, lead, R, Pv, Rt, PTv, vec_ok, sq_partial, sq_nb, scale_out, col_coef, col_coef_period, (int)blockIdx.x,
+                         (int)blockIdx.y);
+}
+// Grouped form for many SMALL matrices (a net's weight matrices at the start of a step: 36 x (norm pass + split) launches, strictly serial on
+// the caller's stream, nothing else in flight): matrix i owns the blocks [first[i], first[i + 1]) of each of the two launches.
+struct PlanesSplitItem {
+  const float *X;
+  long long ld, R, Rt;
+  int rows, cols, lead, vec_ok;
+  void *P, *PT;
+  float *scale;
+  const float *col_coef;
+  int col_coef_period;
+  int sq_first, sq_nb;  // its norm-pass blocks / partials: [sq_first, sq_first + sq_nb)
+  int sp_first, sp_gx;  // its split blocks: sp_first + by * sp_gx + bx
+};
+__device__ __forceinline__ int planes_item_of(const int *first, int n, int b) {
+  int lo = 0, hi = n;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (b >= first[mid]) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void planes_sumsq4_group_kernel(const PlanesSplitItem *items, const int *first, int n, double *partial) {
+  __shared__ double red[4];
+  const PlanesSplitItem it = items[planes_item_of(first, n, (int)blockIdx.x)];
+  const int b = (int)blockIdx.x - it.sq_first;
+  const int c4 = (it.cols + 3) >> 2;
+  const long long total = (long long)it.rows * c4;
+  double acc = 0;
+  float run = 0.f;
+  int cnt = 0;
+  for (long long e = b * 256LL + threadIdx.x; e < total; e += (long long)it.sq_nb * 256) {  // (exactly planes_sumsq4_kernel's walk with sq_nb blocks)
+    const int r = (int)(e / c4), c = (int)(e % c4);
+    const float *src = it.X + (long long)r * it.ld + 4 * c;
+    if (4 * c + 3 < it.cols) {
+      const float4 v = *reinterpret_cast<const float4 *>(src);
+      run += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    } else {
+      for (int j = 0; 4 * c + j < it.cols; j++) run += src[j] * src[j];
+    }
+    if (++cnt == 16) {
+      acc += run;
+      run = 0.f;
+      cnt = 0;
+    }
+  }
+  acc += run;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void planes_split_group_kernel(const PlanesSplitItem *items, const int *first, int n, const double *partial) {
+  const PlanesSplitItem it = items[planes_item_of(first, n, (int)blockIdx.x)];
+  const int b = (int)blockIdx.x - it.sp_first;
+  planes_split_block<2>(it.X, it.ld, it.rows, it.cols, it.scale, it.lead, it.R, it.P, it.Rt, it.PT, it.vec_ok, partial + it.sq_first, it.sq_nb, it.scale, it.col_coef,
+                        it.col_coef_period, b % it.sp_gx, b / it.sp_gx);
 }
 
 // zero the rows [0, lead) and [lead + rows, R) of every (kb, plane) chunk (32-byte records of 2-byte elements, whatever the type)
@@ -876,6 +942,77 @@ hipError_t planes_split(const PlanesSplitArgs &a, hipStream_t s) {
   else
     hipLaunchKernelGGL(planes_split_kernel<3>, grid, dim3(256), 0, s, x.data, (long long)x.stride, x.rows, x.cols, (const float *)nullptr, a.lead, a.R, a.P, a.Rt, a.PT, vec4 ? 1 : 0,
                        (const double *)nullptr, 0, (float *)nullptr, a.col_coef, a.col_coef_period);
+  return hipGetLastError();
+}
+
+struct PlanesSplitGroup {
+  std::vector<PlanesSplitItem> items;
+  std::vector<int> sq_first, sp_first;
+  PlanesSplitItem *d_items = nullptr;
+  int *d_sq_first = nullptr, *d_sp_first = nullptr;
+  double *d_partial = nullptr;
+  int cap = 0, cap_partial = 0;
+};
+void planes_split_group_destroy(PlanesSplitGroup *g) {
+  if (!g) return;
+  for (void *p : {(void *)g->d_items, (void *)g->d_sq_first, (void *)g->d_sp_first, (void *)g->d_partial})
+    if (p) hipFree(p);
+  delete g;
+}
+bool planes_split_group_ok(const PlanesSplitArgs &a) {
+  const MatView &x = a.x;
+  return a.np == 2 && x.rows > 0 && x.cols > 0 && (a.P || a.PT) && a.scale && !(a.fro2_bound && a.fro2_blocks > 0) && a.pads_done &&
+         (long long)x.rows * x.cols <= (4LL << 20) && (reinterpret_cast<uintptr_t>(x.data) & 15) == 0 && x.stride % 4 == 0;
+}
+hipError_t planes_split_group(const std::vector<PlanesSplitArgs> &v, PlanesSplitGroup **cache, hipStream_t s) {
+  if (v.empty()) return hipSuccess;
+  if (!*cache) *cache = new PlanesSplitGroup();
+  PlanesSplitGroup &g = **cache;
+  std::vector<PlanesSplitItem> items(v.size());
+  std::vector<int> sqf(v.size() + 1, 0), spf(v.size() + 1, 0);
+  double bytes = 0;
+  for (size_t i = 0; i < v.size(); i++) {
+    const PlanesSplitArgs &a = v[i];
+    if (!planes_split_group_ok(a)) return hipErrorInvalidValue;
+    PlanesSplitItem it;
+    memset(&it, 0, sizeof(it));
+    it.X = a.x.data; it.ld = a.x.stride; it.rows = a.x.rows; it.cols = a.x.cols; it.lead = a.lead; it.R = a.R; it.Rt = a.Rt; it.P = a.P; it.PT = a.PT;
+    it.scale = a.scale; it.col_coef = a.col_coef; it.col_coef_period = a.col_coef_period; it.vec_ok = 1;
+    it.sq_nb = (int)std::max<long long>(1, std::min<long long>(kSumsqBlocks, ((long long)a.x.rows * a.x.cols + 16383) / 16384));  // (as planes_split for a small matrix)
+    it.sq_first = sqf[i];
+    it.sp_gx = (a.x.rows + 63) / 64;
+    it.sp_first = spf[i];
+    sqf[i + 1] = sqf[i] + it.sq_nb;
+    spf[i + 1] = spf[i] + it.sp_gx * ((a.x.cols + 63) / 64);
+    items[i] = it;
+    bytes += (double)a.x.rows * a.x.cols * (4.0 + 4.0 * ((a.P ? 1 : 0) + (a.PT ? 1 : 0)));
+  }
+  const bool same = g.items.size() == items.size() && memcmp(g.items.data(), items.data(), sizeof(PlanesSplitItem) * items.size()) == 0;
+  if (!same) {
+    if (g.cap < (int)items.size()) {
+      for (void *p : {(void *)g.d_items, (void *)g.d_sq_first, (void *)g.d_sp_first})
+        if (p) hipFree(p);
+      hipError_t e = hipMalloc((void **)&g.d_items, sizeof(PlanesSplitItem) * items.size());
+      if (e == hipSuccess) e = hipMalloc((void **)&g.d_sq_first, sizeof(int) * (items.size() + 1));
+      if (e == hipSuccess) e = hipMalloc((void **)&g.d_sp_first, sizeof(int) * (items.size() + 1));
+      if (e != hipSuccess) return e;
+      g.cap = (int)items.size();
+    }
+    if (g.cap_partial < sqf.back()) {
+      if (g.d_partial) hipFree(g.d_partial);
+      hipError_t e = hipMalloc((void **)&g.d_partial, sizeof(double) * sqf.back());
+      if (e != hipSuccess) return e;
+      g.cap_partial = sqf.back();
+    }
+    g.items = items; g.sq_first = sqf; g.sp_first = spf;
+    hipError_t e = hipMemcpyAsync(g.d_items, g.items.data(), sizeof(PlanesSplitItem) * items.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(g.d_sq_first, g.sq_first.data(), sizeof(int) * sqf.size(), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(g.d_sp_first, g.sp_first.data(), sizeof(int) * spf.size(), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+  }
+  ProfHbmRange prof(7, bytes, s);
+  hipLaunchKernelGGL(planes_sumsq4_group_kernel, dim3(sqf.back()), dim3(256), 0, s, g.d_items, g.d_sq_first, (int)items.size(), g.d_partial);
+  hipLaunchKernelGGL(planes_split_group_kernel, dim3(spf.back()), dim3(256), 0, s, g.d_items, g.d_sp_first, (int)items.size(), (const double *)g.d_partial);
   return hipGetLastError();
 }
 

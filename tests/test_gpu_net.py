@@ -629,3 +629,40 @@ def test_three_weight_gradient_streams_give_the_same_step(pkg):
     for i, ((ga, ra), (gb, rb)) in enumerate(zip(a, b)):
         assert np.array_equal(ga, gb), (i, rel_l2(ga, gb))
         assert ra is None or np.array_equal(ra, rb)
+
+
+@pytest.mark.parametrize("kind", ["7q", "darts-softmax", "darts-uniform"])
+def test_grouped_weight_plane_split_is_bit_identical(pkg, kind):
+    """f16x3: the weight matrices of a step (the TdnnDARTSV3Components' with their tap coefficients folded in, formed at the start of the step
+    for it) split by ONE grouped pair of launches (planes_split_group, option planes_group) against a norm pass + split per matrix: the same
+    blocks, partial sums and scales, so the whole step agrees bit for bit."""
+    T = pkg.trainer
+    kw = dict(frames_per_chunk=30, num_sequences=8, strides=[1, 1, 0, 3, 3], bottleneck=16, feat_dim=8, ivector_dim=4, hidden_dim=64, small_dim=32,
+              num_pdfs=50, use_natural_gradient=1, gemm_precision=3)
+    if kind != "7q":
+        kw.update(darts_num_offsets=3, darts_flags=4 if kind == "darts-uniform" else 0)
+
+    def run(group):
+        with pkg.hipabi.option("planes_group", group), pkg.hipabi.option("wgrad_stream", 0):
+            net = T.ChainNet(T.make_config(**kw))
+            cfg = net.cfg
+            net.set_params(net.init_params_numpy(seed=1, output_stddev=0.1))
+            den = pkg.hipabi.DenGraph(pkg.synth.make_den_graph(30, cfg.num_pdfs, mean_out_degree=4.0, seed=5))
+            out = []
+            for i in range(4):
+                feats, iv = T.synthetic_egs(net, seed=100 + i)
+                sup = pkg.hipabi.Supervision(pkg.synth.make_supervision(cfg.num_sequences, cfg.frames_per_chunk // 3, cfg.num_pdfs, seed=200 + i))
+                net.set_random_draws(np.random.default_rng(300 + i).uniform(1e-3, 1 - 1e-3, max(net.num_draws, 1)).astype(np.float32))
+                net.grads.zero_()
+                r = host(net.forward_backward(dev(feats), dev(iv), den, sup, step=i))
+                out.append((host(net.grads).copy(), r.copy()))
+                net.update(1e-3, step=i)
+            out.append((host(net.params).copy(), None))
+            net.close()
+        return out
+
+    a, b = run(1), run(0)
+    for i, ((ga, ra), (gb, rb)) in enumerate(zip(a, b)):
+        assert np.isfinite(ga).all()
+        assert np.array_equal(ga, gb), (i, rel_l2(ga, gb))
+        assert ra is None or np.array_equal(ra, rb)
