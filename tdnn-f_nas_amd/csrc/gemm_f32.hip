@@ -1547,7 +1547,12 @@ hipError_t rows_gemm(const RowsGemmArgs &a_in, bool b_kc, hipStream_t s) {
     // (option ng_bk: 1 = K steps twice as long for these HBM-bound passes -- twice the bytes in flight per resident block)
     if (a.N <= 32) return (options().ng_bk & 1) ? launch_rows_sumsq<4, 1, 1, 1, 64>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 1, 32>(a, b_kc, vec, s);
     if (a.N <= 64 && a.N > 32 && (options().ng_bk & 8) == 0) return launch_rows_sumsq<4, 1, 1, 2, 32>(a, b_kc, vec, s);  // both taps' rank-20 products side by side (ng.hip, P form)
-    if (a.N <= 96 && (options().ng_bk & 4)) return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);  // (measured: the 128 x 128 tile with 48 idle columns)
+    {  // long reductions (the rank-80 pass over the 6034-wide output derivative): the 128 x 128 tile, 48 idle columns and all, 1291 -> 1144 us;
+       // short ones (160 columns) lose by it, 79 -> 106 (option ng_bk 4 forces it for both)
+      long long ktot = 0;
+      for (int i = 0; i < a.nseg; i++) ktot += a.seg[i].klen;
+      if (a.N <= 96 && a.N > 64 && ((options().ng_bk & 4) || ktot >= 2048)) return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);
+    }
     if (a.N <= 96) return (options().ng_bk & 2) ? launch_rows_sumsq<4, 1, 1, 3, 32>(a, b_kc, vec, s) : launch_rows_sumsq<4, 1, 1, 3, 16>(a, b_kc, vec, s);  // rank-80 preconditioners: 96 of 96 columns, not 80 of 128
     return launch_rows_sumsq<2, 2, 2, 2, 32>(a, b_kc, vec, s);
   }
